@@ -1,0 +1,291 @@
+#!/usr/bin/env python
+"""
+bench.py -- BASELINE.json's metric on its configs[1] workload:
+
+    pixel-Gaussian evals/sec (render+loglike), 48x48x6-gauss stamps
+
+One "step" = one pass of the hot path over one batch resident in HBM: a
+render (accumulating into a model image, render_nb.py:9-36) followed by a
+get_loglike (gmix_nb.py:824-874) of every stamp, one kernel launch each.
+Weak scaling: every rank holds its own --nstamps stamps; objects are
+independent, so there is no data-path collective -- only the all-gather of the
+32-byte per-stamp result records named by north_star, overlapped on a side
+stream.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nstamps S]
+
+N > 1 is launched by torch.distributed.run (one process per GPU, RCCL).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NROW = NCOL = 48
+NGAUSS = 6
+NPIX = NROW * NCOL
+PAIRS_PER_STAMP = NPIX * NGAUSS  # 13,824 pixel-gaussian evaluations
+SCALE = 0.263
+# algorithmic bytes per stamp evaluation (SURVEY.md 8d / BASELINE.md section 3)
+LOGLIKE_BYTES = 16 * NPIX + 64 + 48 + 32   # 37,008
+RENDER_BYTES = 16 * NPIX                   # 36,864 (8 read + 8 written)
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def make_workload(nstamps, seed, device):
+    """per-stamp 'exp' model x gaussian psf T=0.27, noise
+    sigma = 0.01*flux/100, uniform weight; images rendered on the device by the
+    render kernel itself (truth + N(0, sigma^2))"""
+    import torch
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    rng = np.random.RandomState(seed)
+    pars = np.zeros((nstamps, 6))
+    pars[:, 0:2] = rng.uniform(-0.5, 0.5, size=(nstamps, 2)) * SCALE
+    g = rng.normal(scale=0.1, size=(nstamps, 2))
+    gmag = np.sqrt((g ** 2).sum(axis=1))
+    g *= np.where(gmag > 0.7, 0.7 / np.maximum(gmag, 1e-30), 1.0)[:, None]
+    pars[:, 2:4] = g
+    pars[:, 4] = rng.uniform(0.3, 1.5, size=nstamps)
+    pars[:, 5] = rng.uniform(50.0, 500.0, size=nstamps)
+    psfpars = np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (nstamps, 1))
+
+    gm0, st0 = GMixBatch.from_pars(pars, "exp", device=device)
+    psf, _ = GMixBatch.from_pars(psfpars, "gauss", device=device)
+    gm, _ = gm0.convolve(psf)
+    assert int(gm.set_norms().abs().sum()) == 0 and int(st0.abs().sum()) == 0
+
+    jac = np.array([23.5, 23.5, SCALE, 0.0, 0.0, SCALE, SCALE ** 2, SCALE])
+    geom = StampBatch(None, None,
+                      torch.from_numpy(np.tile(jac, (nstamps, 1))).to(device),
+                      np.full(nstamps, NROW), np.full(nstamps, NCOL),
+                      np.arange(nstamps, dtype=np.int64) * NPIX, True)
+    truth, _ = geom.render(gm, fast_exp=True)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    sigma = torch.from_numpy(0.01 * pars[:, 5] / 100.0).to(device)
+    val = truth.reshape(nstamps, NPIX)
+    val += torch.randn(val.shape, generator=gen, device=device,
+                       dtype=torch.float64) * sigma[:, None]
+    ierr = (1.0 / sigma)[:, None].expand(nstamps, NPIX).contiguous()
+    sb = StampBatch(val.reshape(-1), ierr.reshape(-1), geom.jac,
+                    np.full(nstamps, NROW), np.full(nstamps, NCOL),
+                    np.arange(nstamps, dtype=np.int64) * NPIX, True)
+    # evaluate at a perturbed parameter set, as an LM iteration would
+    pert = pars.copy()
+    pert[:, 4] *= 1.02
+    pert[:, 5] *= 0.99
+    gmp0, _ = GMixBatch.from_pars(pert, "exp", device=device)
+    gmp, _ = gmp0.convolve(psf)
+    gmp.set_norms()
+    return sb, gmp, pars
+
+
+def cpu_baseline(sb, gm, target_seconds=12.0):
+    """the CPU oracle (a port of the numba loops: oracle/ngmix_oracle.c) timed
+    on this box's host cores on a bounded sample of the same workload"""
+    from oracle import oracle as ora
+    nthreads = ora.num_threads()
+    S = min(sb.n, 64 * max(nthreads, 1), 4096)
+    gmh = gm.to_numpy()[:S]
+    gm_all = np.zeros((S, NGAUSS), dtype=ora.GAUSS2D_DTYPE)
+    for name in ora.GAUSS2D_DTYPE.names:
+        gm_all[name] = gmh[name]
+    val = sb.val[:S * NPIX].cpu().numpy().reshape(S, NROW, NCOL)
+    ierr = sb.ierr[:S * NPIX].cpu().numpy().reshape(S, NROW, NCOL)
+    jac = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+    jac[0] = tuple(sb.jac[0].cpu().numpy())
+    pixels = np.zeros((S, NPIX), dtype=ora.PIXEL_DTYPE)
+    coords = np.zeros((S, NPIX), dtype=ora.COORD_DTYPE)
+    for i in range(S):
+        ora.fill_pixels(pixels[i], val[i], ierr[i] ** 2, jac, True)
+        ora.fill_coords(coords[i], NROW, NCOL, jac)
+    images = np.zeros((S, NPIX))
+    ora.render_loglike_batch(gm_all[:8], pixels[:8], coords[:8], images[:8],
+                             nthreads)  # warm up threads / pages
+    t0 = time.perf_counter()
+    ora.render_loglike_batch(gm_all, pixels, coords, images, nthreads)
+    t1 = time.perf_counter() - t0
+    reps = int(max(1, min(200, target_seconds / max(t1, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ora.render_loglike_batch(gm_all, pixels, coords, images, nthreads)
+    dt = time.perf_counter() - t0
+    pairs = 2.0 * S * PAIRS_PER_STAMP * reps
+    return {
+        "value": pairs / dt,
+        "unit": "pixel-gaussian evals/s",
+        "cores": int(nthreads),
+        "kind": "port",
+        "sample": "%d stamps x %d passes of render+loglike (48x48x6), OpenMP "
+                  "over stamps, C port of the numba loops, -O2 no-FMA" % (S, reps),
+        "seconds": dt,
+    }
+
+
+def load_traffic():
+    """HBM bytes per loglike launch from the committed rocprofv3 PMC pass
+    (profiles/), if one exists for this workload size"""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(path):
+        try:
+            return json.load(open(path))
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nstamps", type=int, default=100000,
+                    help="stamps per GPU (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP kernels are the product)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    n = args.nstamps
+    sb, gm, _ = make_workload(n, seed=1000 + rank, device=device)
+    image = torch.zeros(sb.total_pix, dtype=torch.float64, device=device)
+    out = torch.empty((n, 4), dtype=torch.float64, device=device)
+    status = torch.empty(n, dtype=torch.int32, device=device)
+    gathered = None
+    side = None
+    if distributed:
+        gathered = torch.empty((world * n, 4), dtype=torch.float64, device=device)
+        side = torch.cuda.Stream(device=device)
+
+    ev_r0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev_r1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev_l1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    pending = None
+
+    def step(i=None):
+        nonlocal pending
+        if i is not None:
+            ev_r0[i].record()
+        sb.render(gm, image=image, fast_exp=True, status=status)
+        if i is not None:
+            ev_r1[i].record()
+        if pending is not None:
+            # the previous step's gather must have consumed `out`
+            torch.cuda.current_stream().wait_event(pending)
+        sb.loglike(gm, out=out, status=status)
+        if i is not None:
+            ev_l1[i].record()
+        if distributed:
+            # north_star's all-gather of per-object result records, on a side
+            # stream so it overlaps the next step's render
+            done = torch.cuda.Event()
+            done.record()
+            with torch.cuda.stream(side):
+                side.wait_event(done)
+                dist.all_gather_into_tensor(gathered, out)
+                pending = torch.cuda.Event()
+                pending.record()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    bad = int((status != 0).sum().item())
+    render_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_r0, ev_r1)]))
+    loglike_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_r1, ev_l1)]))
+
+    if rank == 0:
+        pairs_per_step = 2.0 * world * n * PAIRS_PER_STAMP
+        value = pairs_per_step * args.steps / elapsed
+        dominant = "loglike" if loglike_ms >= render_ms else "render"
+        dom_ms = max(loglike_ms, render_ms)
+        dom_bytes = (LOGLIKE_BYTES if dominant == "loglike" else RENDER_BYTES) * n
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        traffic = load_traffic()
+        traffic_bytes = None
+        if traffic and traffic.get("nstamps") == n:
+            traffic_bytes = traffic.get(dominant + "_hbm_bytes_per_launch")
+        line = {
+            "metric": "pixel-Gaussian evals/sec (render+loglike), 48x48x6-gauss stamps",
+            "value": value,
+            "unit": "pixel-gaussian evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "C2: %d stamps/GPU, 48x48 px, 6-gaussian 'exp' (x) "
+                            "gaussian psf; one step = render + get_loglike of "
+                            "every stamp" % n,
+                "stamps_per_gpu": n,
+                "parallelism": "stamps sharded across %d rank(s); all-gather of "
+                               "32-B result records" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "pixpass_grid_kernel<%s>" % dominant,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic_bytes,
+                "algorithmic_bytes_per_launch": dom_bytes,
+                "avg_launch_ms": dom_ms,
+            },
+            "kernels_ms": {"render": render_ms, "loglike": loglike_ms},
+            "loglike_stamp_evals_per_s_per_gpu": n / (loglike_ms * 1e-3),
+            "render_stamp_evals_per_s_per_gpu": n / (render_ms * 1e-3),
+            "bad_status": bad,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sb, gm)
+        print(json.dumps(line))
+        sys.stdout.flush()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,348 @@
+/*
+ * ngmix_hip.h -- C ABI of libngmix_hip.so, the MI355X (gfx950) implementation
+ * of ngmix's numba pixel hot path.
+ *
+ * The reference has no FFI: its seam is the import of the njit functions in
+ * ngmix/gmix/gmix_nb.py, ngmix/gmix/render_nb.py, ngmix/admom/admom_nb.py,
+ * ngmix/em/em_nb.py, ngmix/fitting/derivs_nb.py, ngmix/pixels/pixels_nb.py and
+ * ngmix/jacobian/jacobian_nb.py into the host classes (call sites listed at
+ * each entry; paths relative to the reference checkout).  This header declares
+ *
+ *   (1) SEAM FORMS  -- one entry per njit function, same arguments (numpy
+ *       structured arrays by pointer, HOST memory, caller-owned, results in
+ *       place), so a maintainer can swap the import for a ctypes stub
+ *       (INTEGRATION.md).  Pixel loops run on the GPU; O(ngauss) parameter
+ *       prep (norms, model fills, convolution) is host arithmetic compiled
+ *       from the same source as the device kernels.
+ *   (2) BATCH FORMS -- the same operations over N independent stamps resident
+ *       in HBM in a compact layout (8-byte val + 8-byte ierr per pixel,
+ *       one 64-byte jacobian and one mixture per stamp); DEVICE pointers,
+ *       asynchronous on the given hipStream_t.  This is the form the
+ *       throughput numbers are quoted on.
+ *
+ * All arithmetic is IEEE float64 with no FMA contraction, in the reference's
+ * operation order: per-pixel values (render, fdiff) are bit-identical to the
+ * reference; sums over pixels differ only by summation order.
+ *
+ * Return value: 0 = NGMIX_OK, >0 = the reference would have raised (code
+ * below), <0 = runtime failure (ngmix_last_error() has the message).  Batch
+ * forms additionally write one int32 status per stamp (same positive codes);
+ * one bad stamp never aborts the batch.
+ */
+#ifndef NGMIX_HIP_H
+#define NGMIX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------ */
+#define NGMIX_OK 0
+#define NGMIX_ERR_DET_TOO_LOW 1       /* GMixRangeError("det too low")  gmix_nb.py:203 */
+#define NGMIX_ERR_T_TOO_LOW 2         /* GMixRangeError("T too low")    gmix_nb.py:207 */
+#define NGMIX_ERR_G_RANGE 3           /* GMixRangeError("g >= 1")       gmix_nb.py:660 */
+#define NGMIX_ERR_GTOT_ZERO 4         /* GMixRangeError("gtot == 0")    em_nb.py:91 */
+#define NGMIX_ERR_ELOGL_ZERO 5        /* GMixRangeError("elogL == 0")   em_nb.py:113 */
+#define NGMIX_ERR_ZERO_DIV 6          /* ZeroDivisionError (numba python error model) */
+#define NGMIX_ERR_PIXELS_NOT_FILLED 7 /* RuntimeError               pixels_nb.py:57 */
+#define NGMIX_ERR_HIP (-100)          /* HIP runtime / no device */
+#define NGMIX_ERR_BAD_ARG (-101)
+
+/* ---- flag bits written into result records (ngmix/flags.py:3-11) ------- */
+#define NGMIX_FLAG_CEN_SHIFT 2
+#define NGMIX_FLAG_NONPOS_FLUX 4
+#define NGMIX_FLAG_NONPOS_SIZE 8
+#define NGMIX_FLAG_LOW_DET 16
+#define NGMIX_FLAG_MAXITER 32
+
+/* ---- model ids (ngmix/gmix/gmix.py:1100-1110) -------------------------- */
+#define NGMIX_MODEL_FULL 0
+#define NGMIX_MODEL_GAUSS 1
+#define NGMIX_MODEL_TURB 2
+#define NGMIX_MODEL_EXP 3
+#define NGMIX_MODEL_DEV 4
+#define NGMIX_MODEL_BDF 6
+#define NGMIX_MODEL_COELLIP 7
+#define NGMIX_MODEL_CM 9
+#define NGMIX_MODEL_BD 10
+
+/* ---- record layouts = the reference's numpy dtypes --------------------- */
+
+/* _gauss2d_dtype, ngmix/gmix/gmix.py:1196-1210 (104 bytes) */
+typedef struct {
+    double p, row, col, irr, irc, icc, det;
+    int64_t norm_set;
+    double drr, drc, dcc, norm, pnorm;
+} ngmix_gauss2d;
+
+/* _pixels_dtype / _coords_dtype, ngmix/pixels/pixels.py:72-86 */
+typedef struct { double u, v, area, val, ierr, fdiff; } ngmix_pixel; /* 48 B */
+typedef struct { double u, v, area; } ngmix_coord;                  /* 24 B */
+
+/* _jacobian_dtype, ngmix/jacobian/jacobian.py:406-414 (64 bytes) */
+typedef struct {
+    double row0, col0, dvdrow, dvdcol, dudrow, dudcol, det, scale;
+} ngmix_jacobian;
+
+/* _admom_conf_dtype / _admom_result_dtype (align=True),
+   ngmix/admom/admom.py:571-591 */
+typedef struct {
+    int32_t maxiter;
+    double shiftmax, etol, Ttol;
+    uint8_t cenonly;
+} ngmix_admom_conf; /* 40 B */
+
+typedef struct {
+    int32_t flags, numiter, npix;
+    double wsum;
+    double sums[7];
+    double sums_cov[49];
+    double pars[6];
+    double rho4;
+    double F[7];
+} ngmix_admom_result; /* 584 B */
+
+/* _em_conf_dtype (align=True), ngmix/em/em.py:440-449 */
+typedef struct {
+    double tol;
+    int32_t maxiter, miniter;
+    double sky;
+    uint8_t vary_sky;
+} ngmix_em_conf; /* 32 B */
+
+/* EM run kinds: em_run / em_run_fixcen / em_run_fixcov / em_run_fluxonly.
+   The per-gaussian sums record is the reference dtype of that kind
+   (ngmix/em/em.py:451-521): 14 / 10 / 8 / 2 doubles. */
+#define NGMIX_EM_FULL 0
+#define NGMIX_EM_FIXCEN 1
+#define NGMIX_EM_FIXCOV 2
+#define NGMIX_EM_FLUXONLY 3
+
+/* Weighted-moments result record for nmom in {6, 17}
+   (get_moments_result_dtype, ngmix/gmix/gmix.py:1314-1330, align=True):
+     int32 flags; int32 npix; double wsum; double sums[nmom];
+     double sums_cov[nmom*nmom]; double pars[nmom]; double F[nmom];
+   448 bytes for nmom=6, 2736 for nmom=17.  Passed as void*. */
+#define NGMIX_MOMENTS_RESULT_BYTES(nmom) (16 + 8 * ((nmom) * (nmom) + 3 * (nmom)))
+
+/* ======================================================================
+ * runtime
+ * ====================================================================== */
+const char *ngmix_version(void);
+const char *ngmix_last_error(void);
+int ngmix_device_count(void);
+int ngmix_set_device(int device);
+/* thin wrappers so a numpy-only host can own device buffers */
+int ngmix_device_malloc(void **ptr, size_t nbytes);
+int ngmix_device_free(void *ptr);
+int ngmix_memcpy_h2d(void *dst_dev, const void *src_host, size_t nbytes, void *stream);
+int ngmix_memcpy_d2h(void *dst_host, const void *src_dev, size_t nbytes, void *stream);
+int ngmix_memset_device(void *dst_dev, int value, size_t nbytes, void *stream);
+int ngmix_stream_synchronize(void *stream);
+
+/* ======================================================================
+ * (1) SEAM FORMS -- host pointers, synchronous
+ * ====================================================================== */
+
+/* -- O(ngauss) parameter prep (host arithmetic) -- */
+
+/* gmix_set_norms(gmix), gmix_nb.py:176-218; called at gmix.py:400,409 */
+int ngmix_set_norms(ngmix_gauss2d *gmix, int64_t ngauss);
+/* _gmix_fill_functions[name](gmix, pars), gmix_nb.py:307-427,469-558;
+   called at gmix.py:443-445.  model = NGMIX_MODEL_* except CM */
+int ngmix_fill_model(ngmix_gauss2d *gmix, int64_t ngauss, int model,
+                     const double *pars, int64_t npars);
+/* gmix_fill_cm(gmix, fracdev, TdByTe, Tfactor, pars), gmix_nb.py:430-466;
+   called at gmix.py:1028-1030 */
+int ngmix_fill_cm(ngmix_gauss2d *gmix, double fracdev, double TdByTe,
+                  double Tfactor, const double *pars);
+/* get_cm_Tfactor(fracdev, TdByTe), gmix_nb.py:561-593; gmix.py:1005 */
+int ngmix_get_cm_Tfactor(double fracdev, double TdByTe, double *Tfactor);
+/* g1g2_to_e1e2(g1, g2), gmix_nb.py:652-678 */
+int ngmix_g1g2_to_e1e2(double g1, double g2, double *e1, double *e2);
+/* gmix_convolve_fill(self, gmix, psf), gmix_nb.py:609-649;
+   called at gmix.py:539, results.py:304 */
+int ngmix_convolve_fill(ngmix_gauss2d *out, const ngmix_gauss2d *gmix,
+                        int64_t ngauss, const ngmix_gauss2d *psf, int64_t npsf);
+/* jacobian_get_vu / jacobian_get_rowcol, jacobian_nb.py:4-30;
+   called at jacobian.py:160-182 */
+void ngmix_jacobian_get_vu(const ngmix_jacobian *jacob, double row, double col,
+                           double *v, double *u);
+int ngmix_jacobian_get_rowcol(const ngmix_jacobian *jacob, double v, double u,
+                              double *row, double *col);
+
+/* -- pixel loops (GPU) -- */
+
+/* fill_pixels(pixels, image, weight, jacob, ignore_zero_weight),
+   pixels_nb.py:6-58; called at pixels.py:44-50 */
+int ngmix_fill_pixels(ngmix_pixel *pixels, int64_t npixels, const double *image,
+                      const double *weight, int64_t nrow, int64_t ncol,
+                      const ngmix_jacobian *jacob, int ignore_zero_weight);
+/* fill_coords(coords, nrow, ncol, jacob), pixels_nb.py:61-94; pixels.py:65-67 */
+int ngmix_fill_coords(ngmix_coord *coords, int64_t nrow, int64_t ncol,
+                      const ngmix_jacobian *jacob);
+/* render(gmix, coords, image, fast_exp), render_nb.py:9-36; gmix.py:641-643.
+   Adds into image; sets norms lazily (written back to gmix). */
+int ngmix_render(ngmix_gauss2d *gmix, int64_t ngauss, const ngmix_coord *coords,
+                 int64_t ncoords, double *image, int fast_exp);
+/* get_loglike(gmix, pixels) -> (loglike, s2n_numer, s2n_denom, npix),
+   gmix_nb.py:824-874; called at gmix.py:812 */
+int ngmix_get_loglike(ngmix_gauss2d *gmix, int64_t ngauss,
+                      const ngmix_pixel *pixels, int64_t npix, double *loglike,
+                      double *s2n_numer, double *s2n_denom, int64_t *npix_out);
+/* fill_fdiff(gmix, pixels, fdiff, start), gmix_nb.py:877-900;
+   called at gmix.py:670-672, results.py:457-459 */
+int ngmix_fill_fdiff(ngmix_gauss2d *gmix, int64_t ngauss,
+                     const ngmix_pixel *pixels, int64_t npix, double *fdiff,
+                     int64_t start);
+/* get_model_s2n_sum(gmix, pixels), gmix_nb.py:903-937; gmix.py:775 */
+int ngmix_get_model_s2n_sum(ngmix_gauss2d *gmix, int64_t ngauss,
+                            const ngmix_pixel *pixels, int64_t npix,
+                            double *s2n_sum);
+/* get_weighted_sums / get_higher_order_weighted_sums(wt, pixels, res, maxrad),
+   gmix_nb.py:681-821; called at gmix.py:750-752.  nmom = 6 or 17; adds into
+   res.  wt must have its norms set (gmix.py:733). */
+int ngmix_get_weighted_sums(const ngmix_gauss2d *wt, int64_t ngauss,
+                            const ngmix_pixel *pixels, int64_t npix, void *res,
+                            int nmom, double maxrad);
+/* admom(confarray, wt, pixels, resarray), admom_nb.py:13-108; admom.py:349-354.
+   wt (one gaussian) is updated in place, as in the reference. */
+int ngmix_admom(const ngmix_admom_conf *conf, ngmix_gauss2d *wt,
+                const ngmix_pixel *pixels, int64_t npix,
+                ngmix_admom_result *res);
+/* em_run{,_fixcen,_fixcov,_fluxonly}(conf, pixels, sums, gmix, gmix_psf,
+   gmix_conv, fill_zero_weight) -> (numiter, frac_diff, sky),
+   em_nb.py:15-127,357-469,702-816,1005-1106; called at em.py:278-286.
+   pixels may be modified (zero-weight fill); gmix, gmix_conv are updated. */
+int ngmix_em_run(int kind, const ngmix_em_conf *conf, ngmix_pixel *pixels,
+                 int64_t npix, double *sums, ngmix_gauss2d *gmix, int64_t ngauss,
+                 ngmix_gauss2d *gmix_psf, int64_t npsf, ngmix_gauss2d *gmix_conv,
+                 int fill_zero_weight, int32_t *numiter, double *frac_diff,
+                 double *sky);
+/* deriv_images(gpars, dcov, vv, uu, area, out), derivs_nb.py:40-127;
+   called at results.py:551-554, noise_cov.py:181-184.  out is (6, npix),
+   accumulated into. */
+int ngmix_deriv_images(const double *gpars, const double *dcov, int64_t ngauss,
+                       const double *vv, const double *uu, const double *area,
+                       int64_t npix, double *out);
+
+/* ======================================================================
+ * (2) BATCH FORMS -- device pointers, asynchronous on `stream`
+ *
+ * Compact stamp store in HBM:
+ *   val[], ierr[]   float64, full-frame row-major stamps back to back;
+ *                   ierr = sqrt(max(weight,0)) (pixels_nb.py:49-52)
+ *   jac[]           one ngmix_jacobian per stamp
+ *   stamps[]        one ngmix_stamp per stamp
+ *   gmix[]          ngmix_gauss2d records, stamps[i].gm_off .. +ngauss
+ * (v,u,area) are affine in (row,col) and are recomputed in-kernel with the
+ * exact expression of jacobian_get_vu; the reference's pixel list (row-major,
+ * weight<=0 dropped when ignore_zero_weight) is implicit: the k-th kept pixel
+ * of a stamp is the reference's pixels[k].
+ * ====================================================================== */
+
+#define NGMIX_STAMP_IGNORE_ZERO_WEIGHT 1
+
+typedef struct {
+    int64_t pix_off; /* first pixel of the stamp in val/ierr/image arrays */
+    int32_t nrow, ncol;
+    int32_t gm_off;  /* first gaussian of the stamp's mixture in gmix[] */
+    int32_t ngauss;
+    int32_t flags;   /* NGMIX_STAMP_* */
+    int32_t npix_kept; /* size of the reference's pixel list for this stamp
+                          (== nrow*ncol when nothing is masked) */
+} ngmix_stamp; /* 32 B */
+
+/* diagnostic: evaluate every (gaussian, pixel) pair, no exact skipping */
+#define NGMIX_BATCH_NO_SKIP 1
+
+/* A batch of stamps: HOST struct holding DEVICE pointers plus the few host
+   facts a launch needs (LDS sizing, tile schedule). */
+typedef struct {
+    int64_t nstamps;
+    const ngmix_stamp *stamps;  /* device, nstamps records */
+    const double *val;          /* device; may be NULL for render / s2n */
+    const double *ierr;         /* device; may be NULL for render */
+    const ngmix_jacobian *jac;  /* device, nstamps records */
+    int32_t max_ngauss;         /* max stamps[i].ngauss */
+    int32_t max_npix;           /* max nrow*ncol */
+    int32_t any_masked;         /* some stamp has npix_kept != nrow*ncol */
+    int32_t flags;              /* NGMIX_BATCH_* */
+} ngmix_batch;
+
+/* ierr = sqrt(max(weight,0)) elementwise (pixels_nb.py:49-52) */
+int ngmix_weight_to_ierr_batch(const double *weight, double *ierr, int64_t n,
+                               void *stream);
+/* count kept pixels per stamp into stamps[i].npix_kept (pixels.py:33-37);
+   a stamp with no positive weight gets npix_kept = 0 (the host raises
+   GMixFatalError("no weights > 0") from that) */
+int ngmix_count_kept_batch(ngmix_stamp *stamps, int64_t nstamps,
+                           const double *ierr, void *stream);
+
+/* per-stamp model fill: pars is (nstamps, npars) row-major; gmix gets
+   nstamps*ngauss records.  cm_extra is (nstamps,3) [fracdev,TdByTe,Tfactor]
+   for NGMIX_MODEL_CM, else NULL. */
+int ngmix_fill_model_batch(ngmix_gauss2d *gmix, int64_t nstamps, int ngauss,
+                           int model, const double *pars, int npars,
+                           const double *cm_extra, int32_t *status,
+                           void *stream);
+/* per-stamp convolution; psf holds nstamps*npsf records (one psf per stamp),
+   out nstamps*ngauss*npsf */
+int ngmix_convolve_fill_batch(ngmix_gauss2d *out, const ngmix_gauss2d *gmix,
+                              int ngauss, const ngmix_gauss2d *psf, int npsf,
+                              int64_t nstamps, int32_t *status, void *stream);
+/* gmix_set_norms on every stamp's mixture of ngauss records */
+int ngmix_set_norms_batch(ngmix_gauss2d *gmix, int ngauss, int64_t nstamps,
+                          int32_t *status, void *stream);
+
+/* get_loglike per stamp: out is (nstamps, 4) float64 =
+   [loglike, s2n_numer, s2n_denom, npix].  Norms are set lazily in-kernel
+   (written back) when gmix[gm_off].norm_set == 0, as the reference does. */
+int ngmix_loglike_batch(const ngmix_batch *batch, ngmix_gauss2d *gmix,
+                        double *out, int32_t *status, void *stream);
+/* fill_fdiff per stamp: the k-th kept pixel writes fdiff[fdiff_start[i]+k] */
+int ngmix_fill_fdiff_batch(const ngmix_batch *batch, ngmix_gauss2d *gmix,
+                           double *fdiff, const int64_t *fdiff_start,
+                           int32_t *status, void *stream);
+/* render per stamp into image[pix_off + row*ncol + col] (adds) */
+int ngmix_render_batch(const ngmix_batch *batch, ngmix_gauss2d *gmix,
+                       double *image, int fast_exp, int32_t *status,
+                       void *stream);
+/* get_model_s2n_sum per stamp: out is (nstamps,) */
+int ngmix_model_s2n_sum_batch(const ngmix_batch *batch, ngmix_gauss2d *gmix,
+                              double *out, int32_t *status, void *stream);
+/* get_weighted_sums per stamp: res is nstamps records of
+   NGMIX_MOMENTS_RESULT_BYTES(nmom), added into; maxrad is (nstamps,) */
+int ngmix_weighted_sums_batch(const ngmix_batch *batch,
+                              const ngmix_gauss2d *gmix, void *res, int nmom,
+                              const double *maxrad, int32_t *status,
+                              void *stream);
+/* admom per stamp: wt is one gaussian per stamp (stamps[i].gm_off, ngauss=1),
+   updated in place; conf is a single record (host pointer) shared by all */
+int ngmix_admom_batch(const ngmix_admom_conf *conf, const ngmix_batch *batch,
+                      ngmix_gauss2d *wt, ngmix_admom_result *res,
+                      int32_t *status, void *stream);
+/* em_run per stamp.  gmix: nstamps*ngauss, gmix_psf: nstamps*npsf,
+   gmix_conv: nstamps*ngauss*npsf, all updated as in the reference.
+   sky_in (nstamps,) per-stamp sky (conf->sky is ignored); out (nstamps,3) =
+   [numiter, frac_diff, sky].  val is read-only: the zero-weight fill of the
+   reference acts on an on-chip copy. */
+int ngmix_em_batch(int kind, const ngmix_em_conf *conf, const ngmix_batch *batch,
+                   ngmix_gauss2d *gmix, int ngauss, ngmix_gauss2d *gmix_psf,
+                   int npsf, ngmix_gauss2d *gmix_conv, const double *sky_in,
+                   int fill_zero_weight, double *out, int32_t *status,
+                   void *stream);
+/* deriv_images per stamp over its kept pixels: gpars (sum ngauss,6) and dcov
+   (sum ngauss,3,3) indexed by stamps[i].gm_off; out[out_start[i] + a*nk + k]
+   for a in 0..5 and the k-th kept pixel, nk = npix_kept; accumulated into */
+int ngmix_deriv_images_batch(const ngmix_batch *batch, const double *gpars,
+                             const double *dcov, double *out,
+                             const int64_t *out_start, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGMIX_HIP_H */

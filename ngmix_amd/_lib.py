@@ -1,0 +1,220 @@
+"""
+ctypes binding of libngmix_hip.so (include/ngmix_hip.h).
+
+The HIP library IS the product: there is no CPU fallback.  If the shared
+object is missing we try to build it in-tree with hipcc (same image on the
+GPU box); if that fails, importing any compute entry point raises.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from . import gexceptions
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libngmix_hip.so")
+
+# ---- status codes (include/ngmix_hip.h) ----
+OK = 0
+ERR_DET_TOO_LOW = 1
+ERR_T_TOO_LOW = 2
+ERR_G_RANGE = 3
+ERR_GTOT_ZERO = 4
+ERR_ELOGL_ZERO = 5
+ERR_ZERO_DIV = 6
+ERR_PIXELS_NOT_FILLED = 7
+ERR_HIP = -100
+ERR_BAD_ARG = -101
+
+_RANGE_MESSAGES = {
+    ERR_DET_TOO_LOW: "det too low",
+    ERR_T_TOO_LOW: "T too low",
+    ERR_G_RANGE: "g >= 1",
+    ERR_GTOT_ZERO: "gtot == 0",
+    ERR_ELOGL_ZERO: "elogL == 0",
+}
+
+STAMP_IGNORE_ZERO_WEIGHT = 1
+BATCH_NO_SKIP = 1
+
+# ---- record layouts = the reference's numpy dtypes ----
+GAUSS2D_DTYPE = np.dtype([
+    ("p", "f8"), ("row", "f8"), ("col", "f8"),
+    ("irr", "f8"), ("irc", "f8"), ("icc", "f8"), ("det", "f8"),
+    ("norm_set", "i8"),
+    ("drr", "f8"), ("drc", "f8"), ("dcc", "f8"), ("norm", "f8"), ("pnorm", "f8"),
+])
+PIXEL_DTYPE = np.dtype([
+    ("u", "f8"), ("v", "f8"), ("area", "f8"),
+    ("val", "f8"), ("ierr", "f8"), ("fdiff", "f8"),
+])
+COORD_DTYPE = np.dtype([("u", "f8"), ("v", "f8"), ("area", "f8")])
+JACOBIAN_DTYPE = np.dtype([
+    ("row0", "f8"), ("col0", "f8"), ("dvdrow", "f8"), ("dvdcol", "f8"),
+    ("dudrow", "f8"), ("dudcol", "f8"), ("det", "f8"), ("scale", "f8"),
+])
+ADMOM_CONF_DTYPE = np.dtype([
+    ("maxiter", "i4"), ("shiftmax", "f8"), ("etol", "f8"), ("Ttol", "f8"),
+    ("cenonly", bool),
+], align=True)
+ADMOM_RESULT_DTYPE = np.dtype([
+    ("flags", "i4"), ("numiter", "i4"), ("npix", "i4"), ("wsum", "f8"),
+    ("sums", "f8", 7), ("sums_cov", "f8", (7, 7)), ("pars", "f8", 6),
+    ("rho4", "f8"), ("F", "f8", 7),
+], align=True)
+EM_CONF_DTYPE = np.dtype([
+    ("tol", "f8"), ("maxiter", "i4"), ("miniter", "i4"), ("sky", "f8"),
+    ("vary_sky", "bool"),
+], align=True)
+STAMP_DTYPE = np.dtype([
+    ("pix_off", "i8"), ("nrow", "i4"), ("ncol", "i4"), ("gm_off", "i4"),
+    ("ngauss", "i4"), ("flags", "i4"), ("npix_kept", "i4"),
+])
+EM_SUMS_NDOUBLE = {0: 14, 1: 10, 2: 8, 3: 2}
+
+assert GAUSS2D_DTYPE.itemsize == 104 and PIXEL_DTYPE.itemsize == 48
+assert ADMOM_CONF_DTYPE.itemsize == 40 and ADMOM_RESULT_DTYPE.itemsize == 584
+assert EM_CONF_DTYPE.itemsize == 32 and STAMP_DTYPE.itemsize == 32
+
+
+def moments_result_dtype(nmom):
+    """get_moments_result_dtype, ngmix/gmix/gmix.py:1314-1330 (align=True)"""
+    return np.dtype([
+        ("flags", "i4"), ("npix", "i4"), ("wsum", "f8"),
+        ("sums", "f8", nmom), ("sums_cov", "f8", (nmom, nmom)),
+        ("pars", "f8", nmom), ("F", "f8", nmom),
+    ], align=True)
+
+
+class Batch(ctypes.Structure):
+    """ngmix_batch: host struct of device pointers"""
+    _fields_ = [
+        ("nstamps", ctypes.c_int64),
+        ("stamps", ctypes.c_void_p),
+        ("val", ctypes.c_void_p),
+        ("ierr", ctypes.c_void_p),
+        ("jac", ctypes.c_void_p),
+        ("max_ngauss", ctypes.c_int32),
+        ("max_npix", ctypes.c_int32),
+        ("any_masked", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
+    ]
+
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int
+_f64 = ctypes.c_double
+_sz = ctypes.c_size_t
+_pd = ctypes.POINTER(ctypes.c_double)
+_pb = ctypes.POINTER(Batch)
+
+# name -> (restype, argtypes); every symbol include/ngmix_hip.h declares
+SIGNATURES = {
+    "ngmix_version": (ctypes.c_char_p, []),
+    "ngmix_last_error": (ctypes.c_char_p, []),
+    "ngmix_device_count": (_i32, []),
+    "ngmix_set_device": (_i32, [_i32]),
+    "ngmix_device_malloc": (_i32, [ctypes.POINTER(_vp), _sz]),
+    "ngmix_device_free": (_i32, [_vp]),
+    "ngmix_memcpy_h2d": (_i32, [_vp, _vp, _sz, _vp]),
+    "ngmix_memcpy_d2h": (_i32, [_vp, _vp, _sz, _vp]),
+    "ngmix_memset_device": (_i32, [_vp, _i32, _sz, _vp]),
+    "ngmix_stream_synchronize": (_i32, [_vp]),
+    # seam forms
+    "ngmix_set_norms": (_i32, [_vp, _i64]),
+    "ngmix_fill_model": (_i32, [_vp, _i64, _i32, _vp, _i64]),
+    "ngmix_fill_cm": (_i32, [_vp, _f64, _f64, _f64, _vp]),
+    "ngmix_get_cm_Tfactor": (_i32, [_f64, _f64, _pd]),
+    "ngmix_g1g2_to_e1e2": (_i32, [_f64, _f64, _pd, _pd]),
+    "ngmix_convolve_fill": (_i32, [_vp, _vp, _i64, _vp, _i64]),
+    "ngmix_jacobian_get_vu": (None, [_vp, _f64, _f64, _pd, _pd]),
+    "ngmix_jacobian_get_rowcol": (_i32, [_vp, _f64, _f64, _pd, _pd]),
+    "ngmix_fill_pixels": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _i32]),
+    "ngmix_fill_coords": (_i32, [_vp, _i64, _i64, _vp]),
+    "ngmix_render": (_i32, [_vp, _i64, _vp, _i64, _vp, _i32]),
+    "ngmix_get_loglike": (_i32, [_vp, _i64, _vp, _i64, _pd, _pd, _pd,
+                                 ctypes.POINTER(_i64)]),
+    "ngmix_fill_fdiff": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64]),
+    "ngmix_get_model_s2n_sum": (_i32, [_vp, _i64, _vp, _i64, _pd]),
+    "ngmix_get_weighted_sums": (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _f64]),
+    "ngmix_admom": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "ngmix_em_run": (_i32, [_i32, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64,
+                            _vp, _i32, ctypes.POINTER(ctypes.c_int32), _pd, _pd]),
+    "ngmix_deriv_images": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    # batch forms
+    "ngmix_weight_to_ierr_batch": (_i32, [_vp, _vp, _i64, _vp]),
+    "ngmix_count_kept_batch": (_i32, [_vp, _i64, _vp, _vp]),
+    "ngmix_fill_model_batch": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp,
+                                      _vp, _vp]),
+    "ngmix_convolve_fill_batch": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _vp,
+                                         _vp]),
+    "ngmix_set_norms_batch": (_i32, [_vp, _i32, _i64, _vp, _vp]),
+    "ngmix_loglike_batch": (_i32, [_pb, _vp, _vp, _vp, _vp]),
+    "ngmix_fill_fdiff_batch": (_i32, [_pb, _vp, _vp, _vp, _vp, _vp]),
+    "ngmix_render_batch": (_i32, [_pb, _vp, _vp, _i32, _vp, _vp]),
+    "ngmix_model_s2n_sum_batch": (_i32, [_pb, _vp, _vp, _vp, _vp]),
+    "ngmix_weighted_sums_batch": (_i32, [_pb, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "ngmix_admom_batch": (_i32, [_vp, _pb, _vp, _vp, _vp, _vp]),
+    "ngmix_em_batch": (_i32, [_i32, _vp, _pb, _vp, _i32, _vp, _i32, _vp, _vp,
+                              _i32, _vp, _vp, _vp]),
+    "ngmix_deriv_images_batch": (_i32, [_pb, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+def build(verbose=False):
+    """compile libngmix_hip.so in-tree for gfx950 (hipcc)"""
+    res = subprocess.run(["make", "-C", _CSRC, "-j4"], capture_output=True,
+                         text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise RuntimeError("building libngmix_hip.so failed")
+
+
+_lib = None
+
+
+def lib():
+    """load the HIP library; raises (never falls back) if unavailable"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if a symbol is missing
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().ngmix_last_error().decode()
+
+
+def check(status, context=""):
+    """map a C-ABI status onto the exception the reference would raise"""
+    if status == OK:
+        return
+    if status in _RANGE_MESSAGES:
+        raise gexceptions.GMixRangeError(_RANGE_MESSAGES[status])
+    if status == ERR_ZERO_DIV:
+        raise ZeroDivisionError("division by zero")
+    if status == ERR_PIXELS_NOT_FILLED:
+        raise RuntimeError("some pixels were not filled")
+    if status == ERR_BAD_ARG:
+        raise ValueError("%s: bad argument: %s" % (context, last_error()))
+    raise RuntimeError("%s: HIP failure (%d): %s" % (context, status, last_error()))
+
+
+def ptr(a):
+    """address of a C-contiguous numpy array"""
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("array must be C contiguous")
+    return ctypes.c_void_p(a.ctypes.data)

@@ -1,0 +1,411 @@
+"""
+Device-resident batches: the MI355X-native form of the reference's
+per-Observation loops.
+
+The reference has no batch API (every entry point takes one Observation and
+loops in Python); here N independent stamps live in HBM
+in a compact layout -- 8 B val + 8 B ierr per pixel, one 64-byte jacobian and
+one gaussian mixture per stamp -- and each operation of the hot path is ONE
+kernel launch over the whole batch (one work-group per stamp).
+
+torch is used only as the owner of device memory and streams; every compute
+call goes through the C ABI in include/ngmix_hip.h.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream():
+    torch = _torch()
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _as_device_f64(x, device):
+    torch = _torch()
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
+    return x.to(device=device, dtype=torch.float64).contiguous()
+
+
+def _require_cuda(device):
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "ngmix_amd needs a GPU: the HIP kernels are the only compute path")
+    dev = torch.device(device if device is not None else "cuda")
+    if dev.type != "cuda":
+        raise ValueError("device must be a cuda (ROCm) device")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+class GMixBatch(object):
+    """
+    n mixtures of `ngauss` gaussians each, on the device, in the reference's
+    gauss2d record layout (ngmix/gmix/gmix.py:1196-1210): a float64 tensor of
+    shape (n*ngauss, 13) whose column 7 carries the int64 norm_set bits.
+    """
+
+    def __init__(self, data, n, ngauss):
+        self.data = data
+        self.n = int(n)
+        self.ngauss = int(ngauss)
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @classmethod
+    def empty(cls, n, ngauss, device=None):
+        torch = _torch()
+        dev = _require_cuda(device)
+        data = torch.zeros((n * ngauss, 13), dtype=torch.float64, device=dev)
+        return cls(data, n, ngauss)
+
+    @classmethod
+    def from_numpy(cls, arr, device=None):
+        """arr: structured array of shape (n, ngauss) or (ngauss,) with
+        _lib.GAUSS2D_DTYPE"""
+        torch = _torch()
+        dev = _require_cuda(device)
+        arr = np.ascontiguousarray(arr, dtype=_lib.GAUSS2D_DTYPE)
+        if arr.ndim == 1:
+            arr = arr[None, :]
+        n, ngauss = arr.shape
+        flat = arr.reshape(-1).view(np.float64).reshape(-1, 13)
+        return cls(torch.from_numpy(flat.copy()).to(dev), n, ngauss)
+
+    @classmethod
+    def from_pars(cls, pars, model, device=None, cm_extra=None, ngauss=None):
+        """
+        Fill n model mixtures on the device (gmix_nb.py:307-558).  pars is
+        (n, npars).  Returns (GMixBatch, status) where status[i] != 0 marks
+        a stamp whose fill the reference would have rejected (g >= 1 ...).
+        """
+        torch = _torch()
+        from .gmix import get_model_num, get_model_ngauss
+        dev = _require_cuda(device)
+        modnum = get_model_num(model)
+        pars = _as_device_f64(pars, dev)
+        if pars.ndim == 1:
+            pars = pars[None, :]
+        n, npars = pars.shape
+        if ngauss is None:
+            ngauss = get_model_ngauss(modnum)
+        out = cls.empty(n, ngauss, dev)
+        status = torch.zeros(n, dtype=torch.int32, device=dev)
+        extra = None
+        if cm_extra is not None:
+            extra = _as_device_f64(cm_extra, dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib().ngmix_fill_model_batch(
+                _dptr(out.data), n, ngauss, modnum, _dptr(pars), npars,
+                _dptr(extra), _dptr(status), _stream())
+        _lib.check(st, "ngmix_fill_model_batch")
+        return out, status
+
+    def convolve(self, psf):
+        """per-stamp gmix_convolve_fill (gmix_nb.py:609-649);
+        returns (GMixBatch, status)"""
+        torch = _torch()
+        assert psf.n == self.n
+        out = GMixBatch.empty(self.n, self.ngauss * psf.ngauss, self.device)
+        status = torch.zeros(self.n, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            st = _lib.lib().ngmix_convolve_fill_batch(
+                _dptr(out.data), _dptr(self.data), self.ngauss, _dptr(psf.data),
+                psf.ngauss, self.n, _dptr(status), _stream())
+        _lib.check(st, "ngmix_convolve_fill_batch")
+        return out, status
+
+    def set_norms(self):
+        """gmix_set_norms per stamp (gmix_nb.py:176-218); returns status"""
+        torch = _torch()
+        status = torch.zeros(self.n, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            st = _lib.lib().ngmix_set_norms_batch(
+                _dptr(self.data), self.ngauss, self.n, _dptr(status), _stream())
+        _lib.check(st, "ngmix_set_norms_batch")
+        return status
+
+    def to_numpy(self):
+        """structured (n, ngauss) array with the reference dtype"""
+        flat = self.data.detach().cpu().numpy()
+        return flat.reshape(-1).view(_lib.GAUSS2D_DTYPE).reshape(
+            self.n, self.ngauss).copy()
+
+    def clone(self):
+        return GMixBatch(self.data.clone(), self.n, self.ngauss)
+
+
+class StampBatch(object):
+    """
+    N stamps resident in HBM.
+
+    val / ierr: float64 tensors, full-frame row-major stamps back to back
+    jac:        (N, 8) float64, the reference's jacobian record per stamp
+    geometry:   host structured array (nrow, ncol, pix_off, flags, npix_kept)
+
+    The reference's pixel list (Observation.pixels) is implicit: the k-th
+    pixel with weight > 0 in row-major order (pixels_nb.py:33-38).
+    """
+
+    def __init__(self, val, ierr, jac, nrow, ncol, pix_off, ignore_zero_weight):
+        torch = _torch()
+        self.val = val
+        self.ierr = ierr
+        self.jac = jac
+        self.device = ierr.device if ierr is not None else jac.device
+        self.n = int(jac.shape[0])
+        self.nrow = np.ascontiguousarray(nrow, dtype=np.int32)
+        self.ncol = np.ascontiguousarray(ncol, dtype=np.int32)
+        self.pix_off = np.ascontiguousarray(pix_off, dtype=np.int64)
+        izw = np.broadcast_to(np.asarray(ignore_zero_weight, dtype=bool), (self.n,))
+        self.flags = np.where(izw, _lib.STAMP_IGNORE_ZERO_WEIGHT, 0).astype(np.int32)
+        self.npix = self.nrow.astype(np.int64) * self.ncol
+        self.max_npix = int(self.npix.max()) if self.n else 0
+        self.total_pix = int(self.npix.sum())
+        self._stamp_tables = {}
+        # count kept pixels once (device) so masked stamps are known
+        self.npix_kept = self.npix.astype(np.int32).copy()
+        if ierr is not None and self.n:
+            tab = self._make_table(self.npix_kept, 0, 0)
+            with torch.cuda.device(self.device):
+                st = _lib.lib().ngmix_count_kept_batch(
+                    _dptr(tab), self.n, _dptr(self.ierr), _stream())
+            _lib.check(st, "ngmix_count_kept_batch")
+            host = tab.cpu().numpy().reshape(-1).view(_lib.STAMP_DTYPE)
+            self.npix_kept = host["npix_kept"].copy()
+        self.any_masked = bool(np.any(self.npix_kept != self.npix))
+
+    # ------------------------------------------------------------ builders
+    @classmethod
+    def from_images(cls, images, weights=None, jacobians=None,
+                    ignore_zero_weight=True, device=None):
+        """
+        images:    (N, nrow, ncol) array/tensor (same shape for every stamp)
+        weights:   same shape, or None for all-ones (observation.py:376)
+        jacobians: (N, 8) / (8,) reference jacobian records, Jacobian objects,
+                   or None for a unit jacobian at the stamp centre
+        """
+        torch = _torch()
+        dev = _require_cuda(device)
+        val = _as_device_f64(images, dev)
+        if val.ndim == 2:
+            val = val[None]
+        n, nrow, ncol = val.shape
+        if weights is None:
+            ierr = torch.ones_like(val)
+        else:
+            w = _as_device_f64(weights, dev)
+            if w.ndim == 2:
+                w = w[None]
+            assert w.shape == val.shape, "image and weight must match"
+            ierr = torch.empty_like(w)
+            with torch.cuda.device(dev):
+                st = _lib.lib().ngmix_weight_to_ierr_batch(
+                    _dptr(w), _dptr(ierr), w.numel(), _stream())
+            _lib.check(st, "ngmix_weight_to_ierr_batch")
+        jac = cls._jacobian_tensor(jacobians, n, nrow, ncol, dev)
+        npix = nrow * ncol
+        return cls(val.reshape(-1), ierr.reshape(-1), jac,
+                   np.full(n, nrow), np.full(n, ncol),
+                   np.arange(n, dtype=np.int64) * npix, ignore_zero_weight)
+
+    @classmethod
+    def from_observations(cls, obs_list, device=None):
+        """ragged batch from Observation objects (any mix of shapes)"""
+        torch = _torch()
+        dev = _require_cuda(device)
+        n = len(obs_list)
+        nrow = np.array([o.image.shape[0] for o in obs_list], dtype=np.int32)
+        ncol = np.array([o.image.shape[1] for o in obs_list], dtype=np.int32)
+        npix = nrow.astype(np.int64) * ncol
+        off = np.concatenate([[0], np.cumsum(npix)[:-1]]).astype(np.int64)
+        val = np.concatenate([np.asarray(o.image, dtype="f8").ravel()
+                              for o in obs_list])
+        wt = np.concatenate([np.asarray(o.weight, dtype="f8").ravel()
+                             for o in obs_list])
+        jac = np.stack([o.jacobian.get_data().view(np.float64).reshape(8)
+                        for o in obs_list])
+        izw = np.array([o.ignore_zero_weight for o in obs_list], dtype=bool)
+        dval = _as_device_f64(val, dev)
+        dw = _as_device_f64(wt, dev)
+        ierr = torch.empty_like(dw)
+        with torch.cuda.device(dev):
+            st = _lib.lib().ngmix_weight_to_ierr_batch(
+                _dptr(dw), _dptr(ierr), dw.numel(), _stream())
+        _lib.check(st, "ngmix_weight_to_ierr_batch")
+        return cls(dval, ierr, _as_device_f64(jac, dev), nrow, ncol, off, izw)
+
+    @staticmethod
+    def _jacobian_tensor(jacobians, n, nrow, ncol, dev):
+        if jacobians is None:
+            rec = np.zeros(8)
+            rec[0] = (nrow - 1.0) / 2.0
+            rec[1] = (ncol - 1.0) / 2.0
+            rec[2] = rec[5] = rec[6] = rec[7] = 1.0
+            arr = np.tile(rec, (n, 1))
+        elif hasattr(jacobians, "get_data"):
+            arr = np.tile(jacobians.get_data().view(np.float64).reshape(8), (n, 1))
+        elif isinstance(jacobians, (list, tuple)):
+            arr = np.stack([j.get_data().view(np.float64).reshape(8)
+                            for j in jacobians])
+        else:
+            torch = _torch()
+            if isinstance(jacobians, torch.Tensor):
+                t = jacobians.to(device=dev, dtype=torch.float64)
+                if t.ndim == 1:
+                    t = t[None].expand(n, 8)
+                return t.contiguous()
+            arr = np.asarray(jacobians)
+            if arr.dtype.names is not None:
+                arr = arr.view(np.float64)
+            arr = arr.reshape(-1, 8)
+            if arr.shape[0] == 1 and n > 1:
+                arr = np.tile(arr, (n, 1))
+        assert arr.shape == (n, 8)
+        return _as_device_f64(arr, dev)
+
+    # ----------------------------------------------------------- internals
+    def _make_table(self, npix_kept, gm_off, ngauss):
+        torch = _torch()
+        tab = np.zeros(self.n, dtype=_lib.STAMP_DTYPE)
+        tab["pix_off"] = self.pix_off
+        tab["nrow"] = self.nrow
+        tab["ncol"] = self.ncol
+        tab["gm_off"] = gm_off
+        tab["ngauss"] = ngauss
+        tab["flags"] = self.flags
+        tab["npix_kept"] = npix_kept
+        flat = tab.view(np.int32).reshape(self.n, 8)
+        return torch.from_numpy(flat.copy()).to(self.device)
+
+    def stamp_table(self, ngauss):
+        """device ngmix_stamp records for mixtures of `ngauss` gaussians laid
+        out stamp-major (gm_off = i*ngauss); cached per ngauss"""
+        if ngauss not in self._stamp_tables:
+            gm_off = np.arange(self.n, dtype=np.int64) * ngauss
+            assert gm_off[-1] < 2 ** 31 if self.n else True
+            self._stamp_tables[ngauss] = self._make_table(
+                self.npix_kept, gm_off.astype(np.int32), ngauss)
+        return self._stamp_tables[ngauss]
+
+    def _batch(self, ngauss, no_skip=False):
+        b = _lib.Batch()
+        b.nstamps = self.n
+        b.stamps = self.stamp_table(ngauss).data_ptr()
+        b.val = self.val.data_ptr() if self.val is not None else None
+        b.ierr = self.ierr.data_ptr() if self.ierr is not None else None
+        b.jac = self.jac.data_ptr()
+        b.max_ngauss = ngauss
+        b.max_npix = self.max_npix
+        b.any_masked = int(self.any_masked)
+        b.flags = _lib.BATCH_NO_SKIP if no_skip else 0
+        return b
+
+    def kept_offsets(self):
+        """start of each stamp's segment in a packed per-kept-pixel array
+        (the layout of the LM residual vector, results.py:410-421)"""
+        kept = self.npix_kept.astype(np.int64)
+        return np.concatenate([[0], np.cumsum(kept)[:-1]]).astype(np.int64)
+
+    # ----------------------------------------------------------- operations
+    def loglike(self, gm, out=None, status=None, no_skip=False):
+        """
+        get_loglike for every stamp (gmix_nb.py:824-874) in one launch.
+        Returns (out, status): out is (N, 4) = loglike, s2n_numer, s2n_denom,
+        npix.  Norms are set lazily in-kernel as in the reference.
+        """
+        torch = _torch()
+        assert gm.n == self.n
+        if out is None:
+            out = torch.empty((self.n, 4), dtype=torch.float64, device=self.device)
+        if status is None:
+            status = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        b = self._batch(gm.ngauss, no_skip)
+        with torch.cuda.device(self.device):
+            st = _lib.lib().ngmix_loglike_batch(
+                ctypes.byref(b), _dptr(gm.data), _dptr(out), _dptr(status),
+                _stream())
+        _lib.check(st, "ngmix_loglike_batch")
+        return out, status
+
+    def fill_fdiff(self, gm, fdiff=None, fdiff_start=None, status=None,
+                   no_skip=False):
+        """
+        fill_fdiff for every stamp (gmix_nb.py:877-900): the k-th kept pixel
+        of stamp i goes to fdiff[fdiff_start[i] + k].  Default layout packs the
+        stamps back to back.  Returns (fdiff, status).
+        """
+        torch = _torch()
+        assert gm.n == self.n
+        if fdiff_start is None:
+            fdiff_start = self.kept_offsets()
+        if isinstance(fdiff_start, np.ndarray):
+            fdiff_start = torch.from_numpy(
+                np.ascontiguousarray(fdiff_start, dtype=np.int64)).to(self.device)
+        if fdiff is None:
+            fdiff = torch.zeros(int(self.npix_kept.sum()), dtype=torch.float64,
+                                device=self.device)
+        if status is None:
+            status = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        b = self._batch(gm.ngauss, no_skip)
+        with torch.cuda.device(self.device):
+            st = _lib.lib().ngmix_fill_fdiff_batch(
+                ctypes.byref(b), _dptr(gm.data), _dptr(fdiff),
+                _dptr(fdiff_start), _dptr(status), _stream())
+        _lib.check(st, "ngmix_fill_fdiff_batch")
+        return fdiff, status
+
+    def render(self, gm, image=None, fast_exp=True, status=None, no_skip=False):
+        """
+        render every stamp's mixture (render_nb.py:9-36), ADDING into `image`
+        (flat, same layout as val); a zeroed image is made when none is given
+        (GMix.make_image, gmix.py:561-562).  Returns (image, status).
+        """
+        torch = _torch()
+        assert gm.n == self.n
+        if image is None:
+            image = torch.zeros(self.total_pix, dtype=torch.float64,
+                                device=self.device)
+        if status is None:
+            status = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        b = self._batch(gm.ngauss, no_skip)
+        with torch.cuda.device(self.device):
+            st = _lib.lib().ngmix_render_batch(
+                ctypes.byref(b), _dptr(gm.data), _dptr(image), int(fast_exp),
+                _dptr(status), _stream())
+        _lib.check(st, "ngmix_render_batch")
+        return image, status
+
+    def model_s2n_sum(self, gm, out=None, status=None):
+        """get_model_s2n_sum per stamp (gmix_nb.py:903-937)"""
+        torch = _torch()
+        assert gm.n == self.n
+        if out is None:
+            out = torch.empty(self.n, dtype=torch.float64, device=self.device)
+        if status is None:
+            status = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        b = self._batch(gm.ngauss)
+        with torch.cuda.device(self.device):
+            st = _lib.lib().ngmix_model_s2n_sum_batch(
+                ctypes.byref(b), _dptr(gm.data), _dptr(out), _dptr(status),
+                _stream())
+        _lib.check(st, "ngmix_model_s2n_sum_batch")
+        return out, status

@@ -1,0 +1,402 @@
+// capi.hip -- extern "C" entry points of libngmix_hip.so (include/ngmix_hip.h).
+//
+// Seam forms take HOST pointers: they stage the arrays through a grow-only
+// per-thread device workspace, run the kernel on the null stream and copy the
+// results back.  Batch forms take DEVICE pointers and only enqueue work.
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "launch.hpp"
+#include "launch_iter.hpp"
+
+namespace ngmix {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const char *what, hipError_t err)
+{
+    g_last_error = std::string(what) + ": " + hipGetErrorString(err);
+}
+
+void set_last_error_msg(const char *msg) { g_last_error = msg; }
+
+// grow-only device scratch, one set per host thread
+class Workspace {
+public:
+    static constexpr int NSLOT = 8;
+    void *get(int slot, size_t nbytes)
+    {
+        if (nbytes == 0) nbytes = 8;
+        if (cap_[slot] < nbytes) {
+            if (ptr_[slot]) (void)hipFree(ptr_[slot]);
+            ptr_[slot] = nullptr;
+            cap_[slot] = 0;
+            size_t want = nbytes + nbytes / 4 + 256;
+            if (hipMalloc(&ptr_[slot], want) != hipSuccess) {
+                ptr_[slot] = nullptr;
+                return nullptr;
+            }
+            cap_[slot] = want;
+        }
+        return ptr_[slot];
+    }
+    ~Workspace()
+    {
+        // the HIP runtime may already be gone at thread/process exit; leak
+    }
+
+private:
+    void *ptr_[NSLOT] = {nullptr};
+    size_t cap_[NSLOT] = {0};
+};
+
+static thread_local Workspace g_ws;
+
+static const double h_exp_table[16] = NGMIX_EXP_TABLE;
+static const ModelTables h_tables = NGMIX_MODEL_TABLES;
+
+#define WS_GET(var, type, slot, nbytes)                                  \
+    type *var = (type *)g_ws.get(slot, nbytes);                          \
+    if (!var) {                                                          \
+        set_last_error_msg("device workspace allocation failed");        \
+        return NGMIX_ERR_HIP;                                            \
+    }
+
+static int host_norms_if_needed(ngmix_gauss2d *gm, int64_t ng)
+{
+    if (ng > 0 && gm[0].norm_set == 0) return ngmix_set_norms(gm, ng);
+    return NGMIX_OK;
+}
+
+}  // namespace ngmix
+
+using namespace ngmix;
+
+extern "C" {
+
+// ------------------------------------------------------------------ runtime
+
+const char *ngmix_version(void) { return "ngmix_amd 0.1.0 (gfx950)"; }
+
+const char *ngmix_last_error(void) { return g_last_error.c_str(); }
+
+int ngmix_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ngmix_set_device(int device)
+{
+    NGMIX_HIP_CHECK(hipSetDevice(device));
+    return NGMIX_OK;
+}
+
+int ngmix_device_malloc(void **ptr, size_t nbytes)
+{
+    NGMIX_HIP_CHECK(hipMalloc(ptr, nbytes ? nbytes : 8));
+    return NGMIX_OK;
+}
+
+int ngmix_device_free(void *ptr)
+{
+    NGMIX_HIP_CHECK(hipFree(ptr));
+    return NGMIX_OK;
+}
+
+int ngmix_memcpy_h2d(void *dst, const void *src, size_t nbytes, void *stream)
+{
+    if (nbytes == 0) return NGMIX_OK;
+    NGMIX_HIP_CHECK(hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice,
+                                   (hipStream_t)stream));
+    return NGMIX_OK;
+}
+
+int ngmix_memcpy_d2h(void *dst, const void *src, size_t nbytes, void *stream)
+{
+    if (nbytes == 0) return NGMIX_OK;
+    NGMIX_HIP_CHECK(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost,
+                                   (hipStream_t)stream));
+    NGMIX_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return NGMIX_OK;
+}
+
+int ngmix_memset_device(void *dst, int value, size_t nbytes, void *stream)
+{
+    if (nbytes == 0) return NGMIX_OK;
+    NGMIX_HIP_CHECK(hipMemsetAsync(dst, value, nbytes, (hipStream_t)stream));
+    return NGMIX_OK;
+}
+
+int ngmix_stream_synchronize(void *stream)
+{
+    NGMIX_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return NGMIX_OK;
+}
+
+// ------------------------------------------------ host parameter prep (O(G))
+
+int ngmix_set_norms(ngmix_gauss2d *gmix, int64_t ngauss)
+{
+    for (int64_t i = 0; i < ngauss; i++) {
+        int st = gauss_set_norm(gmix[i]);
+        if (st) return st;
+    }
+    return NGMIX_OK;
+}
+
+int ngmix_fill_model(ngmix_gauss2d *gmix, int64_t ngauss, int model,
+                     const double *pars, int64_t npars)
+{
+    (void)npars;
+    if (model == NGMIX_MODEL_CM) return NGMIX_ERR_BAD_ARG;
+    FillCtx c;
+    int st = fill_prepare(h_tables, model, (int)ngauss, pars, nullptr, c);
+    if (st) return st;
+    for (int i = 0; i < (int)ngauss; i++)
+        fill_component(h_tables, c, pars, i, gmix[i]);
+    return NGMIX_OK;
+}
+
+int ngmix_fill_cm(ngmix_gauss2d *gmix, double fracdev, double TdByTe,
+                  double Tfactor, const double *pars)
+{
+    const double extra[3] = {fracdev, TdByTe, Tfactor};
+    FillCtx c;
+    int st = fill_prepare(h_tables, NGMIX_MODEL_CM, 16, pars, extra, c);
+    if (st) return st;
+    for (int i = 0; i < 16; i++) fill_component(h_tables, c, pars, i, gmix[i]);
+    return NGMIX_OK;
+}
+
+int ngmix_get_cm_Tfactor(double fracdev, double TdByTe, double *Tfactor)
+{
+    return cm_Tfactor(h_tables, fracdev, TdByTe, *Tfactor);
+}
+
+int ngmix_g1g2_to_e1e2(double g1, double g2, double *e1, double *e2)
+{
+    return g1g2_to_e1e2(g1, g2, *e1, *e2);
+}
+
+int ngmix_convolve_fill(ngmix_gauss2d *out, const ngmix_gauss2d *gmix,
+                        int64_t ngauss, const ngmix_gauss2d *psf, int64_t npsf)
+{
+    double rowcen, colcen, psum;
+    int st = gmix_cen(psf, (int)npsf, rowcen, colcen, psum);
+    if (st) return st;
+    const double ipsum = 1.0 / psum;
+    int64_t itot = 0;
+    for (int64_t io = 0; io < ngauss; io++)
+        for (int64_t ip = 0; ip < npsf; ip++)
+            convolve_component(gmix[io], psf[ip], rowcen, colcen, ipsum,
+                               out[itot++]);
+    return NGMIX_OK;
+}
+
+void ngmix_jacobian_get_vu(const ngmix_jacobian *jacob, double row, double col,
+                           double *v, double *u)
+{
+    jacobian_vu(*jacob, row, col, *v, *u);
+}
+
+int ngmix_jacobian_get_rowcol(const ngmix_jacobian *j, double v, double u,
+                              double *row, double *col)
+{
+    // jacobian_get_rowcol, jacobian_nb.py:19-30
+    double rowdiff = j->dudcol * v - j->dvdcol * u;
+    double coldiff = -j->dudrow * v + j->dvdrow * u;
+    if (j->det == 0.0) return NGMIX_ERR_ZERO_DIV;
+    *row = j->row0 + rowdiff / j->det;
+    *col = j->col0 + coldiff / j->det;
+    return NGMIX_OK;
+}
+
+// ------------------------------------------------------- seam pixel loops
+
+int ngmix_fill_pixels(ngmix_pixel *pixels, int64_t npixels, const double *image,
+                      const double *weight, int64_t nrow, int64_t ncol,
+                      const ngmix_jacobian *jacob, int ignore_zero_weight)
+{
+    const int64_t npix = nrow * ncol;
+    if (npix <= 0 || npix > (1ll << 30)) return NGMIX_ERR_BAD_ARG;
+    WS_GET(d_img, double, 0, npix * 8);
+    WS_GET(d_wt, double, 1, npix * 8);
+    WS_GET(d_pix, ngmix_pixel, 2, (size_t)(npixels > 0 ? npixels : 1) * sizeof(ngmix_pixel));
+    WS_GET(d_cnt, int, 3, 8);
+    NGMIX_HIP_CHECK(hipMemcpy(d_img, image, npix * 8, hipMemcpyHostToDevice));
+    NGMIX_HIP_CHECK(hipMemcpy(d_wt, weight, npix * 8, hipMemcpyHostToDevice));
+    int st = launch_fill_pixels(d_pix, npixels, d_img, d_wt, (int)nrow, (int)ncol,
+                                *jacob, ignore_zero_weight, d_cnt, nullptr);
+    if (st) return st;
+    int count = 0;
+    NGMIX_HIP_CHECK(hipMemcpy(&count, d_cnt, sizeof(int), hipMemcpyDeviceToHost));
+    const int64_t ncopy = count < npixels ? count : npixels;
+    if (ncopy > 0)
+        NGMIX_HIP_CHECK(hipMemcpy(pixels, d_pix, ncopy * sizeof(ngmix_pixel),
+                                  hipMemcpyDeviceToHost));
+    if (count != npixels) return NGMIX_ERR_PIXELS_NOT_FILLED;
+    return NGMIX_OK;
+}
+
+int ngmix_fill_coords(ngmix_coord *coords, int64_t nrow, int64_t ncol,
+                      const ngmix_jacobian *jacob)
+{
+    const int64_t npix = nrow * ncol;
+    if (npix <= 0 || npix > (1ll << 30)) return NGMIX_ERR_BAD_ARG;
+    WS_GET(d_c, ngmix_coord, 0, npix * sizeof(ngmix_coord));
+    int st = launch_fill_coords(d_c, (int)nrow, (int)ncol, *jacob, nullptr);
+    if (st) return st;
+    NGMIX_HIP_CHECK(hipMemcpy(coords, d_c, npix * sizeof(ngmix_coord),
+                              hipMemcpyDeviceToHost));
+    return NGMIX_OK;
+}
+
+int ngmix_render(ngmix_gauss2d *gmix, int64_t ngauss, const ngmix_coord *coords,
+                 int64_t ncoords, double *image, int fast_exp)
+{
+    int st = host_norms_if_needed(gmix, ngauss);
+    if (st) return st;
+    if (ncoords <= 0) return NGMIX_OK;
+    WS_GET(d_gm, ngmix_gauss2d, 0, ngauss * sizeof(ngmix_gauss2d));
+    WS_GET(d_c, ngmix_coord, 1, ncoords * sizeof(ngmix_coord));
+    WS_GET(d_im, double, 2, ncoords * 8);
+    NGMIX_HIP_CHECK(hipMemcpy(d_gm, gmix, ngauss * sizeof(ngmix_gauss2d), hipMemcpyHostToDevice));
+    NGMIX_HIP_CHECK(hipMemcpy(d_c, coords, ncoords * sizeof(ngmix_coord), hipMemcpyHostToDevice));
+    NGMIX_HIP_CHECK(hipMemcpy(d_im, image, ncoords * 8, hipMemcpyHostToDevice));
+    st = launch_render_list(d_gm, (int)ngauss, d_c, ncoords, d_im, fast_exp, nullptr);
+    if (st) return st;
+    NGMIX_HIP_CHECK(hipMemcpy(image, d_im, ncoords * 8, hipMemcpyDeviceToHost));
+    return NGMIX_OK;
+}
+
+static int seam_pixpass(int op, ngmix_gauss2d *gmix, int64_t ngauss,
+                        const ngmix_pixel *pixels, int64_t npix, double *fdiff,
+                        int64_t start, double out4[4])
+{
+    int st = host_norms_if_needed(gmix, ngauss);
+    if (st) return st;
+    out4[0] = out4[1] = out4[2] = out4[3] = 0.0;
+    if (npix <= 0) return NGMIX_OK;
+    WS_GET(d_gm, ngmix_gauss2d, 0, ngauss * sizeof(ngmix_gauss2d));
+    WS_GET(d_px, ngmix_pixel, 1, npix * sizeof(ngmix_pixel));
+    WS_GET(d_part, double, 2, list_partial_doubles() * 8);
+    double *d_fd = nullptr;
+    if (op == 1) {
+        d_fd = (double *)g_ws.get(3, npix * 8);
+        if (!d_fd) return NGMIX_ERR_HIP;
+    }
+    NGMIX_HIP_CHECK(hipMemcpy(d_gm, gmix, ngauss * sizeof(ngmix_gauss2d), hipMemcpyHostToDevice));
+    NGMIX_HIP_CHECK(hipMemcpy(d_px, pixels, npix * sizeof(ngmix_pixel), hipMemcpyHostToDevice));
+    st = launch_pixpass_list(op, d_gm, (int)ngauss, d_px, npix, d_fd, 0, d_part, nullptr);
+    if (st) return st;
+    if (op == 1) {
+        NGMIX_HIP_CHECK(hipMemcpy(fdiff + start, d_fd, npix * 8, hipMemcpyDeviceToHost));
+    } else {
+        NGMIX_HIP_CHECK(hipMemcpy(out4, d_part + (list_partial_doubles() - 4), 32,
+                                  hipMemcpyDeviceToHost));
+    }
+    return NGMIX_OK;
+}
+
+int ngmix_get_loglike(ngmix_gauss2d *gmix, int64_t ngauss,
+                      const ngmix_pixel *pixels, int64_t npix, double *loglike,
+                      double *s2n_numer, double *s2n_denom, int64_t *npix_out)
+{
+    double o[4];
+    int st = seam_pixpass(0, gmix, ngauss, pixels, npix, nullptr, 0, o);
+    if (st) return st;
+    *loglike = o[0] * -0.5;
+    *s2n_numer = o[1];
+    *s2n_denom = o[2];
+    *npix_out = (int64_t)o[3];
+    return NGMIX_OK;
+}
+
+int ngmix_fill_fdiff(ngmix_gauss2d *gmix, int64_t ngauss,
+                     const ngmix_pixel *pixels, int64_t npix, double *fdiff,
+                     int64_t start)
+{
+    double o[4];
+    return seam_pixpass(1, gmix, ngauss, pixels, npix, fdiff, start, o);
+}
+
+int ngmix_get_model_s2n_sum(ngmix_gauss2d *gmix, int64_t ngauss,
+                            const ngmix_pixel *pixels, int64_t npix,
+                            double *s2n_sum)
+{
+    double o[4];
+    int st = seam_pixpass(4, gmix, ngauss, pixels, npix, nullptr, 0, o);
+    if (st) return st;
+    *s2n_sum = o[2];
+    return NGMIX_OK;
+}
+
+// ------------------------------------------------------------- batch forms
+
+int ngmix_weight_to_ierr_batch(const double *weight, double *ierr, int64_t n,
+                               void *stream)
+{
+    return launch_weight_to_ierr(weight, ierr, n, (hipStream_t)stream);
+}
+
+int ngmix_count_kept_batch(ngmix_stamp *stamps, int64_t nstamps,
+                           const double *ierr, void *stream)
+{
+    return launch_count_kept(stamps, nstamps, ierr, (hipStream_t)stream);
+}
+
+int ngmix_fill_model_batch(ngmix_gauss2d *gmix, int64_t nstamps, int ngauss,
+                           int model, const double *pars, int npars,
+                           const double *cm_extra, int32_t *status, void *stream)
+{
+    return launch_fill_model(gmix, nstamps, ngauss, model, pars, npars, cm_extra,
+                             status, (hipStream_t)stream);
+}
+
+int ngmix_convolve_fill_batch(ngmix_gauss2d *out, const ngmix_gauss2d *gmix,
+                              int ngauss, const ngmix_gauss2d *psf, int npsf,
+                              int64_t nstamps, int32_t *status, void *stream)
+{
+    return launch_convolve_fill(out, gmix, ngauss, psf, npsf, nstamps, status,
+                                (hipStream_t)stream);
+}
+
+int ngmix_set_norms_batch(ngmix_gauss2d *gmix, int ngauss, int64_t nstamps,
+                          int32_t *status, void *stream)
+{
+    return launch_set_norms(gmix, ngauss, nstamps, status, (hipStream_t)stream);
+}
+
+int ngmix_loglike_batch(const ngmix_batch *batch, ngmix_gauss2d *gmix,
+                        double *out, int32_t *status, void *stream)
+{
+    return launch_loglike_grid(batch, gmix, out, status, stream);
+}
+
+int ngmix_fill_fdiff_batch(const ngmix_batch *batch, ngmix_gauss2d *gmix,
+                           double *fdiff, const int64_t *fdiff_start,
+                           int32_t *status, void *stream)
+{
+    return launch_fdiff_grid(batch, gmix, fdiff, fdiff_start, status, stream);
+}
+
+int ngmix_render_batch(const ngmix_batch *batch, ngmix_gauss2d *gmix,
+                       double *image, int fast_exp, int32_t *status,
+                       void *stream)
+{
+    return launch_render_grid(batch, gmix, image, fast_exp, status, stream);
+}
+
+int ngmix_model_s2n_sum_batch(const ngmix_batch *batch, ngmix_gauss2d *gmix,
+                              double *out, int32_t *status, void *stream)
+{
+    return launch_s2n_grid(batch, gmix, out, status, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// device_utils.hpp -- wave64 / work-group helpers for the gfx950 kernels.
+#pragma once
+
+#include "common.hpp"
+
+namespace ngmix {
+
+constexpr int WAVE = 64;     // CDNA wavefront
+constexpr int BLOCK = 256;   // 4 waves: one per SIMD of a CU
+constexpr int NWAVES = BLOCK / WAVE;
+
+// tile of pixels owned by one wave at a time: 16 columns x 4 rows, so a
+// wave's loads are four 128-byte row segments and a small gaussian's
+// chi2<25 ellipse misses most tiles entirely
+constexpr int TILE_W = 16;
+constexpr int TILE_H = 4;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// butterfly-free, fixed-order wave reduction: after the call lane 0 holds the
+// sum of all 64 lanes (deterministic order; no atomics anywhere)
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
+    return x;
+}
+
+__device__ __forceinline__ int wave_sum_int(int x)
+{
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
+    return x;
+}
+
+// Sum NV doubles held per thread over the whole 256-thread work-group.
+// scratch: NWAVES*NV doubles of LDS.  Result valid in thread 0 (vals[]).
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&vals)[NV], double *scratch)
+{
+#pragma unroll
+    for (int i = 0; i < NV; i++) vals[i] = wave_sum(vals[i]);
+    const int lane = lane_id(), w = wave_id();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) scratch[w * NV + i] = vals[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            double s = scratch[i];
+#pragma unroll
+            for (int k = 1; k < NWAVES; k++) s += scratch[k * NV + i];
+            vals[i] = s;
+        }
+    }
+}
+
+// Conservative pixel-index bounding box of the region where a gaussian's
+// chi2 can be < 25.  Outside it every evaluation of gauss2d_eval_pixel_fast
+// returns exactly 0.0 (gmix_nb.py:46,58), and x + 0.0 == x, so skipping those
+// pixel-gaussian pairs leaves results bit-identical.  Derived from the very
+// coefficients the evaluation uses (dcc, drr, drc), inflated for rounding;
+// any doubt (non positive-definite form, near-degenerate correlation or
+// jacobian, non-finite input) returns the "everything" box.
+struct PixBox {
+    int rmin, rmax, cmin, cmax;
+};
+
+__device__ __forceinline__ PixBox full_box()
+{
+    PixBox b;
+    b.rmin = -(1 << 30);
+    b.cmin = -(1 << 30);
+    b.rmax = (1 << 30);
+    b.cmax = (1 << 30);
+    return b;
+}
+
+__device__ __forceinline__ PixBox gauss_pixel_box(const ngmix_gauss2d &g,
+                                                 const ngmix_jacobian &j)
+{
+    PixBox full = full_box();
+    const double dcc = g.dcc, drr = g.drr, drc = g.drc;
+    // chi2 = dcc dv^2 + drr du^2 - 2 drc dv du
+    const double detq = dcc * drr - drc * drc;
+    if (!(dcc > 0.0) || !(drr > 0.0) || !(detq > 0.0)) return full;
+    const double rho2 = (drc * drc) / (dcc * drr);
+    if (!(rho2 < 1.0 - 1.0e-6)) return full;
+    // covariance of the form: [[var_v, cov],[cov, var_u]]
+    const double var_v = drr / detq, var_u = dcc / detq, cov = drc / detq;
+    // pixel = Jinv (v,u):  dr = ( d*v - b*u)/det ; dc = (-c*v + a*u)/det
+    const double a = j.dvdrow, b = j.dvdcol, c = j.dudrow, d = j.dudcol;
+    const double det = a * d - b * c;
+    const double jn = a * a + b * b + c * c + d * d;
+    if (!(fabs(det) > 1.0e-6 * jn) || !(jn > 0.0)) return full;
+    const double idet = 1.0 / det;
+    const double rr = d * idet, ru = -b * idet;   // dr = rr*v + ru*u
+    const double cr = -c * idet, cu = a * idet;   // dc = cr*v + cu*u
+    const double var_r = rr * rr * var_v + 2.0 * rr * ru * cov + ru * ru * var_u;
+    const double var_c = cr * cr * var_v + 2.0 * cr * cu * cov + cu * cu * var_u;
+    const double cen_r = j.row0 + (rr * g.row + ru * g.col);
+    const double cen_c = j.col0 + (cr * g.row + cu * g.col);
+    if (!(var_r >= 0.0) || !(var_c >= 0.0)) return full;
+    // 5 sigma, +1e-6 relative, +0.5 pixel absolute
+    const double hr = 5.0 * sqrt(var_r) * (1.0 + 1.0e-6) + 0.5;
+    const double hc = 5.0 * sqrt(var_c) * (1.0 + 1.0e-6) + 0.5;
+    const double lo_r = cen_r - hr, hi_r = cen_r + hr;
+    const double lo_c = cen_c - hc, hi_c = cen_c + hc;
+    const double big = 1.0e9;
+    if (!(lo_r > -big) || !(hi_r < big) || !(lo_c > -big) || !(hi_c < big))
+        return full;
+    PixBox box;
+    box.rmin = (int)floor(lo_r);
+    box.rmax = (int)ceil(hi_r);
+    box.cmin = (int)floor(lo_c);
+    box.cmax = (int)ceil(hi_c);
+    return box;
+}
+
+}  // namespace ngmix

@@ -1,0 +1,43 @@
+// launch.hpp -- host-side launcher prototypes shared by the .hip files.
+#pragma once
+
+#include "common.hpp"
+
+namespace ngmix {
+
+// pixpass.hip
+int launch_loglike_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
+                        int32_t *status, void *stream);
+int launch_fdiff_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *fdiff,
+                      const int64_t *fdiff_start, int32_t *status, void *stream);
+int launch_render_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *image,
+                       int fast_exp, int32_t *status, void *stream);
+int launch_s2n_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
+                    int32_t *status, void *stream);
+int list_partial_doubles(void);
+int launch_render_list(const ngmix_gauss2d *gm, int ng, const ngmix_coord *coords,
+                       int64_t n, double *image, int fast_exp, hipStream_t s);
+int launch_pixpass_list(int op, const ngmix_gauss2d *gm, int ng,
+                        const ngmix_pixel *pixels, int64_t n, double *fdiff,
+                        int64_t start, double *partial, hipStream_t s);
+int launch_fill_pixels(ngmix_pixel *pixels, int64_t npixels, const double *image,
+                       const double *weight, int nrow, int ncol,
+                       const ngmix_jacobian &jac, int izw, int *count_out,
+                       hipStream_t s);
+int launch_fill_coords(ngmix_coord *coords, int nrow, int ncol,
+                       const ngmix_jacobian &jac, hipStream_t s);
+int launch_weight_to_ierr(const double *w, double *ierr, int64_t n, hipStream_t s);
+int launch_count_kept(ngmix_stamp *stamps, int64_t nstamps, const double *ierr,
+                      hipStream_t s);
+
+// gmixprep.hip
+int launch_fill_model(ngmix_gauss2d *gmix, int64_t nstamps, int ngauss, int model,
+                      const double *pars, int npars, const double *cm_extra,
+                      int32_t *status, hipStream_t s);
+int launch_convolve_fill(ngmix_gauss2d *out, const ngmix_gauss2d *gmix, int ngauss,
+                         const ngmix_gauss2d *psf, int npsf, int64_t nstamps,
+                         int32_t *status, hipStream_t s);
+int launch_set_norms(ngmix_gauss2d *gmix, int ngauss, int64_t nstamps,
+                     int32_t *status, hipStream_t s);
+
+}  // namespace ngmix

@@ -1,0 +1,654 @@
+// pixpass.hip -- single-pass pixel kernels: render / get_loglike / fill_fdiff /
+// get_model_s2n_sum (reference: ngmix/gmix/render_nb.py:9-36,
+// ngmix/gmix/gmix_nb.py:824-937), plus fill_pixels / fill_coords
+// (ngmix/pixels/pixels_nb.py:6-94).
+//
+// GRID kernels (batch forms): one 256-thread work-group per stamp, compact
+// val/ierr arrays, (v,u) recomputed from (row,col) and the 64-byte jacobian.
+// Each wave owns K tiles of 16x4 pixels per round; the stamp's gaussians are
+// staged in LDS together with a conservative pixel-space box of their
+// chi2<25 region, and a wave skips (gaussian, tile) pairs that cannot
+// intersect -- exact, because those evaluations are exactly 0.0.
+// HBM-bound by design: 16 B/pixel read (+8 written for fdiff / +8+8 for
+// render), everything else stays on chip.
+//
+// LIST kernels (seam forms): the reference's AoS pixel / coord arrays,
+// arbitrary coordinates, one thread per pixel.
+#include "device_utils.hpp"
+#include "launch.hpp"
+
+namespace ngmix {
+
+__constant__ double c_exp_table[16] = NGMIX_EXP_TABLE;
+
+enum PassOp { OP_LOGLIKE = 0, OP_FDIFF = 1, OP_RENDER_FAST = 2,
+              OP_RENDER_EXACT = 3, OP_S2N = 4 };
+
+struct GaussLds {
+    EvalGauss e;   // 48 B
+    PixBox box;    // 16 B
+};
+static_assert(sizeof(GaussLds) == 64, "GaussLds");
+
+// LDS layout (dynamic): [exp table 16 d][reduce scratch 16 d][int ctl 4]
+//                       [GaussLds x max_ngauss][chunk prefix (masked stamps)]
+struct LdsLayout {
+    double *tab;
+    double *red;
+    int *ctl;
+    GaussLds *gl;
+    unsigned long long *cmask;
+    int *cpre;
+};
+
+__device__ __forceinline__ LdsLayout carve(char *base, int max_ngauss,
+                                           int nchunks_cap)
+{
+    LdsLayout L;
+    L.tab = (double *)base;
+    L.red = L.tab + 16;
+    L.ctl = (int *)(L.red + 16);
+    L.gl = (GaussLds *)(base + 16 * 8 + 16 * 8 + 16);
+    L.cmask = (unsigned long long *)(L.gl + max_ngauss);
+    L.cpre = (int *)(L.cmask + nchunks_cap);
+    return L;
+}
+
+static size_t lds_bytes(int max_ngauss, int nchunks_cap)
+{
+    return 16 * 8 + 16 * 8 + 16 + (size_t)max_ngauss * sizeof(GaussLds) +
+           (size_t)nchunks_cap * 12 + 16;
+}
+
+// Stage table + gaussians; set norms lazily exactly as the reference does
+// (gmix_nb.py:850-851: all of them when gmix[0].norm_set == 0, stopping at
+// the first failure).  Returns the status for the stamp (uniform).
+__device__ __forceinline__ int stage_gaussians(const LdsLayout &L,
+                                               ngmix_gauss2d *gm, int ng,
+                                               const ngmix_jacobian &jac,
+                                               bool want_box)
+{
+    const int tid = threadIdx.x;
+    if (tid < 16) L.tab[tid] = c_exp_table[tid];
+    if (tid == 0) {
+        L.ctl[0] = 1 << 30;  // index of first failing gaussian
+        L.ctl[1] = 0;        // its error code
+    }
+    __syncthreads();
+    const bool need = ng > 0 && gm[0].norm_set == 0;
+    if (need) {
+        for (int g = tid; g < ng; g += BLOCK) {
+            ngmix_gauss2d t = gm[g];
+            int st = gauss_set_norm(t);
+            if (st) atomicMin(&L.ctl[0], g);
+        }
+        __syncthreads();
+        const int first_fail = L.ctl[0];
+        for (int g = tid; g < ng; g += BLOCK) {
+            if (g < first_fail) {
+                ngmix_gauss2d t = gm[g];
+                gauss_set_norm(t);
+                gm[g] = t;  // the reference mutates the caller's array
+            } else if (g == first_fail) {
+                ngmix_gauss2d t = gm[g];
+                L.ctl[1] = gauss_set_norm(t);
+            }
+        }
+        __syncthreads();
+        if (L.ctl[1] != 0) return L.ctl[1];
+    }
+    for (int g = tid; g < ng; g += BLOCK) {
+        ngmix_gauss2d t = gm[g];
+        GaussLds r;
+        r.e = make_eval(t);
+        r.box = want_box ? gauss_pixel_box(t, jac) : full_box();
+        L.gl[g] = r;
+    }
+    __syncthreads();
+    return NGMIX_OK;
+}
+
+// Row-major rank of pixel p among the kept pixels of a masked stamp:
+// per-64-pixel keep masks and their exclusive prefix counts live in LDS.
+__device__ __forceinline__ void build_rank_tables(const LdsLayout &L,
+                                                  const double *ierr, int npix)
+{
+    const int nchunks = (npix + 63) >> 6;
+    for (int base = wave_id() * WAVE; base < nchunks * WAVE; base += BLOCK) {
+        const int p = base + lane_id();
+        const bool kept = p < npix && ierr[p] > 0.0;
+        const unsigned long long m = __ballot(kept);
+        if (lane_id() == 0) L.cmask[base >> 6] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int c = 0; c < nchunks; c++) {
+            L.cpre[c] = run;
+            run += __popcll(L.cmask[c]);
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int kept_rank(const LdsLayout &L, int p)
+{
+    const unsigned long long m = L.cmask[p >> 6];
+    const unsigned long long below = m & ((1ull << (p & 63)) - 1ull);
+    return L.cpre[p >> 6] + __popcll(below);
+}
+
+template <int OP, int K>
+__global__ __launch_bounds__(BLOCK) void pixpass_grid_kernel(
+    const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
+    const double *__restrict__ ierr, const ngmix_jacobian *__restrict__ jacs,
+    ngmix_gauss2d *gmix, double *out, const int64_t *__restrict__ out_start,
+    int32_t *status, int max_ngauss, int nchunks_cap, int no_skip)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LdsLayout L = carve(smem, max_ngauss, nchunks_cap);
+
+    const int s = blockIdx.x;
+    const ngmix_stamp st = stamps[s];
+    const ngmix_jacobian jac = jacs[s];
+    const int nrow = st.nrow, ncol = st.ncol, ng = st.ngauss;
+    const int npix = nrow * ncol;
+    ngmix_gauss2d *gm = gmix + st.gm_off;
+    const double *sval = val + st.pix_off;
+    const double *sierr = ierr + st.pix_off;
+    const bool izw = (st.flags & NGMIX_STAMP_IGNORE_ZERO_WEIGHT) != 0;
+    constexpr bool kFast = (OP != OP_RENDER_EXACT);
+    constexpr bool kNeedsVal = (OP == OP_LOGLIKE || OP == OP_FDIFF);
+    constexpr bool kNeedsIerr = (OP != OP_RENDER_FAST && OP != OP_RENDER_EXACT);
+
+    const int stcode = stage_gaussians(L, gm, ng, jac, kFast && !no_skip);
+    if (stcode != NGMIX_OK) {
+        if (threadIdx.x == 0) status[s] = stcode;
+        return;
+    }
+    const bool masked = kNeedsIerr && izw && st.npix_kept != npix;
+    if (OP == OP_FDIFF && masked) build_rank_tables(L, sierr, npix);
+
+    const double area = jac.scale * jac.scale;  // jacobian_nb.py:33-40
+    const int lane = lane_id(), w = wave_id();
+    const int lrow = lane >> 4, lcol = lane & 15;
+    const int ntx = (ncol + TILE_W - 1) / TILE_W;
+    const int nty = (nrow + TILE_H - 1) / TILE_H;
+    const int ntiles = ntx * nty;
+    const int nrounds = (ntiles + NWAVES * K - 1) / (NWAVES * K);
+
+    double acc_ll = 0.0, acc_sn = 0.0, acc_sd = 0.0;
+    int acc_np = 0;
+
+    for (int round = 0; round < nrounds; round++) {
+        const int tbase = (round * NWAVES + w) * K;
+        double pv[K], pu[K], pval[K], pierr[K], model[K];
+        int pidx[K];
+        bool inb[K];
+        // lane k (< K) also carries tile k's extent for the skip test
+        int my_r0 = 0, my_c0 = 0;
+        bool my_valid = false;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int T = tbase + k;
+            const int ty = T / ntx, tx = T - ty * ntx;
+            const int r0 = ty * TILE_H, c0 = tx * TILE_W;
+            if (lane == k) {
+                my_r0 = r0;
+                my_c0 = c0;
+                my_valid = T < ntiles;
+            }
+            const int row = r0 + lrow, col = c0 + lcol;
+            inb[k] = (T < ntiles) && row < nrow && col < ncol;
+            pidx[k] = row * ncol + col;
+            pval[k] = 0.0;
+            pierr[k] = 0.0;
+            if (inb[k]) {
+                if (kNeedsVal) pval[k] = sval[pidx[k]];
+                if (kNeedsIerr) pierr[k] = sierr[pidx[k]];
+                if (OP == OP_RENDER_FAST || OP == OP_RENDER_EXACT)
+                    pval[k] = out[st.pix_off + pidx[k]];
+            }
+            jacobian_vu(jac, (double)row, (double)col, pv[k], pu[k]);
+            model[k] = 0.0;
+        }
+
+        for (int g = 0; g < ng; g++) {
+            const GaussLds gl = L.gl[g];
+            unsigned long long tmask;
+            if (kFast) {
+                const bool hit = my_valid && my_r0 <= gl.box.rmax &&
+                                 my_r0 + TILE_H - 1 >= gl.box.rmin &&
+                                 my_c0 <= gl.box.cmax &&
+                                 my_c0 + TILE_W - 1 >= gl.box.cmin;
+                tmask = __ballot(hit);
+            } else {
+                tmask = ~0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if ((tmask >> k) & 1ull) {
+                    if (kFast)
+                        model[k] += gauss_eval_fast(gl.e, pv[k], pu[k], area, L.tab);
+                    else
+                        model[k] += gauss_eval_exact(gl.e, pv[k], pu[k], area);
+                }
+            }
+        }
+
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (!inb[k]) continue;
+            const bool kept = !izw || pierr[k] > 0.0 || !kNeedsIerr;
+            if (OP == OP_LOGLIKE) {
+                if (kept) {
+                    const double ivar = pierr[k] * pierr[k];
+                    const double diff = model[k] - pval[k];
+                    acc_ll += diff * diff * ivar;
+                    acc_sn += pval[k] * model[k] * ivar;
+                    acc_sd += model[k] * model[k] * ivar;
+                    acc_np += 1;
+                }
+            } else if (OP == OP_S2N) {
+                if (kept) {
+                    const double ivar = pierr[k] * pierr[k];
+                    acc_sd += model[k] * model[k] * ivar;
+                }
+            } else if (OP == OP_FDIFF) {
+                if (kept) {
+                    const int rank = masked ? kept_rank(L, pidx[k]) : pidx[k];
+                    out[out_start[s] + rank] = (model[k] - pval[k]) * pierr[k];
+                }
+            } else {
+                out[st.pix_off + pidx[k]] = pval[k] + model[k];
+            }
+        }
+    }
+
+    if (OP == OP_LOGLIKE) {
+        double v[4] = {acc_ll, acc_sn, acc_sd, (double)acc_np};
+        block_sum<4>(v, L.red);
+        if (threadIdx.x == 0) {
+            out[4 * (int64_t)s + 0] = v[0] * -0.5;  // gmix_nb.py:872
+            out[4 * (int64_t)s + 1] = v[1];
+            out[4 * (int64_t)s + 2] = v[2];
+            out[4 * (int64_t)s + 3] = v[3];
+            status[s] = NGMIX_OK;
+        }
+    } else if (OP == OP_S2N) {
+        double v[1] = {acc_sd};
+        block_sum<1>(v, L.red);
+        if (threadIdx.x == 0) {
+            out[s] = v[0];
+            status[s] = NGMIX_OK;
+        }
+    } else {
+        if (threadIdx.x == 0) status[s] = NGMIX_OK;
+    }
+}
+
+// ---------------------------------------------------------------- launchers
+
+static int pick_k(int max_npix)
+{
+    // tiles per wave per round: 9 covers 48x48 in one round, 4 covers 32x32
+    if (max_npix <= 32 * 32) return 4;
+    return 9;
+}
+
+template <int OP>
+static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
+                       const int64_t *out_start, int32_t *status, void *stream)
+{
+    if (b->nstamps <= 0) return NGMIX_OK;
+    const bool need_rank = (OP == OP_FDIFF) && b->any_masked;
+    const int nchunks_cap = need_rank ? (b->max_npix + 63) / 64 : 0;
+    const int max_ng = b->max_ngauss > 0 ? b->max_ngauss : 1;
+    const size_t lds = lds_bytes(max_ng, nchunks_cap);
+    if (lds > 160 * 1024) {
+        set_last_error_msg("stamp needs more than 160 KiB of LDS "
+                           "(too many gaussians or masked stamp too large)");
+        return NGMIX_ERR_BAD_ARG;
+    }
+    const int no_skip = (b->flags & NGMIX_BATCH_NO_SKIP) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)b->nstamps), block(BLOCK);
+    if (pick_k(b->max_npix) == 4) {
+        auto kern = pixpass_grid_kernel<OP, 4>;
+        if (lds > 64 * 1024)
+            NGMIX_HIP_CHECK(hipFuncSetAttribute(
+                (const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                (int)lds));
+        hipLaunchKernelGGL(kern, grid, block, lds, s, b->stamps, b->val, b->ierr,
+                           b->jac, gmix, out, out_start, status, max_ng,
+                           nchunks_cap, no_skip);
+    } else {
+        auto kern = pixpass_grid_kernel<OP, 9>;
+        if (lds > 64 * 1024)
+            NGMIX_HIP_CHECK(hipFuncSetAttribute(
+                (const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                (int)lds));
+        hipLaunchKernelGGL(kern, grid, block, lds, s, b->stamps, b->val, b->ierr,
+                           b->jac, gmix, out, out_start, status, max_ng,
+                           nchunks_cap, no_skip);
+    }
+    NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
+}
+
+int launch_loglike_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
+                        int32_t *status, void *stream)
+{
+    return launch_grid<OP_LOGLIKE>(b, gmix, out, nullptr, status, stream);
+}
+
+int launch_fdiff_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *fdiff,
+                      const int64_t *fdiff_start, int32_t *status, void *stream)
+{
+    return launch_grid<OP_FDIFF>(b, gmix, fdiff, fdiff_start, status, stream);
+}
+
+int launch_render_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *image,
+                       int fast_exp, int32_t *status, void *stream)
+{
+    if (fast_exp)
+        return launch_grid<OP_RENDER_FAST>(b, gmix, image, nullptr, status, stream);
+    return launch_grid<OP_RENDER_EXACT>(b, gmix, image, nullptr, status, stream);
+}
+
+int launch_s2n_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
+                    int32_t *status, void *stream)
+{
+    return launch_grid<OP_S2N>(b, gmix, out, nullptr, status, stream);
+}
+
+// =========================================================================
+// LIST kernels: the reference's AoS arrays, one thread per pixel
+// =========================================================================
+
+constexpr int LIST_MAX_BLOCKS = 1024;
+
+// stage up to `ng` gaussians in LDS; the seam form has already set the norms
+// on the host (ngmix_set_norms) so no lazy path is needed here
+__device__ __forceinline__ void stage_list(double *tab, EvalGauss *ge,
+                                           const ngmix_gauss2d *gm, int ng)
+{
+    if (threadIdx.x < 16) tab[threadIdx.x] = c_exp_table[threadIdx.x];
+    for (int g = threadIdx.x; g < ng; g += BLOCK) ge[g] = make_eval(gm[g]);
+    __syncthreads();
+}
+
+__device__ __forceinline__ double eval_all_fast(const EvalGauss *ge, int ng,
+                                                double v, double u, double area,
+                                                const double *tab)
+{
+    double m = 0.0;
+    for (int g = 0; g < ng; g++) m += gauss_eval_fast(ge[g], v, u, area, tab);
+    return m;
+}
+
+__device__ __forceinline__ double eval_all_exact(const EvalGauss *ge, int ng,
+                                                 double v, double u, double area)
+{
+    double m = 0.0;
+    for (int g = 0; g < ng; g++) m += gauss_eval_exact(ge[g], v, u, area);
+    return m;
+}
+
+// render over a coord list (render_nb.py:31-36)
+__global__ __launch_bounds__(BLOCK) void render_list_kernel(
+    const ngmix_gauss2d *gm, int ng, const ngmix_coord *coords, int64_t n,
+    double *image, int fast_exp)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *tab = (double *)smem;
+    EvalGauss *ge = (EvalGauss *)(tab + 16);
+    stage_list(tab, ge, gm, ng);
+    for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * BLOCK) {
+        const ngmix_coord c = coords[i];
+        const double m = fast_exp ? eval_all_fast(ge, ng, c.v, c.u, c.area, tab)
+                                  : eval_all_exact(ge, ng, c.v, c.u, c.area);
+        image[i] += m;
+    }
+}
+
+// get_loglike / get_model_s2n_sum / fill_fdiff over a pixel list.
+// partial: gridDim.x * 4 doubles of per-block sums (OP_LOGLIKE / OP_S2N).
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void pixpass_list_kernel(
+    const ngmix_gauss2d *gm, int ng, const ngmix_pixel *pixels, int64_t n,
+    double *fdiff, int64_t start, double *partial)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *tab = (double *)smem;
+    double *red = tab + 16;
+    EvalGauss *ge = (EvalGauss *)(red + 16);
+    stage_list(tab, ge, gm, ng);
+    double a_ll = 0.0, a_sn = 0.0, a_sd = 0.0, a_np = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * BLOCK) {
+        const ngmix_pixel p = pixels[i];
+        const double m = eval_all_fast(ge, ng, p.v, p.u, p.area, tab);
+        if (OP == OP_FDIFF) {
+            fdiff[start + i] = (m - p.val) * p.ierr;
+        } else {
+            const double ivar = p.ierr * p.ierr;
+            if (OP == OP_LOGLIKE) {
+                const double diff = m - p.val;
+                a_ll += diff * diff * ivar;
+                a_sn += p.val * m * ivar;
+                a_np += 1.0;
+            }
+            a_sd += m * m * ivar;
+        }
+    }
+    if (OP != OP_FDIFF) {
+        double v[4] = {a_ll, a_sn, a_sd, a_np};
+        block_sum<4>(v, red);
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < 4; k++) partial[4 * blockIdx.x + k] = v[k];
+        }
+    }
+}
+
+// fixed-order final sum of the per-block partials
+__global__ void sum_partials_kernel(const double *partial, int nblocks,
+                                    double *out4)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < nblocks; b++)
+            for (int k = 0; k < 4; k++) s[k] += partial[4 * b + k];
+        for (int k = 0; k < 4; k++) out4[k] = s[k];
+    }
+}
+
+static int list_blocks(int64_t n)
+{
+    int64_t nb = (n + BLOCK - 1) / BLOCK;
+    if (nb < 1) nb = 1;
+    if (nb > LIST_MAX_BLOCKS) nb = LIST_MAX_BLOCKS;
+    return (int)nb;
+}
+
+int list_partial_doubles(void) { return LIST_MAX_BLOCKS * 4 + 4; }
+
+int launch_render_list(const ngmix_gauss2d *gm, int ng, const ngmix_coord *coords,
+                       int64_t n, double *image, int fast_exp, hipStream_t s)
+{
+    const size_t lds = 16 * 8 + (size_t)ng * sizeof(EvalGauss);
+    hipLaunchKernelGGL(render_list_kernel, dim3(list_blocks(n)), dim3(BLOCK), lds,
+                       s, gm, ng, coords, n, image, fast_exp);
+    NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
+}
+
+// op: 0 loglike (out4 = sum diff^2 ivar, s2n_numer, s2n_denom, npix),
+//     1 fdiff, 4 s2n (out4[2])
+int launch_pixpass_list(int op, const ngmix_gauss2d *gm, int ng,
+                        const ngmix_pixel *pixels, int64_t n, double *fdiff,
+                        int64_t start, double *partial, hipStream_t s)
+{
+    const size_t lds = 32 * 8 + (size_t)ng * sizeof(EvalGauss);
+    const int nb = list_blocks(n);
+    if (op == OP_FDIFF) {
+        hipLaunchKernelGGL(pixpass_list_kernel<OP_FDIFF>, dim3(nb), dim3(BLOCK),
+                           lds, s, gm, ng, pixels, n, fdiff, start, partial);
+    } else if (op == OP_LOGLIKE) {
+        hipLaunchKernelGGL(pixpass_list_kernel<OP_LOGLIKE>, dim3(nb), dim3(BLOCK),
+                           lds, s, gm, ng, pixels, n, fdiff, start, partial);
+    } else {
+        hipLaunchKernelGGL(pixpass_list_kernel<OP_S2N>, dim3(nb), dim3(BLOCK),
+                           lds, s, gm, ng, pixels, n, fdiff, start, partial);
+    }
+    NGMIX_HIP_CHECK(hipGetLastError());
+    if (op != OP_FDIFF) {
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, partial,
+                           nb, partial + 4 * LIST_MAX_BLOCKS);
+        NGMIX_HIP_CHECK(hipGetLastError());
+    }
+    return NGMIX_OK;
+}
+
+// =========================================================================
+// fill_pixels / fill_coords (pixels_nb.py:6-94) and store preparation
+// =========================================================================
+
+// One work-group scans the image in row-major chunks of 256 pixels; kept
+// pixels are compacted in order with a ballot prefix, so pixels[k] is the
+// k-th kept pixel exactly as the reference's sequential loop produces it.
+__global__ __launch_bounds__(BLOCK) void fill_pixels_kernel(
+    ngmix_pixel *pixels, int64_t npixels, const double *image,
+    const double *weight, int nrow, int ncol, ngmix_jacobian jac, int izw,
+    int *count_out)
+{
+    __shared__ int wcount[NWAVES];
+    __shared__ int base;
+    const double area = jac.scale * jac.scale;
+    const int64_t npix = (int64_t)nrow * ncol;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < npix; c0 += BLOCK) {
+        const int64_t p = c0 + threadIdx.x;
+        double ivar = 0.0;
+        bool kept = false;
+        if (p < npix) {
+            ivar = weight[p];
+            kept = !(izw && ivar <= 0.0);
+        }
+        const unsigned long long m = __ballot(kept);
+        const int lane = lane_id(), w = wave_id();
+        if (lane == 0) wcount[w] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int k = 0; k < w; k++) off += wcount[k];
+        off += __popcll(m & ((1ull << lane) - 1ull));
+        if (kept && off < npixels) {
+            const int row = (int)(p / ncol), col = (int)(p - (int64_t)row * ncol);
+            ngmix_pixel px;
+            jacobian_vu(jac, (double)row, (double)col, px.v, px.u);
+            px.area = area;
+            px.val = image[p];
+            if (ivar < 0.0) ivar = 0.0;
+            px.ierr = sqrt(ivar);
+            px.fdiff = 0.0;
+            pixels[off] = px;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int k = 0; k < NWAVES; k++) t += wcount[k];
+            base += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count_out = base;
+}
+
+__global__ __launch_bounds__(BLOCK) void fill_coords_kernel(ngmix_coord *coords,
+                                                           int nrow, int ncol,
+                                                           ngmix_jacobian jac)
+{
+    const double area = jac.scale * jac.scale;
+    const int64_t npix = (int64_t)nrow * ncol;
+    for (int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x; p < npix;
+         p += (int64_t)gridDim.x * BLOCK) {
+        const int row = (int)(p / ncol), col = (int)(p - (int64_t)row * ncol);
+        ngmix_coord c;
+        jacobian_vu(jac, (double)row, (double)col, c.v, c.u);
+        c.area = area;
+        coords[p] = c;
+    }
+}
+
+int launch_fill_pixels(ngmix_pixel *pixels, int64_t npixels, const double *image,
+                       const double *weight, int nrow, int ncol,
+                       const ngmix_jacobian &jac, int izw, int *count_out,
+                       hipStream_t s)
+{
+    hipLaunchKernelGGL(fill_pixels_kernel, dim3(1), dim3(BLOCK), 0, s, pixels,
+                       npixels, image, weight, nrow, ncol, jac, izw, count_out);
+    NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
+}
+
+int launch_fill_coords(ngmix_coord *coords, int nrow, int ncol,
+                       const ngmix_jacobian &jac, hipStream_t s)
+{
+    const int64_t npix = (int64_t)nrow * ncol;
+    hipLaunchKernelGGL(fill_coords_kernel, dim3(list_blocks(npix)), dim3(BLOCK), 0,
+                       s, coords, nrow, ncol, jac);
+    NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
+}
+
+__global__ __launch_bounds__(BLOCK) void weight_to_ierr_kernel(const double *w,
+                                                              double *ierr,
+                                                              int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * BLOCK) {
+        double ivar = w[i];
+        if (ivar < 0.0) ivar = 0.0;
+        ierr[i] = sqrt(ivar);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void count_kept_kernel(ngmix_stamp *stamps,
+                                                          const double *ierr)
+{
+    __shared__ double red[16];
+    ngmix_stamp st = stamps[blockIdx.x];
+    const int npix = st.nrow * st.ncol;
+    const bool izw = (st.flags & NGMIX_STAMP_IGNORE_ZERO_WEIGHT) != 0;
+    double cnt = 0.0;
+    for (int p = threadIdx.x; p < npix; p += BLOCK)
+        if (!izw || ierr[st.pix_off + p] > 0.0) cnt += 1.0;
+    double v[1] = {cnt};
+    block_sum<1>(v, red);
+    if (threadIdx.x == 0) stamps[blockIdx.x].npix_kept = (int)v[0];
+}
+
+int launch_weight_to_ierr(const double *w, double *ierr, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return NGMIX_OK;
+    int64_t nb = (n + BLOCK - 1) / BLOCK;
+    if (nb > 256 * 8) nb = 256 * 8;
+    hipLaunchKernelGGL(weight_to_ierr_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, s,
+                       w, ierr, n);
+    NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
+}
+
+int launch_count_kept(ngmix_stamp *stamps, int64_t nstamps, const double *ierr,
+                      hipStream_t s)
+{
+    if (nstamps <= 0) return NGMIX_OK;
+    hipLaunchKernelGGL(count_kept_kernel, dim3((unsigned)nstamps), dim3(BLOCK), 0,
+                       s, stamps, ierr);
+    NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
+}
+
+}  // namespace ngmix

@@ -1,0 +1,161 @@
+"""
+CPU-only checks of the C ABI: the library loads, exports every symbol
+include/ngmix_hip.h declares, and its O(ngauss) HOST parameter-prep entry
+points (norms, fills, convolve, jacobian transforms) reproduce the reference
+goldens.  No kernel is launched here.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ngmix_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GFIELDS = ("p", "row", "col", "irr", "irc", "icc", "det")
+NFIELDS = ("drr", "drc", "dcc", "norm", "pnorm")
+
+
+def as_gauss(a):
+    out = np.zeros(a.size, dtype=_lib.GAUSS2D_DTYPE)
+    for n in _lib.GAUSS2D_DTYPE.names:
+        out[n] = a[n]
+    return out
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    header = open(os.path.join(ROOT, "include", "ngmix_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(ngmix_[A-Za-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 41
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), "library does not export " + name
+    assert declared == set(_lib.SIGNATURES), (
+        declared ^ set(_lib.SIGNATURES))
+    L = _lib.lib()
+    assert b"gfx950" in L.ngmix_version()
+
+
+def test_struct_layouts_match_reference():
+    """SURVEY.md 8b, measured from the reference's dtypes"""
+    d = _lib.GAUSS2D_DTYPE
+    assert [d.fields[n][1] for n in ("p", "det", "norm_set", "drr", "pnorm")] == \
+        [0, 48, 56, 64, 96]
+    d = _lib.PIXEL_DTYPE
+    assert [d.fields[n][1] for n in ("u", "v", "area", "val", "ierr", "fdiff")] == \
+        [0, 8, 16, 24, 32, 40]
+    d = _lib.ADMOM_RESULT_DTYPE
+    assert [d.fields[n][1] for n in ("flags", "numiter", "npix", "wsum", "sums",
+                                     "sums_cov", "pars", "rho4", "F")] == \
+        [0, 4, 8, 16, 24, 80, 472, 520, 528]
+    d = _lib.ADMOM_CONF_DTYPE
+    assert [d.fields[n][1] for n in d.names] == [0, 8, 16, 24, 32]
+    d = _lib.EM_CONF_DTYPE
+    assert [d.fields[n][1] for n in d.names] == [0, 8, 12, 16, 24]
+    assert _lib.moments_result_dtype(6).itemsize == 448
+    assert _lib.moments_result_dtype(17).itemsize == 2736
+
+
+FILL_CASES = ["gauss", "exp", "dev", "turb", "bdf", "bd", "coellip", "full",
+              "exp_round", "exp_highg"]
+MODEL_IDS = {"full": 0, "gauss": 1, "turb": 2, "exp": 3, "dev": 4, "bdf": 6,
+             "coellip": 7, "cm": 9, "bd": 10}
+
+
+@pytest.mark.parametrize("name", FILL_CASES)
+def test_host_fill_convolve_norms(golden, name):
+    g = golden("fills")
+    L = _lib.lib()
+    model = name.split("_")[0]
+    ref = g["gmix_" + name]
+    pars = np.ascontiguousarray(g["pars_" + name])
+    gm = np.zeros(ref.size, dtype=_lib.GAUSS2D_DTYPE)
+    assert L.ngmix_fill_model(_lib.ptr(gm), gm.size, MODEL_IDS[model],
+                              _lib.ptr(pars), pars.size) == 0
+    for n in GFIELDS:
+        np.testing.assert_allclose(gm[n], ref[n], rtol=1e-14, atol=0)
+    assert np.all(gm["norm_set"] == 0) and np.all(np.isnan(gm["pnorm"]))
+    gm = as_gauss(ref)
+    for pname in ("psf1", "psf3", "psf_off"):
+        psf = as_gauss(g[pname])
+        out = np.zeros(gm.size * psf.size, dtype=_lib.GAUSS2D_DTYPE)
+        assert L.ngmix_convolve_fill(_lib.ptr(out), _lib.ptr(gm), gm.size,
+                                     _lib.ptr(psf), psf.size) == 0
+        refc = g["conv_%s_%s" % (name, pname)]
+        for n in GFIELDS:
+            np.testing.assert_array_equal(out[n], refc[n])
+        refn = g["convnorm_%s_%s" % (name, pname)]
+        st = L.ngmix_set_norms(_lib.ptr(out), out.size)
+        if np.all(refn["norm_set"] == 1):
+            assert st == 0
+            for n in GFIELDS + NFIELDS:
+                np.testing.assert_array_equal(out[n], refn[n])
+
+
+def test_host_cm_shape_errors(golden):
+    g = golden("fills")
+    L = _lib.lib()
+    tf = ctypes.c_double()
+    assert L.ngmix_get_cm_Tfactor(float(g["cm_fracdev"]), float(g["cm_TdByTe"]),
+                                  ctypes.byref(tf)) == 0
+    assert tf.value == float(g["cm_Tfactor"])
+    gm = np.zeros(16, dtype=_lib.GAUSS2D_DTYPE)
+    pars = np.ascontiguousarray(g["pars_exp"])
+    assert L.ngmix_fill_cm(_lib.ptr(gm), float(g["cm_fracdev"]),
+                           float(g["cm_TdByTe"]), tf.value, _lib.ptr(pars)) == 0
+    for n in GFIELDS:
+        np.testing.assert_allclose(gm[n], g["gmix_cm"][n], rtol=1e-14, atol=0)
+    e1, e2 = ctypes.c_double(), ctypes.c_double()
+    assert L.ngmix_g1g2_to_e1e2(0.8, 0.7, ctypes.byref(e1),
+                                ctypes.byref(e2)) == _lib.ERR_G_RANGE
+    bad = np.array([0.0, 0.0, 0.9, 0.9, 1.0, 1.0])
+    gm6 = np.zeros(6, dtype=_lib.GAUSS2D_DTYPE)
+    assert L.ngmix_fill_model(_lib.ptr(gm6), 6, 3, _lib.ptr(bad), 6) == \
+        _lib.ERR_G_RANGE
+    with pytest.raises(_lib.gexceptions.GMixRangeError):
+        _lib.check(_lib.ERR_G_RANGE)
+    with pytest.raises(ZeroDivisionError):
+        _lib.check(_lib.ERR_ZERO_DIV)
+    # psf with zero total flux: numba raises ZeroDivisionError
+    psf = np.zeros(1, dtype=_lib.GAUSS2D_DTYPE)
+    out = np.zeros(6, dtype=_lib.GAUSS2D_DTYPE)
+    assert L.ngmix_convolve_fill(_lib.ptr(out), _lib.ptr(gm6), 6, _lib.ptr(psf),
+                                 1) == _lib.ERR_ZERO_DIV
+
+
+@pytest.mark.parametrize("jname", ["unit", "diag", "sheared"])
+def test_host_jacobian_transforms(golden, jname):
+    g = golden("pixels")
+    L = _lib.lib()
+    jac = np.ascontiguousarray(g["jac_" + jname]).astype(_lib.JACOBIAN_DTYPE)
+    a, b = ctypes.c_double(), ctypes.c_double()
+    for (r, c), (v, u), (r2, c2) in zip(g["pts_" + jname], g["vu_" + jname],
+                                        g["rowcol_" + jname]):
+        L.ngmix_jacobian_get_vu(_lib.ptr(jac), r, c, ctypes.byref(a), ctypes.byref(b))
+        assert (a.value, b.value) == (v, u)
+        assert L.ngmix_jacobian_get_rowcol(_lib.ptr(jac), v, u, ctypes.byref(a),
+                                           ctypes.byref(b)) == 0
+        assert (a.value, b.value) == (r2, c2)
+
+
+def test_compute_fails_loudly_without_gpu():
+    """no silent CPU path: a pixel loop without a device is an error"""
+    L = _lib.lib()
+    if L.ngmix_device_count() > 0:
+        pytest.skip("a GPU is present")
+    gm = np.zeros(1, dtype=_lib.GAUSS2D_DTYPE)
+    gm["p"] = gm["irr"] = gm["icc"] = gm["det"] = 1.0
+    pix = np.zeros(4, dtype=_lib.PIXEL_DTYPE)
+    ll = ctypes.c_double()
+    npix = ctypes.c_int64()
+    st = L.ngmix_get_loglike(_lib.ptr(gm), 1, _lib.ptr(pix), 4, ctypes.byref(ll),
+                             ctypes.byref(ll), ctypes.byref(ll), ctypes.byref(npix))
+    assert st == _lib.ERR_HIP
+    with pytest.raises(RuntimeError):
+        _lib.check(st, "ngmix_get_loglike")
+    from ngmix_amd.batch import StampBatch
+    with pytest.raises(RuntimeError):
+        StampBatch.from_images(np.zeros((1, 4, 4)))

@@ -1,0 +1,434 @@
+"""
+GPU parity tests for the single-pass pixel kernels (render / get_loglike /
+fill_fdiff / get_model_s2n_sum / fill_pixels / fill_coords), through the C ABI.
+
+Checks, in order of strength:
+  * seam forms and batch forms against the committed goldens (outputs of the
+    reference itself) and against the CPU oracle on seeded random inputs;
+  * bit-exact (==) for pixel indexing, coordinates, fdiff and fast renders;
+    loglike / s2n sums to 1e-12 relative (north_star: 1e-10) because only the
+    summation order differs;
+  * size-independent properties at BASELINE's full stamp size: exact skipping
+    (skip == no-skip bitwise), loglike == -0.5*sum(fdiff^2), render linearity.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from ngmix_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+RENDER_NAMES = ["c1_exp48", "exp48_psf", "gauss32", "bdf64_psf", "masked13x15",
+                "masked13x15_keepzero", "tiny20x17"]
+SUM_RTOL = 1e-12  # north_star tolerance is 1e-10; only summation order differs
+
+
+def as_gauss(a):
+    out = np.zeros(a.size, dtype=_lib.GAUSS2D_DTYPE)
+    for n in _lib.GAUSS2D_DTYPE.names:
+        out[n] = a[n]
+    return out
+
+
+def as_pixels(a):
+    out = np.zeros(a.size, dtype=_lib.PIXEL_DTYPE)
+    for n in _lib.PIXEL_DTYPE.names:
+        out[n] = a[n]
+    return out
+
+
+def jac_rec(a):
+    return np.ascontiguousarray(a).astype(_lib.JACOBIAN_DTYPE)
+
+
+def seam_make_pixels(image, weight, jac, izw):
+    L = _lib.lib()
+    image = np.ascontiguousarray(image, dtype="f8")
+    weight = np.ascontiguousarray(weight, dtype="f8")
+    n = int((weight > 0).sum()) if izw else image.size
+    pix = np.zeros(n, dtype=_lib.PIXEL_DTYPE)
+    st = L.ngmix_fill_pixels(_lib.ptr(pix), n, _lib.ptr(image), _lib.ptr(weight),
+                             image.shape[0], image.shape[1], _lib.ptr(jac), int(izw))
+    return st, pix
+
+
+# --------------------------------------------------------------- seam forms
+@pytest.mark.parametrize("jname", ["unit", "diag", "sheared"])
+def test_seam_fill_pixels_coords_exact(golden, jname):
+    g = golden("pixels")
+    L = _lib.lib()
+    jac = jac_rec(g["jac_" + jname])
+    nrow, ncol = g["image"].shape
+    coords = np.zeros(nrow * ncol, dtype=_lib.COORD_DTYPE)
+    assert L.ngmix_fill_coords(_lib.ptr(coords), nrow, ncol, _lib.ptr(jac)) == 0
+    for n in ("u", "v", "area"):
+        np.testing.assert_array_equal(coords[n], g["coords_" + jname][n])
+    for izw in (1, 0):
+        st, pix = seam_make_pixels(g["image"], g["weight"], jac, izw)
+        assert st == 0
+        ref = g["pixels_%s_izw%d" % (jname, izw)]
+        assert pix.size == ref.size
+        for n in ("u", "v", "area", "val", "ierr"):
+            np.testing.assert_array_equal(pix[n], ref[n], err_msg=n)
+    # wrong-sized pixel array: RuntimeError('some pixels were not filled')
+    pix = np.zeros(5, dtype=_lib.PIXEL_DTYPE)
+    im = np.ascontiguousarray(g["image"])
+    wt = np.ascontiguousarray(g["weight"])
+    st = L.ngmix_fill_pixels(_lib.ptr(pix), 5, _lib.ptr(im), _lib.ptr(wt), nrow,
+                             ncol, _lib.ptr(jac), 1)
+    assert st == _lib.ERR_PIXELS_NOT_FILLED
+
+
+@pytest.mark.parametrize("name", RENDER_NAMES)
+def test_seam_render_loglike_fdiff(golden, name):
+    g = golden("render_loglike")
+    L = _lib.lib()
+    gm = as_gauss(g[name + "_gmix_in"])
+    pixels = as_pixels(g[name + "_pixels"])
+    jac = jac_rec(g[name + "_jac"])
+    shape = g[name + "_image"].shape
+
+    ll, sn, sd = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    npix = ctypes.c_int64()
+    assert gm["norm_set"][0] == 0
+    st = L.ngmix_get_loglike(_lib.ptr(gm), gm.size, _lib.ptr(pixels), pixels.size,
+                             ctypes.byref(ll), ctypes.byref(sn), ctypes.byref(sd),
+                             ctypes.byref(npix))
+    assert st == 0
+    # lazy norm side effect on the caller's array, exact
+    refn = g[name + "_gmix_normed"]
+    for n in _lib.GAUSS2D_DTYPE.names:
+        np.testing.assert_array_equal(gm[n], refn[n], err_msg=n)
+    ref = g[name + "_loglike"]
+    np.testing.assert_allclose([ll.value, sn.value, sd.value], ref[:3],
+                               rtol=SUM_RTOL, atol=0)
+    assert npix.value == int(ref[3])
+
+    for start in (0, 13):
+        ref_fd = g[name + "_fdiff_start%d" % start]
+        fdiff = np.zeros(ref_fd.size) + 7.0
+        assert L.ngmix_fill_fdiff(_lib.ptr(gm), gm.size, _lib.ptr(pixels),
+                                  pixels.size, _lib.ptr(fdiff), start) == 0
+        np.testing.assert_array_equal(fdiff, ref_fd)
+
+    s2n = ctypes.c_double()
+    assert L.ngmix_get_model_s2n_sum(_lib.ptr(gm), gm.size, _lib.ptr(pixels),
+                                     pixels.size, ctypes.byref(s2n)) == 0
+    np.testing.assert_allclose(s2n.value, float(g[name + "_s2n_sum"]),
+                               rtol=SUM_RTOL, atol=0)
+
+    coords = np.zeros(shape[0] * shape[1], dtype=_lib.COORD_DTYPE)
+    assert L.ngmix_fill_coords(_lib.ptr(coords), shape[0], shape[1],
+                               _lib.ptr(jac)) == 0
+    im = np.zeros(coords.size)
+    assert L.ngmix_render(_lib.ptr(gm), gm.size, _lib.ptr(coords), coords.size,
+                          _lib.ptr(im), 1) == 0
+    np.testing.assert_array_equal(im.reshape(shape), g[name + "_render_fast"])
+    im = np.zeros(coords.size)
+    assert L.ngmix_render(_lib.ptr(gm), gm.size, _lib.ptr(coords), coords.size,
+                          _lib.ptr(im), 0) == 0
+    # true exp: device libm vs numpy, a few ulp
+    np.testing.assert_allclose(im.reshape(shape), g[name + "_render_exact"],
+                               rtol=1e-14, atol=1e-300)
+    acc = g[name + "_render_base"].copy().ravel()
+    assert L.ngmix_render(_lib.ptr(gm), gm.size, _lib.ptr(coords), coords.size,
+                          _lib.ptr(acc), 1) == 0
+    np.testing.assert_array_equal(acc.reshape(shape), g[name + "_render_accum"])
+
+
+def test_seam_range_error():
+    L = _lib.lib()
+    gm = np.zeros(2, dtype=_lib.GAUSS2D_DTYPE)
+    gm["p"] = gm["irr"] = gm["icc"] = gm["det"] = 1.0
+    gm["det"][1] = 0.0
+    pix = np.zeros(4, dtype=_lib.PIXEL_DTYPE)
+    out = np.zeros(4)
+    st = L.ngmix_fill_fdiff(_lib.ptr(gm), 2, _lib.ptr(pix), 4, _lib.ptr(out), 0)
+    assert st == _lib.ERR_DET_TOO_LOW
+    assert gm["norm_set"][0] == 1 and gm["norm_set"][1] == 0
+
+
+# -------------------------------------------------------------- batch forms
+def _batch_from_case(g, name):
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    sb = StampBatch.from_images(g[name + "_image"], g[name + "_weight"],
+                                g[name + "_jac"],
+                                ignore_zero_weight=bool(g[name + "_izw"]))
+    gm = GMixBatch.from_numpy(as_gauss(g[name + "_gmix_in"]))
+    return sb, gm
+
+
+@pytest.mark.parametrize("name", RENDER_NAMES)
+def test_batch_single_stamp_vs_golden(golden, name):
+    import torch
+    g = golden("render_loglike")
+    sb, gm = _batch_from_case(g, name)
+    ref = g[name + "_loglike"]
+    assert int(sb.npix_kept[0]) == int(ref[3])
+    out, status = sb.loglike(gm)
+    out = out.cpu().numpy()[0]
+    assert int(status.cpu()[0]) == 0
+    np.testing.assert_allclose(out[:3], ref[:3], rtol=SUM_RTOL, atol=0)
+    assert out[3] == ref[3]
+    # lazy norms written back on the device, exact
+    refn = g[name + "_gmix_normed"]
+    back = gm.to_numpy()[0]
+    for n in _lib.GAUSS2D_DTYPE.names:
+        np.testing.assert_array_equal(back[n], refn[n], err_msg=n)
+
+    nk = int(ref[3])
+    for start in (0, 13):
+        ref_fd = g[name + "_fdiff_start%d" % start]
+        fdiff = torch.full((ref_fd.size,), 7.0, dtype=torch.float64, device="cuda")
+        sb.fill_fdiff(gm, fdiff=fdiff, fdiff_start=np.array([start]))
+        np.testing.assert_array_equal(fdiff.cpu().numpy(), ref_fd)
+        assert nk + start <= ref_fd.size
+
+    s2n, _ = sb.model_s2n_sum(gm)
+    np.testing.assert_allclose(float(s2n.cpu()[0]), float(g[name + "_s2n_sum"]),
+                               rtol=SUM_RTOL, atol=0)
+    shape = g[name + "_image"].shape
+    im, _ = sb.render(gm, fast_exp=True)
+    np.testing.assert_array_equal(im.cpu().numpy().reshape(shape),
+                                  g[name + "_render_fast"])
+    im, _ = sb.render(gm, fast_exp=False)
+    np.testing.assert_allclose(im.cpu().numpy().reshape(shape),
+                               g[name + "_render_exact"], rtol=1e-14, atol=1e-300)
+    acc = torch.from_numpy(g[name + "_render_base"].copy().ravel()).cuda()
+    sb.render(gm, image=acc, fast_exp=True)
+    np.testing.assert_array_equal(acc.cpu().numpy().reshape(shape),
+                                  g[name + "_render_accum"])
+
+
+def _random_mixtures(rng, n, ngauss, scale):
+    """random, sometimes nasty, mixtures with norms unset"""
+    gm = np.zeros((n, ngauss), dtype=_lib.GAUSS2D_DTYPE)
+    T = rng.uniform(0.05, 2.5, size=(n, ngauss)) * scale ** 2 * 10
+    e1 = rng.uniform(-0.7, 0.7, size=(n, ngauss))
+    e2 = rng.uniform(-0.6, 0.6, size=(n, ngauss))
+    emag = np.sqrt(e1 ** 2 + e2 ** 2)
+    shrink = np.where(emag > 0.95, 0.95 / emag, 1.0)
+    e1 *= shrink
+    e2 *= shrink
+    gm["p"] = rng.uniform(-0.2, 5.0, size=(n, ngauss))
+    gm["row"] = rng.uniform(-6, 6, size=(n, ngauss)) * scale
+    gm["col"] = rng.uniform(-6, 6, size=(n, ngauss)) * scale
+    gm["irr"] = T / 2 * (1 - e1)
+    gm["irc"] = T / 2 * e2
+    gm["icc"] = T / 2 * (1 + e1)
+    gm["det"] = gm["irr"] * gm["icc"] - gm["irc"] ** 2
+    for f in ("drr", "drc", "dcc", "norm", "pnorm"):
+        gm[f] = np.nan
+    return gm
+
+
+def _oracle_eval(gmrow, image, weight, jac, izw):
+    from oracle import oracle as ora
+    gm = np.zeros(gmrow.size, dtype=ora.GAUSS2D_DTYPE)
+    for n in ora.GAUSS2D_DTYPE.names:
+        gm[n] = gmrow[n]
+    j = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+    j[0] = tuple(jac)
+    pix = ora.make_pixels(image, weight, j, izw)
+    st, res = ora.get_loglike(gm, pix)
+    assert st == 0
+    fd = np.zeros(pix.size)
+    ora.fill_fdiff(gm, pix, fd, 0)
+    coords = ora.make_coords(image.shape, j)
+    im = np.zeros(image.size)
+    ora.render(gm, coords, im, 1)
+    return res, fd, im.reshape(image.shape)
+
+
+@pytest.mark.parametrize("dims,ngauss", [((48, 48), 6), ((32, 32), 1),
+                                         ((25, 25), 3), ((64, 64), 16),
+                                         ((7, 50), 2), ((70, 9), 4)])
+def test_batch_random_vs_oracle(dims, ngauss):
+    """seeded random batches, sheared jacobians, masks: batch kernels == oracle"""
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    rng = np.random.RandomState(1234 + dims[0] * 100 + ngauss)
+    n = 12
+    scale = 0.263
+    nrow, ncol = dims
+    images = rng.normal(size=(n, nrow, ncol))
+    weights = rng.uniform(0.5, 2.0, size=(n, nrow, ncol))
+    weights[rng.uniform(size=weights.shape) < 0.03] = 0.0
+    weights[0] = 1.0  # one unmasked stamp
+    weights[1, 0, 0] = -3.0
+    jac = np.zeros((n, 8))
+    for i in range(n):
+        a = scale * (1 + rng.uniform(-0.1, 0.1))
+        d = scale * (1 + rng.uniform(-0.1, 0.1))
+        b, c = rng.uniform(-0.03, 0.03, size=2)
+        if i % 3 == 0:
+            b = c = 0.0
+        jac[i] = [(nrow - 1) / 2 + rng.uniform(-0.5, 0.5),
+                  (ncol - 1) / 2 + rng.uniform(-0.5, 0.5), a, b, c, d,
+                  a * d - b * c, np.sqrt(abs(a * d - b * c))]
+    gmh = _random_mixtures(rng, n, ngauss, scale)
+    for izw in (True, False):
+        sb = StampBatch.from_images(images, weights, jac, ignore_zero_weight=izw)
+        gm = GMixBatch.from_numpy(gmh)
+        out, status = sb.loglike(gm)
+        fd, _ = sb.fill_fdiff(gm)
+        im, _ = sb.render(gm, fast_exp=True)
+        out = out.cpu().numpy()
+        fd = fd.cpu().numpy()
+        im = im.cpu().numpy().reshape(n, nrow, ncol)
+        assert np.all(status.cpu().numpy() == 0)
+        offs = sb.kept_offsets()
+        for i in range(n):
+            res, rfd, rim = _oracle_eval(gmh[i], images[i], weights[i], jac[i], izw)
+            assert int(sb.npix_kept[i]) == res[3] == out[i, 3]
+            np.testing.assert_array_equal(fd[offs[i]:offs[i] + res[3]], rfd,
+                                          err_msg="fdiff stamp %d" % i)
+            np.testing.assert_array_equal(im[i], rim)
+            scale_ll = max(abs(res[0]), 1e-300)
+            assert abs(out[i, 0] - res[0]) <= SUM_RTOL * scale_ll
+            # s2n_numer = sum(val*model*ivar) has mixed signs: bound the error
+            # by sum|terms| <= sqrt(sum val^2 ivar * sum model^2 ivar)
+            wk = np.where(weights[i] > 0, weights[i], 0.0)
+            aa = float((images[i] ** 2 * wk).sum())
+            assert abs(out[i, 1] - res[1]) <= 1e-12 * np.sqrt(aa * res[2]) + 1e-300
+            np.testing.assert_allclose(out[i, 2], res[2], rtol=SUM_RTOL, atol=0)
+
+
+def test_batch_status_per_stamp():
+    """one bad stamp (det too low) must not abort the batch"""
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    rng = np.random.RandomState(7)
+    n = 5
+    images = rng.normal(size=(n, 16, 16))
+    gmh = _random_mixtures(rng, n, 2, 0.263)
+    gmh["det"][2, 1] = 1e-250
+    sb = StampBatch.from_images(images)
+    gm = GMixBatch.from_numpy(gmh)
+    out, status = sb.loglike(gm)
+    status = status.cpu().numpy()
+    assert list(status) == [0, 0, _lib.ERR_DET_TOO_LOW, 0, 0]
+    back = gm.to_numpy()
+    assert back["norm_set"][2, 0] == 1 and back["norm_set"][2, 1] == 0
+    assert np.all(back["norm_set"][[0, 1, 3, 4]] == 1)
+
+
+def test_batch_fill_convolve_norms_vs_host():
+    """device param prep == host param prep (same source), exact"""
+    import torch
+    from ngmix_amd.batch import GMixBatch
+    L = _lib.lib()
+    rng = np.random.RandomState(99)
+    n = 64
+    pars = np.zeros((n, 6))
+    pars[:, 0:2] = rng.uniform(-0.1, 0.1, size=(n, 2))
+    pars[:, 2:4] = rng.normal(scale=0.2, size=(n, 2))
+    pars[:, 4] = rng.uniform(0.2, 1.5, size=n)
+    pars[:, 5] = rng.uniform(50, 500, size=n)
+    pars[5, 2:4] = [0.9, 0.9]  # g >= 1
+    psfpars = np.tile([0.0, 0.0, 0.01, -0.02, 0.27, 1.0], (n, 1))
+    for model, mid, ng in (("exp", 3, 6), ("dev", 4, 10), ("gauss", 1, 1)):
+        gm, st = GMixBatch.from_pars(pars, model)
+        psf, _ = GMixBatch.from_pars(psfpars, "turb")
+        st = st.cpu().numpy()
+        assert st[5] == _lib.ERR_G_RANGE and np.all(np.delete(st, 5) == 0)
+        conv, _ = gm.convolve(psf)
+        nst = conv.set_norms().cpu().numpy()
+        dev = conv.to_numpy()
+        hpsf = np.zeros(3, dtype=_lib.GAUSS2D_DTYPE)
+        L.ngmix_fill_model(_lib.ptr(hpsf), 3, 2,
+                           _lib.ptr(np.ascontiguousarray(psfpars[0])), 6)
+        for i in range(n):
+            if i == 5:
+                continue
+            h = np.zeros(ng, dtype=_lib.GAUSS2D_DTYPE)
+            assert L.ngmix_fill_model(_lib.ptr(h), ng, mid,
+                                      _lib.ptr(np.ascontiguousarray(pars[i])), 6) == 0
+            hc = np.zeros(ng * 3, dtype=_lib.GAUSS2D_DTYPE)
+            L.ngmix_convolve_fill(_lib.ptr(hc), _lib.ptr(h), ng, _lib.ptr(hpsf), 3)
+            assert L.ngmix_set_norms(_lib.ptr(hc), hc.size) == 0
+            assert nst[i] == 0
+            for f in _lib.GAUSS2D_DTYPE.names:
+                # atanh/tanh differ between device and host libm by ulps
+                np.testing.assert_allclose(dev[i][f], hc[f], rtol=1e-14, atol=0,
+                                           err_msg=f)
+    assert torch.cuda.is_available()
+
+
+# ------------------------------------ properties at BASELINE's full stamp size
+def _c2_batch(n, seed=5):
+    """SURVEY.md 8(d) C2-style synthetic batch: 48x48, 'exp' x gaussian psf"""
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    import torch
+    rng = np.random.RandomState(seed)
+    scale = 0.263
+    pars = np.zeros((n, 6))
+    pars[:, 0:2] = rng.uniform(-0.5, 0.5, size=(n, 2)) * scale
+    g = np.clip(rng.normal(scale=0.1, size=(n, 2)), -0.45, 0.45)
+    pars[:, 2:4] = g
+    pars[:, 4] = rng.uniform(0.3, 1.5, size=n)
+    pars[:, 5] = rng.uniform(50, 500, size=n)
+    psfpars = np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (n, 1))
+    gm0, _ = GMixBatch.from_pars(pars, "exp")
+    psf, _ = GMixBatch.from_pars(psfpars, "gauss")
+    gm, _ = gm0.convolve(psf)
+    jac = np.array([23.5, 23.5, scale, 0.0, 0.0, scale, scale ** 2, scale])
+    zeros = torch.zeros((n, 48, 48), dtype=torch.float64, device="cuda")
+    sb = StampBatch.from_images(zeros, None, jac)
+    truth, _ = sb.render(gm, fast_exp=True)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    noise = torch.randn(truth.shape, generator=gen, device="cuda",
+                        dtype=torch.float64)
+    sigma = torch.from_numpy(0.01 * pars[:, 5] / 100).cuda()
+    img = truth.reshape(n, -1) + noise.reshape(n, -1) * sigma[:, None]
+    w = (1.0 / sigma ** 2)[:, None, None].expand(n, 48, 48).contiguous()
+    sb = StampBatch.from_images(img.reshape(n, 48, 48), w, jac)
+    return sb, gm, pars
+
+
+def test_full_size_properties():
+    import torch
+    n = 4096
+    sb, gm, pars = _c2_batch(n)
+    out, status = sb.loglike(gm)
+    assert int(status.abs().sum()) == 0
+    # (1) exact skipping: bitwise identical with and without tile skipping
+    out_ns, _ = sb.loglike(gm, no_skip=True)
+    assert torch.equal(out, out_ns)
+    fd, _ = sb.fill_fdiff(gm)
+    fd_ns, _ = sb.fill_fdiff(gm, no_skip=True)
+    assert torch.equal(fd, fd_ns)
+    im, _ = sb.render(gm)
+    im_ns, _ = sb.render(gm, no_skip=True)
+    assert torch.equal(im, im_ns)
+    # (2) loglike == -0.5 * sum(fdiff^2) per stamp (gmix_nb.py:866,900)
+    chk = -0.5 * (fd.reshape(n, -1) ** 2).sum(dim=1)
+    np.testing.assert_allclose(out[:, 0].cpu().numpy(), chk.cpu().numpy(),
+                               rtol=1e-11, atol=0)
+    assert torch.all(out[:, 3] == 2304)
+    # chi2 per pixel ~ 1 at the true parameters
+    chi2per = (-2 * out[:, 0] / 2304).cpu().numpy()
+    assert 0.9 < chi2per.mean() < 1.1
+    # (3) render linearity: scaling p by 2 (exact in binary) doubles the image
+    gm2 = gm.clone()
+    gm2.data[:, 0] *= 2.0
+    gm2.data[:, 7] = 0.0  # norm_set = 0 -> lazy norms recomputed
+    im2, _ = sb.render(gm2)
+    assert torch.equal(im2, 2.0 * im)
+    # (4) determinism: same launch twice gives the same bits
+    out_b, _ = sb.loglike(gm)
+    assert torch.equal(out, out_b)
+    # (5) a sample of stamps against the CPU oracle
+    from oracle import oracle as ora
+    gmh = gm.to_numpy()
+    val = sb.val.reshape(n, 48, 48).cpu().numpy()
+    ierr = sb.ierr.reshape(n, 48, 48).cpu().numpy()
+    jac = sb.jac.cpu().numpy()
+    outh = out.cpu().numpy()
+    fdh = fd.reshape(n, -1).cpu().numpy()
+    for i in (0, 1, 777, n - 1):
+        res, rfd, _ = _oracle_eval(gmh[i], val[i], ierr[i] ** 2, jac[i], True)
+        np.testing.assert_allclose(outh[i, :3], res[:3], rtol=1e-10, atol=0)
+        # ierr**2 then sqrt is not always the identity: compare fdiff to rounding
+        np.testing.assert_allclose(fdh[i], rfd, rtol=1e-12, atol=1e-12)
