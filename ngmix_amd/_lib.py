@@ -185,6 +185,14 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             build()
+        # One HIP runtime per process: PyTorch-ROCm ships its own
+        # libamdhip64; importing torch first makes our library bind to that
+        # copy (same SONAME) instead of initialising a second runtime that
+        # cannot see the devices the first one opened.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if a symbol is missing

@@ -409,3 +409,125 @@ class StampBatch(object):
                 _stream())
         _lib.check(st, "ngmix_model_s2n_sum_batch")
         return out, status
+
+    # ------------------------------------------------ moments / iterative ops
+    def weighted_sums(self, wt, maxrad, nmom=6, res=None, status=None):
+        """
+        get_weighted_sums / get_higher_order_weighted_sums per stamp
+        (gmix_nb.py:681-821); wt must have its norms set.  res: (N, nbytes/8)
+        float64 tensor of result records, ADDED into (zeros when None).
+        Returns (res, status); view res with records_to_numpy(res, dtype).
+        """
+        torch = _torch()
+        assert wt.n == self.n and nmom in (6, 17)
+        nd = _lib.moments_result_dtype(nmom).itemsize // 8
+        if res is None:
+            res = torch.zeros((self.n, nd), dtype=torch.float64, device=self.device)
+        if status is None:
+            status = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        maxrad = _as_device_f64(np.broadcast_to(np.asarray(maxrad, dtype="f8"),
+                                                (self.n,)).copy(), self.device) \
+            if not isinstance(maxrad, torch.Tensor) else maxrad
+        b = self._batch(wt.ngauss)
+        with torch.cuda.device(self.device):
+            st = _lib.lib().ngmix_weighted_sums_batch(
+                ctypes.byref(b), _dptr(wt.data), _dptr(res), nmom, _dptr(maxrad),
+                _dptr(status), _stream())
+        _lib.check(st, "ngmix_weighted_sums_batch")
+        return res, status
+
+    def admom(self, wt, maxiter=200, shiftmax=5.0, etol=1.0e-5, Ttol=1.0e-3,
+              cenonly=False, res=None, status=None):
+        """
+        adaptive moments of every stamp (admom_nb.py:13-108) in one launch.
+        wt: GMixBatch with ONE gaussian per stamp, the guess; updated in place
+        (it is the weight, as in the reference).  Returns (res, status) with
+        res an (N, 73) float64 tensor of 584-byte result records.
+        """
+        torch = _torch()
+        assert wt.n == self.n and wt.ngauss == 1
+        conf = np.zeros(1, dtype=_lib.ADMOM_CONF_DTYPE)
+        conf["maxiter"] = maxiter
+        conf["shiftmax"] = shiftmax
+        conf["etol"] = etol
+        conf["Ttol"] = Ttol
+        conf["cenonly"] = cenonly
+        if res is None:
+            res = torch.zeros((self.n, 73), dtype=torch.float64, device=self.device)
+        if status is None:
+            status = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        b = self._batch(1)
+        with torch.cuda.device(self.device):
+            st = _lib.lib().ngmix_admom_batch(
+                _lib.ptr(conf), ctypes.byref(b), _dptr(wt.data), _dptr(res),
+                _dptr(status), _stream())
+        _lib.check(st, "ngmix_admom_batch")
+        return res, status
+
+    def em(self, gm, psf, conv=None, sky=0.0, kind=0, miniter=40, maxiter=500,
+           tol=1.0e-5, vary_sky=False, fill_zero_weight=False, out=None,
+           status=None):
+        """
+        EM fit of every stamp (em_nb.py em_run / _fixcen / _fixcov / _fluxonly
+        for kind 0..3).  gm: pre-psf guess (updated in place), psf: per-stamp
+        psf mixture normalised as EMFitter.go does, conv: their convolution
+        (made here when None; updated in place).  sky: scalar or (N,).
+        Returns (out, status, conv) with out (N,3) = numiter, frac_diff, sky.
+        """
+        torch = _torch()
+        assert gm.n == self.n and psf.n == self.n
+        if conv is None:
+            conv, _ = gm.convolve(psf)
+        conf = np.zeros(1, dtype=_lib.EM_CONF_DTYPE)
+        conf["tol"] = tol
+        conf["maxiter"] = maxiter
+        conf["miniter"] = miniter
+        conf["vary_sky"] = vary_sky
+        if not isinstance(sky, torch.Tensor):
+            sky = _as_device_f64(np.broadcast_to(np.asarray(sky, dtype="f8"),
+                                                 (self.n,)).copy(), self.device)
+        if out is None:
+            out = torch.empty((self.n, 3), dtype=torch.float64, device=self.device)
+        if status is None:
+            status = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        b = self._batch(conv.ngauss)
+        with torch.cuda.device(self.device):
+            st = _lib.lib().ngmix_em_batch(
+                int(kind), _lib.ptr(conf), ctypes.byref(b), _dptr(gm.data),
+                gm.ngauss, _dptr(psf.data), psf.ngauss, _dptr(conv.data),
+                _dptr(sky), int(fill_zero_weight), _dptr(out), _dptr(status),
+                _stream())
+        _lib.check(st, "ngmix_em_batch")
+        return out, status, conv
+
+    def deriv_images(self, gpars, dcov, ngauss, out=None, out_start=None):
+        """
+        deriv_images per stamp (derivs_nb.py:40-127).  gpars (N*ngauss, 6) and
+        dcov (N*ngauss, 3, 3) device tensors; out is flat, stamp i occupying
+        6*npix_kept[i] doubles from out_start[i], as (6, npix_kept) row-major.
+        """
+        torch = _torch()
+        kept = self.npix_kept.astype(np.int64)
+        if out_start is None:
+            out_start = np.concatenate([[0], np.cumsum(6 * kept)[:-1]])
+        if isinstance(out_start, np.ndarray):
+            out_start = torch.from_numpy(
+                np.ascontiguousarray(out_start, dtype=np.int64)).to(self.device)
+        if out is None:
+            out = torch.zeros(int(6 * kept.sum()), dtype=torch.float64,
+                              device=self.device)
+        gpars = _as_device_f64(gpars, self.device)
+        dcov = _as_device_f64(dcov, self.device)
+        b = self._batch(ngauss)
+        with torch.cuda.device(self.device):
+            st = _lib.lib().ngmix_deriv_images_batch(
+                ctypes.byref(b), _dptr(gpars), _dptr(dcov), _dptr(out),
+                _dptr(out_start), _stream())
+        _lib.check(st, "ngmix_deriv_images_batch")
+        return out
+
+
+def records_to_numpy(t, dtype):
+    """view an (N, nbytes/8) float64 record tensor as a structured array"""
+    a = t.detach().cpu().numpy()
+    return a.reshape(-1).view(dtype).copy()

@@ -337,6 +337,114 @@ int ngmix_get_model_s2n_sum(ngmix_gauss2d *gmix, int64_t ngauss,
     return NGMIX_OK;
 }
 
+// --------------------------------------------- seam moment / iterative forms
+
+int ngmix_get_weighted_sums(const ngmix_gauss2d *wt, int64_t ngauss,
+                            const ngmix_pixel *pixels, int64_t npix, void *res,
+                            int nmom, double maxrad)
+{
+    if (nmom != 6 && nmom != 17) return NGMIX_ERR_BAD_ARG;
+    if (npix <= 0 || ngauss <= 0) return NGMIX_OK;
+    const size_t rbytes = NGMIX_MOMENTS_RESULT_BYTES(nmom);
+    WS_GET(d_gm, ngmix_gauss2d, 0, ngauss * sizeof(ngmix_gauss2d));
+    WS_GET(d_px, ngmix_pixel, 1, npix * sizeof(ngmix_pixel));
+    WS_GET(d_res, char, 2, rbytes);
+    WS_GET(d_st, int32_t, 3, 8);
+    NGMIX_HIP_CHECK(hipMemcpy(d_gm, wt, ngauss * sizeof(ngmix_gauss2d), hipMemcpyHostToDevice));
+    NGMIX_HIP_CHECK(hipMemcpy(d_px, pixels, npix * sizeof(ngmix_pixel), hipMemcpyHostToDevice));
+    NGMIX_HIP_CHECK(hipMemcpy(d_res, res, rbytes, hipMemcpyHostToDevice));
+    int st = launch_weighted_sums_list(d_gm, (int)ngauss, d_px, npix, d_res, nmom,
+                                       maxrad, d_st, nullptr);
+    if (st) return st;
+    int32_t kst = 0;
+    NGMIX_HIP_CHECK(hipMemcpy(&kst, d_st, 4, hipMemcpyDeviceToHost));
+    if (kst) return kst;
+    NGMIX_HIP_CHECK(hipMemcpy(res, d_res, rbytes, hipMemcpyDeviceToHost));
+    return NGMIX_OK;
+}
+
+int ngmix_admom(const ngmix_admom_conf *conf, ngmix_gauss2d *wt,
+                const ngmix_pixel *pixels, int64_t npix, ngmix_admom_result *res)
+{
+    WS_GET(d_wt, ngmix_gauss2d, 0, sizeof(ngmix_gauss2d));
+    WS_GET(d_px, ngmix_pixel, 1, (npix > 0 ? npix : 1) * sizeof(ngmix_pixel));
+    WS_GET(d_res, ngmix_admom_result, 2, sizeof(ngmix_admom_result));
+    WS_GET(d_st, int32_t, 3, 8);
+    NGMIX_HIP_CHECK(hipMemcpy(d_wt, wt, sizeof(ngmix_gauss2d), hipMemcpyHostToDevice));
+    if (npix > 0)
+        NGMIX_HIP_CHECK(hipMemcpy(d_px, pixels, npix * sizeof(ngmix_pixel), hipMemcpyHostToDevice));
+    NGMIX_HIP_CHECK(hipMemcpy(d_res, res, sizeof(ngmix_admom_result), hipMemcpyHostToDevice));
+    int st = launch_admom_list(conf, d_px, npix, d_wt, d_res, d_st, nullptr);
+    if (st) return st;
+    int32_t kst = 0;
+    NGMIX_HIP_CHECK(hipMemcpy(&kst, d_st, 4, hipMemcpyDeviceToHost));
+    NGMIX_HIP_CHECK(hipMemcpy(res, d_res, sizeof(ngmix_admom_result), hipMemcpyDeviceToHost));
+    NGMIX_HIP_CHECK(hipMemcpy(wt, d_wt, sizeof(ngmix_gauss2d), hipMemcpyDeviceToHost));
+    return kst;
+}
+
+int ngmix_em_run(int kind, const ngmix_em_conf *conf, ngmix_pixel *pixels,
+                 int64_t npix, double *sums, ngmix_gauss2d *gmix, int64_t ngauss,
+                 ngmix_gauss2d *gmix_psf, int64_t npsf, ngmix_gauss2d *gmix_conv,
+                 int fill_zero_weight, int32_t *numiter, double *frac_diff,
+                 double *sky)
+{
+    if (kind < 0 || kind > 3 || ngauss < 1 || npsf < 1) return NGMIX_ERR_BAD_ARG;
+    static const int stride[4] = {14, 10, 8, 2};
+    const int64_t nconv = ngauss * npsf;
+    const size_t sbytes = (size_t)ngauss * stride[kind] * 8;
+    WS_GET(d_gm, ngmix_gauss2d, 0, ngauss * sizeof(ngmix_gauss2d));
+    WS_GET(d_psf, ngmix_gauss2d, 1, npsf * sizeof(ngmix_gauss2d));
+    WS_GET(d_conv, ngmix_gauss2d, 2, nconv * sizeof(ngmix_gauss2d));
+    WS_GET(d_px, ngmix_pixel, 3, (npix > 0 ? npix : 1) * sizeof(ngmix_pixel));
+    WS_GET(d_sums, double, 4, sbytes);
+    WS_GET(d_out, double, 5, 64);
+    NGMIX_HIP_CHECK(hipMemcpy(d_gm, gmix, ngauss * sizeof(ngmix_gauss2d), hipMemcpyHostToDevice));
+    NGMIX_HIP_CHECK(hipMemcpy(d_psf, gmix_psf, npsf * sizeof(ngmix_gauss2d), hipMemcpyHostToDevice));
+    NGMIX_HIP_CHECK(hipMemcpy(d_conv, gmix_conv, nconv * sizeof(ngmix_gauss2d), hipMemcpyHostToDevice));
+    if (npix > 0)
+        NGMIX_HIP_CHECK(hipMemcpy(d_px, pixels, npix * sizeof(ngmix_pixel), hipMemcpyHostToDevice));
+    NGMIX_HIP_CHECK(hipMemcpy(d_sums, sums, sbytes, hipMemcpyHostToDevice));
+    int32_t *d_st = (int32_t *)(d_out + 4);
+    int st = launch_em_list(kind, conf, d_px, npix, d_sums, d_gm, (int)ngauss, d_psf,
+                            (int)npsf, d_conv, fill_zero_weight, d_out, d_st, nullptr);
+    if (st) return st;
+    double out[5];
+    NGMIX_HIP_CHECK(hipMemcpy(out, d_out, 40, hipMemcpyDeviceToHost));
+    int32_t kst;
+    memcpy(&kst, &out[4], 4);
+    NGMIX_HIP_CHECK(hipMemcpy(gmix, d_gm, ngauss * sizeof(ngmix_gauss2d), hipMemcpyDeviceToHost));
+    NGMIX_HIP_CHECK(hipMemcpy(gmix_conv, d_conv, nconv * sizeof(ngmix_gauss2d), hipMemcpyDeviceToHost));
+    NGMIX_HIP_CHECK(hipMemcpy(sums, d_sums, sbytes, hipMemcpyDeviceToHost));
+    *numiter = (int32_t)out[0];
+    *frac_diff = out[1];
+    *sky = out[2];
+    return kst;
+}
+
+int ngmix_deriv_images(const double *gpars, const double *dcov, int64_t ngauss,
+                       const double *vv, const double *uu, const double *area,
+                       int64_t npix, double *out)
+{
+    if (npix <= 0 || ngauss <= 0) return NGMIX_OK;
+    WS_GET(d_gp, double, 0, ngauss * 6 * 8);
+    WS_GET(d_dc, double, 1, ngauss * 9 * 8);
+    WS_GET(d_v, double, 2, npix * 8);
+    WS_GET(d_u, double, 3, npix * 8);
+    WS_GET(d_a, double, 4, npix * 8);
+    WS_GET(d_o, double, 5, npix * 6 * 8);
+    NGMIX_HIP_CHECK(hipMemcpy(d_gp, gpars, ngauss * 6 * 8, hipMemcpyHostToDevice));
+    NGMIX_HIP_CHECK(hipMemcpy(d_dc, dcov, ngauss * 9 * 8, hipMemcpyHostToDevice));
+    NGMIX_HIP_CHECK(hipMemcpy(d_v, vv, npix * 8, hipMemcpyHostToDevice));
+    NGMIX_HIP_CHECK(hipMemcpy(d_u, uu, npix * 8, hipMemcpyHostToDevice));
+    NGMIX_HIP_CHECK(hipMemcpy(d_a, area, npix * 8, hipMemcpyHostToDevice));
+    NGMIX_HIP_CHECK(hipMemcpy(d_o, out, npix * 6 * 8, hipMemcpyHostToDevice));
+    int st = launch_deriv_list(d_gp, d_dc, (int)ngauss, d_v, d_u, d_a, npix, d_o, nullptr);
+    if (st) return st;
+    NGMIX_HIP_CHECK(hipMemcpy(out, d_o, npix * 6 * 8, hipMemcpyDeviceToHost));
+    return NGMIX_OK;
+}
+
 // ------------------------------------------------------------- batch forms
 
 int ngmix_weight_to_ierr_batch(const double *weight, double *ierr, int64_t n,
@@ -397,6 +505,37 @@ int ngmix_model_s2n_sum_batch(const ngmix_batch *batch, ngmix_gauss2d *gmix,
                               double *out, int32_t *status, void *stream)
 {
     return launch_s2n_grid(batch, gmix, out, status, stream);
+}
+
+int ngmix_weighted_sums_batch(const ngmix_batch *batch, const ngmix_gauss2d *gmix,
+                              void *res, int nmom, const double *maxrad,
+                              int32_t *status, void *stream)
+{
+    return launch_weighted_sums_grid(batch, gmix, res, nmom, maxrad, status,
+                                     (hipStream_t)stream);
+}
+
+int ngmix_admom_batch(const ngmix_admom_conf *conf, const ngmix_batch *batch,
+                      ngmix_gauss2d *wt, ngmix_admom_result *res, int32_t *status,
+                      void *stream)
+{
+    return launch_admom_grid(conf, batch, wt, res, status, (hipStream_t)stream);
+}
+
+int ngmix_em_batch(int kind, const ngmix_em_conf *conf, const ngmix_batch *batch,
+                   ngmix_gauss2d *gmix, int ngauss, ngmix_gauss2d *gmix_psf,
+                   int npsf, ngmix_gauss2d *gmix_conv, const double *sky_in,
+                   int fill_zero_weight, double *out, int32_t *status, void *stream)
+{
+    return launch_em_grid(kind, conf, batch, gmix, ngauss, gmix_psf, npsf, gmix_conv,
+                          sky_in, fill_zero_weight, out, status, (hipStream_t)stream);
+}
+
+int ngmix_deriv_images_batch(const ngmix_batch *batch, const double *gpars,
+                             const double *dcov, double *out,
+                             const int64_t *out_start, void *stream)
+{
+    return launch_deriv_grid(batch, gpars, dcov, out, out_start, (hipStream_t)stream);
 }
 
 }  // extern "C"

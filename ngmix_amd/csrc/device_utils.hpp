@@ -120,4 +120,37 @@ __device__ __forceinline__ PixBox gauss_pixel_box(const ngmix_gauss2d &g,
     return box;
 }
 
+// Row-major rank of position p among the kept pixels of a masked stamp
+// (the index into the reference's pixel list): per-64-pixel keep masks and
+// their exclusive prefix counts live in LDS (cmask/cpre, one entry per chunk).
+__device__ __forceinline__ void build_rank_tables(unsigned long long *cmask,
+                                                  int *cpre, const double *ierr,
+                                                  int npix)
+{
+    const int nchunks = (npix + 63) >> 6;
+    for (int base = wave_id() * WAVE; base < nchunks * WAVE; base += BLOCK) {
+        const int p = base + lane_id();
+        const bool kept = p < npix && ierr[p] > 0.0;
+        const unsigned long long m = __ballot(kept);
+        if (lane_id() == 0) cmask[base >> 6] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int c = 0; c < nchunks; c++) {
+            cpre[c] = run;
+            run += __popcll(cmask[c]);
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int kept_rank(const unsigned long long *cmask,
+                                         const int *cpre, int p)
+{
+    const unsigned long long m = cmask[p >> 6];
+    const unsigned long long below = m & ((1ull << (p & 63)) - 1ull);
+    return cpre[p >> 6] + __popcll(below);
+}
+
 }  // namespace ngmix

@@ -108,36 +108,6 @@ __device__ __forceinline__ int stage_gaussians(const LdsLayout &L,
     return NGMIX_OK;
 }
 
-// Row-major rank of pixel p among the kept pixels of a masked stamp:
-// per-64-pixel keep masks and their exclusive prefix counts live in LDS.
-__device__ __forceinline__ void build_rank_tables(const LdsLayout &L,
-                                                  const double *ierr, int npix)
-{
-    const int nchunks = (npix + 63) >> 6;
-    for (int base = wave_id() * WAVE; base < nchunks * WAVE; base += BLOCK) {
-        const int p = base + lane_id();
-        const bool kept = p < npix && ierr[p] > 0.0;
-        const unsigned long long m = __ballot(kept);
-        if (lane_id() == 0) L.cmask[base >> 6] = m;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int c = 0; c < nchunks; c++) {
-            L.cpre[c] = run;
-            run += __popcll(L.cmask[c]);
-        }
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ int kept_rank(const LdsLayout &L, int p)
-{
-    const unsigned long long m = L.cmask[p >> 6];
-    const unsigned long long below = m & ((1ull << (p & 63)) - 1ull);
-    return L.cpre[p >> 6] + __popcll(below);
-}
-
 template <int OP, int K>
 __global__ __launch_bounds__(BLOCK) void pixpass_grid_kernel(
     const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
@@ -167,7 +137,7 @@ __global__ __launch_bounds__(BLOCK) void pixpass_grid_kernel(
         return;
     }
     const bool masked = kNeedsIerr && izw && st.npix_kept != npix;
-    if (OP == OP_FDIFF && masked) build_rank_tables(L, sierr, npix);
+    if (OP == OP_FDIFF && masked) build_rank_tables(L.cmask, L.cpre, sierr, npix);
 
     const double area = jac.scale * jac.scale;  // jacobian_nb.py:33-40
     const int lane = lane_id(), w = wave_id();
@@ -256,7 +226,7 @@ __global__ __launch_bounds__(BLOCK) void pixpass_grid_kernel(
                 }
             } else if (OP == OP_FDIFF) {
                 if (kept) {
-                    const int rank = masked ? kept_rank(L, pidx[k]) : pidx[k];
+                    const int rank = masked ? kept_rank(L.cmask, L.cpre, pidx[k]) : pidx[k];
                     out[out_start[s] + rank] = (model[k] - pval[k]) * pierr[k];
                 }
             } else {

@@ -1,0 +1,360 @@
+"""
+GPU parity tests for the moment / iterative kernels: weighted sums (6 and 17
+moments), adaptive moments, EM (4 kinds) and deriv_images -- seam forms on the
+reference's own AoS inputs and batch forms on the compact stamp store, both
+against goldens produced by the reference itself.
+
+Tolerances: these kernels reduce over pixels in a tree, not sequentially, and
+admom / EM iterate on those sums, so results agree to rounding, not bitwise:
+1e-10 relative (north_star) on converged quantities, exact on numiter / flags
+for these fixtures.  deriv_images has no reduction and is compared exactly;
+weighted sums keep the reference's summation order (exact up to device exp()).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from ngmix_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+def conv_rec(a, dtype):
+    out = np.zeros(a.size, dtype=dtype)
+    for n in dtype.names:
+        out[n] = a[n]
+    return out
+
+
+def as_gauss(a):
+    return conv_rec(a, _lib.GAUSS2D_DTYPE)
+
+
+def as_pixels(a):
+    return conv_rec(a, _lib.PIXEL_DTYPE)
+
+
+def close(a, b, rtol=RTOL, scale=None, err_msg=""):
+    a = np.asarray(a, dtype="f8")
+    b = np.asarray(b, dtype="f8")
+    if scale is None:
+        scale = np.abs(b).max() if b.size else 0.0
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=rtol * scale, err_msg=err_msg)
+
+
+# ------------------------------------------------------------ weighted sums
+def test_weighted_sums_seam_and_batch(golden):
+    from ngmix_amd.batch import StampBatch, GMixBatch, records_to_numpy
+    g = golden("wsums")
+    L = _lib.lib()
+    for name in [str(n) for n in g["names"]]:
+        ref = g[name + "_res"]
+        nmom = ref["sums"].shape[-1]
+        dt = _lib.moments_result_dtype(nmom)
+        wt = as_gauss(g[name + "_wt"])
+        pixels = as_pixels(g[name + "_pixels"])
+        maxrad = float(g[name + "_maxrad"])
+        res = np.zeros(1, dtype=dt)
+        assert L.ngmix_get_weighted_sums(_lib.ptr(wt), wt.size, _lib.ptr(pixels),
+                                         pixels.size, _lib.ptr(res), nmom,
+                                         maxrad) == 0, name
+        sb = StampBatch.from_images(g[name + "_image"], g[name + "_weight"],
+                                    g[name + "_jac"],
+                                    ignore_zero_weight=bool(g[name + "_izw"]))
+        bres, status = sb.weighted_sums(GMixBatch.from_numpy(wt), maxrad, nmom=nmom)
+        assert int(status.cpu()[0]) == 0
+        bres = records_to_numpy(bres, dt)
+        for got in (res, bres):
+            assert got["npix"][0] == ref["npix"][0], name
+            # same summation order as the reference; only exp() differs (ulps)
+            for f in ("wsum", "sums", "sums_cov"):
+                close(got[f][0], ref[f][0], rtol=1e-13, err_msg="%s %s" % (name, f))
+            np.testing.assert_allclose(got["F"][0], ref["F"][0], rtol=1e-15, atol=0)
+        # seam and batch forms run the same arithmetic in the same order
+        for f in ("wsum", "sums", "sums_cov", "F"):
+            np.testing.assert_array_equal(res[f], bres[f])
+        # accumulate-into: a second call doubles
+        assert L.ngmix_get_weighted_sums(_lib.ptr(wt), wt.size, _lib.ptr(pixels),
+                                         pixels.size, _lib.ptr(res), nmom,
+                                         maxrad) == 0
+        close(res["sums"][0], 2 * ref["sums"][0], rtol=1e-13)
+        assert res["npix"][0] == 2 * ref["npix"][0]
+
+
+def test_weighted_sums_zero_ierr():
+    L = _lib.lib()
+    wt = np.zeros(1, dtype=_lib.GAUSS2D_DTYPE)
+    wt["p"] = wt["irr"] = wt["icc"] = wt["det"] = 1.0
+    assert L.ngmix_set_norms(_lib.ptr(wt), 1) == 0
+    pix = np.zeros(3, dtype=_lib.PIXEL_DTYPE)
+    pix["area"] = 1.0
+    pix["ierr"] = [1.0, 0.0, 1.0]
+    res = np.zeros(1, dtype=_lib.moments_result_dtype(17))
+    assert L.ngmix_get_weighted_sums(_lib.ptr(wt), 1, _lib.ptr(pix), 3,
+                                     _lib.ptr(res), 17, 100.0) == _lib.ERR_ZERO_DIV
+    res = np.zeros(1, dtype=_lib.moments_result_dtype(6))
+    assert L.ngmix_get_weighted_sums(_lib.ptr(wt), 1, _lib.ptr(pix), 3,
+                                     _lib.ptr(res), 6, 100.0) == 0
+    assert res["npix"][0] == 2
+
+
+# -------------------------------------------------------------------- admom
+def _check_admom(name, res, wt, ref, ref_wt):
+    assert res["flags"][0] == ref["flags"][0], name
+    assert res["numiter"][0] == ref["numiter"][0], name
+    assert res["npix"][0] == ref["npix"][0], name
+    close(res["wsum"][0], ref["wsum"][0], err_msg=name)
+    close(res["sums"][0], ref["sums"][0], err_msg=name + " sums")
+    close(res["sums_cov"][0], ref["sums_cov"][0], err_msg=name + " cov")
+    np.testing.assert_array_equal(np.isnan(res["pars"][0]), np.isnan(ref["pars"][0]))
+    if not np.isnan(ref["pars"][0]).any():
+        close(res["pars"][0], ref["pars"][0], err_msg=name + " pars")
+        close(res["rho4"][0], ref["rho4"][0], err_msg=name + " rho4")
+    close(res["F"][0], ref["F"][0], rtol=1e-9, err_msg=name + " F")
+    for f in ("row", "col", "irr", "irc", "icc", "det"):
+        close(wt[f], ref_wt[f], scale=1.0, err_msg=name + " wt " + f)
+
+
+def test_admom_seam_and_batch(golden):
+    from ngmix_amd.batch import StampBatch, GMixBatch, records_to_numpy
+    g = golden("admom")
+    L = _lib.lib()
+    for name in [str(n) for n in g["names"]]:
+        conf = conv_rec(g[name + "_conf"], _lib.ADMOM_CONF_DTYPE)
+        ref = g[name + "_res"]
+        ref_wt = g[name + "_wt_out"]
+        # seam form on the reference's pixel array
+        wt = as_gauss(g[name + "_wt_in"])
+        pixels = as_pixels(g[name + "_pixels"])
+        res = np.zeros(1, dtype=_lib.ADMOM_RESULT_DTYPE)
+        st = L.ngmix_admom(_lib.ptr(conf), _lib.ptr(wt), _lib.ptr(pixels),
+                           pixels.size, _lib.ptr(res))
+        assert st == 0, name
+        _check_admom(name + " seam", res, wt, ref, ref_wt)
+        # batch form on the compact store
+        sb = StampBatch.from_images(g[name + "_image"], g[name + "_weight"],
+                                    g[name + "_jac"],
+                                    ignore_zero_weight=bool(g[name + "_izw"]))
+        wtb = GMixBatch.from_numpy(as_gauss(g[name + "_wt_in"]))
+        bres, status = sb.admom(wtb, maxiter=int(conf["maxiter"][0]),
+                                shiftmax=float(conf["shiftmax"][0]),
+                                etol=float(conf["etol"][0]),
+                                Ttol=float(conf["Ttol"][0]),
+                                cenonly=bool(conf["cenonly"][0]))
+        assert int(status.cpu()[0]) == 0, name
+        bres = records_to_numpy(bres, _lib.ADMOM_RESULT_DTYPE)
+        _check_admom(name + " batch", bres, wtb.to_numpy()[0], ref, ref_wt)
+
+
+def test_admom_batch_many_vs_oracle():
+    """32x32 config-4-like stamps: every record against the CPU oracle"""
+    from ngmix_amd.batch import StampBatch, GMixBatch, records_to_numpy
+    from oracle import oracle as ora
+    rng = np.random.RandomState(31)
+    n, dim, scale = 48, 32, 0.263
+    pars = np.zeros((n, 6))
+    pars[:, 0:2] = rng.uniform(-0.5, 0.5, size=(n, 2)) * scale
+    pars[:, 2:4] = rng.normal(scale=0.1, size=(n, 2))
+    pars[:, 4] = rng.uniform(0.3, 0.9, size=n) + 0.27
+    pars[:, 5] = rng.uniform(50, 200, size=n)
+    gm, _ = GMixBatch.from_pars(pars, "gauss")
+    jac = np.array([15.5, 15.5, scale, 0, 0, scale, scale ** 2, scale])
+    sb0 = StampBatch.from_images(np.zeros((n, dim, dim)), None, jac)
+    truth, _ = sb0.render(gm)
+    images = truth.cpu().numpy().reshape(n, dim, dim) + \
+        rng.normal(scale=0.01, size=(n, dim, dim))
+    weights = np.full((n, dim, dim), 1e4)
+    weights[3, 5, 5] = 0.0
+    sb = StampBatch.from_images(images, weights, jac)
+    guess = np.zeros((n, 6))
+    guess[:, 4] = pars[:, 4] * rng.uniform(0.9, 1.1, size=n)
+    guess[:, 5] = 1.0
+    wt, _ = GMixBatch.from_pars(guess, "gauss")
+    wt_in = wt.to_numpy()
+    res, status = sb.admom(wt)
+    assert int(status.abs().sum()) == 0
+    res = records_to_numpy(res, _lib.ADMOM_RESULT_DTYPE)
+    wt_out = wt.to_numpy()
+    j = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+    j[0] = tuple(jac)
+    conf = np.zeros(1, dtype=ora.ADMOM_CONF_DTYPE)
+    conf["maxiter"], conf["shiftmax"], conf["etol"], conf["Ttol"] = 200, 5.0, 1e-5, 1e-3
+    for i in range(n):
+        pix = ora.make_pixels(images[i], weights[i], j, True)
+        w = conv_rec(wt_in[i], ora.GAUSS2D_DTYPE)
+        r = np.zeros(1, dtype=ora.ADMOM_RESULT_DTYPE)
+        assert ora.admom(conf, w, pix, r) == 0
+        _check_admom("stamp %d" % i, res[i:i + 1], wt_out[i], r, w)
+        assert r["flags"][0] == 0 and 3 <= r["numiter"][0] <= 30
+
+
+def test_admom_errors():
+    """ierr == 0 in the list -> ZeroDivisionError; maxiter=0 -> MAXITER"""
+    L = _lib.lib()
+    conf = np.zeros(1, dtype=_lib.ADMOM_CONF_DTYPE)
+    conf["maxiter"], conf["shiftmax"], conf["etol"], conf["Ttol"] = 10, 5.0, 1e-5, 1e-3
+    wt = np.zeros(1, dtype=_lib.GAUSS2D_DTYPE)
+    wt["p"] = 1.0
+    wt["irr"] = wt["icc"] = 2.0
+    wt["det"] = 4.0
+    pix = np.zeros(25, dtype=_lib.PIXEL_DTYPE)
+    pix["v"] = np.repeat(np.arange(5.0) - 2, 5)
+    pix["u"] = np.tile(np.arange(5.0) - 2, 5)
+    pix["area"] = 1.0
+    pix["val"] = np.exp(-0.25 * (pix["v"] ** 2 + pix["u"] ** 2))
+    pix["ierr"] = 1.0
+    pix["ierr"][7] = 0.0
+    res = np.zeros(1, dtype=_lib.ADMOM_RESULT_DTYPE)
+    st = L.ngmix_admom(_lib.ptr(conf), _lib.ptr(wt.copy()), _lib.ptr(pix), 25,
+                       _lib.ptr(res))
+    assert st == _lib.ERR_ZERO_DIV
+    conf["maxiter"] = 0
+    res = np.zeros(1, dtype=_lib.ADMOM_RESULT_DTYPE)
+    st = L.ngmix_admom(_lib.ptr(conf), _lib.ptr(wt.copy()), _lib.ptr(pix), 25,
+                       _lib.ptr(res))
+    assert st == 0 and res["numiter"][0] == 0 and res["flags"][0] == 32
+
+
+# ----------------------------------------------------------------------- em
+def _check_em(name, numiter, frac, sky, gm, conv, g):
+    assert numiter == int(g[name + "_numiter"]), name
+    assert abs(frac - float(g[name + "_frac_diff"])) <= \
+        1e-6 * abs(float(g[name + "_frac_diff"])) + 1e-11, name
+    close(sky, float(g[name + "_sky"]), scale=1.0, err_msg=name)
+    for f in ("p", "row", "col", "irr", "irc", "icc", "det"):
+        close(gm[f], g[name + "_gmix_out"][f], err_msg="%s gmix %s" % (name, f),
+              scale=max(np.abs(g[name + "_gmix_out"][f]).max(), 1e-3))
+        close(conv[f], g[name + "_conv_out"][f], err_msg="%s conv %s" % (name, f),
+              scale=max(np.abs(g[name + "_conv_out"][f]).max(), 1e-3))
+    assert np.all(gm["norm_set"] == 0)
+    assert np.all(conv["norm_set"] == 1)
+
+
+def test_em_seam_and_batch(golden):
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    g = golden("em")
+    L = _lib.lib()
+    for name in [str(n) for n in g["names"]]:
+        kind = int(g[name + "_kind"])
+        conf = conv_rec(g[name + "_conf"], _lib.EM_CONF_DTYPE)
+        fzw = bool(g[name + "_fzw"])
+        # seam
+        pixels = as_pixels(g[name + "_pixels"])
+        gm = as_gauss(g[name + "_gmix_in"])
+        psf = as_gauss(g[name + "_psf_in"])
+        conv = as_gauss(g[name + "_conv_in"])
+        sums = np.zeros((gm.size, _lib.EM_SUMS_NDOUBLE[kind]))
+        numiter = ctypes.c_int32()
+        frac, sky = ctypes.c_double(), ctypes.c_double()
+        st = L.ngmix_em_run(kind, _lib.ptr(conf), _lib.ptr(pixels), pixels.size,
+                            _lib.ptr(sums), _lib.ptr(gm), gm.size, _lib.ptr(psf),
+                            psf.size, _lib.ptr(conv), int(fzw),
+                            ctypes.byref(numiter), ctypes.byref(frac),
+                            ctypes.byref(sky))
+        assert st == 0, name
+        _check_em(name, numiter.value, frac.value, sky.value, gm, conv, g)
+        # batch
+        sb = StampBatch.from_images(g[name + "_image"], g[name + "_weight"],
+                                    g[name + "_jac"],
+                                    ignore_zero_weight=bool(g[name + "_izw"]))
+        gmb = GMixBatch.from_numpy(as_gauss(g[name + "_gmix_in"]))
+        psfb = GMixBatch.from_numpy(as_gauss(g[name + "_psf_in"]))
+        convb = GMixBatch.from_numpy(as_gauss(g[name + "_conv_in"]))
+        out, status, _ = sb.em(gmb, psfb, convb, sky=float(conf["sky"][0]),
+                               kind=kind, miniter=int(conf["miniter"][0]),
+                               maxiter=int(conf["maxiter"][0]),
+                               tol=float(conf["tol"][0]),
+                               vary_sky=bool(conf["vary_sky"][0]),
+                               fill_zero_weight=fzw)
+        assert int(status.cpu()[0]) == 0, name
+        out = out.cpu().numpy()[0]
+        _check_em(name + " batch", int(out[0]), out[1], out[2], gmb.to_numpy()[0],
+                  convb.to_numpy()[0], g)
+
+
+def test_em_errors():
+    L = _lib.lib()
+    conf = np.zeros(1, dtype=_lib.EM_CONF_DTYPE)
+    conf["maxiter"], conf["miniter"], conf["tol"] = 10, 2, 1e-5
+    pix = np.zeros(9, dtype=_lib.PIXEL_DTYPE)
+    pix["area"] = pix["ierr"] = pix["val"] = 1.0
+    pix["v"] = np.repeat(np.arange(3.0) + 100, 3)
+    pix["u"] = np.tile(np.arange(3.0) + 100, 3)
+
+    def setup():
+        gm = np.zeros(1, dtype=_lib.GAUSS2D_DTYPE)
+        L.ngmix_fill_model(_lib.ptr(gm), 1, 1,
+                           _lib.ptr(np.array([0, 0, 0, 0, 1.0, 1.0])), 6)
+        psf = np.zeros(1, dtype=_lib.GAUSS2D_DTYPE)
+        L.ngmix_fill_model(_lib.ptr(psf), 1, 1,
+                           _lib.ptr(np.array([0, 0, 0, 0, 0.0, 1.0])), 6)
+        conv = np.zeros(1, dtype=_lib.GAUSS2D_DTYPE)
+        L.ngmix_convolve_fill(_lib.ptr(conv), _lib.ptr(gm), 1, _lib.ptr(psf), 1)
+        return gm, psf, conv
+
+    def run():
+        gm, psf, conv = setup()
+        sums = np.zeros((1, 14))
+        numiter = ctypes.c_int32()
+        frac, sky = ctypes.c_double(), ctypes.c_double()
+        st = L.ngmix_em_run(0, _lib.ptr(conf), _lib.ptr(pix), 9, _lib.ptr(sums),
+                            _lib.ptr(gm), 1, _lib.ptr(psf), 1, _lib.ptr(conv), 0,
+                            ctypes.byref(numiter), ctypes.byref(frac),
+                            ctypes.byref(sky))
+        return st, numiter.value
+
+    assert run()[0] == _lib.ERR_GTOT_ZERO        # sky 0, all values 0
+    conf["sky"] = 1.0
+    assert run()[0] == _lib.ERR_ZERO_DIV         # pnew == 0 -> 1/p
+    conf["maxiter"] = 0
+    st, numiter = run()
+    assert st == 0 and numiter == 0              # EM_MAXITER by numiter>=maxiter
+
+
+# ------------------------------------------------------------- deriv_images
+def test_deriv_images_seam_and_batch(golden):
+    from ngmix_amd.batch import StampBatch
+    g = golden("derivs")
+    L = _lib.lib()
+    nrow, ncol = [int(x) for x in g["dims"]]
+    v = np.ascontiguousarray(g["v"])
+    u = np.ascontiguousarray(g["u"])
+    area = np.ascontiguousarray(g["area"])
+    for name in [str(n) for n in g["names"]]:
+        gpars = np.ascontiguousarray(g[name + "_gpars"])
+        dcov = np.ascontiguousarray(g[name + "_dcov"])
+        out = np.zeros((6, v.size))
+        assert L.ngmix_deriv_images(_lib.ptr(gpars), _lib.ptr(dcov), gpars.shape[0],
+                                    _lib.ptr(v), _lib.ptr(u), _lib.ptr(area),
+                                    v.size, _lib.ptr(out)) == 0
+        np.testing.assert_array_equal(out, g[name + "_out"], err_msg=name)
+        sb = StampBatch.from_images(np.zeros((1, nrow, ncol)), None, g["jac"])
+        bout = sb.deriv_images(gpars, dcov, gpars.shape[0])
+        np.testing.assert_array_equal(bout.cpu().numpy().reshape(6, -1),
+                                      g[name + "_out"], err_msg=name + " batch")
+
+
+def test_deriv_images_masked_layout(golden):
+    """masked stamps: the batch form writes only the reference's pixel list"""
+    from ngmix_amd.batch import StampBatch
+    g = golden("derivs")
+    nrow, ncol = [int(x) for x in g["dims"]]
+    name = "exp_psf1"
+    gpars, dcov = g[name + "_gpars"], g[name + "_dcov"]
+    w = np.ones((2, nrow, ncol))
+    w[1, 3, 4] = 0.0
+    w[1, 10, :5] = 0.0
+    sb = StampBatch.from_images(np.zeros((2, nrow, ncol)), w,
+                                np.tile(g["jac"].view("f8").reshape(1, 8), (2, 1)))
+    gp2 = np.concatenate([gpars, gpars])
+    dc2 = np.concatenate([dcov, dcov])
+    out = sb.deriv_images(gp2, dc2, gpars.shape[0]).cpu().numpy()
+    n0 = nrow * ncol
+    full = g[name + "_out"]
+    np.testing.assert_array_equal(out[:6 * n0].reshape(6, n0), full)
+    keep = (w[1] > 0).ravel()
+    nk = int(keep.sum())
+    np.testing.assert_array_equal(out[6 * n0:].reshape(6, nk), full[:, keep])
