@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--nstamps", type=int, default=100000,
                     help="stamps per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact", action="store_true",
+                    help="time the exact (no-FMA, bit-identical) kernels "
+                         "instead of the default fused ones")
     args = ap.parse_args()
 
     import torch
@@ -186,13 +189,13 @@ def main():
         nonlocal pending
         if i is not None:
             ev_r0[i].record()
-        sb.render(gm, image=image, fast_exp=True, status=status)
+        sb.render(gm, image=image, fast_exp=True, status=status, exact=args.exact)
         if i is not None:
             ev_r1[i].record()
         if pending is not None:
             # the previous step's gather must have consumed `out`
             torch.cuda.current_stream().wait_event(pending)
-        sb.loglike(gm, out=out, status=status)
+        sb.loglike(gm, out=out, status=status, exact=args.exact)
         if i is not None:
             ev_l1[i].record()
         if distributed:
@@ -264,7 +267,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "pixpass_grid_kernel<%s>" % dominant,
+                "kernel": "pixpass_%s_kernel<%s>" % (
+                    "grid" if args.exact else "fused", dominant),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -277,6 +281,7 @@ def main():
             "loglike_stamp_evals_per_s_per_gpu": n / (loglike_ms * 1e-3),
             "render_stamp_evals_per_s_per_gpu": n / (render_ms * 1e-3),
             "bad_status": bad,
+            "kernel_mode": "exact" if args.exact else "fused",
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sb, gm)

@@ -258,6 +258,11 @@ typedef struct {
 
 /* diagnostic: evaluate every (gaussian, pixel) pair, no exact skipping */
 #define NGMIX_BATCH_NO_SKIP 1
+/* render / loglike / fdiff / s2n: use the EXACT kernels (no FMA contraction,
+   the reference's operation order: per-pixel values bit-identical to the
+   reference) instead of the default FUSED kernels (FMA + shared-centre
+   algebra: the same values to <= ~1e-13 relative, about twice as fast) */
+#define NGMIX_BATCH_EXACT 2
 
 /* A batch of stamps: HOST struct holding DEVICE pointers plus the few host
    facts a launch needs (LDS sizing, tile schedule). */

@@ -39,6 +39,7 @@ _RANGE_MESSAGES = {
 
 STAMP_IGNORE_ZERO_WEIGHT = 1
 BATCH_NO_SKIP = 1
+BATCH_EXACT = 2
 
 # ---- record layouts = the reference's numpy dtypes ----
 GAUSS2D_DTYPE = np.dtype([

@@ -306,7 +306,7 @@ class StampBatch(object):
                 self.npix_kept, gm_off.astype(np.int32), ngauss)
         return self._stamp_tables[ngauss]
 
-    def _batch(self, ngauss, no_skip=False):
+    def _batch(self, ngauss, no_skip=False, exact=False):
         b = _lib.Batch()
         b.nstamps = self.n
         b.stamps = self.stamp_table(ngauss).data_ptr()
@@ -316,7 +316,8 @@ class StampBatch(object):
         b.max_ngauss = ngauss
         b.max_npix = self.max_npix
         b.any_masked = int(self.any_masked)
-        b.flags = _lib.BATCH_NO_SKIP if no_skip else 0
+        b.flags = (_lib.BATCH_NO_SKIP if no_skip else 0) | \
+            (_lib.BATCH_EXACT if exact else 0)
         return b
 
     def kept_offsets(self):
@@ -326,11 +327,16 @@ class StampBatch(object):
         return np.concatenate([[0], np.cumsum(kept)[:-1]]).astype(np.int64)
 
     # ----------------------------------------------------------- operations
-    def loglike(self, gm, out=None, status=None, no_skip=False):
+    def loglike(self, gm, out=None, status=None, no_skip=False, exact=False):
         """
         get_loglike for every stamp (gmix_nb.py:824-874) in one launch.
         Returns (out, status): out is (N, 4) = loglike, s2n_numer, s2n_denom,
         npix.  Norms are set lazily in-kernel as in the reference.
+
+        exact=False (default): fused kernels (FMA, shared-centre algebra),
+        per-pixel model values within ~1e-13 relative of the reference.
+        exact=True: no-FMA kernels in the reference's operation order,
+        per-pixel values bit-identical to the reference (about 2x slower).
         """
         torch = _torch()
         assert gm.n == self.n
@@ -338,7 +344,7 @@ class StampBatch(object):
             out = torch.empty((self.n, 4), dtype=torch.float64, device=self.device)
         if status is None:
             status = torch.empty(self.n, dtype=torch.int32, device=self.device)
-        b = self._batch(gm.ngauss, no_skip)
+        b = self._batch(gm.ngauss, no_skip, exact)
         with torch.cuda.device(self.device):
             st = _lib.lib().ngmix_loglike_batch(
                 ctypes.byref(b), _dptr(gm.data), _dptr(out), _dptr(status),
@@ -347,7 +353,7 @@ class StampBatch(object):
         return out, status
 
     def fill_fdiff(self, gm, fdiff=None, fdiff_start=None, status=None,
-                   no_skip=False):
+                   no_skip=False, exact=False):
         """
         fill_fdiff for every stamp (gmix_nb.py:877-900): the k-th kept pixel
         of stamp i goes to fdiff[fdiff_start[i] + k].  Default layout packs the
@@ -365,7 +371,7 @@ class StampBatch(object):
                                 device=self.device)
         if status is None:
             status = torch.empty(self.n, dtype=torch.int32, device=self.device)
-        b = self._batch(gm.ngauss, no_skip)
+        b = self._batch(gm.ngauss, no_skip, exact)
         with torch.cuda.device(self.device):
             st = _lib.lib().ngmix_fill_fdiff_batch(
                 ctypes.byref(b), _dptr(gm.data), _dptr(fdiff),
@@ -373,7 +379,8 @@ class StampBatch(object):
         _lib.check(st, "ngmix_fill_fdiff_batch")
         return fdiff, status
 
-    def render(self, gm, image=None, fast_exp=True, status=None, no_skip=False):
+    def render(self, gm, image=None, fast_exp=True, status=None, no_skip=False,
+               exact=False):
         """
         render every stamp's mixture (render_nb.py:9-36), ADDING into `image`
         (flat, same layout as val); a zeroed image is made when none is given
@@ -386,7 +393,7 @@ class StampBatch(object):
                                 device=self.device)
         if status is None:
             status = torch.empty(self.n, dtype=torch.int32, device=self.device)
-        b = self._batch(gm.ngauss, no_skip)
+        b = self._batch(gm.ngauss, no_skip, exact)
         with torch.cuda.device(self.device):
             st = _lib.lib().ngmix_render_batch(
                 ctypes.byref(b), _dptr(gm.data), _dptr(image), int(fast_exp),
@@ -394,7 +401,7 @@ class StampBatch(object):
         _lib.check(st, "ngmix_render_batch")
         return image, status
 
-    def model_s2n_sum(self, gm, out=None, status=None):
+    def model_s2n_sum(self, gm, out=None, status=None, exact=False):
         """get_model_s2n_sum per stamp (gmix_nb.py:903-937)"""
         torch = _torch()
         assert gm.n == self.n
@@ -402,7 +409,7 @@ class StampBatch(object):
             out = torch.empty(self.n, dtype=torch.float64, device=self.device)
         if status is None:
             status = torch.empty(self.n, dtype=torch.int32, device=self.device)
-        b = self._batch(gm.ngauss)
+        b = self._batch(gm.ngauss, False, exact)
         with torch.cuda.device(self.device):
             st = _lib.lib().ngmix_model_s2n_sum_batch(
                 ctypes.byref(b), _dptr(gm.data), _dptr(out), _dptr(status),
@@ -531,3 +538,129 @@ def records_to_numpy(t, dtype):
     """view an (N, nbytes/8) float64 record tensor as a structured array"""
     a = t.detach().cpu().numpy()
     return a.reshape(-1).view(dtype).copy()
+
+
+# ---------------------------------------------------------------------------
+# single-object conveniences used by the GMix / Observation host classes: a
+# one-stamp batch kept resident on the device so repeated evaluations (an LM
+# fit calls fill_fdiff hundreds of times on the same pixels) upload only the
+# 104-byte-per-gaussian mixture.
+# ---------------------------------------------------------------------------
+
+def _gm_batch(gm_data, device):
+    return GMixBatch.from_numpy(np.ascontiguousarray(gm_data), device=device)
+
+
+def _raise_status(status, context):
+    st = int(status.cpu()[0])
+    if st != 0:
+        _lib.check(st, context)
+
+
+def _writeback_gm(gm_data, gmb):
+    """mirror in-kernel mutation of the mixture (norms, admom/em updates)
+    onto the caller's host record array, as the reference mutates it"""
+    gm_data[:] = gmb.to_numpy()[0]
+
+
+def render_single(gm_data, image, jac_record, fast_exp, exact=False):
+    """ADD the mixture into a host image (GMix._fill_image)"""
+    torch = _torch()
+    dev = _require_cuda(None)
+    nrow, ncol = image.shape
+    jac = np.ascontiguousarray(jac_record).view(np.float64).reshape(1, 8)
+    sb = StampBatch(None, None, _as_device_f64(jac, dev), [nrow], [ncol], [0], True)
+    gmb = _gm_batch(gm_data, dev)
+    dimg = torch.from_numpy(np.ascontiguousarray(image, dtype="f8").ravel()).to(dev)
+    _, status = sb.render(gmb, image=dimg, fast_exp=fast_exp, exact=exact)
+    _raise_status(status, "render")
+    _writeback_gm(gm_data, gmb)
+    image[:, :] = dimg.cpu().numpy().reshape(nrow, ncol)
+
+
+class SingleStamp(object):
+    """an Observation's pixels resident on the device (1-stamp StampBatch)"""
+
+    def __init__(self, image, weight, jac_record, ignore_zero_weight, device=None):
+        self.sb = StampBatch.from_images(
+            np.asarray(image, dtype="f8")[None], np.asarray(weight, dtype="f8")[None],
+            np.ascontiguousarray(jac_record).view(np.float64).reshape(1, 8),
+            ignore_zero_weight=ignore_zero_weight, device=device)
+        self.device = self.sb.device
+
+    @property
+    def npix_kept(self):
+        return int(self.sb.npix_kept[0])
+
+    def loglike_single(self, gm_data, exact=False):
+        gmb = _gm_batch(gm_data, self.device)
+        out, status = self.sb.loglike(gmb, exact=exact)
+        _raise_status(status, "get_loglike")
+        _writeback_gm(gm_data, gmb)
+        o = out.cpu().numpy()[0]
+        return float(o[0]), float(o[1]), float(o[2]), int(o[3])
+
+    def fdiff_single(self, gm_data, fdiff, start, exact=False):
+        torch = _torch()
+        gmb = _gm_batch(gm_data, self.device)
+        nk = self.npix_kept
+        d = torch.empty(nk, dtype=torch.float64, device=self.device)
+        _, status = self.sb.fill_fdiff(gmb, fdiff=d, fdiff_start=np.zeros(1, "i8"),
+                                       exact=exact)
+        _raise_status(status, "fill_fdiff")
+        _writeback_gm(gm_data, gmb)
+        fdiff[start:start + nk] = d.cpu().numpy()
+
+    def s2n_single(self, gm_data, exact=False):
+        gmb = _gm_batch(gm_data, self.device)
+        out, status = self.sb.model_s2n_sum(gmb, exact=exact)
+        _raise_status(status, "get_model_s2n_sum")
+        _writeback_gm(gm_data, gmb)
+        return float(out.cpu()[0])
+
+    def wsums_single(self, gm_data, res, nmom, maxrad):
+        """res: numpy record (void scalar) accumulated into"""
+        torch = _torch()
+        gmb = _gm_batch(gm_data, self.device)
+        dt = _lib.moments_result_dtype(nmom)
+        host = np.zeros(1, dtype=dt)
+        for n in dt.names:
+            host[n] = res[n]
+        dres = torch.from_numpy(host.view(np.float64).reshape(1, -1).copy()).to(self.device)
+        _, status = self.sb.weighted_sums(gmb, maxrad, nmom=nmom, res=dres)
+        _raise_status(status, "get_weighted_sums")
+        back = records_to_numpy(dres, dt)
+        for n in dt.names:
+            res[n] = back[n][0]
+
+    def admom_single(self, wt_data, conf, res):
+        """conf / res: 1-element record arrays (reference dtypes); wt and res
+        are updated in place.  Returns the C-ABI status."""
+        torch = _torch()
+        wtb = _gm_batch(wt_data, self.device)
+        dres = torch.from_numpy(
+            np.ascontiguousarray(res).view(np.float64).reshape(1, -1).copy()
+        ).to(self.device)
+        c = conf[0] if conf.ndim else conf
+        _, status = self.sb.admom(
+            wtb, maxiter=int(c["maxiter"]), shiftmax=float(c["shiftmax"]),
+            etol=float(c["etol"]), Ttol=float(c["Ttol"]), cenonly=bool(c["cenonly"]),
+            res=dres)
+        res[:] = records_to_numpy(dres, _lib.ADMOM_RESULT_DTYPE)
+        _writeback_gm(wt_data, wtb)
+        return int(status.cpu()[0])
+
+    def em_single(self, kind, conf, gm_data, psf_data, conv_data, fill_zero_weight):
+        """returns (status, numiter, frac_diff, sky); mixtures updated in place"""
+        gmb = _gm_batch(gm_data, self.device)
+        psfb = _gm_batch(psf_data, self.device)
+        convb = _gm_batch(conv_data, self.device)
+        out, status, _ = self.sb.em(
+            gmb, psfb, convb, sky=float(conf["sky"]), kind=kind,
+            miniter=int(conf["miniter"]), maxiter=int(conf["maxiter"]),
+            tol=float(conf["tol"]), vary_sky=bool(conf["vary_sky"]),
+            fill_zero_weight=fill_zero_weight)
+        o = out.cpu().numpy()[0]
+        _writeback_gm(gm_data, gmb)
+        _writeback_gm(conv_data, convb)
+        return int(status.cpu()[0]), int(o[0]), float(o[1]), float(o[2])

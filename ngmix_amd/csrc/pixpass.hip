@@ -60,19 +60,20 @@ static size_t lds_bytes(int max_ngauss, int nchunks_cap)
            (size_t)nchunks_cap * 12 + 16;
 }
 
-// Stage table + gaussians; set norms lazily exactly as the reference does
-// (gmix_nb.py:850-851: all of them when gmix[0].norm_set == 0, stopping at
-// the first failure).  Returns the status for the stamp (uniform).
-__device__ __forceinline__ int stage_gaussians(const LdsLayout &L,
-                                               ngmix_gauss2d *gm, int ng,
-                                               const ngmix_jacobian &jac,
-                                               bool want_box)
+// Set norms lazily exactly as the reference does (gmix_nb.py:850-851: all of
+// them when gmix[0].norm_set == 0, stopping at the first failure; gaussians
+// before the failing one keep their fresh norms).  Also stages the exp table.
+// Returns the status for the stamp (uniform across the work-group).
+__device__ __forceinline__ int lazy_norms(const LdsLayout &L, ngmix_gauss2d *gm,
+                                          int ng)
 {
     const int tid = threadIdx.x;
     if (tid < 16) L.tab[tid] = c_exp_table[tid];
     if (tid == 0) {
         L.ctl[0] = 1 << 30;  // index of first failing gaussian
         L.ctl[1] = 0;        // its error code
+        L.ctl[2] = 1;        // all gaussians share one centre (fused kernel)
+        L.ctl[3] = 1;        // all chi2 forms positive definite (fused kernel)
     }
     __syncthreads();
     const bool need = ng > 0 && gm[0].norm_set == 0;
@@ -97,7 +98,17 @@ __device__ __forceinline__ int stage_gaussians(const LdsLayout &L,
         __syncthreads();
         if (L.ctl[1] != 0) return L.ctl[1];
     }
-    for (int g = tid; g < ng; g += BLOCK) {
+    return NGMIX_OK;
+}
+
+__device__ __forceinline__ int stage_gaussians(const LdsLayout &L,
+                                               ngmix_gauss2d *gm, int ng,
+                                               const ngmix_jacobian &jac,
+                                               bool want_box)
+{
+    const int st = lazy_norms(L, gm, ng);
+    if (st != NGMIX_OK) return st;
+    for (int g = threadIdx.x; g < ng; g += BLOCK) {
         ngmix_gauss2d t = gm[g];
         GaussLds r;
         r.e = make_eval(t);
@@ -257,6 +268,273 @@ __global__ __launch_bounds__(BLOCK) void pixpass_grid_kernel(
     }
 }
 
+// ===========================================================================
+// FUSED kernel: same results to rounding (<= ~1e-13 relative per pixel for
+// ordinary ellipticities; north_star tolerance 1e-10), about half the VALU
+// instructions of the exact kernel, which is what bounds this path.
+//
+//  * chi2 with FMAs; when every gaussian of the stamp has the same centre
+//    (object (x) centred psf) dv^2, du^2, dv*du are formed once per pixel and
+//    each gaussian costs 3 FMAs;
+//  * the gates 0 <= chi2 < 25 and chi2 >= 20 are single unsigned compares on
+//    the high word of chi2 -- exactly the reference's predicate when the form
+//    is positive definite (chi2 is then never -0.0; negative, NaN and inf fail
+//    the unsigned compare as they fail the reference's); W(20) == 1 exactly;
+//  * Horner with FMAs, pnorm*area folded into the accumulation;
+//  * tile-outer / gaussian-inner: one tile's state in registers, the mask of
+//    gaussians whose chi2<25 box touches the tile comes from one ballot.
+// The summation order over gaussians (index order) and the gate semantics
+// are the reference's; only the rounding of individual operations differs.
+// ===========================================================================
+
+struct GaussFused {
+    double a, b, c, pa;  // chi2 = a dv^2 + b du^2 + c dv du ; pa = pnorm*area
+    double row, col;
+    PixBox box;
+};
+static_assert(sizeof(GaussFused) == 64, "GaussFused");
+
+__device__ __forceinline__ int stage_gaussians_fused(const LdsLayout &L,
+                                                     ngmix_gauss2d *gm, int ng,
+                                                     const ngmix_jacobian &jac,
+                                                     double area, bool want_box)
+{
+    const int st = lazy_norms(L, gm, ng);
+    if (st != NGMIX_OK) return st;
+    GaussFused *gf = (GaussFused *)L.gl;
+    const double row0 = ng > 0 ? gm[0].row : 0.0, col0 = ng > 0 ? gm[0].col : 0.0;
+    for (int g = threadIdx.x; g < ng; g += BLOCK) {
+        const ngmix_gauss2d t = gm[g];
+        GaussFused r;
+        r.a = t.dcc;
+        r.b = t.drr;
+        r.c = -2.0 * t.drc;
+        r.pa = t.pnorm * area;
+        r.row = t.row;
+        r.col = t.col;
+        r.box = want_box ? gauss_pixel_box(t, jac) : full_box();
+        gf[g] = r;
+        if (!(t.row == row0 && t.col == col0)) L.ctl[2] = 0;
+        const double detq = t.dcc * t.drr - t.drc * t.drc;
+        if (!(t.dcc > 0.0 && t.drr > 0.0 && detq > 0.0)) L.ctl[3] = 0;
+    }
+    __syncthreads();
+    return NGMIX_OK;
+}
+
+__device__ __forceinline__ double fexp_fused(double x, const double *tab)
+{
+    const int ival = (int)(x - 0.5);
+    const double f = x - (double)ival;
+    double p = fma(f, 0.008197933236258961, 0.042330947141114836);
+    p = fma(f, p, 0.16674612720799442);
+    p = fma(f, p, 0.49992478810274166);
+    p = fma(f, p, 0.999993601071577);
+    p = fma(f, p, 1.0000011318561302);
+    return tab[ival + 15] * p;
+}
+
+// Each wave walks its tiles of the stamp in a runtime loop with one tile's
+// state in registers (and the next tile's val/ierr loads already in flight):
+// ~68 VGPRs, so 7-8 waves per SIMD hide the HBM latency without staging the
+// pixels through LDS.  FAST = every gaussian of the stamp is positive
+// definite and shares one centre.
+template <int OP, bool FAST>
+__device__ __forceinline__ void fused_tiles(
+    const LdsLayout &L, const GaussFused *gf, int ng, const ngmix_stamp &st,
+    const ngmix_jacobian &jac, const double *__restrict__ sval,
+    const double *__restrict__ sierr, bool masked, double *out, int64_t out_base,
+    double &acc_ll, double &acc_sn, double &acc_sd)
+{
+    constexpr bool kNeedsVal = (OP == OP_LOGLIKE || OP == OP_FDIFF);
+    constexpr bool kNeedsIerr = (OP != OP_RENDER_FAST);
+    const int lane = lane_id(), w = wave_id();
+    const int lrow = lane >> 4, lcol = lane & 15;
+    const int nrow = st.nrow, ncol = st.ncol;
+    const int ntx = (ncol + TILE_W - 1) / TILE_W;
+    const int nty = (nrow + TILE_H - 1) / TILE_H;
+    const double cen_row = gf[0].row, cen_col = gf[0].col;
+
+    int ty = w / ntx, tx = w - ty * ntx;
+    // prefetch of the first tile
+    double nval = 0.0, nierr = 0.0;
+    {
+        const int row = ty * TILE_H + lrow, col = tx * TILE_W + lcol;
+        if (ty < nty && row < nrow && col < ncol) {
+            const int idx = row * ncol + col;
+            if (kNeedsVal) nval = sval[idx];
+            if (kNeedsIerr) nierr = sierr[idx];
+            if (OP == OP_RENDER_FAST) nval = out[st.pix_off + idx];
+        }
+    }
+    while (ty < nty) {
+        const int r0 = ty * TILE_H, c0 = tx * TILE_W;
+        const int row = r0 + lrow, col = c0 + lcol;
+        const bool inb = row < nrow && col < ncol;
+        const int idx = row * ncol + col;
+        const double pval = nval, pierr = nierr;
+        // next tile of this wave: issue its loads before computing this one
+        int nty_ = ty, ntx_ = tx + NWAVES;
+        while (ntx_ >= ntx) {
+            ntx_ -= ntx;
+            nty_++;
+        }
+        nval = 0.0;
+        nierr = 0.0;
+        {
+            const int row2 = nty_ * TILE_H + lrow, col2 = ntx_ * TILE_W + lcol;
+            if (nty_ < nty && row2 < nrow && col2 < ncol) {
+                const int idx2 = row2 * ncol + col2;
+                if (kNeedsVal) nval = sval[idx2];
+                if (kNeedsIerr) nierr = sierr[idx2];
+                if (OP == OP_RENDER_FAST) nval = out[st.pix_off + idx2];
+            }
+        }
+
+        const double rowdiff = (double)row - jac.row0;
+        const double coldiff = (double)col - jac.col0;
+        const double v = fma(jac.dvdrow, rowdiff, jac.dvdcol * coldiff);
+        const double u = fma(jac.dudrow, rowdiff, jac.dudcol * coldiff);
+        double dv = v - cen_row, du = u - cen_col;
+        double v2 = dv * dv, u2 = du * du, vu = dv * du;
+        double model = 0.0;
+
+        for (int g0 = 0; g0 < ng; g0 += WAVE) {
+            bool hit = false;
+            if (g0 + lane < ng) {
+                const PixBox box = gf[g0 + lane].box;
+                hit = r0 <= box.rmax && r0 + TILE_H - 1 >= box.rmin &&
+                      c0 <= box.cmax && c0 + TILE_W - 1 >= box.cmin;
+            }
+            unsigned long long gmask = __ballot(hit);
+            while (gmask) {
+                const int g = g0 + __builtin_ctzll(gmask);
+                gmask &= gmask - 1ull;
+                const GaussFused &G = gf[g];
+                const double ga = G.a, gb = G.b, gc = G.c, gpa = G.pa;
+                if (!FAST) {
+                    dv = v - G.row;
+                    du = u - G.col;
+                    v2 = dv * dv;
+                    u2 = du * du;
+                    vu = dv * du;
+                }
+                const double chi2 = fma(ga, v2, fma(gb, u2, gc * vu));
+                const unsigned hi = (unsigned)__double2hiint(chi2);
+                const bool pass = FAST ? (hi < 0x40390000u)
+                                       : (chi2 < MAX_CHI2 && chi2 >= 0.0);
+                if (pass) {
+                    double e = fexp_fused(-0.5 * chi2, L.tab);
+                    const bool band = FAST ? (hi >= 0x40340000u) : (chi2 > APOD_CHI2);
+                    if (band) e *= apod_window(chi2);
+                    model = fma(gpa, e, model);
+                }
+            }
+        }
+
+        if (inb) {
+            if (OP == OP_RENDER_FAST) {
+                out[st.pix_off + idx] = pval + model;
+            } else if (!masked || pierr > 0.0) {
+                if (OP == OP_LOGLIKE) {
+                    const double ivar = pierr * pierr;
+                    const double diff = model - pval;
+                    acc_ll = fma(diff * diff, ivar, acc_ll);
+                    acc_sn = fma(pval * model, ivar, acc_sn);
+                    acc_sd = fma(model * model, ivar, acc_sd);
+                } else if (OP == OP_S2N) {
+                    const double ivar = pierr * pierr;
+                    acc_sd = fma(model * model, ivar, acc_sd);
+                } else {
+                    const int rank = masked ? kept_rank(L.cmask, L.cpre, idx) : idx;
+                    out[out_base + rank] = (model - pval) * pierr;
+                }
+            }
+        }
+        ty = nty_;
+        tx = ntx_;
+    }
+}
+
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void pixpass_fused_kernel(
+    const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
+    const double *__restrict__ ierr, const ngmix_jacobian *__restrict__ jacs,
+    ngmix_gauss2d *gmix, double *out, const int64_t *__restrict__ out_start,
+    int32_t *status, int max_ngauss, int nchunks_cap, int no_skip)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LdsLayout L = carve(smem, max_ngauss, nchunks_cap);
+    const GaussFused *gf = (const GaussFused *)L.gl;
+
+    const int s = blockIdx.x;
+    const ngmix_stamp st = stamps[s];
+    const ngmix_jacobian jac = jacs[s];
+    const int nrow = st.nrow, ncol = st.ncol, ng = st.ngauss;
+    const int npix = nrow * ncol;
+    ngmix_gauss2d *gm = gmix + st.gm_off;
+    const double *sval = val + st.pix_off;
+    const double *sierr = ierr + st.pix_off;
+    const bool izw = (st.flags & NGMIX_STAMP_IGNORE_ZERO_WEIGHT) != 0;
+    constexpr bool kNeedsVal = (OP == OP_LOGLIKE || OP == OP_FDIFF);
+    constexpr bool kNeedsIerr = (OP != OP_RENDER_FAST);
+    const double area = jac.scale * jac.scale;
+    const int tid = threadIdx.x;
+
+    const int stcode = stage_gaussians_fused(L, gm, ng, jac, area, !no_skip);
+    if (stcode != NGMIX_OK) {
+        if (tid == 0) status[s] = stcode;
+        return;
+    }
+    const bool fast = L.ctl[2] != 0 && L.ctl[3] != 0;
+    const bool masked = kNeedsIerr && izw && st.npix_kept != npix;
+    if (OP == OP_FDIFF && masked) build_rank_tables(L.cmask, L.cpre, sierr, npix);
+    const int64_t out_base = (OP == OP_FDIFF) ? out_start[s] : 0;
+
+    double acc_ll = 0.0, acc_sn = 0.0, acc_sd = 0.0;
+    if (ng > 0) {
+        if (fast)
+            fused_tiles<OP, true>(L, gf, ng, st, jac, sval, sierr, masked, out,
+                                  out_base, acc_ll, acc_sn, acc_sd);
+        else
+            fused_tiles<OP, false>(L, gf, ng, st, jac, sval, sierr, masked, out,
+                                   out_base, acc_ll, acc_sn, acc_sd);
+    } else if (OP != OP_RENDER_FAST) {
+        // an empty mixture: model == 0 everywhere
+        for (int p = tid; p < npix; p += BLOCK) {
+            const double pv = kNeedsVal ? sval[p] : 0.0, pe = sierr[p];
+            if (masked && !(pe > 0.0)) continue;
+            if (OP == OP_LOGLIKE) acc_ll = fma(pv * pv, pe * pe, acc_ll);
+            if (OP == OP_FDIFF) {
+                const int rank = masked ? kept_rank(L.cmask, L.cpre, p) : p;
+                out[out_base + rank] = (0.0 - pv) * pe;
+            }
+        }
+    }
+
+    if (OP == OP_LOGLIKE) {
+        double v[3] = {acc_ll, acc_sn, acc_sd};
+        block_sum<3>(v, L.red);
+        if (tid == 0) {
+            out[4 * (int64_t)s + 0] = v[0] * -0.5;
+            out[4 * (int64_t)s + 1] = v[1];
+            out[4 * (int64_t)s + 2] = v[2];
+            // the number of listed pixels is a property of the stamp
+            out[4 * (int64_t)s + 3] = (double)(izw ? st.npix_kept : npix);
+            status[s] = NGMIX_OK;
+        }
+    } else if (OP == OP_S2N) {
+        double v[1] = {acc_sd};
+        block_sum<1>(v, L.red);
+        if (tid == 0) {
+            out[s] = v[0];
+            status[s] = NGMIX_OK;
+        }
+    } else {
+        if (tid == 0) status[s] = NGMIX_OK;
+    }
+}
+
 // ---------------------------------------------------------------- launchers
 
 static int pick_k(int max_npix)
@@ -281,28 +559,34 @@ static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
         return NGMIX_ERR_BAD_ARG;
     }
     const int no_skip = (b->flags & NGMIX_BATCH_NO_SKIP) ? 1 : 0;
+    // the true-exp render has no cut and no fused form
+    const bool exact = (b->flags & NGMIX_BATCH_EXACT) || OP == OP_RENDER_EXACT;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)b->nstamps), block(BLOCK);
-    if (pick_k(b->max_npix) == 4) {
-        auto kern = pixpass_grid_kernel<OP, 4>;
+    const ngmix_stamp *a_stamps = b->stamps;
+    const double *a_val = b->val, *a_ierr = b->ierr;
+    const ngmix_jacobian *a_jac = b->jac;
+    int a_ng = max_ng, a_nc = nchunks_cap, a_ns = no_skip;
+    if (exact) {
+        const bool k4 = pick_k(b->max_npix) == 4;
+        const void *kern = k4 ? (const void *)pixpass_grid_kernel<OP, 4>
+                              : (const void *)pixpass_grid_kernel<OP, 9>;
         if (lds > 64 * 1024)
             NGMIX_HIP_CHECK(hipFuncSetAttribute(
-                (const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                (int)lds));
-        hipLaunchKernelGGL(kern, grid, block, lds, s, b->stamps, b->val, b->ierr,
-                           b->jac, gmix, out, out_start, status, max_ng,
-                           nchunks_cap, no_skip);
-    } else {
-        auto kern = pixpass_grid_kernel<OP, 9>;
-        if (lds > 64 * 1024)
-            NGMIX_HIP_CHECK(hipFuncSetAttribute(
-                (const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                (int)lds));
-        hipLaunchKernelGGL(kern, grid, block, lds, s, b->stamps, b->val, b->ierr,
-                           b->jac, gmix, out, out_start, status, max_ng,
-                           nchunks_cap, no_skip);
+                kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        void *args[] = {&a_stamps, &a_val, &a_ierr, &a_jac, &gmix, &out, &out_start,
+                        &status, &a_ng, &a_nc, &a_ns};
+        NGMIX_HIP_CHECK(hipLaunchKernel(kern, grid, block, args, lds, s));
+        return NGMIX_OK;
     }
-    NGMIX_HIP_CHECK(hipGetLastError());
+    constexpr int FOP = (OP == OP_RENDER_EXACT) ? OP_RENDER_FAST : OP;
+    const void *kern = (const void *)pixpass_fused_kernel<FOP>;
+    if (lds > 64 * 1024)
+        NGMIX_HIP_CHECK(hipFuncSetAttribute(
+            kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void *args[] = {&a_stamps, &a_val, &a_ierr, &a_jac, &gmix, &out, &out_start,
+                    &status, &a_ng, &a_nc, &a_ns};
+    NGMIX_HIP_CHECK(hipLaunchKernel(kern, grid, block, args, lds, s));
     return NGMIX_OK;
 }
 

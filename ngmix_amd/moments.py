@@ -1,0 +1,216 @@
+"""
+Moment / size conversions and the summary statistics of a set of weighted
+moment sums (reference: ngmix/moments.py).  Host scalar math only: the sums
+themselves come from the weighted-sums kernel.
+"""
+import numpy as np
+
+from . import flags as ngflags
+from . import shape
+from .util import get_ratio_error
+
+FWHM_FAC = 2.3548200450309493  # 2 sqrt(2 ln 2)
+
+# index of each named moment in the sums vector (gmix_nb.py:790-813)
+MOMENTS_NAME_MAP = {
+    "Mv": 0, "Mu": 1, "M1": 2, "M2": 3, "MT": 4, "MF": 5,
+    "M00": 5, "M10": 1, "M01": 0, "M11": 4, "M20": 2, "M02": 3,
+    "M21": 6, "M12": 7, "M30": 8, "M03": 9,
+    "M22": 10, "M31": 11, "M13": 12, "M40": 13, "M14": 14,
+    "M33": 15, "M44": 16,
+}
+
+
+def sigma_to_fwhm(sigma):
+    return sigma * FWHM_FAC
+
+
+def T_to_fwhm(T):
+    return sigma_to_fwhm(np.sqrt(T / 2.0))
+
+
+def fwhm_to_sigma(fwhm):
+    return fwhm / FWHM_FAC
+
+
+def fwhm_to_T(fwhm):
+    return 2 * fwhm_to_sigma(fwhm) ** 2
+
+
+def r50_to_sigma(r50):
+    return fwhm_to_sigma(2.0 * r50)
+
+
+def sigma_to_r50(sigma):
+    return sigma_to_fwhm(sigma) / 2.0
+
+
+def r50_to_T(r50):
+    return 2 * r50_to_sigma(r50) ** 2
+
+
+def T_to_r50(T):
+    return sigma_to_r50(np.sqrt(T / 2.0))
+
+
+def moms_to_e1e2(M1, M2, T):
+    if isinstance(M1, np.ndarray):
+        return M1 / T, M2 / T
+    if T == 0:
+        return -9999.0, -9999.0
+    return M1 / T, M2 / T
+
+
+def get_Tround(T, g1, g2):
+    gsq = g1 ** 2 + g2 ** 2
+    return T * (1 - gsq) / (1 + gsq)
+
+
+def get_T(Tround, g1, g2):
+    gsq = g1 ** 2 + g2 ** 2
+    return Tround * (1 + gsq) / (1 - gsq)
+
+
+def mom2e(Irr, Irc, Icc):
+    T = Irr + Icc
+    return (Icc - Irr) / T, 2.0 * Irc / T, T
+
+
+def mom2g(Irr, Irc, Icc):
+    e1, e2, T = mom2e(Irr, Irc, Icc)
+    g1, g2 = shape.e1e2_to_g1g2(e1, e2)
+    return g1, g2, T
+
+
+def e2mom(e1, e2, T):
+    Irc = e2 * T / 2.0
+    Icc = (1 + e1) * T / 2.0
+    Irr = (1 - e1) * T / 2.0
+    return Irr, Irc, Icc
+
+
+def g2mom(g1, g2, T):
+    e1, e2 = shape.g1g2_to_e1e2(g1, g2)
+    return e2mom(e1, e2, T)
+
+
+def get_sheared_g1g2T(g1, g2, T, s1, s2):
+    g1s, g2s = shape.shear_reduced(g1, g2, s1, s2)
+    Ts = get_T(get_Tround(T, g1, g2), g1s, g2s)
+    return g1s, g2s, Ts
+
+
+def get_sheared_M1M2T(M1, M2, T, s1, s2):
+    e1, e2 = moms_to_e1e2(M1, M2, T)
+    g1, g2 = shape.e1e2_to_g1g2(e1, e2)
+    g1s, g2s, Ts = get_sheared_g1g2T(g1, g2, T, s1, s2)
+    e1s, e2s = shape.g1g2_to_e1e2(g1s, g2s)
+    return Ts * e1s, Ts * e2s, Ts
+
+
+def get_sheared_moments(irr, irc, icc, s1, s2):
+    g1, g2, T = mom2g(irr, irc, icc)
+    g1s, g2s, Ts = get_sheared_g1g2T(g1, g2, T, s1, s2)
+    return g2mom(g1s, g2s, Ts)
+
+
+def make_mom_result(sums, sums_cov, sums_norm=None):
+    """
+    Summary statistics (flux, T, e, their errors and flags) of unnormalised
+    weighted moment sums ordered [Mv, Mu, M1, M2, MT, MF, ...]
+    (reference: ngmix/moments.py:398-539).
+    """
+    if len(sums) not in (6, 17):
+        raise ValueError(
+            "You must pass exactly 6 or 17 unnormalized moments in the order "
+            "[Mv, Mu, M1, M2, MT, MF, ...] for ngmix.moments.make_mom_result.")
+    if sums_cov.shape not in ((6, 6), (17, 17)):
+        raise ValueError(
+            "You must pass a 6x6 or 17x17 matrix for ngmix.moments.make_mom_result.")
+
+    iv, iu, i1, i2, it, iflux = 0, 1, 2, 3, 4, 5
+    nan2 = np.array([np.nan, np.nan])
+    res = {
+        "flags": 0, "flagstr": "",
+        "flux": sums[iflux],
+        "sums": sums, "sums_cov": sums_cov,
+        "sums_norm": sums_norm if sums_norm is not None else np.nan,
+        "flux_flags": 0, "flux_flagstr": "",
+        "T_flags": 0, "T_flagstr": "",
+        "flux_err": np.nan, "T": np.nan, "T_err": np.nan, "s2n": np.nan,
+        "e1": np.nan, "e2": np.nan,
+        "e": nan2.copy(), "e_err": nan2.copy(), "e_cov": np.diag(nan2),
+        "sums_err": np.full(6, np.nan),
+    }
+    var_f = sums_cov[iflux, iflux]
+    var_t = sums_cov[it, it]
+
+    if var_f > 0:
+        res["flux_err"] = np.sqrt(var_f)
+        res["s2n"] = res["flux"] / res["flux_err"]
+    else:
+        res["flux_flags"] |= ngflags.NONPOS_VAR
+
+    if var_f > 0 and var_t > 0:
+        if sums[iflux] > 0:
+            res["T"] = sums[it] / sums[iflux]
+            res["T_err"] = get_ratio_error(sums[it], sums[iflux], var_t, var_f,
+                                           sums_cov[it, iflux])
+        else:
+            res["T_flags"] |= ngflags.NONPOS_FLUX
+    else:
+        res["T_flags"] |= ngflags.NONPOS_VAR
+
+    diag = np.diagonal(sums_cov)
+    if np.all(diag > 0):
+        res["sums_err"] = np.sqrt(diag)
+    else:
+        res["flags"] |= ngflags.NONPOS_VAR
+
+    if res["flags"] == 0:
+        if res["flux"] > 0:
+            if res["T"] > 0:
+                res["e1"] = sums[i1] / sums[it]
+                res["e2"] = sums[i2] / sums[it]
+                res["e"] = np.array([res["e1"], res["e2"]])
+                res["pars"] = np.array([sums[iv], sums[iu], res["e1"], res["e2"],
+                                        res["T"], res["flux"]])
+                e_err = np.array([
+                    get_ratio_error(sums[i1], sums[it], sums_cov[i1, i1], var_t,
+                                    sums_cov[i1, it]),
+                    get_ratio_error(sums[i2], sums[it], sums_cov[i2, i2], var_t,
+                                    sums_cov[i2, it]),
+                ])
+                if np.all(np.isfinite(e_err)):
+                    res["e_err"] = e_err
+                    res["e_cov"] = np.diag(e_err ** 2)
+                else:
+                    res["flags"] |= ngflags.NONPOS_SHAPE_VAR
+            else:
+                res["flags"] |= ngflags.NONPOS_SIZE
+        else:
+            res["flags"] |= ngflags.NONPOS_FLUX
+
+    res["flagstr"] = ngflags.get_flags_str(res["flags"])
+    res["flux_flagstr"] = ngflags.get_flags_str(res["flux_flags"])
+    res["T_flagstr"] = ngflags.get_flags_str(res["T_flags"])
+
+    # moments by name, normalised by the flux sum (moments.py:542-575)
+    fsum = sums[iflux]
+    with np.errstate(invalid="ignore"):
+        fsum_err = np.sqrt(var_f)
+    for name, ind in MOMENTS_NAME_MAP.items():
+        if ind > sums.size - 1:
+            continue
+        err_name = "%s_err" % name
+        if name in ("MF", "M00"):
+            res[name] = fsum
+            res[err_name] = fsum_err
+        elif fsum > 0:
+            res[name] = sums[ind] / fsum
+            res[err_name] = get_ratio_error(sums[ind], fsum, sums_cov[ind, ind],
+                                            var_f, sums_cov[ind, iflux])
+        else:
+            res[name] = np.nan
+            res[err_name] = np.nan
+    return res

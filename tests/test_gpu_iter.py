@@ -219,7 +219,7 @@ def test_admom_errors():
 
 
 # ----------------------------------------------------------------------- em
-def _check_em(name, numiter, frac, sky, gm, conv, g):
+def _check_em(name, numiter, frac, sky, gm, conv, g, label=""):
     assert numiter == int(g[name + "_numiter"]), name
     assert abs(frac - float(g[name + "_frac_diff"])) <= \
         1e-6 * abs(float(g[name + "_frac_diff"])) + 1e-11, name
@@ -271,8 +271,8 @@ def test_em_seam_and_batch(golden):
                                fill_zero_weight=fzw)
         assert int(status.cpu()[0]) == 0, name
         out = out.cpu().numpy()[0]
-        _check_em(name + " batch", int(out[0]), out[1], out[2], gmb.to_numpy()[0],
-                  convb.to_numpy()[0], g)
+        _check_em(name, int(out[0]), out[1], out[2], gmb.to_numpy()[0],
+                  convb.to_numpy()[0], g, label="batch")
 
 
 def test_em_errors():
