@@ -16,7 +16,12 @@ constexpr int TILE_W = 16;
 constexpr int TILE_H = 4;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
-__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+// the wave index is uniform across a wave: tell the compiler so that everything
+// derived from it (tile coordinates, loop control) stays in scalar registers
+__device__ __forceinline__ int wave_id()
+{
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
 
 // butterfly-free, fixed-order wave reduction: after the call lane 0 holds the
 // sum of all 64 lanes (deterministic order; no atomics anywhere)
@@ -104,19 +109,24 @@ __device__ __forceinline__ PixBox gauss_pixel_box(const ngmix_gauss2d &g,
     const double cen_r = j.row0 + (rr * g.row + ru * g.col);
     const double cen_c = j.col0 + (cr * g.row + cu * g.col);
     if (!(var_r >= 0.0) || !(var_c >= 0.0)) return full;
-    // 5 sigma, +1e-6 relative, +0.5 pixel absolute
-    const double hr = 5.0 * sqrt(var_r) * (1.0 + 1.0e-6) + 0.5;
-    const double hc = 5.0 * sqrt(var_c) * (1.0 + 1.0e-6) + 0.5;
+    // A pixel (integer row r) can have chi2 < 25 only if |r - cen_r| <=
+    // 5 sigma_r.  Inflate by 1e-6 relative (chi2 at the edge is then
+    // >= 25(1+2e-6), far above the <=1e-9 relative rounding of the evaluated
+    // chi2 given rho2 < 1-1e-6) plus 1e-6 pixel absolute for the rounding of
+    // the centre and pixel coordinates; the integer pixels inside
+    // [lo, hi] are ceil(lo) .. floor(hi).
+    const double hr = 5.0 * sqrt(var_r) * (1.0 + 1.0e-6) + 1.0e-6;
+    const double hc = 5.0 * sqrt(var_c) * (1.0 + 1.0e-6) + 1.0e-6;
     const double lo_r = cen_r - hr, hi_r = cen_r + hr;
     const double lo_c = cen_c - hc, hi_c = cen_c + hc;
     const double big = 1.0e9;
     if (!(lo_r > -big) || !(hi_r < big) || !(lo_c > -big) || !(hi_c < big))
         return full;
     PixBox box;
-    box.rmin = (int)floor(lo_r);
-    box.rmax = (int)ceil(hi_r);
-    box.cmin = (int)floor(lo_c);
-    box.cmax = (int)ceil(hi_c);
+    box.rmin = (int)ceil(lo_r);
+    box.rmax = (int)floor(hi_r);
+    box.cmin = (int)ceil(lo_c);
+    box.cmax = (int)floor(hi_c);
     return box;
 }
 

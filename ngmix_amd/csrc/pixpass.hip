@@ -322,15 +322,25 @@ __device__ __forceinline__ int stage_gaussians_fused(const LdsLayout &L,
     return NGMIX_OK;
 }
 
+// a*b + c with the constant c taken from a scalar register pair: one
+// v_fma_f64 per Horner step (left to itself hipcc keeps the coefficients in
+// VGPRs and emits v_mov_b64 + v_fmac_f64, two issue slots per step)
+__device__ __forceinline__ double fma_sconst(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+
 __device__ __forceinline__ double fexp_fused(double x, const double *tab)
 {
     const int ival = (int)(x - 0.5);
     const double f = x - (double)ival;
-    double p = fma(f, 0.008197933236258961, 0.042330947141114836);
-    p = fma(f, p, 0.16674612720799442);
-    p = fma(f, p, 0.49992478810274166);
-    p = fma(f, p, 0.999993601071577);
-    p = fma(f, p, 1.0000011318561302);
+    double p = fma_sconst(f, 0.008197933236258961, 0.042330947141114836);
+    p = fma_sconst(f, p, 0.16674612720799442);
+    p = fma_sconst(f, p, 0.49992478810274166);
+    p = fma_sconst(f, p, 0.999993601071577);
+    p = fma_sconst(f, p, 1.0000011318561302);
     return tab[ival + 15] * p;
 }
 
@@ -400,12 +410,12 @@ __device__ __forceinline__ void fused_tiles(
         double model = 0.0;
 
         for (int g0 = 0; g0 < ng; g0 += WAVE) {
-            bool hit = false;
-            if (g0 + lane < ng) {
-                const PixBox box = gf[g0 + lane].box;
-                hit = r0 <= box.rmax && r0 + TILE_H - 1 >= box.rmin &&
-                      c0 <= box.cmax && c0 + TILE_W - 1 >= box.cmin;
-            }
+            // lane g tests gaussian g's box against this tile (branch-free)
+            const int gi = (g0 + lane < ng) ? g0 + lane : g0;
+            const PixBox box = gf[gi].box;
+            const bool hit = (g0 + lane < ng) & (r0 <= box.rmax) &
+                             (r0 + TILE_H - 1 >= box.rmin) & (c0 <= box.cmax) &
+                             (c0 + TILE_W - 1 >= box.cmin);
             unsigned long long gmask = __ballot(hit);
             while (gmask) {
                 const int g = g0 + __builtin_ctzll(gmask);
@@ -426,7 +436,12 @@ __device__ __forceinline__ void fused_tiles(
                 if (pass) {
                     double e = fexp_fused(-0.5 * chi2, L.tab);
                     const bool band = FAST ? (hi >= 0x40340000u) : (chi2 > APOD_CHI2);
-                    if (band) e *= apod_window(chi2);
+                    if (band) {
+                        // apod_window with FMAs (fastexp_nb.py:97-117)
+                        const double au = (MAX_CHI2 - chi2) * APOD_IWIDTH;
+                        const double aq = fma(au, fma(au, 6.0, -15.0), 10.0);
+                        e *= (au * au) * (au * aq);
+                    }
                     model = fma(gpa, e, model);
                 }
             }
