@@ -5,6 +5,11 @@ GMix / Observation / Jacobian / Fitter API.
 
 All pixel arithmetic runs in hand-written HIP kernels (ngmix_amd/csrc) reached
 through the C ABI declared in include/ngmix_hip.h; there is no CPU fallback.
+
+    single objects:  GMix, GMixModel, Observation, Jacobian, Fitter,
+                     run_admom, run_em  (the reference's API)
+    batches:         ngmix_amd.batch.StampBatch / GMixBatch (N stamps resident
+                     in HBM, one kernel launch per operation)
 """
 from . import flags  # noqa: F401
 from . import defaults  # noqa: F401
@@ -14,6 +19,28 @@ from .gexceptions import (  # noqa: F401
     BootPSFFailure, BootGalFailure, FFTRangeError,
 )
 from . import _lib  # noqa: F401
+from . import util  # noqa: F401
+from .util import print_pars, srandu  # noqa: F401
+from . import shape  # noqa: F401
+from .shape import Shape  # noqa: F401
+from . import moments  # noqa: F401
+from . import jacobian  # noqa: F401
+from .jacobian import Jacobian, DiagonalJacobian, UnitJacobian  # noqa: F401
+from . import pixels  # noqa: F401
 from . import gmix  # noqa: F401
+from .gmix import (  # noqa: F401
+    GMix, GMixModel, GMixCM, GMixCoellip, make_gmix_model, gmix_concat,
+    set_exact_kernels, get_exact_kernels,
+)
+from . import observation  # noqa: F401
+from .observation import (  # noqa: F401
+    Observation, ObsList, MultiBandObsList, get_mb_obs,
+)
+from . import admom  # noqa: F401
+from . import em  # noqa: F401
+from . import fitting  # noqa: F401
+from . import runners  # noqa: F401
+from . import bootstrap  # noqa: F401
+from . import batch  # noqa: F401
 
 __version__ = "0.1.0"

@@ -297,19 +297,29 @@ class StampBatch(object):
         return torch.from_numpy(flat.copy()).to(self.device)
 
     def stamp_table(self, ngauss):
-        """device ngmix_stamp records for mixtures of `ngauss` gaussians laid
-        out stamp-major (gm_off = i*ngauss); cached per ngauss"""
-        if ngauss not in self._stamp_tables:
-            gm_off = np.arange(self.n, dtype=np.int64) * ngauss
-            assert gm_off[-1] < 2 ** 31 if self.n else True
-            self._stamp_tables[ngauss] = self._make_table(
-                self.npix_kept, gm_off.astype(np.int32), ngauss)
-        return self._stamp_tables[ngauss]
+        """device ngmix_stamp records for mixtures laid out stamp-major.
+        ngauss: one int (gm_off = i*ngauss) or a per-stamp sequence (ragged,
+        gm_off = running sum); cached per layout"""
+        if np.ndim(ngauss) == 0:
+            key = int(ngauss)
+            ng = np.full(self.n, key, dtype=np.int64)
+        else:
+            ng = np.asarray(ngauss, dtype=np.int64)
+            assert ng.shape == (self.n,)
+            key = tuple(ng.tolist())
+        if key not in self._stamp_tables:
+            gm_off = np.concatenate([[0], np.cumsum(ng)[:-1]]) if self.n else ng
+            assert (gm_off[-1] + ng[-1]) < 2 ** 31 if self.n else True
+            self._stamp_tables[key] = self._make_table(
+                self.npix_kept, gm_off.astype(np.int32), ng.astype(np.int32))
+        return self._stamp_tables[key]
 
     def _batch(self, ngauss, no_skip=False, exact=False):
         b = _lib.Batch()
         b.nstamps = self.n
         b.stamps = self.stamp_table(ngauss).data_ptr()
+        if np.ndim(ngauss) != 0:
+            ngauss = int(np.max(ngauss)) if self.n else 0
         b.val = self.val.data_ptr() if self.val is not None else None
         b.ierr = self.ierr.data_ptr() if self.ierr is not None else None
         b.jac = self.jac.data_ptr()

@@ -1,0 +1,693 @@
+"""
+Levenberg-Marquardt model fitting (reference API: ngmix/fitting/fitters.py,
+results.py, leastsqbound.py).
+
+Orchestration stays on the host, as north_star asks: scipy's MINPACK drives the
+iteration and calls back into FitModel.  What changes is the callback body:
+all observations of the object (bands x epochs) live in ONE device-resident
+StampBatch, and each evaluation is a single kernel launch
+
+    calc_fdiff    -> ngmix_fill_fdiff_batch   (residuals written straight into
+                                               the LM vector layout)
+    calc_jacobian -> ngmix_deriv_images_batch (6 derivative images per obs)
+    calc_lnprob   -> ngmix_loglike_batch
+
+instead of the reference's Python loop of one njit call per observation
+(results.py:176-189, 456-461, 533-565).  The O(ngauss) model fill / psf
+convolution / norms per evaluation go through the C ABI's host entry points.
+"""
+import copy
+import logging
+
+import numpy as np
+from numpy import diag, sqrt
+
+from . import _lib
+from . import gmix as gmix_mod
+from .defaults import PDEF, CDEF, LOWVAL, BIGVAL, DEFAULT_LM_PARS
+from .flags import (
+    ZERO_DOF, DIV_ZERO, LM_SINGULAR_MATRIX, LM_NEG_COV_EIG, LM_NEG_COV_DIAG,
+    EIG_NOTFINITE, LM_FUNC_NOTFINITE,
+)
+from .gexceptions import GMixRangeError
+from .observation import get_mb_obs
+from .util import print_pars
+
+__all__ = ["Fitter", "CoellipFitter", "FitModel", "CoellipFitModel",
+           "run_leastsq", "leastsqbound"]
+
+LOGGER = logging.getLogger(__name__)
+
+SIMPLE_ANALYTIC_MODELS = ("gauss", "exp", "dev")
+# relative step for differencing the (smooth) prior rows of the jacobian
+STEP_PRIOR = 1.0e-7
+
+
+# ---------------------------------------------------------------------------
+# bounded least squares (reference: ngmix/fitting/leastsqbound.py)
+# ---------------------------------------------------------------------------
+
+def _get_def_stuff(npars):
+    return (np.zeros(npars) + PDEF, np.zeros((npars, npars)) + CDEF,
+            np.zeros(npars) + CDEF)
+
+
+def _test_cov(pcov):
+    flags = 0
+    try:
+        e, _ = np.linalg.eig(pcov)
+        if np.any(e < 0):
+            flags |= LM_NEG_COV_EIG
+        if np.any(np.diag(pcov) < 0):
+            flags |= LM_NEG_COV_DIAG
+    except np.linalg.LinAlgError:
+        flags |= EIG_NOTFINITE
+    return flags
+
+
+class _BoundsTransform(object):
+    """
+    MINUIT-style maps between external (bounded) and internal (free)
+    parameters, per parameter kind: none / lower only / upper only / both
+    (leastsqbound.py:183-264).
+    """
+
+    def __init__(self, bounds):
+        self.bounds = [tuple(b) for b in bounds]
+
+    def i2e(self, xi):
+        xe = np.empty_like(xi)
+        for i, (v, (lo, hi)) in enumerate(zip(xi, self.bounds)):
+            if lo is None and hi is None:
+                xe[i] = v
+            elif hi is None:
+                xe[i] = lo - 1.0 + np.sqrt(v * v + 1.0)
+            elif lo is None:
+                xe[i] = hi + 1.0 - np.sqrt(v * v + 1.0)
+            else:
+                xe[i] = lo + ((hi - lo) / 2.0) * (np.sin(v) + 1.0)
+        return xe
+
+    def e2i(self, xe):
+        xi = np.empty_like(xe)
+        for i, (v, (lo, hi)) in enumerate(zip(xe, self.bounds)):
+            if lo is None and hi is None:
+                xi[i] = v
+            elif hi is None:
+                xi[i] = np.sqrt((v - lo + 1.0) ** 2 - 1)
+            elif lo is None:
+                xi[i] = np.sqrt((hi - v + 1.0) ** 2 - 1)
+            else:
+                xi[i] = np.arcsin((2.0 * (v - lo) / (hi - lo)) - 1.0)
+        return xi
+
+    def grad(self, xi):
+        g = np.empty_like(xi)
+        for i, (v, (lo, hi)) in enumerate(zip(xi, self.bounds)):
+            if lo is None and hi is None:
+                g[i] = 1.0
+            elif hi is None:
+                g[i] = v / np.sqrt(v * v + 1.0)
+            elif lo is None:
+                g[i] = -v / np.sqrt(v * v + 1.0)
+            else:
+                g[i] = (hi - lo) * np.cos(v) / 2.0
+        return g
+
+
+def leastsqbound(func, x0, args=(), bounds=None, Dfun=None, full_output=0,
+                 col_deriv=0, ftol=1.49012e-8, xtol=1.49012e-8, gtol=0.0,
+                 maxfev=0, epsfcn=None, factor=100, diag=None):
+    """
+    scipy.optimize.leastsq (MINPACK lmdif / lmder) with optional (min, max)
+    bounds per parameter enforced through the MINUIT internal<->external
+    transformation; the returned covariance is in external parameters.
+    """
+    from scipy.optimize import leastsq
+    if bounds is None:
+        return leastsq(func, x0, args, Dfun, full_output, col_deriv, ftol, xtol,
+                       gtol, maxfev, epsfcn, factor, diag)
+
+    tr = _BoundsTransform(bounds)
+    x0 = np.asarray(x0, dtype="f8").flatten()
+    n = len(x0)
+    if len(bounds) != n:
+        raise ValueError("length of x0 != length of bounds")
+    if not isinstance(args, tuple):
+        args = (args,)
+    i0 = tr.e2i(x0)
+
+    def wfunc(x, *a):
+        return func(tr.i2e(x), *a)
+
+    wDfun = None
+    if Dfun is not None:
+        def wDfun(x, *a):
+            scale = tr.grad(x)
+            if col_deriv == 1:
+                scale = scale.reshape(len(x), 1)
+            return Dfun(tr.i2e(x), *a) * scale
+
+    xi, _, infodict, mesg, ier = leastsq(
+        wfunc, i0, args, wDfun, 1, col_deriv, ftol, xtol, gtol, maxfev, epsfcn,
+        factor, diag)
+    x = tr.i2e(xi)
+    if not full_output:
+        return x, ier
+    # R of the final jacobian's QR, rescaled from internal to external pars
+    grad = tr.grad(xi)
+    ipvt = infodict["ipvt"]
+    infodict["fjac"] = (infodict["fjac"].T / np.take(grad, ipvt - 1)).T
+    cov_x = None
+    if ier in (1, 2, 3, 4):
+        perm = np.take(np.eye(n), ipvt - 1, 0)
+        r = np.triu(np.transpose(infodict["fjac"])[:n, :])
+        R = np.dot(r, perm)
+        try:
+            cov_x = np.linalg.inv(np.dot(np.transpose(R), R))
+        except (np.linalg.LinAlgError, ValueError):
+            pass
+    return x, cov_x, infodict, mesg, ier
+
+
+def run_leastsq(func, guess, n_prior_pars, **keys):
+    """
+    Run the (bounded) LM fit and package flags / covariance the way the
+    reference does (leastsqbound.py:33-155): ier > 4 -> flags 2**(ier-5) with
+    default pars, singular -> LM_SINGULAR_MATRIX, pars_cov = cov0 * chi2/dof,
+    covariance sanity flags, ZERO_DOF, DIV_ZERO, LM_FUNC_NOTFINITE.
+    """
+    npars = guess.size
+    k_space = keys.pop("k_space", False)
+    res = {}
+    try:
+        pars, pcov0, infodict, errmsg, ier = leastsqbound(
+            func, guess, full_output=1, **keys)
+        if ier == 0:
+            raise ValueError(errmsg)
+        flags = 0
+        if ier > 4:
+            flags |= 2 ** (ier - 5)
+            pars, pcov, perr = _get_def_stuff(npars)
+            LOGGER.debug(errmsg)
+        elif pcov0 is None:
+            flags |= LM_SINGULAR_MATRIX
+            errmsg = "singular covariance"
+            LOGGER.debug(errmsg)
+            print_pars(pars, front="    pars at singular:", logger=LOGGER)
+            _, pcov, perr = _get_def_stuff(npars)
+        else:
+            fdiff = func(pars)
+            if k_space:
+                dof = (fdiff.size - n_prior_pars) // 2 - npars
+            else:
+                dof = fdiff.size - n_prior_pars - npars
+            if dof == 0:
+                _, pcov, perr = _get_def_stuff(npars)
+                flags |= ZERO_DOF
+            else:
+                s_sq = (fdiff[n_prior_pars:] ** 2).sum() / dof
+                pcov = pcov0 * s_sq
+                cflags = _test_cov(pcov)
+                if cflags != 0:
+                    flags |= cflags
+                    errmsg = "bad covariance matrix"
+                    LOGGER.debug(errmsg)
+                    _, _, perr = _get_def_stuff(npars)
+                else:
+                    perr = sqrt(diag(pcov))
+        res.update(flags=flags, nfev=infodict["nfev"], ier=ier, errmsg=errmsg,
+                   pars=pars, pars_err=perr, pars_cov0=pcov0, pars_cov=pcov)
+    except ValueError as e:
+        serr = str(e)
+        if "NaNs" in serr or "infs" in serr:
+            pars, pcov, perr = _get_def_stuff(npars)
+            res.update(pars=pars, pars_cov0=pcov, pars_cov=pcov, nfev=-1,
+                       flags=LM_FUNC_NOTFINITE, errmsg="not finite")
+            LOGGER.debug("not finite")
+        else:
+            raise e
+    except ZeroDivisionError:
+        pars, pcov, perr = _get_def_stuff(npars)
+        res.update(pars=pars, pars_cov0=pcov, pars_cov=pcov, nfev=-1,
+                   flags=DIV_ZERO, errmsg="zero division")
+        LOGGER.debug("zero division")
+    return res
+
+
+# ---------------------------------------------------------------------------
+# model bookkeeping
+# ---------------------------------------------------------------------------
+
+def get_band_pars(model, pars, band):
+    """shared shape parameters + the flux of `band` (results.py:1013-1047)"""
+    num = gmix_mod.get_model_npars(model)
+    band_pars = np.zeros(num)
+    assert model != "coellip"
+    nshared = {"bd": 7, "bdf": 6}.get(model, 5)
+    band_pars[0:nshared] = pars[0:nshared]
+    band_pars[nshared] = pars[nshared + band]
+    return band_pars
+
+
+def get_lm_n_prior_pars(model, nband):
+    """number of residual rows reserved for the prior (results.py:1050-1078)"""
+    if model == "bd":
+        return 6 + nband
+    if model == "bdf":
+        return 5 + nband
+    if model in ("exp", "dev", "gauss", "turb"):
+        return 5 + nband
+    raise ValueError("bad model: %s" % model)
+
+
+def get_model_deriv_data(gm0, gmc, g1, g2, T):
+    """
+    composed gaussians [p, v, u, irr, irc, icc] and d(irr, irc, icc)/d(g1, g2,
+    T) of each, for models whose components share one shape
+    (results.py:955-1010): Sigma_k = (T_k/2) [[1-e1, e2],[e2, 1+e1]] with
+    e = 2g/(1+g^2).
+    """
+    gpars = gmc.get_full_pars().reshape(-1, 6)
+    modpars = gm0.get_full_pars().reshape(-1, 6)
+    npsf = gpars.shape[0] // modpars.shape[0]
+    modcov = np.repeat(modpars[:, 3:6], npsf, axis=0)
+
+    gsq = g1 * g1 + g2 * g2
+    f = 2.0 / (1.0 + gsq)
+    dfac = -f / (1.0 + gsq)
+    de1dg1 = f + 2.0 * g1 * g1 * dfac
+    de1dg2 = 2.0 * g1 * g2 * dfac
+    de2dg1 = de1dg2
+    de2dg2 = f + 2.0 * g2 * g2 * dfac
+
+    Tk = modcov[:, 0] + modcov[:, 2]
+    dcov = np.zeros((gpars.shape[0], 3, 3))
+    for i, (de1, de2) in enumerate(((de1dg1, de2dg1), (de1dg2, de2dg2))):
+        dcov[:, i, 0] = -0.5 * Tk * de1
+        dcov[:, i, 1] = 0.5 * Tk * de2
+        dcov[:, i, 2] = 0.5 * Tk * de1
+    dcov[:, 2, :] = modcov / T
+    return gpars, dcov
+
+
+class _RaggedGMix(object):
+    """device mixtures with a per-stamp gaussian count (duck-types GMixBatch
+    for the StampBatch operations)"""
+
+    def __init__(self, data, ngauss):
+        self.data = data
+        self.ngauss = np.asarray(ngauss, dtype=np.int64)
+        self.n = self.ngauss.size
+
+
+class FitModel(dict):
+    """
+    The LM objective of one object (all its bands and epochs), and after the
+    fit the result dict with statistics and model accessors.
+    """
+
+    def __init__(self, obs, model, guess, prior=None):
+        self.prior = prior
+        self.model = gmix_mod.get_model_num(model)
+        self.model_name = gmix_mod.get_model_name(self.model)
+        self["model"] = self.model_name
+        self.obs = get_mb_obs(obs)
+        self.nband = len(self.obs)
+        self._flat_obs = [o for obslist in self.obs for o in obslist]
+        self.nimage = len(self._flat_obs)
+        self._set_npars()
+        self._set_n_prior_pars()
+        self._set_bounds()
+        self._setup_device()
+        self.fdiff_size = self.totpix + self.n_prior_pars
+        self._setup_fit(guess)
+
+    # ---- sizes
+    def _set_npars(self):
+        self.npars = gmix_mod.get_model_npars(self.model) + self.nband - 1
+
+    def _set_n_prior_pars(self):
+        if self.prior is None:
+            self.n_prior_pars = 0
+        else:
+            self.n_prior_pars = get_lm_n_prior_pars(model=self.model_name,
+                                                    nband=self.nband)
+
+    def _set_bounds(self):
+        self._bounds = None
+        if self.prior is not None and hasattr(self.prior, "bounds"):
+            self._bounds = self.prior.bounds
+
+    @property
+    def bounds(self):
+        return copy.deepcopy(self._bounds)
+
+    # ---- device state
+    def _setup_device(self):
+        """one StampBatch for every observation of the object"""
+        from .batch import StampBatch
+        self._batch = StampBatch.from_observations(self._flat_obs)
+        self._kept = self._batch.npix_kept.astype(np.int64)
+        self.totpix = int(self._kept.sum())
+        self._pix_start = np.concatenate([[0], np.cumsum(self._kept)[:-1]]).astype(np.int64)
+        # sqrt(weight) of each listed pixel, in residual order (host copy)
+        ierr = []
+        for o in self._flat_obs:
+            w = np.asarray(o.weight, dtype="f8").ravel()
+            if o.ignore_zero_weight:
+                w = w[w > 0.0]
+            ierr.append(np.sqrt(np.where(w > 0.0, w, 0.0)))
+        self._ierr_host = np.concatenate(ierr) if ierr else np.zeros(0)
+
+    def _setup_fit(self, guess):
+        guess = np.array(guess, dtype="f8")
+        assert guess.size == self.npars, (
+            "guess has npars=%d, expected %d" % (guess.size, self.npars))
+        self.dopsf = self.obs[0][0].has_psf_gmix()
+        self._psf_list = []
+        self._band_of = []
+        for band, obslist in enumerate(self.obs):
+            for o in obslist:
+                self._psf_list.append(o.psf.gmix if self.dopsf else None)
+                self._band_of.append(band)
+        ng0 = self._model_ngauss()
+        self._ngauss_per_obs = np.array(
+            [ng0 * (len(p) if p is not None else 1) for p in self._psf_list],
+            dtype=np.int64)
+        self._gm_off = np.concatenate([[0], np.cumsum(self._ngauss_per_obs)[:-1]])
+        self._gm_host = np.zeros(int(self._ngauss_per_obs.sum()),
+                                 dtype=_lib.GAUSS2D_DTYPE)
+        self._gm0 = [self._make_model(self.get_band_pars(guess, b))
+                     for b in range(self.nband)]
+        try:
+            self._fill_gmix_all(guess)
+        except ZeroDivisionError:
+            raise GMixRangeError("got zero division")
+
+    def _model_ngauss(self):
+        return gmix_mod.get_model_ngauss(self.model)
+
+    def _make_model(self, band_pars):
+        return gmix_mod.make_gmix_model(band_pars, self.model)
+
+    def get_band_pars(self, pars, band):
+        return get_band_pars(model=self.model_name, pars=pars, band=band)
+
+    def _fill_gmix_all(self, pars):
+        """model fill per band, psf convolution per observation, norms; the
+        composed mixtures land back to back in self._gm_host
+        (results.py:306-347).  Raises GMixRangeError like the reference."""
+        L = _lib.lib()
+        for band in range(self.nband):
+            self._gm0[band]._fill(self.get_band_pars(pars, band))
+        for i, psf in enumerate(self._psf_list):
+            gm0 = self._gm0[self._band_of[i]]
+            lo = int(self._gm_off[i])
+            seg = self._gm_host[lo:lo + int(self._ngauss_per_obs[i])]
+            if psf is None:
+                seg[:] = gm0._data
+            else:
+                st = L.ngmix_convolve_fill(_lib.ptr(seg), _lib.ptr(gm0._data),
+                                           len(gm0), _lib.ptr(psf._data), len(psf))
+                _lib.check(st, "ngmix_convolve_fill")
+            st = L.ngmix_set_norms(_lib.ptr(seg), seg.size)
+            _lib.check(st, "ngmix_set_norms")
+
+    def _device_gmix(self):
+        import torch
+        flat = self._gm_host.view(np.float64).reshape(-1, 13)
+        return _RaggedGMix(torch.from_numpy(flat.copy()).to(self._batch.device),
+                           self._ngauss_per_obs)
+
+    # ---- objective
+    def _get_priors(self, pars):
+        if self.prior is None:
+            return 0.0
+        return self.prior.get_lnprob_scalar(pars)
+
+    def _fill_priors(self, pars, fdiff):
+        if self.prior is None:
+            return 0
+        return self.prior.fill_fdiff(pars, fdiff)
+
+    def calc_lnprob(self, pars, more=False):
+        """sum of get_loglike over all observations + ln prior
+        (results.py:142-210): one kernel launch"""
+        try:
+            ln_priors = self._get_priors(pars)
+            self._fill_gmix_all(pars)
+            out, status = self._batch.loglike(self._device_gmix(),
+                                              exact=gmix_mod.get_exact_kernels())
+            st = status.cpu().numpy()
+            if np.any(st != 0):
+                _lib.check(int(st[st != 0][0]), "get_loglike")
+            o = out.cpu().numpy()
+            lnprob = float(np.sum(o[:, 0])) + ln_priors
+            s2n_numer = float(np.sum(o[:, 1]))
+            s2n_denom = float(np.sum(o[:, 2]))
+            npix = int(np.sum(o[:, 3]))
+        except GMixRangeError:
+            lnprob = LOWVAL
+            s2n_numer = 0.0
+            s2n_denom = BIGVAL
+            npix = 0
+        if more:
+            return {"lnprob": lnprob, "s2n_numer": s2n_numer,
+                    "s2n_denom": s2n_denom, "npix": npix}
+        return lnprob
+
+    def calc_fdiff(self, pars):
+        """[prior rows | (model-data)/err of obs0 | obs1 ...]
+        (results.py:439-466): one kernel launch for all observations"""
+        import torch
+        fdiff = np.zeros(self.fdiff_size)
+        try:
+            self._fill_gmix_all(pars)
+            start = self._fill_priors(pars=pars, fdiff=fdiff)
+            dfd = torch.empty(self.totpix, dtype=torch.float64,
+                              device=self._batch.device)
+            _, status = self._batch.fill_fdiff(
+                self._device_gmix(), fdiff=dfd, fdiff_start=self._pix_start,
+                exact=gmix_mod.get_exact_kernels())
+            st = status.cpu().numpy()
+            if np.any(st != 0):
+                _lib.check(int(st[st != 0][0]), "fill_fdiff")
+            fdiff[start:start + self.totpix] = dfd.cpu().numpy()
+        except GMixRangeError:
+            fdiff[:] = LOWVAL
+        return fdiff
+
+    def calc_jacobian(self, pars):
+        """d calc_fdiff / d pars for gauss / exp / dev (results.py:487-570):
+        one deriv_images launch for all observations"""
+        if self.model_name not in SIMPLE_ANALYTIC_MODELS:
+            raise ValueError("analytic jacobian is not available for model %s"
+                             % self.model_name)
+        jac = np.zeros((self.fdiff_size, self.npars))
+        try:
+            start = self._fill_prior_jacobian(pars=pars, jac=jac)
+            self._fill_gmix_all(pars)
+            gpars_all, dcov_all, fluxes = [], [], []
+            for i, psf in enumerate(self._psf_list):
+                band = self._band_of[i]
+                band_pars = self.get_band_pars(pars=pars, band=band)
+                g1, g2, T, flux = band_pars[2:6]
+                if T == 0.0 or flux == 0.0:
+                    raise GMixRangeError("zero T or flux")
+                lo = int(self._gm_off[i])
+                gmc = _HostMix(self._gm_host[lo:lo + int(self._ngauss_per_obs[i])])
+                gm0 = self._gm0[band]
+                gp, dc = get_model_deriv_data(gm0=gm0, gmc=gmc, g1=g1, g2=g2, T=T)
+                gpars_all.append(gp)
+                dcov_all.append(dc)
+                fluxes.append(flux)
+            gpars = np.concatenate(gpars_all)
+            dcov = np.concatenate(dcov_all)
+            out = self._batch.deriv_images(gpars, dcov, self._ngauss_per_obs)
+            out = out.cpu().numpy()
+            for i in range(self.nimage):
+                nk = int(self._kept[i])
+                o = out[6 * int(self._pix_start[i]):6 * int(self._pix_start[i]) + 6 * nk]
+                o = o.reshape(6, nk)
+                ierr = self._ierr_host[int(self._pix_start[i]):int(self._pix_start[i]) + nk]
+                sl = slice(start, start + nk)
+                for k in range(5):
+                    jac[sl, k] = o[1 + k] * ierr
+                jac[sl, 5 + self._band_of[i]] = o[0] * (ierr / fluxes[i])
+                start += nk
+        except GMixRangeError:
+            jac[:] = 0.0
+        return jac
+
+    def _fill_prior_jacobian(self, pars, jac):
+        """forward (else backward) differences of prior.fill_fdiff
+        (results.py:572-625); returns the number of prior rows"""
+        if self.prior is None:
+            return 0
+        f0 = np.zeros(self.n_prior_pars)
+        fs = np.zeros(self.n_prior_pars)
+        n = self.prior.fill_fdiff(pars, f0)
+        good0 = np.isfinite(f0[:n])
+        p = pars.copy()
+        for ipar in range(self.npars):
+            step = STEP_PRIOR * max(1.0, abs(pars[ipar]))
+            p[:] = pars
+            p[ipar] = pars[ipar] + step
+            try:
+                self.prior.fill_fdiff(p, fs)
+            except GMixRangeError:
+                try:
+                    step = -step
+                    p[ipar] = pars[ipar] + step
+                    self.prior.fill_fdiff(p, fs)
+                except GMixRangeError:
+                    raise GMixRangeError(
+                        "prior not evaluable within a step of parameter %d" % ipar)
+            good = good0 & np.isfinite(fs[:n])
+            d = np.zeros(n)
+            d[good] = (fs[:n][good] - f0[:n][good]) / step
+            jac[:n, ipar] = d
+        return n
+
+    # ---- results
+    def set_fit_result(self, result):
+        self.update(result)
+        if self["flags"] == 0:
+            self.update(self.calc_lnprob(self["pars"], more=True))
+            if self["s2n_denom"] > 0:
+                s2n = self["s2n_numer"] / np.sqrt(self["s2n_denom"])
+            else:
+                s2n = 0.0
+            dof = self["npix"] - self.npars
+            self["chi2per"] = self["lnprob"] / (-0.5) / dof
+            self["dof"] = dof
+            self["s2n_w"] = s2n
+            self["s2n"] = s2n
+            self._set_g()
+            self._set_T()
+            self._set_flux()
+
+    def _set_g(self):
+        self["g"] = self["pars"][2:4].copy()
+        self["g_cov"] = self["pars_cov"][2:4, 2:4].copy()
+        self["g_err"] = self["pars_err"][2:4].copy()
+
+    def _set_T(self):
+        self["T"] = self["pars"][4]
+        self["T_err"] = np.sqrt(self["pars_cov"][4, 4])
+
+    def _set_flux(self):
+        start = {"bd": 7, "bdf": 6}.get(self["model"], 5)
+        if self.nband == 1:
+            self["flux"] = self["pars"][start]
+            self["flux_err"] = np.sqrt(self["pars_cov"][start, start])
+        else:
+            self["flux"] = self["pars"][start:]
+            self["flux_cov"] = self["pars_cov"][start:, start:]
+            self["flux_err"] = sqrt(diag(self["flux_cov"]))
+
+    def get_gmix(self, band=0):
+        pars = self.get_band_pars(pars=self["pars"], band=band)
+        return gmix_mod.make_gmix_model(pars, self.model)
+
+    def get_convolved_gmix(self, band=0, obsnum=0):
+        gm = self.get_gmix(band)
+        obs = self.obs[band][obsnum]
+        if obs.has_psf_gmix():
+            gm = gm.convolve(obs.psf.gmix)
+        return gm
+
+    def make_image(self, band=0, obsnum=0):
+        gm = self.get_convolved_gmix(band=band, obsnum=obsnum)
+        obs = self.obs[band][obsnum]
+        return gm.make_image(obs.image.shape, jacobian=obs.jacobian)
+
+
+class _HostMix(object):
+    """minimal read-only view so get_model_deriv_data can take a record slice"""
+
+    def __init__(self, data):
+        self._data = data
+
+    def get_full_pars(self):
+        gm = self._data
+        pars = np.zeros(6 * gm.size)
+        for k, name in enumerate(("p", "row", "col", "irr", "irc", "icc")):
+            pars[k::6] = gm[name]
+        return pars
+
+
+class CoellipFitModel(FitModel):
+    """co-elliptical gaussians, single band (results.py:628-674)"""
+
+    def __init__(self, obs, ngauss, guess, prior=None):
+        self._ngauss = ngauss
+        super().__init__(obs=obs, model="coellip", guess=guess, prior=prior)
+
+    def _model_ngauss(self):
+        return self._ngauss
+
+    def _set_flux(self):
+        pass
+
+    def _set_n_prior_pars(self):
+        assert self.nband == 1, "Coellip can only fit one band"
+        self.n_prior_pars = 0 if self.prior is None else 3 + 2 * self._ngauss
+
+    def _set_npars(self):
+        self.npars = 4 + 2 * self._ngauss
+
+    def get_band_pars(self, pars, band):
+        return np.array(pars, dtype="f8").copy()
+
+
+class Fitter(object):
+    """
+    Maximum-likelihood fit of `model` with Levenberg-Marquardt.  .go(obs,
+    guess) returns the FitModel (a dict) with flags, nfev, ier, errmsg, pars,
+    pars_err, pars_cov0, pars_cov and, when flags == 0, lnprob, s2n, chi2per,
+    dof, g, g_cov, g_err, T, T_err, flux, flux_err.
+    """
+
+    def __init__(self, model, prior=None, fit_pars=None, use_noise_image=False,
+                 analytic_jacobian=True):
+        self.prior = prior
+        self.model = gmix_mod.get_model_num(model)
+        self.model_name = gmix_mod.get_model_name(self.model)
+        if use_noise_image:
+            raise NotImplementedError(
+                "use_noise_image (noise-power sandwich covariance) is outside "
+                "the pixel hot path this build covers")
+        self.use_noise_image = use_noise_image
+        self.analytic_jacobian = analytic_jacobian
+        self.fit_pars = (fit_pars.copy() if fit_pars is not None
+                         else DEFAULT_LM_PARS.copy())
+
+    def go(self, obs, guess):
+        guess = np.asarray(guess, dtype="f8")
+        fit_model = self._make_fit_model(obs=obs, guess=guess)
+        if self.analytic_jacobian and self.model_name in SIMPLE_ANALYTIC_MODELS:
+            dfun = fit_model.calc_jacobian
+        else:
+            dfun = None
+        result = run_leastsq(fit_model.calc_fdiff, guess=guess,
+                             n_prior_pars=fit_model.n_prior_pars,
+                             bounds=fit_model.bounds, Dfun=dfun, **self.fit_pars)
+        fit_model.set_fit_result(result)
+        return fit_model
+
+    def _make_fit_model(self, obs, guess):
+        return FitModel(obs=obs, model=self.model, guess=guess, prior=self.prior)
+
+
+class CoellipFitter(Fitter):
+    """LM fit of ngauss co-elliptical gaussians"""
+
+    def __init__(self, ngauss, prior=None, fit_pars=None):
+        self._ngauss = ngauss
+        super().__init__(model="coellip", prior=prior, fit_pars=fit_pars)
+
+    def _make_fit_model(self, obs, guess):
+        return CoellipFitModel(obs=obs, ngauss=self._ngauss, guess=guess,
+                               prior=self.prior)

@@ -532,6 +532,148 @@ GENERATORS = {
     "derivs": gen_derivs,
 }
 
+
+
+# --------------------------------------------------------------------------
+# host-level callers: outputs of the reference's
+# own classes, for the API shell to reproduce
+def _obs_arrays(prefix, obs, out):
+    out[prefix + "_image"] = obs.image.copy()
+    out[prefix + "_weight"] = obs.weight.copy()
+    out[prefix + "_jac"] = jac_data(obs.jacobian)
+    if obs.has_psf():
+        out[prefix + "_psf_image"] = obs.psf.image.copy()
+        out[prefix + "_psf_weight"] = obs.psf.weight.copy()
+        out[prefix + "_psf_jac"] = jac_data(obs.psf.jacobian)
+        if obs.psf.has_gmix():
+            out[prefix + "_psf_gmix_pars"] = obs.psf.gmix.get_full_pars()
+
+
+def gen_api():
+    sys.path.insert(0, "/root/reference/ngmix/tests")
+    import _sims
+    from ngmix.fitting import Fitter
+    from ngmix.fitting.results import FitModel
+    out = {}
+
+    # ---- LM: 2 bands x 2 epochs, 'exp' with a turb psf gmix set
+    rng = np.random.RandomState(8821)
+    data = _sims.get_model_obs(rng=rng, model="exp", noise=0.005,
+                               set_psf_gmix=True, nepoch=2, nband=2)
+    mbobs = data["obs"]
+    truth = np.array(data["pars"])
+    out["lm_truth"] = truth
+    out["lm_nband"] = np.array(len(mbobs))
+    out["lm_nepoch"] = np.array(len(mbobs[0]))
+    for b, obslist in enumerate(mbobs):
+        for e, obs in enumerate(obslist):
+            _obs_arrays("lm_b%d_e%d" % (b, e), obs, out)
+    guess = truth.copy()
+    guess[0:2] += rng.uniform(-0.02, 0.02, size=2)
+    guess[2:4] += rng.uniform(-0.02, 0.02, size=2)
+    guess[4] *= 1.0 + rng.uniform(-0.1, 0.1)
+    guess[5:] *= 1.0 + rng.uniform(-0.1, 0.1, size=guess.size - 5)
+    out["lm_guess"] = guess
+    fm = FitModel(obs=mbobs, model="exp", guess=guess)
+    for tag, p in (("guess", guess), ("truth", truth)):
+        out["lm_fdiff_" + tag] = fm.calc_fdiff(p)
+        out["lm_jac_" + tag] = fm.calc_jacobian(p)
+        ln = fm.calc_lnprob(p, more=True)
+        out["lm_lnprob_" + tag] = np.array(
+            [ln["lnprob"], ln["s2n_numer"], ln["s2n_denom"], ln["npix"]])
+    bad = guess.copy()
+    bad[2:4] = [0.8, 0.7]
+    out["lm_bad_pars"] = bad
+    out["lm_fdiff_bad"] = fm.calc_fdiff(bad)
+    out["lm_jac_bad"] = fm.calc_jacobian(bad)
+    for analytic in (True, False):
+        tag = "lm_fit_analytic%d" % int(analytic)
+        res = Fitter(model="exp", analytic_jacobian=analytic).go(obs=mbobs, guess=guess)
+        for k in ("flags", "nfev", "ier", "pars", "pars_err", "pars_cov0",
+                  "pars_cov", "lnprob", "s2n_numer", "s2n_denom", "npix",
+                  "chi2per", "dof", "s2n", "g", "g_cov", "g_err", "T", "T_err",
+                  "flux", "flux_cov", "flux_err"):
+            out[tag + "_" + k] = np.array(res[k])
+        print("  LM analytic=%s flags=%d nfev=%d ier=%d" % (
+            analytic, res["flags"], res["nfev"], res["ier"]))
+
+    # ---- single obs, gauss model, no psf: simplest Fitter path
+    rng = np.random.RandomState(311)
+    jac = ngmix.DiagonalJacobian(row=15.4, col=15.7, scale=SCALE)
+    gm_true = ngmix.GMixModel([0.05, -0.03, 0.1, -0.05, 0.7, 60.0], "gauss")
+    im = gm_true.make_image((32, 32), jacobian=jac, fast_exp=True)
+    im = im + rng.normal(scale=0.01, size=im.shape)
+    obs1 = ngmix.Observation(im, weight=np.full(im.shape, 1e4), jacobian=jac)
+    _obs_arrays("g1", obs1, out)
+    g1_guess = np.array([0.0, 0.0, 0.05, 0.0, 0.8, 55.0])
+    out["g1_guess"] = g1_guess
+    res = Fitter(model="gauss").go(obs=obs1, guess=g1_guess)
+    for k in ("flags", "nfev", "ier", "pars", "pars_err", "pars_cov", "lnprob",
+              "chi2per", "dof", "s2n", "flux", "flux_err", "T", "T_err"):
+        out["g1_fit_" + k] = np.array(res[k])
+    print("  LM gauss flags=%d nfev=%d" % (res["flags"], res["nfev"]))
+
+    # ---- admom through the public API: every derived key
+    rng = np.random.RandomState(911)
+    guess_gm = ngmix.GMixModel([0.01, 0.02, 0.0, 0.0, 0.8, 1.0], "gauss")
+    ares = ngmix.admom.run_admom(obs1, guess_gm)
+    for k, v in ares.items():
+        if isinstance(v, str):
+            continue
+        out["am_" + k] = np.array(v)
+    out["am_gmix_pars"] = ares.get_gmix().get_full_pars()
+    ares2 = ngmix.admom.run_admom(obs1, 0.8, rng=np.random.RandomState(12))
+    out["am_T_guess_pars"] = np.array(ares2["pars"])
+    out["am_T_guess_numiter"] = np.array(ares2["numiter"])
+    cen = ngmix.admom.find_cen_admom(obs1, fwhm=1.2)
+    out["am_cen"] = np.array(cen["cen"])
+    out["am_cen_flags"] = np.array(cen["flags"])
+
+    # ---- em through the public API
+    rng = np.random.RandomState(42587)
+    d = _sims.get_ngauss_obs(rng=rng, ngauss=2, noise=0.01)
+    obs_em = d["obs"]
+    _obs_arrays("em", obs_em, out)
+    guess_em = d["gmix"].copy()
+    gd = guess_em.get_data()
+    gd["p"] *= 1.04
+    gd["row"] += 0.02
+    gd["irr"] *= 0.97
+    gd["det"] = gd["irr"] * gd["icc"] - gd["irc"] ** 2
+    out["em_guess_pars"] = guess_em.get_full_pars()
+    for tag, kw in (("full", {}), ("fixcen", {"fixcen": True}),
+                    ("fluxonly", {"fluxonly": True})):
+        r = ngmix.em.run_em(obs_em, guess_em, miniter=10, maxiter=80, **kw)
+        out["em_%s_numiter" % tag] = np.array(r["numiter"])
+        out["em_%s_fdiff" % tag] = np.array(r["fdiff"])
+        out["em_%s_sky" % tag] = np.array(r["sky"])
+        out["em_%s_flags" % tag] = np.array(r["flags"])
+        out["em_%s_pars" % tag] = r.get_gmix().get_full_pars()
+        out["em_%s_image" % tag] = r.make_image()
+        print("  em %s numiter=%d flags=%d" % (tag, r["numiter"], r["flags"]))
+
+    # ---- GMix API odds and ends
+    gm = ngmix.GMixModel([0.1, -0.05, 0.1, 0.05, 0.6, 100.0], "exp")
+    out["gm_default_jac_image"] = gm.make_image((21, 24), fast_exp=True)
+    out["gm_e1e2T"] = np.array(gm.get_e1e2T())
+    out["gm_g1g2T"] = np.array(gm.get_g1g2T())
+    out["gm_cen"] = np.array(gm.get_cen())
+    out["gm_sheared_pars"] = gm.get_sheared(0.02, -0.01).get_full_pars()
+    out["gm_round_pars"] = gm.make_round().get_full_pars()
+    wm = ngmix.GMixModel([0.0, 0.0, 0.0, 0.0, 0.8, 1.0], "gauss")
+    wres = wm.get_weighted_moments(obs1)
+    for k in ("flags", "flux", "flux_err", "T", "T_err", "e1", "e2", "s2n",
+              "e_err", "wsum", "npix", "sums", "sums_cov"):
+        out["wm_" + k] = np.array(wres[k])
+    out["gm_loglike_more"] = np.array(list(gm_true.get_loglike(obs1, more=True).values()),
+                                      dtype="f8")
+    out["gm_model_s2n"] = np.array(gm_true.get_model_s2n(obs1))
+    out["obs_s2n"] = np.array(obs1.get_s2n())
+    save("api", **out)
+
+
+GENERATORS["api"] = gen_api
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)

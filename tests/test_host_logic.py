@@ -1,0 +1,221 @@
+"""
+CPU tests of host orchestration that involves no pixel arithmetic: runners and
+bootstrap control flow with stub fitters (mirrors the behaviours pinned by the
+reference's test_runners.py / test_bootstrap.py), Observation container
+semantics, flags, scalar shape / moment helpers and admom.get_result branches.
+"""
+import numpy as np
+import pytest
+
+import ngmix_amd as ngmix
+from ngmix_amd import flags
+from ngmix_amd.admom import get_result
+from ngmix_amd.bootstrap import bootstrap, remove_failed_psf_obs
+from ngmix_amd.runners import Runner, PSFRunner, run_fitter
+
+
+class StubResult(dict):
+    def get_gmix(self):
+        return ngmix.GMix(pars=[1.0, 0.0, 0.0, 1.0, 0.0, 1.0])
+
+
+class StubFitter(object):
+    """returns the scripted flags in order"""
+
+    def __init__(self, flag_sequence):
+        self.seq = list(flag_sequence)
+        self.calls = []
+
+    def go(self, obs, guess=None):
+        self.calls.append((obs, guess))
+        return StubResult(flags=self.seq.pop(0))
+
+
+def _obs(with_psf=True):
+    # store_pixels=False: no device work in this CPU-only module
+    psf = ngmix.Observation(np.ones((5, 5)), store_pixels=False) if with_psf else None
+    return ngmix.Observation(np.ones((8, 8)), psf=psf, store_pixels=False)
+
+
+def test_run_fitter_retries_until_success():
+    f = StubFitter([4, 2, 0, 0])
+    res = run_fitter(_obs(), f, guesser=lambda obs: np.zeros(6), ntry=5)
+    assert res["flags"] == 0 and len(f.calls) == 3
+    f = StubFitter([4, 2])
+    res = Runner(f, guesser=lambda obs: 1.0, ntry=2).go(_obs())
+    assert res["flags"] == 2 and len(f.calls) == 2
+    f = StubFitter([0])
+    run_fitter(_obs(), f)            # no guesser: go(obs=obs) only
+    assert f.calls[0][1] is None
+
+
+def test_psf_runner_sets_result_and_gmix():
+    mb = ngmix.MultiBandObsList()
+    for _ in range(2):
+        ol = ngmix.ObsList()
+        ol.append(_obs())
+        ol.append(_obs())
+        mb.append(ol)
+    f = StubFitter([0, 8, 0, 0])
+    res = PSFRunner(f, guesser=lambda obs: 1.0).go(mb)
+    assert [[r["flags"] for r in rl] for rl in res] == [[0, 8], [0, 0]]
+    assert mb[0][0].psf.has_gmix() and not mb[0][1].psf.has_gmix()
+    assert mb[0][1].psf.meta["result"]["flags"] == 8
+    # fits the observation itself when it has no psf
+    o = _obs(with_psf=False)
+    PSFRunner(StubFitter([0])).go(o)
+    assert o.has_gmix() and o.meta["result"]["flags"] == 0
+    with pytest.raises(ValueError):
+        PSFRunner(StubFitter([0])).go("not an obs")
+
+
+def test_bootstrap_drops_failed_psf_epochs():
+    mb = ngmix.MultiBandObsList()
+    ol = ngmix.ObsList()
+    for _ in range(3):
+        ol.append(_obs())
+    mb.append(ol)
+    psf_runner = PSFRunner(StubFitter([0, 16, 0]))
+    obj = StubFitter([0])
+    res = bootstrap(mb, Runner(obj), psf_runner=psf_runner)
+    assert res["flags"] == 0
+    fitted = obj.calls[0][0]
+    assert isinstance(fitted, ngmix.MultiBandObsList) and len(fitted[0]) == 2
+    # all psf fits of a band failed
+    ol2 = ngmix.ObsList()
+    ol2.append(_obs())
+    PSFRunner(StubFitter([32])).go(ol2)
+    with pytest.raises(ngmix.BootPSFFailure):
+        remove_failed_psf_obs(ol2)
+    with pytest.raises(ValueError):
+        remove_failed_psf_obs(3)
+    # ignore_failed_psf=False keeps everything
+    obj = StubFitter([0])
+    bootstrap(ol2, Runner(obj), psf_runner=PSFRunner(StubFitter([32])),
+              ignore_failed_psf=False)
+    assert len(obj.calls[0][0]) == 1
+
+
+def test_observation_containers():
+    o = _obs()
+    assert o.has_psf() and not o.has_gmix() and not o.has_bmask()
+    assert o.pixels is None            # store_pixels=False
+    o.set_gmix(ngmix.GMix(pars=[1.0, 0.0, 0.0, 1.0, 0.0, 1.0]))
+    g1 = o.gmix
+    g1.get_data()["p"] = 5.0           # a copy: the stored gmix is untouched
+    assert o.gmix.get_flux() == 1.0
+    with pytest.raises(AssertionError):
+        o.set_image(np.ones((3, 3)))   # shape must not change
+    with pytest.raises(TypeError):
+        o.meta = 3
+    o2 = o.copy()
+    assert o2 == o
+    o2.meta["x"] = 1
+    assert not (o2 == o)
+    with pytest.raises(ValueError):
+        o == 3
+    ol = ngmix.ObsList()
+    with pytest.raises(AssertionError):
+        ol.append(3)
+    ol.append(o)
+    assert ngmix.get_mb_obs(o)[0][0] is o and ngmix.get_mb_obs(ol)[0] is ol
+    Isum, Vsum, Npix = ngmix.get_mb_obs(ol).get_s2n_sums()
+    assert (Isum, Vsum, Npix) == (64.0, 64.0, 64)
+    assert ol.get_s2n() == 8.0
+    with pytest.raises(ValueError):
+        ngmix.get_mb_obs(3)
+    j = o.jacobian
+    with pytest.raises(ValueError):
+        j._data["row0"] = 3.0          # read-only view of the obs's jacobian
+
+
+def test_flags_and_helpers():
+    assert flags.get_flags_str(0) == ""
+    assert flags.get_flags_str(flags.MAXITER | flags.LOW_DET) == \
+        "determinant near zero|max iterations reached"
+    assert flags.get_flags_str(2 ** 20) == "bit 2**20"
+    with pytest.raises(ValueError):
+        flags.get_flags_str(-1)
+    assert flags.EM_RANGE_ERROR == 2 ** 7 and flags.EM_MAXITER == 2 ** 5
+    e1, e2 = ngmix.shape.g1g2_to_e1e2(0.2, -0.1)
+    g1, g2 = ngmix.shape.e1e2_to_g1g2(e1, e2)
+    np.testing.assert_allclose([g1, g2], [0.2, -0.1], rtol=1e-14)
+    with pytest.raises(ngmix.GMixRangeError):
+        ngmix.shape.g1g2_to_e1e2(0.9, 0.9)
+    T = ngmix.moments.fwhm_to_T(1.2)
+    np.testing.assert_allclose(ngmix.moments.T_to_fwhm(T), 1.2, rtol=1e-14)
+    irr, irc, icc = ngmix.moments.get_sheared_moments(0.3, 0.02, 0.35, 0.0, 0.0)
+    np.testing.assert_allclose([irr, irc, icc], [0.3, 0.02, 0.35], rtol=1e-12)
+    with pytest.raises(ValueError):
+        ngmix.GMix()
+    with pytest.raises(ValueError):
+        ngmix.GMix(pars=[1.0] * 5)
+    with pytest.raises(ValueError):
+        ngmix.GMixModel([1.0] * 5, "exp")
+    with pytest.raises(ValueError):
+        ngmix.GMixModel([1.0] * 6, "nomodel")
+    with pytest.raises(TypeError):
+        ngmix.GMixModel([0, 0, 0, 0, 1.0, 1.0], "gauss").convolve(3)
+    gm = ngmix.GMixModel([0.1, 0.2, 0.0, 0.0, 1.0, 2.0], "exp")
+    c = gm.copy()
+    assert c == gm and len(c) == 6
+    gm.set_flux(4.0)
+    assert gm.copy().get_flux() != 4.0   # GMixModel.copy rebuilds from _pars
+    gm.set_cen(1.0, 2.0)
+    np.testing.assert_allclose(gm.copy().get_cen(), (1.0, 2.0))
+    with pytest.raises(ngmix.GMixRangeError):
+        ngmix.GMixModel([0, 0, 0.9, 0.9, 1.0, 1.0], "gauss")
+    g0 = ngmix.GMix(ngauss=2)
+    with pytest.raises(ngmix.GMixRangeError):
+        g0.set_norms()
+    cm = ngmix.GMixCM(0.3, 1.7, [0.1, -0.05, 0.1, 0.05, 0.6, 100.0])
+    assert len(cm) == 16 and cm.copy() == cm
+
+
+def test_admom_get_result_branches():
+    """hand-built records, as the reference's test_admom.py:109-120"""
+    ares = np.zeros(1, dtype=ngmix._lib.ADMOM_RESULT_DTYPE)
+    ares["sums_cov"] = np.nan
+    res = get_result(ares, 1.0, 1.0)
+    assert res["flags"] & flags.NONPOS_VAR
+    assert np.isnan(res["e1"]) and res["flagstr"] != ""
+    ares = np.zeros(1, dtype=ngmix._lib.ADMOM_RESULT_DTYPE)
+    ares["sums_cov"][0] = np.eye(7)
+    ares["sums"][0][5] = 1.0
+    ares["wsum"] = 1.0
+    ares["pars"][0][4] = -1.0          # negative T
+    res = get_result(ares, 1.0, 1.0)
+    assert res["flags"] == flags.NONPOS_SIZE
+    assert res["flux_flags"] == flags.NONPOS_SIZE
+    ares["flags"] = flags.MAXITER
+    res = get_result(ares, 1.0, 1.0)
+    assert res["flux_flags"] == flags.MAXITER and res["T_flags"] == flags.MAXITER
+
+
+def test_fitting_host_pieces():
+    from ngmix_amd.fitting import (get_band_pars, get_lm_n_prior_pars,
+                                   _BoundsTransform, leastsqbound)
+    pars = np.arange(8.0)
+    np.testing.assert_array_equal(get_band_pars("exp", pars, 2),
+                                  [0, 1, 2, 3, 4, 7])
+    np.testing.assert_array_equal(get_band_pars("bdf", pars, 1),
+                                  [0, 1, 2, 3, 4, 5, 7])
+    assert get_lm_n_prior_pars("exp", 3) == 8 and get_lm_n_prior_pars("bd", 1) == 7
+    with pytest.raises(ValueError):
+        get_lm_n_prior_pars("coellip", 1)
+    tr = _BoundsTransform([(None, None), (0.0, None), (None, 2.0), (-1.0, 1.0)])
+    x = np.array([0.3, 0.5, 1.5, 0.25])
+    np.testing.assert_allclose(tr.i2e(tr.e2i(x)), x, rtol=1e-13)
+    # bounded fit of a line: slope bounded to [0, 1.5] while the truth is 2
+    t = np.linspace(0, 1, 20)
+    y = 2.0 * t + 0.1
+
+    def func(p):
+        return p[0] * t + p[1] - y
+
+    xfit, cov, info, mesg, ier = leastsqbound(func, np.array([1.0, 0.0]),
+                                              bounds=[(0.0, 1.5), (None, None)],
+                                              full_output=1)
+    assert ier in (1, 2, 3, 4) and xfit[0] <= 1.5 + 1e-12
+    xfree, _ = leastsqbound(func, np.array([1.0, 0.0]))
+    np.testing.assert_allclose(xfree, [2.0, 0.1], atol=1e-8)
