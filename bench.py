@@ -156,18 +156,15 @@ def main():
 
     import torch
     import torch.distributed as dist
+    from ngmix_amd import distributed as nd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP kernels are the product)")
+    # one process per GPU; "nccl" is RCCL on ROCm (xGMI inside the node)
+    rank, world, local_rank = nd.init_from_env(backend="nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     distributed = world > 1
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
 
     n = args.nstamps
     sb, gm, _ = make_workload(n, seed=1000 + rank, device=device)
@@ -205,7 +202,7 @@ def main():
             done.record()
             with torch.cuda.stream(side):
                 side.wait_event(done)
-                dist.all_gather_into_tensor(gathered, out)
+                nd.allgather_records(out, n_objects=world * n, out=gathered)
                 pending = torch.cuda.Event()
                 pending.record()
 

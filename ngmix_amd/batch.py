@@ -37,7 +37,10 @@ def _dptr(t):
 def _as_device_f64(x, device):
     torch = _torch()
     if isinstance(x, np.ndarray):
-        x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if not x.flags["WRITEABLE"]:
+            x = x.copy()  # torch cannot wrap read-only arrays (obs.image views)
+        x = torch.from_numpy(x)
     return x.to(device=device, dtype=torch.float64).contiguous()
 
 
