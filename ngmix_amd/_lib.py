@@ -15,7 +15,8 @@ from . import gexceptions
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "libngmix_hip.so")
+# NGMIX_HIP_LIB selects another build of the same library (A/B kernel timing)
+LIB_PATH = os.environ.get("NGMIX_HIP_LIB", os.path.join(_HERE, "libngmix_hip.so"))
 
 # ---- status codes (include/ngmix_hip.h) ----
 OK = 0

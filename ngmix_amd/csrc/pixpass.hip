@@ -5,7 +5,7 @@
 //
 // GRID kernels (batch forms): one 256-thread work-group per stamp, compact
 // val/ierr arrays, (v,u) recomputed from (row,col) and the 64-byte jacobian.
-// Each wave owns K tiles of 16x4 pixels per round; the stamp's gaussians are
+// Each wave owns K tiles of 8x8 pixels per round; the stamp's gaussians are
 // staged in LDS together with a conservative pixel-space box of their
 // chi2<25 region, and a wave skips (gaussian, tile) pairs that cannot
 // intersect -- exact, because those evaluations are exactly 0.0.
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(BLOCK) void pixpass_grid_kernel(
 
     const double area = jac.scale * jac.scale;  // jacobian_nb.py:33-40
     const int lane = lane_id(), w = wave_id();
-    const int lrow = lane >> 4, lcol = lane & 15;
+    const int lrow = lane / TILE_W, lcol = lane % TILE_W;
     const int ntx = (ncol + TILE_W - 1) / TILE_W;
     const int nty = (nrow + TILE_H - 1) / TILE_H;
     const int ntiles = ntx * nty;
@@ -359,13 +359,31 @@ __device__ __forceinline__ void fused_tiles(
     constexpr bool kNeedsVal = (OP == OP_LOGLIKE || OP == OP_FDIFF);
     constexpr bool kNeedsIerr = (OP != OP_RENDER_FAST);
     const int lane = lane_id(), w = wave_id();
-    const int lrow = lane >> 4, lcol = lane & 15;
+    const int lrow = lane / TILE_W, lcol = lane % TILE_W;
     const int nrow = st.nrow, ncol = st.ncol;
     const int ntx = (ncol + TILE_W - 1) / TILE_W;
     const int nty = (nrow + TILE_H - 1) / TILE_H;
     const double cen_row = gf[0].row, cen_col = gf[0].col;
 
     int ty = w / ntx, tx = w - ty * ntx;
+    // When (tiles of this wave) x (gaussians) <= 64, one ballot before the loop
+    // tests every (tile, gaussian) box pair: lane = k*ng + g.  The per-tile
+    // mask is then a scalar shift of that 64-bit word.
+    const int ntiles = ntx * nty;
+    const int my_tiles = (ntiles - w + NWAVES - 1) / NWAVES;
+    const bool premask = ng > 0 && my_tiles * ng <= WAVE;
+    unsigned long long allmask = 0ull;
+    if (premask) {
+        const int k = lane / ng, g = lane - k * ng;
+        const int Tk = w + k * NWAVES;
+        const int tyk = Tk / ntx, txk = Tk - tyk * ntx;
+        const int r0k = tyk * TILE_H, c0k = txk * TILE_W;
+        const PixBox box = gf[g].box;
+        const bool hit = (k < my_tiles) & (r0k <= box.rmax) &
+                         (r0k + TILE_H - 1 >= box.rmin) & (c0k <= box.cmax) &
+                         (c0k + TILE_W - 1 >= box.cmin);
+        allmask = __ballot(hit);
+    }
     // prefetch of the first tile
     double nval = 0.0, nierr = 0.0;
     {
@@ -410,13 +428,19 @@ __device__ __forceinline__ void fused_tiles(
         double model = 0.0;
 
         for (int g0 = 0; g0 < ng; g0 += WAVE) {
-            // lane g tests gaussian g's box against this tile (branch-free)
-            const int gi = (g0 + lane < ng) ? g0 + lane : g0;
-            const PixBox box = gf[gi].box;
-            const bool hit = (g0 + lane < ng) & (r0 <= box.rmax) &
-                             (r0 + TILE_H - 1 >= box.rmin) & (c0 <= box.cmax) &
-                             (c0 + TILE_W - 1 >= box.cmin);
-            unsigned long long gmask = __ballot(hit);
+            unsigned long long gmask;
+            if (premask) {
+                gmask = allmask & ((1ull << ng) - 1ull);
+                allmask >>= ng;
+            } else {
+                // lane g tests gaussian g's box against this tile (branch-free)
+                const int gi = (g0 + lane < ng) ? g0 + lane : g0;
+                const PixBox box = gf[gi].box;
+                const bool hit = (g0 + lane < ng) & (r0 <= box.rmax) &
+                                 (r0 + TILE_H - 1 >= box.rmin) & (c0 <= box.cmax) &
+                                 (c0 + TILE_W - 1 >= box.cmin);
+                gmask = __ballot(hit);
+            }
             while (gmask) {
                 const int g = g0 + __builtin_ctzll(gmask);
                 gmask &= gmask - 1ull;

