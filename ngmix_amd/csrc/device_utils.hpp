@@ -34,6 +34,60 @@ __device__ __forceinline__ double wave_sum(double x)
     return x;
 }
 
+// a*b + c with the constant c taken from a scalar register pair: one
+// v_fma_f64 per Horner step (left to itself hipcc keeps the coefficients in
+// VGPRs and emits v_mov_b64 + v_fmac_f64, two issue slots per step)
+__device__ __forceinline__ double fma_sconst(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+
+__device__ __forceinline__ double fexp_fused(double x, const double *tab)
+{
+    const int ival = (int)(x - 0.5);
+    const double f = x - (double)ival;
+    double p = fma_sconst(f, 0.008197933236258961, 0.042330947141114836);
+    p = fma_sconst(f, p, 0.16674612720799442);
+    p = fma_sconst(f, p, 0.49992478810274166);
+    p = fma_sconst(f, p, 0.999993601071577);
+    p = fma_sconst(f, p, 1.0000011318561302);
+    return tab[ival + 15] * p;
+}
+
+// ---- DPP wave reductions ------------------------------------------------------
+// The sum of x over the 64 lanes of a wave, returned uniform (in every lane):
+// an inclusive scan inside each row of 16 lanes (row_shr 1,2,4,8), row
+// broadcasts 15 and 31 to fold the four rows, then a readlane of lane 63.
+// All VALU (v_mov_b32 dpp + v_add_f64): no LDS traffic, no waitcnt, fixed order.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_or_zero(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_total(double x)
+{
+    x += dpp_move_or_zero<0x111, 0xf>(x);  // row_shr:1
+    x += dpp_move_or_zero<0x112, 0xf>(x);  // row_shr:2
+    x += dpp_move_or_zero<0x114, 0xf>(x);  // row_shr:4
+    x += dpp_move_or_zero<0x118, 0xf>(x);  // row_shr:8
+    x += dpp_move_or_zero<0x142, 0xa>(x);  // row_bcast:15 -> rows 1, 3
+    x += dpp_move_or_zero<0x143, 0xc>(x);  // row_bcast:31 -> rows 2, 3
+    return readlane_f64(x, 63);
+}
+
 __device__ __forceinline__ int wave_sum_int(int x)
 {
 #pragma unroll

@@ -10,6 +10,8 @@
 #include "iter_common.hpp"
 #include "launch_iter.hpp"
 
+#include <stdlib.h>
+
 namespace ngmix {
 
 __constant__ double c_exp_table_m[16] = NGMIX_EXP_TABLE;
@@ -261,7 +263,7 @@ int launch_weighted_sums_list(const ngmix_gauss2d *wt, int ng,
 
 struct AdmomShared {
     double tab[16];
-    double red_scratch[NWAVES * 64];
+    double red_scratch[NWAVES * 64];  // sized for the widest work-group
     double red_out[64];
     ngmix_gauss2d wt;       // current weight
     ngmix_gauss2d wt_used;  // weight of the last moments pass
@@ -317,7 +319,10 @@ __device__ __forceinline__ void admom_deweight(ngmix_gauss2d &wt, double Irr,
     wt.det = wt.irr * wt.icc - wt.irc * wt.irc;
 }
 
-template <class Src, int PPT>
+// NT threads cooperate on one stamp (64, 128 or 256: fewer waves mean fewer
+// reduction instructions and no cross-wave barriers, more waves mean fewer
+// pixels per thread to keep in registers)
+template <class Src, int NT, int PPT>
 __device__ __forceinline__ void admom_body(const Src &src,
                                            const ngmix_admom_conf conf,
                                            ngmix_gauss2d *wt_io,
@@ -325,7 +330,7 @@ __device__ __forceinline__ void admom_body(const Src &src,
                                            int32_t *status, AdmomShared &sh)
 {
     const int tid = threadIdx.x;
-    PixCache<Src, BLOCK, PPT> cache;
+    PixCache<Src, NT, PPT> cache;
     cache.fill(src);
 
     // the moments pass divides by ierr^2 for every listed pixel
@@ -335,8 +340,8 @@ __device__ __forceinline__ void admom_body(const Src &src,
         if (ierr * ierr == 0.0) my_zero = 1;
         my_last = p > my_last ? p : my_last;
     });
-    const int last_pos = group_max_int<BLOCK>(my_last, sh.iscratch);
-    const int has_zero = group_max_int<BLOCK>(my_zero, sh.iscratch);
+    const int last_pos = group_max_int<NT>(my_last, sh.iscratch);
+    const int has_zero = group_max_int<NT>(my_zero, sh.iscratch);
 
     if (tid < 16) sh.tab[tid] = c_exp_table_m[tid];
     if (tid == 0) {
@@ -383,7 +388,7 @@ __device__ __forceinline__ void admom_body(const Src &src,
                 a[1] += wdata * u;
                 a[2] += wdata;
             });
-            group_sum<BLOCK, 4>(a, sh.red_scratch, sh.red_out);
+            group_sum<NT, 4>(a, sh.red_scratch, sh.red_out);
         }
         if (tid == 0) {
             ngmix_admom_result &res = sh.res;
@@ -434,7 +439,7 @@ __device__ __forceinline__ void admom_body(const Src &src,
                 a[7] += weight;
                 a[8] += 1.0;
             });
-            group_sum<BLOCK, 9>(a, sh.red_scratch, sh.red_out);
+            group_sum<NT, 9>(a, sh.red_scratch, sh.red_out);
         }
         if (tid == 0) {
             ngmix_admom_result &res = sh.res;
@@ -536,7 +541,7 @@ __device__ __forceinline__ void admom_body(const Src &src,
 #pragma unroll
                 for (int k = 0; k < 13; k++)
                     part[k] = (slab * 13 + k < 49) ? c[(slab * 13 + k) % 49] : 0.0;
-                group_sum<BLOCK, 13>(part, sh.red_scratch, sh.red_out);
+                group_sum<NT, 13>(part, sh.red_scratch, sh.red_out);
                 if (tid == 0) {
                     for (int k = 0; k < 13; k++)
                         if (slab * 13 + k < 49)
@@ -559,13 +564,380 @@ __device__ __forceinline__ void admom_body(const Src &src,
     }
 }
 
-template <int PPT>
-__global__ __launch_bounds__(BLOCK) void admom_grid_kernel(
+// ---------------------------------------------------------------------------
+// batch form: register-resident, barrier-light adaptive moments
+// ---------------------------------------------------------------------------
+// The stamp's (v, u, val) live in registers for the whole kernel (PPT pixels
+// per thread), the exp table in LDS.  Every lane carries the full iteration
+// state (weight, sums, flags) redundantly in registers: wave reductions are
+// DPP adds returning uniform totals, so a one-wave work-group runs the whole
+// fit without a single barrier or LDS round trip, and wider groups need one
+// barrier per reduction (double-buffered partial slots).  Pixel arithmetic
+// uses FMAs (the sums are tree-reduced, so bitwise agreement with the
+// reference's sequential loop is not available anyway; 1e-10 is the bar);
+// the scalar iteration logic keeps the reference's operations and order.
+// Non-listed and out-of-range pixel slots hold val = 0, so every wdata-
+// weighted sum ignores them without a branch; wsum uses the kept bit.
+
+struct AdmomFusedShared {
+    double tab[16];
+    double slots[2][NWAVES][32];
+    int iscratch[NWAVES + 4];
+};
+
+#define NGMIX_UNIFORM(c) (__builtin_amdgcn_readfirstlane((int)(c)) != 0)
+
+template <int NT, int NV>
+__device__ __forceinline__ void group_total(double (&a)[NV],
+                                            double (*slots)[NWAVES][32], int &phase)
+{
+    constexpr int NW = NT / WAVE;
+#pragma unroll
+    for (int i = 0; i < NV; i++) a[i] = wave_total(a[i]);
+    if (NW > 1) {
+        const int w = wave_id();
+        double(*buf)[32] = slots[phase];
+        if (lane_id() == 0) {
+#pragma unroll
+            for (int i = 0; i < NV; i++) buf[w][i] = a[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            double t = buf[0][i];
+#pragma unroll
+            for (int k = 1; k < NW; k++) t += buf[k][i];
+            a[i] = t;
+        }
+        phase ^= 1;
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ int group_sum_int(int x, int *scratch)
+{
+    constexpr int NW = NT / WAVE;
+    x = wave_sum_int(x);
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+    if (lane == 0) scratch[w] = x;
+    __syncthreads();
+    int m = scratch[0];
+#pragma unroll
+    for (int k = 1; k < NW; k++) m += scratch[k];
+    __syncthreads();
+    return m;
+}
+
+// gauss2d_eval_pixel_fast with FMAs on a precomputed chi2; pa = pnorm*area
+__device__ __forceinline__ double weight_fused(double chi2, double pa,
+                                               const double *tab)
+{
+    double w = 0.0;
+    if (chi2 < MAX_CHI2 && chi2 >= 0.0) {
+        double e = fexp_fused(-0.5 * chi2, tab);
+        if (chi2 > APOD_CHI2) {
+            const double au = (MAX_CHI2 - chi2) * APOD_IWIDTH;
+            const double aq = fma(au, fma(au, 6.0, -15.0), 10.0);
+            e *= (au * au) * (au * aq);
+        }
+        w = pa * e;
+    }
+    return w;
+}
+
+template <int NT, int PPT>
+__device__ __forceinline__ void admom_fused_body(const GridSrc &src,
+                                                 const ngmix_admom_conf conf,
+                                                 ngmix_gauss2d *wt_io,
+                                                 ngmix_admom_result *res_io,
+                                                 int32_t *status,
+                                                 AdmomFusedShared &sh)
+{
+    const int tid = threadIdx.x;
+    const int n = src.count();
+    const int nchunk = (n + NT - 1) / NT;  // uniform
+
+    // ---- the stamp, once from HBM
+    double pv[PPT], pu[PPT], pval[PPT];
+    unsigned kept = 0u;
+    int my_last = -1, my_zero = 0;
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        const int p = tid + k * NT;
+        pv[k] = pu[k] = pval[k] = 0.0;
+        if (p < n) {
+            double a, val, ierr;
+            if (src.load(p, pv[k], pu[k], a, val, ierr)) {
+                kept |= 1u << k;
+                pval[k] = val;
+                my_last = p;
+                if (ierr * ierr == 0.0) my_zero = 1;  // admom_nb.py:146
+            }
+        }
+    }
+    if (tid < 16) sh.tab[tid] = c_exp_table_m[tid];
+    const int last_pos = group_max_int<NT>(my_last, sh.iscratch);
+    const int has_zero = group_max_int<NT>(my_zero, sh.iscratch);
+    const int npix = group_sum_int<NT>(__popc(kept), sh.iscratch);
+    const double area = src.area;
+    int phase = 0;
+
+    // ---- uniform iteration state, replicated in every lane
+    ngmix_gauss2d wt = wt_io[0];
+    const double roworig = wt.row, colorig = wt.col;
+    double e1old = NAN, e2old = NAN, Told = NAN;
+    int flags = res_io[0].flags, st = NGMIX_OK;
+    int last_kind = 0;  // 0: no pass ran, 1: centroid pass, 2: moments pass
+    bool mom_ran = false;
+    int iter_index = -1;
+    double sums[7] = {0, 0, 0, 0, 0, 0, 0}, wsum = 0.0;
+    double pars[6] = {NAN, NAN, NAN, NAN, NAN, NAN}, rho4 = NAN;
+    double used_row = 0, used_col = 0, used_dcc = 0, used_drr = 0, used_drc2 = 0,
+           used_pa = 0;
+
+    for (int it = 0; it < conf.maxiter; it++) {
+        iter_index = it;
+        if (NGMIX_UNIFORM(wt.det < LOW_DETVAL)) {  // admom_nb.py:40-42
+            flags = NGMIX_FLAG_LOW_DET;
+            break;
+        }
+        const int sn = gauss_set_norm(wt);
+        if (NGMIX_UNIFORM(sn != 0)) {  // GMixRangeError escapes admom()
+            st = sn;
+            break;
+        }
+        const double dcc = wt.dcc, drr = wt.drr, mdrc2 = -2.0 * wt.drc;
+        const double pa = wt.pnorm * area;
+
+        // ---- centroid pass (admom_censums, admom_nb.py:111-128)
+        {
+            const double row = wt.row, col = wt.col;
+            double a[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < PPT; k++) {
+                if (k >= nchunk) break;
+                const double vd = pv[k] - row, ud = pu[k] - col;
+                const double chi2 =
+                    fma(dcc * vd, vd, fma(drr * ud, ud, (mdrc2 * vd) * ud));
+                const double wdata = weight_fused(chi2, pa, sh.tab) * pval[k];
+                a[0] = fma(wdata, pv[k], a[0]);
+                a[1] = fma(wdata, pu[k], a[1]);
+                a[2] += wdata;
+            }
+            group_total<NT, 3>(a, sh.slots, phase);
+            last_kind = 1;
+#pragma unroll
+            for (int i = 0; i < 6; i++) pars[i] = NAN;
+            rho4 = NAN;
+            sums[0] = a[0];
+            sums[1] = a[1];
+            sums[5] = a[2];
+        }
+        if (NGMIX_UNIFORM(sums[5] <= 0.0)) {
+            flags = NGMIX_FLAG_NONPOS_FLUX;
+            break;
+        }
+        wt.row = sums[0] / sums[5];
+        wt.col = sums[1] / sums[5];
+        if (NGMIX_UNIFORM(fabs(wt.row - roworig) > conf.shiftmax ||
+                          fabs(wt.col - colorig) > conf.shiftmax)) {
+            flags = NGMIX_FLAG_CEN_SHIFT;
+            break;
+        }
+        if (has_zero) {
+            st = NGMIX_ERR_ZERO_DIV;
+            break;
+        }
+
+        // ---- moments pass without the covariance (admom_momsums, :131-175)
+        {
+            const double row = wt.row, col = wt.col;
+            double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < PPT; k++) {
+                if (k >= nchunk) break;
+                const double vd = pv[k] - row, ud = pu[k] - col;
+                const double vv = vd * vd, uu = ud * ud, vu = vd * ud;
+                const double chi2 = fma(dcc, vv, fma(drr, uu, mdrc2 * vu));
+                const double weight = weight_fused(chi2, pa, sh.tab);
+                const double wdata = weight * pval[k];
+                a[0] = fma(wdata, pv[k], a[0]);
+                a[1] = fma(wdata, pu[k], a[1]);
+                a[2] = fma(wdata, uu - vv, a[2]);
+                a[3] = fma(wdata, vu + vu, a[3]);
+                a[4] = fma(wdata, uu + vv, a[4]);
+                a[5] += wdata;
+                a[6] = fma(wdata, chi2 * chi2, a[6]);
+                a[7] = fma(weight, (double)((kept >> k) & 1u), a[7]);
+            }
+            group_total<NT, 8>(a, sh.slots, phase);
+            last_kind = 2;
+            mom_ran = true;
+#pragma unroll
+            for (int i = 0; i < 7; i++) sums[i] = a[i];
+            wsum = a[7];
+            used_row = row;
+            used_col = col;
+            used_dcc = dcc;
+            used_drr = drr;
+            used_drc2 = mdrc2;
+            used_pa = pa;
+        }
+        if (NGMIX_UNIFORM(sums[5] <= 0.0)) {
+            flags = NGMIX_FLAG_NONPOS_FLUX;
+            break;
+        }
+        {
+            const double finv = 1.0 / sums[5];
+            const double M1 = sums[2] * finv;
+            const double M2 = sums[3] * finv;
+            const double T = sums[4] * finv;
+            const double Irr = 0.5 * (T - M1);
+            const double Icc = 0.5 * (T + M1);
+            const double Irc = 0.5 * M2;
+            if (NGMIX_UNIFORM(T <= 0.0)) {
+                flags = NGMIX_FLAG_NONPOS_SIZE;
+                break;
+            }
+            const double e1 = (Icc - Irr) / T;
+            const double e2 = 2 * Irc / T;
+            if (NGMIX_UNIFORM((fabs(e1 - e1old) < conf.etol) &&
+                              (fabs(e2 - e2old) < conf.etol) &&
+                              (fabs(T / Told - 1.) < conf.Ttol))) {
+                pars[0] = wt.row;
+                pars[1] = wt.col;
+                pars[2] = wt.icc - wt.irr;
+                pars[3] = 2.0 * wt.irc;
+                pars[4] = wt.icc + wt.irr;
+                pars[5] = 1.0;
+                rho4 = sums[6] / sums[5];
+                break;
+            }
+            if (!conf.cenonly) {
+                // deweight_moments, admom_nb.py:178-226
+                const double detm = Irr * Icc - Irc * Irc;
+                if (NGMIX_UNIFORM(detm <= LOW_DETVAL)) {
+                    flags = NGMIX_FLAG_LOW_DET;
+                    break;
+                }
+                const double Wrr = wt.irr, Wrc = wt.irc, Wcc = wt.icc;
+                const double detw = Wrr * Wcc - Wrc * Wrc;
+                if (NGMIX_UNIFORM(detw <= LOW_DETVAL)) {
+                    flags = NGMIX_FLAG_LOW_DET;
+                    break;
+                }
+                const double idetw = 1.0 / detw;
+                const double idetm = 1.0 / detm;
+                const double Nrr = Icc * idetm - Wcc * idetw;
+                const double Ncc = Irr * idetm - Wrr * idetw;
+                const double Nrc = -Irc * idetm + Wrc * idetw;
+                const double detn = Nrr * Ncc - Nrc * Nrc;
+                if (NGMIX_UNIFORM(detn <= LOW_DETVAL)) {
+                    flags = NGMIX_FLAG_LOW_DET;
+                    break;
+                }
+                const double idetn = 1. / detn;
+                wt.irr = Ncc * idetn;
+                wt.icc = Nrr * idetn;
+                wt.irc = -Nrc * idetn;
+                wt.det = wt.irr * wt.icc - wt.irc * wt.irc;
+            }
+            e1old = e1;
+            e2old = e2;
+            Told = T;
+        }
+    }
+
+    // ---- covariance of the last moments pass (admom_nb.py:168-175) and the
+    // F scratch of its last pixel.  sums_cov[i,j] and [j,i] differ in the
+    // reference only by the rounding of (w2var*F[i])*F[j] vs (w2var*F[j])*F[i];
+    // one triangle is accumulated and mirrored.
+    const bool want_cov = last_kind == 2 && st == NGMIX_OK;
+    double c[28];
+#pragma unroll
+    for (int i = 0; i < 28; i++) c[i] = 0.0;
+    if (mom_ran) {
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            if (k >= nchunk) break;
+            const int p = tid + k * NT;
+            const double vd = pv[k] - used_row, ud = pu[k] - used_col;
+            const double vv = vd * vd, uu = ud * ud, vu = vd * ud;
+            const double chi2 = fma(used_dcc, vv, fma(used_drr, uu, used_drc2 * vu));
+            double F[7];
+            F[0] = pv[k];
+            F[1] = pu[k];
+            F[2] = uu - vv;
+            F[3] = vu + vu;
+            F[4] = uu + vv;
+            F[5] = 1.0;
+            F[6] = chi2 * chi2;
+            if (p == last_pos) {
+#pragma unroll
+                for (int i = 0; i < 7; i++) res_io[0].F[i] = F[i];
+            }
+            if (want_cov) {
+                const double weight = weight_fused(chi2, used_pa, sh.tab);
+                double w2var = 0.0;
+                if ((kept >> k) & 1u) {
+                    const double ierr = src.ierr[p];
+                    w2var = weight * weight * (1.0 / (ierr * ierr));
+                }
+                int idx = 0;
+#pragma unroll
+                for (int i = 0; i < 7; i++) {
+                    const double t = w2var * F[i];
+#pragma unroll
+                    for (int j = i; j < 7; j++) {
+                        c[idx] = fma(t, F[j], c[idx]);
+                        idx++;
+                    }
+                }
+            }
+        }
+        if (want_cov) group_total<NT, 28>(c, sh.slots, phase);
+    }
+
+    if (tid == 0) {
+        ngmix_admom_result *r = res_io;
+        // admom_nb.py:105-108; maxiter <= 0 leaves the loop variable undefined
+        // in the reference, numiter = 0 here
+        const int numiter = iter_index + 1;
+        if (numiter == conf.maxiter) flags = NGMIX_FLAG_MAXITER;
+        r->flags = flags;
+        r->numiter = numiter;
+        if (last_kind != 0) {
+            r->npix = npix;
+            r->wsum = last_kind == 2 ? wsum : 0.0;
+#pragma unroll
+            for (int i = 0; i < 7; i++)
+                r->sums[i] = (last_kind == 2 || i == 0 || i == 1 || i == 5) ? sums[i] : 0.0;
+            int idx = 0;
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+#pragma unroll
+                for (int j = i; j < 7; j++) {
+                    const double x = want_cov ? c[idx] : 0.0;
+                    r->sums_cov[i * 7 + j] = x;
+                    r->sums_cov[j * 7 + i] = x;
+                    idx++;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) r->pars[i] = pars[i];
+            r->rho4 = rho4;
+        }
+        wt_io[0] = wt;
+        if (status) *status = st;
+    }
+}
+
+template <int NT, int PPT>
+__global__ __launch_bounds__(NT) void admom_grid_kernel(
     ngmix_admom_conf conf, const ngmix_stamp *stamps, const double *val,
     const double *ierr, const ngmix_jacobian *jacs, ngmix_gauss2d *wt,
     ngmix_admom_result *res, int32_t *status)
 {
-    __shared__ AdmomShared sh;
     const int s = blockIdx.x;
     const ngmix_stamp st = stamps[s];
     GridSrc src;
@@ -576,8 +948,16 @@ __global__ __launch_bounds__(BLOCK) void admom_grid_kernel(
     src.nrow = st.nrow;
     src.ncol = st.ncol;
     src.izw = (st.flags & NGMIX_STAMP_IGNORE_ZERO_WEIGHT) != 0;
-    admom_body<GridSrc, PPT>(src, conf, wt + st.gm_off, res + s,
-                             status ? status + s : nullptr, sh);
+    if constexpr (PPT > 0) {
+        __shared__ AdmomFusedShared sh;
+        admom_fused_body<NT, PPT>(src, conf, wt + st.gm_off, res + s,
+                                  status ? status + s : nullptr, sh);
+    } else {
+        // stamps too large for registers: streaming passes, reference order
+        __shared__ AdmomShared sh;
+        admom_body<GridSrc, NT, 0>(src, conf, wt + st.gm_off, res + s,
+                                   status ? status + s : nullptr, sh);
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void admom_list_kernel(
@@ -588,7 +968,17 @@ __global__ __launch_bounds__(BLOCK) void admom_list_kernel(
     ListSrc src;
     src.pix = pixels;
     src.n = n;
-    admom_body<ListSrc, 0>(src, conf, wt, res, status, sh);
+    admom_body<ListSrc, BLOCK, 0>(src, conf, wt, res, status, sh);
+}
+
+template <int NT, int PPT>
+static void admom_launch(const ngmix_admom_conf *conf, const ngmix_batch *b,
+                         ngmix_gauss2d *wt, ngmix_admom_result *res, int32_t *status,
+                         hipStream_t s)
+{
+    hipLaunchKernelGGL((admom_grid_kernel<NT, PPT>), dim3((unsigned)b->nstamps),
+                       dim3(NT), 0, s, *conf, b->stamps, b->val, b->ierr, b->jac, wt,
+                       res, status);
 }
 
 int launch_admom_grid(const ngmix_admom_conf *conf, const ngmix_batch *b,
@@ -596,17 +986,19 @@ int launch_admom_grid(const ngmix_admom_conf *conf, const ngmix_batch *b,
                       hipStream_t s)
 {
     if (b->nstamps <= 0) return NGMIX_OK;
-    dim3 grid((unsigned)b->nstamps), block(BLOCK);
-    if (b->max_npix <= 4 * BLOCK) {
-        hipLaunchKernelGGL(admom_grid_kernel<4>, grid, block, 0, s, *conf,
-                           b->stamps, b->val, b->ierr, b->jac, wt, res, status);
-    } else if (b->max_npix <= 9 * BLOCK) {
-        hipLaunchKernelGGL(admom_grid_kernel<9>, grid, block, 0, s, *conf,
-                           b->stamps, b->val, b->ierr, b->jac, wt, res, status);
-    } else {
-        hipLaunchKernelGGL(admom_grid_kernel<0>, grid, block, 0, s, *conf,
-                           b->stamps, b->val, b->ierr, b->jac, wt, res, status);
-    }
+    // tuning hook: NGMIX_ADMOM_NT=64|128|256 forces the threads per stamp
+    int nt = 0;
+    if (const char *e = getenv("NGMIX_ADMOM_NT")) nt = atoi(e);
+    const int np = b->max_npix;
+    if (nt == 0) nt = np <= 16 * 64 ? 64 : (np <= 16 * 128 ? 128 : 256);
+    if (nt == 64 && np <= 8 * 64) admom_launch<64, 8>(conf, b, wt, res, status, s);
+    else if (nt == 64 && np <= 16 * 64) admom_launch<64, 16>(conf, b, wt, res, status, s);
+    else if (nt <= 128 && np <= 8 * 128) admom_launch<128, 8>(conf, b, wt, res, status, s);
+    else if (nt <= 128 && np <= 16 * 128) admom_launch<128, 16>(conf, b, wt, res, status, s);
+    else if (np <= 4 * BLOCK) admom_launch<BLOCK, 4>(conf, b, wt, res, status, s);
+    else if (np <= 8 * BLOCK) admom_launch<BLOCK, 8>(conf, b, wt, res, status, s);
+    else if (np <= 16 * BLOCK) admom_launch<BLOCK, 16>(conf, b, wt, res, status, s);
+    else admom_launch<BLOCK, 0>(conf, b, wt, res, status, s);
     NGMIX_HIP_CHECK(hipGetLastError());
     return NGMIX_OK;
 }

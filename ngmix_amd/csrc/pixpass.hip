@@ -322,28 +322,6 @@ __device__ __forceinline__ int stage_gaussians_fused(const LdsLayout &L,
     return NGMIX_OK;
 }
 
-// a*b + c with the constant c taken from a scalar register pair: one
-// v_fma_f64 per Horner step (left to itself hipcc keeps the coefficients in
-// VGPRs and emits v_mov_b64 + v_fmac_f64, two issue slots per step)
-__device__ __forceinline__ double fma_sconst(double a, double b, double c)
-{
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
-    return r;
-}
-
-__device__ __forceinline__ double fexp_fused(double x, const double *tab)
-{
-    const int ival = (int)(x - 0.5);
-    const double f = x - (double)ival;
-    double p = fma_sconst(f, 0.008197933236258961, 0.042330947141114836);
-    p = fma_sconst(f, p, 0.16674612720799442);
-    p = fma_sconst(f, p, 0.49992478810274166);
-    p = fma_sconst(f, p, 0.999993601071577);
-    p = fma_sconst(f, p, 1.0000011318561302);
-    return tab[ival + 15] * p;
-}
-
 // Each wave walks its tiles of the stamp in a runtime loop with one tile's
 // state in registers (and the next tile's val/ierr loads already in flight):
 // ~68 VGPRs, so 7-8 waves per SIMD hide the HBM latency without staging the
