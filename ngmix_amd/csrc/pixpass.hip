@@ -37,27 +37,29 @@ struct LdsLayout {
     double *red;
     int *ctl;
     GaussLds *gl;
+    double *tb;   // fused kernels: TileEnt records (32 B each)
     unsigned long long *cmask;
     int *cpre;
 };
 
 __device__ __forceinline__ LdsLayout carve(char *base, int max_ngauss,
-                                           int nchunks_cap)
+                                           int nchunks_cap, int tile_cap = 0)
 {
     LdsLayout L;
     L.tab = (double *)base;
     L.red = L.tab + 16;
     L.ctl = (int *)(L.red + 16);
     L.gl = (GaussLds *)(base + 16 * 8 + 16 * 8 + 16);
-    L.cmask = (unsigned long long *)(L.gl + max_ngauss);
+    L.tb = (double *)(L.gl + max_ngauss);
+    L.cmask = (unsigned long long *)(L.tb + 4 * tile_cap);
     L.cpre = (int *)(L.cmask + nchunks_cap);
     return L;
 }
 
-static size_t lds_bytes(int max_ngauss, int nchunks_cap)
+static size_t lds_bytes(int max_ngauss, int nchunks_cap, int tile_cap = 0)
 {
     return 16 * 8 + 16 * 8 + 16 + (size_t)max_ngauss * sizeof(GaussLds) +
-           (size_t)nchunks_cap * 12 + 16;
+           (size_t)tile_cap * 32 + (size_t)nchunks_cap * 12 + 16;
 }
 
 // Set norms lazily exactly as the reference does (gmix_nb.py:850-851: all of
@@ -288,27 +290,44 @@ __global__ __launch_bounds__(BLOCK) void pixpass_grid_kernel(
 // ===========================================================================
 
 struct GaussFused {
-    double a, b, c, pa;  // chi2 = a dv^2 + b du^2 + c dv du ; pa = pnorm*area
+    double a, b, c, pa;  // y = chi2/2 = a dv^2 + b du^2 + c dv du ; pa = pnorm*area
     double row, col;
     PixBox box;
 };
 static_assert(sizeof(GaussFused) == 64, "GaussFused");
 
+// One record per 8x8 tile of the stamp, staged in LDS by the work-group and
+// read back by the wave that owns the tile with two broadcast ds_read_b128:
+// everything the tile loop needs without scalar index arithmetic.
+constexpr int FUSED_PF = 3;                         // tiles in flight per wave
+constexpr int FUSED_SENTINELS = FUSED_PF * NWAVES;  // look-ahead past the last tile
+
+struct TileEnt {
+    double bv, bu;   // (v - cen_row, u - cen_col) of the tile's first pixel
+    int off;         // byte offset of the tile's first pixel inside the stamp
+    int r0, c0;      // its row / column (r0 == nrow marks a sentinel)
+    int pad;
+};
+static_assert(sizeof(TileEnt) == 32, "TileEnt");
+
 __device__ __forceinline__ int stage_gaussians_fused(const LdsLayout &L,
                                                      ngmix_gauss2d *gm, int ng,
                                                      const ngmix_jacobian &jac,
-                                                     double area, bool want_box)
+                                                     double area, bool want_box,
+                                                     int nrow, int ncol)
 {
     const int st = lazy_norms(L, gm, ng);
     if (st != NGMIX_OK) return st;
+    // the fused evaluator indexes the table by n = round(chi2/2): exp(-n)
+    if (threadIdx.x < 16) L.tab[threadIdx.x] = c_exp_table[15 - threadIdx.x];
     GaussFused *gf = (GaussFused *)L.gl;
     const double row0 = ng > 0 ? gm[0].row : 0.0, col0 = ng > 0 ? gm[0].col : 0.0;
     for (int g = threadIdx.x; g < ng; g += BLOCK) {
         const ngmix_gauss2d t = gm[g];
         GaussFused r;
-        r.a = t.dcc;
-        r.b = t.drr;
-        r.c = -2.0 * t.drc;
+        r.a = 0.5 * t.dcc;   // exact scalings: y == 0.5 * chi2 bit for bit
+        r.b = 0.5 * t.drr;
+        r.c = -t.drc;
         r.pa = t.pnorm * area;
         r.row = t.row;
         r.col = t.col;
@@ -319,20 +338,72 @@ __device__ __forceinline__ int stage_gaussians_fused(const LdsLayout &L,
         if (!(t.dcc > 0.0 && t.drr > 0.0 && detq > 0.0)) L.ctl[3] = 0;
     }
     __syncthreads();
+    // tile records (coordinates relative to the shared centre when there is
+    // one), followed by NWAVES sentinels so the look-ahead never leaves them
+    const int ntx = (ncol + TILE_W - 1) / TILE_W;
+    const int nty = (nrow + TILE_H - 1) / TILE_H;
+    const int ntiles = ntx * nty;
+    const bool fast = L.ctl[2] != 0 && L.ctl[3] != 0;
+    const double cr = fast ? row0 : 0.0, cc = fast ? col0 : 0.0;
+    TileEnt *te = (TileEnt *)L.tb;
+    for (int T = threadIdx.x; T < ntiles + FUSED_SENTINELS; T += BLOCK) {
+        TileEnt e;
+        if (T < ntiles) {
+            const int ty = T / ntx, tx = T - ty * ntx;
+            e.r0 = ty * TILE_H;
+            e.c0 = tx * TILE_W;
+            const double rd = (double)e.r0 - jac.row0, cd = (double)e.c0 - jac.col0;
+            e.bv = fma(jac.dvdrow, rd, jac.dvdcol * cd) - cr;
+            e.bu = fma(jac.dudrow, rd, jac.dudcol * cd) - cc;
+            e.off = (e.r0 * ncol + e.c0) * 8;
+        } else {
+            e.r0 = nrow;
+            e.c0 = ncol;
+            e.bv = 0.0;
+            e.bu = 0.0;
+            e.off = 0;
+        }
+        e.pad = 0;
+        te[T] = e;
+    }
+    __syncthreads();
     return NGMIX_OK;
 }
 
-// Each wave walks its tiles of the stamp in a runtime loop with one tile's
-// state in registers (and the next tile's val/ierr loads already in flight):
-// ~68 VGPRs, so 7-8 waves per SIMD hide the HBM latency without staging the
-// pixels through LDS.  FAST = every gaussian of the stamp is positive
-// definite and shares one centre.
+// fexp(-y) for 0 <= y < 12.5, y = chi2/2 (fastexp_nb.py:223-262).
+// n = round-to-nearest(y) comes out of the low word of y + 1.5*2^52; the
+// reference takes ival = trunc(-y - 0.5) = -n except on exact ties
+// y = k + 0.5 with k even, where it uses the neighbouring cell of its
+// C2-continuous piecewise polynomial (a 1-ulp difference).
+__device__ __forceinline__ double fexp_neg_fused(double y, const double *tabr)
+{
+    constexpr double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
+    const double t = y + MAGIC;
+    const int n = __double2loint(t);
+    const double nd = t - MAGIC;
+    const double f = nd - y;  // = x - ival of the reference, x = -y
+    const double tv = tabr[n];
+    double p = fma_sconst(f, 0.008197933236258961, 0.042330947141114836);
+    p = fma_sconst(f, p, 0.16674612720799442);
+    p = fma_sconst(f, p, 0.49992478810274166);
+    p = fma_sconst(f, p, 0.999993601071577);
+    p = fma_sconst(f, p, 1.0000011318561302);
+    return tv * p;
+}
+
+// Each wave walks its tiles (T = wave, wave + 4, ...) with one tile's state in
+// registers and the next tile's val/ierr loads already in flight, so 7-8
+// waves per SIMD hide the HBM latency without staging pixels through LDS.
+// All per-tile quantities come from the TileEnt records; the mask of
+// gaussians whose chi2<25 box touches the tile comes from one ballot.
+// FAST = every gaussian of the stamp is positive definite and shares one
+// centre: dv^2, du^2, dv*du are formed once per pixel.
 template <int OP, bool FAST>
 __device__ __forceinline__ void fused_tiles(
     const LdsLayout &L, const GaussFused *gf, int ng, const ngmix_stamp &st,
-    const ngmix_jacobian &jac, const double *__restrict__ sval,
-    const double *__restrict__ sierr, bool masked, double *out, int64_t out_base,
-    double &acc_ll, double &acc_sn, double &acc_sd)
+    const double *__restrict__ sval, const double *__restrict__ sierr, bool masked,
+    double *out, int64_t out_base, const ngmix_jacobian &jac, double &acc_ll,
+    double &acc_sn, double &acc_sd)
 {
     constexpr bool kNeedsVal = (OP == OP_LOGLIKE || OP == OP_FDIFF);
     constexpr bool kNeedsIerr = (OP != OP_RENDER_FAST);
@@ -341,87 +412,75 @@ __device__ __forceinline__ void fused_tiles(
     const int nrow = st.nrow, ncol = st.ncol;
     const int ntx = (ncol + TILE_W - 1) / TILE_W;
     const int nty = (nrow + TILE_H - 1) / TILE_H;
-    const double cen_row = gf[0].row, cen_col = gf[0].col;
+    const int ntiles = ntx * nty;
+    const TileEnt *te = (const TileEnt *)L.tb;
+    // lane-constant parts: offset inside a tile, in (v,u) and in bytes
+    const double olv = fma(jac.dvdrow, (double)lrow, jac.dvdcol * (double)lcol);
+    const double olu = fma(jac.dudrow, (double)lrow, jac.dudcol * (double)lcol);
+    const unsigned lane_off = (unsigned)(lrow * ncol + lcol) * 8u;
+    const int rlim = nrow - lrow, clim = ncol - lcol;  // in bounds: r0 < rlim, c0 < clim
+    const char *bval = (const char *)sval;
+    const char *bierr = (const char *)sierr;
+    char *bimg = (char *)(out + st.pix_off);   // render: the stamp's image
+    char *bfd = (char *)(out + out_base);      // fdiff: the stamp's residuals
 
-    int ty = w / ntx, tx = w - ty * ntx;
     // When (tiles of this wave) x (gaussians) <= 64, one ballot before the loop
     // tests every (tile, gaussian) box pair: lane = k*ng + g.  The per-tile
     // mask is then a scalar shift of that 64-bit word.
-    const int ntiles = ntx * nty;
     const int my_tiles = (ntiles - w + NWAVES - 1) / NWAVES;
-    const bool premask = ng > 0 && my_tiles * ng <= WAVE;
+    const bool premask = ng > 0 && ng <= 32 && my_tiles * ng <= WAVE;
     unsigned long long allmask = 0ull;
     if (premask) {
         const int k = lane / ng, g = lane - k * ng;
-        const int Tk = w + k * NWAVES;
-        const int tyk = Tk / ntx, txk = Tk - tyk * ntx;
-        const int r0k = tyk * TILE_H, c0k = txk * TILE_W;
+        const int Tk = (k < my_tiles) ? w + k * NWAVES : ntiles;  // else a sentinel
+        const int r0k = te[Tk].r0, c0k = te[Tk].c0;
         const PixBox box = gf[g].box;
         const bool hit = (k < my_tiles) & (r0k <= box.rmax) &
                          (r0k + TILE_H - 1 >= box.rmin) & (c0k <= box.cmax) &
                          (c0k + TILE_W - 1 >= box.cmin);
         allmask = __ballot(hit);
     }
-    // prefetch of the first tile
-    double nval = 0.0, nierr = 0.0;
-    {
-        const int row = ty * TILE_H + lrow, col = tx * TILE_W + lcol;
-        if (ty < nty && row < nrow && col < ncol) {
-            const int idx = row * ncol + col;
-            if (kNeedsVal) nval = sval[idx];
-            if (kNeedsIerr) nierr = sierr[idx];
-            if (OP == OP_RENDER_FAST) nval = out[st.pix_off + idx];
-        }
-    }
-    while (ty < nty) {
-        const int r0 = ty * TILE_H, c0 = tx * TILE_W;
-        const int row = r0 + lrow, col = c0 + lcol;
-        const bool inb = row < nrow && col < ncol;
-        const int idx = row * ncol + col;
-        const double pval = nval, pierr = nierr;
-        // next tile of this wave: issue its loads before computing this one
-        int nty_ = ty, ntx_ = tx + NWAVES;
-        while (ntx_ >= ntx) {
-            ntx_ -= ntx;
-            nty_++;
-        }
+
+    // issue the loads of tile Tn of this wave (a sentinel past the last tile
+    // loads nothing); lanes outside the stamp carry val = ierr = 0
+    auto prefetch = [&](int Tn, bool &inb_n, double &nval, double &nierr) {
+        const int r0n = te[Tn].r0, c0n = te[Tn].c0, offn = te[Tn].off;
+        inb_n = (r0n < rlim) & (c0n < clim);
         nval = 0.0;
         nierr = 0.0;
-        {
-            const int row2 = nty_ * TILE_H + lrow, col2 = ntx_ * TILE_W + lcol;
-            if (nty_ < nty && row2 < nrow && col2 < ncol) {
-                const int idx2 = row2 * ncol + col2;
-                if (kNeedsVal) nval = sval[idx2];
-                if (kNeedsIerr) nierr = sierr[idx2];
-                if (OP == OP_RENDER_FAST) nval = out[st.pix_off + idx2];
-            }
+        if (inb_n) {
+            const unsigned off2 = lane_off + (unsigned)offn;
+            if (kNeedsVal) nval = *(const double *)(bval + off2);
+            if (kNeedsIerr) nierr = *(const double *)(bierr + off2);
+            if (OP == OP_RENDER_FAST) nval = *(const double *)(bimg + off2);
         }
-
-        const double rowdiff = (double)row - jac.row0;
-        const double coldiff = (double)col - jac.col0;
-        const double v = fma(jac.dvdrow, rowdiff, jac.dvdcol * coldiff);
-        const double u = fma(jac.dudrow, rowdiff, jac.dudcol * coldiff);
-        double dv = v - cen_row, du = u - cen_col;
+    };
+    // one tile: evaluate the gaussians that can reach it, accumulate / store
+    auto compute = [&](int Tc, bool inb, double pval, double pierr) {
+        const TileEnt cur = te[Tc];
+        const double v = cur.bv + olv, u = cur.bu + olu;  // centre-relative if FAST
+        double dv = v, du = u;
         double v2 = dv * dv, u2 = du * du, vu = dv * du;
         double model = 0.0;
 
-        for (int g0 = 0; g0 < ng; g0 += WAVE) {
-            unsigned long long gmask;
+        for (int g0 = 0; g0 < ng; g0 += 32) {
+            unsigned gmask;
             if (premask) {
-                gmask = allmask & ((1ull << ng) - 1ull);
+                gmask = (unsigned)allmask & (unsigned)((1ull << ng) - 1ull);
                 allmask >>= ng;
             } else {
                 // lane g tests gaussian g's box against this tile (branch-free)
-                const int gi = (g0 + lane < ng) ? g0 + lane : g0;
+                const int gi = (lane < 32 && g0 + lane < ng) ? g0 + lane : g0;
                 const PixBox box = gf[gi].box;
-                const bool hit = (g0 + lane < ng) & (r0 <= box.rmax) &
-                                 (r0 + TILE_H - 1 >= box.rmin) & (c0 <= box.cmax) &
-                                 (c0 + TILE_W - 1 >= box.cmin);
-                gmask = __ballot(hit);
+                const bool hit = (lane < 32) & (g0 + lane < ng) & (cur.r0 <= box.rmax) &
+                                 (cur.r0 >= box.rmin - (TILE_H - 1)) &
+                                 (cur.c0 <= box.cmax) &
+                                 (cur.c0 >= box.cmin - (TILE_W - 1));
+                gmask = (unsigned)__ballot(hit);
             }
             while (gmask) {
-                const int g = g0 + __builtin_ctzll(gmask);
-                gmask &= gmask - 1ull;
+                const int g = g0 + __builtin_ctz(gmask);
+                gmask &= gmask - 1u;
                 const GaussFused &G = gf[g];
                 const double ga = G.a, gb = G.b, gc = G.c, gpa = G.pa;
                 if (!FAST) {
@@ -431,17 +490,21 @@ __device__ __forceinline__ void fused_tiles(
                     u2 = du * du;
                     vu = dv * du;
                 }
-                const double chi2 = fma(ga, v2, fma(gb, u2, gc * vu));
-                const unsigned hi = (unsigned)__double2hiint(chi2);
-                const bool pass = FAST ? (hi < 0x40390000u)
-                                       : (chi2 < MAX_CHI2 && chi2 >= 0.0);
+                const double y = fma(ga, v2, fma(gb, u2, gc * vu));  // chi2/2
+                // 0 <= chi2 < 25  <=>  y in [+0, 12.5): for positive definite
+                // forms one unsigned compare of the high word (negative, NaN
+                // and inf fail it as they fail the reference's predicate)
+                const bool pass = FAST ? ((unsigned)__double2hiint(y) < 0x40290000u)
+                                       : (y < 12.5 && y >= 0.0);
                 if (pass) {
-                    double e = fexp_fused(-0.5 * chi2, L.tab);
-                    const bool band = FAST ? (hi >= 0x40340000u) : (chi2 > APOD_CHI2);
+                    double e = fexp_neg_fused(y, L.tab);
+                    const bool band = FAST ? ((unsigned)__double2hiint(y) >= 0x40240000u)
+                                           : (y > 10.0);
                     if (band) {
-                        // apod_window with FMAs (fastexp_nb.py:97-117)
-                        const double au = (MAX_CHI2 - chi2) * APOD_IWIDTH;
-                        const double aq = fma(au, fma(au, 6.0, -15.0), 10.0);
+                        // apod_window with FMAs (fastexp_nb.py:97-117);
+                        // W(chi2 == 20) == 1 exactly
+                        const double au = (12.5 - y) * 0.4;
+                        const double aq = fma_sconst(au, fma(au, 6.0, -15.0), 10.0);
                         e *= (au * au) * (au * aq);
                     }
                     model = fma(gpa, e, model);
@@ -449,27 +512,66 @@ __device__ __forceinline__ void fused_tiles(
             }
         }
 
-        if (inb) {
+        if (OP == OP_LOGLIKE || OP == OP_S2N) {
+            // lanes outside the stamp have ierr == 0 and add exactly 0; so do
+            // zero-weight pixels, except that a masked pixel may hold a
+            // non-finite val, hence the select on masked stamps
+            const double ivar = pierr * pierr;
+            const double mi = model * ivar;
+            double t_ll = 0.0, t_sn = 0.0;
+            if (OP == OP_LOGLIKE) {
+                const double diff = model - pval;
+                t_ll = fma(diff, diff * ivar, acc_ll);
+                t_sn = fma(pval, mi, acc_sn);
+            }
+            const double t_sd = fma(model, mi, acc_sd);
+            if (!masked) {
+                acc_ll = t_ll;
+                acc_sn = t_sn;
+                acc_sd = t_sd;
+            } else if (pierr > 0.0) {
+                acc_ll = t_ll;
+                acc_sn = t_sn;
+                acc_sd = t_sd;
+            }
+        } else if (inb) {
+            const unsigned off = lane_off + (unsigned)cur.off;
             if (OP == OP_RENDER_FAST) {
-                out[st.pix_off + idx] = pval + model;
-            } else if (!masked || pierr > 0.0) {
-                if (OP == OP_LOGLIKE) {
-                    const double ivar = pierr * pierr;
-                    const double diff = model - pval;
-                    acc_ll = fma(diff * diff, ivar, acc_ll);
-                    acc_sn = fma(pval * model, ivar, acc_sn);
-                    acc_sd = fma(model * model, ivar, acc_sd);
-                } else if (OP == OP_S2N) {
-                    const double ivar = pierr * pierr;
-                    acc_sd = fma(model * model, ivar, acc_sd);
-                } else {
-                    const int rank = masked ? kept_rank(L.cmask, L.cpre, idx) : idx;
-                    out[out_base + rank] = (model - pval) * pierr;
-                }
+                *(double *)(bimg + off) = pval + model;
+            } else if (!masked) {
+                *(double *)(bfd + off) = (model - pval) * pierr;
+            } else if (pierr > 0.0) {
+                const int rank = kept_rank(L.cmask, L.cpre, (int)(off >> 3));
+                out[out_base + rank] = (model - pval) * pierr;
             }
         }
-        ty = nty_;
-        tx = ntx_;
+    };
+
+    // PF tiles of this wave are in flight while one is being evaluated: the
+    // kernel is bound by HBM latency x bytes in flight, not by arithmetic.
+    // The register sets rotate by unrolling, not by copying.
+    int T = w;
+    bool in0, in1, in2, in3;
+    double va0, va1, va2, va3, ie0, ie1, ie2, ie3;
+    prefetch(T, in0, va0, ie0);
+    prefetch(T + NWAVES, in1, va1, ie1);
+    prefetch(T + 2 * NWAVES, in2, va2, ie2);
+    while (T < ntiles) {
+        prefetch(T + 3 * NWAVES, in3, va3, ie3);
+        compute(T, in0, va0, ie0);
+        T += NWAVES;
+        if (T >= ntiles) break;
+        prefetch(T + 3 * NWAVES, in0, va0, ie0);
+        compute(T, in1, va1, ie1);
+        T += NWAVES;
+        if (T >= ntiles) break;
+        prefetch(T + 3 * NWAVES, in1, va1, ie1);
+        compute(T, in2, va2, ie2);
+        T += NWAVES;
+        if (T >= ntiles) break;
+        prefetch(T + 3 * NWAVES, in2, va2, ie2);
+        compute(T, in3, va3, ie3);
+        T += NWAVES;
     }
 }
 
@@ -478,10 +580,10 @@ __global__ __launch_bounds__(BLOCK) void pixpass_fused_kernel(
     const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
     const double *__restrict__ ierr, const ngmix_jacobian *__restrict__ jacs,
     ngmix_gauss2d *gmix, double *out, const int64_t *__restrict__ out_start,
-    int32_t *status, int max_ngauss, int nchunks_cap, int no_skip)
+    int32_t *status, int max_ngauss, int nchunks_cap, int no_skip, int tile_cap)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const LdsLayout L = carve(smem, max_ngauss, nchunks_cap);
+    const LdsLayout L = carve(smem, max_ngauss, nchunks_cap, tile_cap);
     const GaussFused *gf = (const GaussFused *)L.gl;
 
     const int s = blockIdx.x;
@@ -498,7 +600,7 @@ __global__ __launch_bounds__(BLOCK) void pixpass_fused_kernel(
     const double area = jac.scale * jac.scale;
     const int tid = threadIdx.x;
 
-    const int stcode = stage_gaussians_fused(L, gm, ng, jac, area, !no_skip);
+    const int stcode = stage_gaussians_fused(L, gm, ng, jac, area, !no_skip, nrow, ncol);
     if (stcode != NGMIX_OK) {
         if (tid == 0) status[s] = stcode;
         return;
@@ -511,11 +613,11 @@ __global__ __launch_bounds__(BLOCK) void pixpass_fused_kernel(
     double acc_ll = 0.0, acc_sn = 0.0, acc_sd = 0.0;
     if (ng > 0) {
         if (fast)
-            fused_tiles<OP, true>(L, gf, ng, st, jac, sval, sierr, masked, out,
-                                  out_base, acc_ll, acc_sn, acc_sd);
+            fused_tiles<OP, true>(L, gf, ng, st, sval, sierr, masked, out, out_base,
+                                  jac, acc_ll, acc_sn, acc_sd);
         else
-            fused_tiles<OP, false>(L, gf, ng, st, jac, sval, sierr, masked, out,
-                                   out_base, acc_ll, acc_sn, acc_sd);
+            fused_tiles<OP, false>(L, gf, ng, st, sval, sierr, masked, out, out_base,
+                                   jac, acc_ll, acc_sn, acc_sd);
     } else if (OP != OP_RENDER_FAST) {
         // an empty mixture: model == 0 everywhere
         for (int p = tid; p < npix; p += BLOCK) {
@@ -554,6 +656,10 @@ __global__ __launch_bounds__(BLOCK) void pixpass_fused_kernel(
 
 // ---------------------------------------------------------------- launchers
 
+// fused kernels keep one 32-byte record per 8x8 tile in LDS; batches with a
+// stamp of more tiles than this (> ~360x360 pixels) run the exact kernels
+constexpr int FUSED_TILE_CAP = 2048;
+
 static int pick_k(int max_npix)
 {
     // tiles per wave per round: 9 covers 48x48 in one round, 4 covers 32x32
@@ -576,8 +682,11 @@ static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
         return NGMIX_ERR_BAD_ARG;
     }
     const int no_skip = (b->flags & NGMIX_BATCH_NO_SKIP) ? 1 : 0;
+    // per-tile records: ntiles <= npix/8 + 1 for any stamp shape, + sentinels
+    int a_tc = b->max_npix / 8 + 1 + FUSED_SENTINELS;
     // the true-exp render has no cut and no fused form
-    const bool exact = (b->flags & NGMIX_BATCH_EXACT) || OP == OP_RENDER_EXACT;
+    const bool exact = (b->flags & NGMIX_BATCH_EXACT) || OP == OP_RENDER_EXACT ||
+                       a_tc > FUSED_TILE_CAP;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)b->nstamps), block(BLOCK);
     const ngmix_stamp *a_stamps = b->stamps;
@@ -598,12 +707,17 @@ static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
     }
     constexpr int FOP = (OP == OP_RENDER_EXACT) ? OP_RENDER_FAST : OP;
     const void *kern = (const void *)pixpass_fused_kernel<FOP>;
-    if (lds > 64 * 1024)
+    const size_t flds = lds_bytes(max_ng, nchunks_cap, a_tc);
+    if (flds > 160 * 1024) {
+        set_last_error_msg("stamp needs more than 160 KiB of LDS");
+        return NGMIX_ERR_BAD_ARG;
+    }
+    if (flds > 64 * 1024)
         NGMIX_HIP_CHECK(hipFuncSetAttribute(
-            kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
     void *args[] = {&a_stamps, &a_val, &a_ierr, &a_jac, &gmix, &out, &out_start,
-                    &status, &a_ng, &a_nc, &a_ns};
-    NGMIX_HIP_CHECK(hipLaunchKernel(kern, grid, block, args, lds, s));
+                    &status, &a_ng, &a_nc, &a_ns, &a_tc};
+    NGMIX_HIP_CHECK(hipLaunchKernel(kern, grid, block, args, flds, s));
     return NGMIX_OK;
 }
 
