@@ -276,6 +276,9 @@ typedef struct {
     int32_t max_npix;           /* max nrow*ncol */
     int32_t any_masked;         /* some stamp has npix_kept != nrow*ncol */
     int32_t flags;              /* NGMIX_BATCH_* */
+    int32_t max_nrow;           /* max stamps[i].nrow, 0 = unknown */
+    int32_t max_ncol;           /* max stamps[i].ncol, 0 = unknown (LDS is
+                                   then sized from max_npix alone) */
 } ngmix_batch;
 
 /* ierr = sqrt(max(weight,0)) elementwise (pixels_nb.py:49-52) */

@@ -103,6 +103,8 @@ class Batch(ctypes.Structure):
         ("max_npix", ctypes.c_int32),
         ("any_masked", ctypes.c_int32),
         ("flags", ctypes.c_int32),
+        ("max_nrow", ctypes.c_int32),
+        ("max_ncol", ctypes.c_int32),
     ]
 
 

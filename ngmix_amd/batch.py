@@ -329,6 +329,8 @@ class StampBatch(object):
         b.max_ngauss = ngauss
         b.max_npix = self.max_npix
         b.any_masked = int(self.any_masked)
+        b.max_nrow = int(self.nrow.max()) if self.n else 0
+        b.max_ncol = int(self.ncol.max()) if self.n else 0
         b.flags = (_lib.BATCH_NO_SKIP if no_skip else 0) | \
             (_lib.BATCH_EXACT if exact else 0)
         return b

@@ -189,12 +189,13 @@ __device__ __forceinline__ PixBox gauss_pixel_box(const ngmix_gauss2d &g,
 // Row-major rank of position p among the kept pixels of a masked stamp
 // (the index into the reference's pixel list): per-64-pixel keep masks and
 // their exclusive prefix counts live in LDS (cmask/cpre, one entry per chunk).
+template <int NT = BLOCK>
 __device__ __forceinline__ void build_rank_tables(unsigned long long *cmask,
                                                   int *cpre, const double *ierr,
                                                   int npix)
 {
     const int nchunks = (npix + 63) >> 6;
-    for (int base = wave_id() * WAVE; base < nchunks * WAVE; base += BLOCK) {
+    for (int base = wave_id() * WAVE; base < nchunks * WAVE; base += NT) {
         const int p = base + lane_id();
         const bool kept = p < npix && ierr[p] > 0.0;
         const unsigned long long m = __ballot(kept);

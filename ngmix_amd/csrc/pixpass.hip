@@ -66,6 +66,7 @@ static size_t lds_bytes(int max_ngauss, int nchunks_cap, int tile_cap = 0)
 // them when gmix[0].norm_set == 0, stopping at the first failure; gaussians
 // before the failing one keep their fresh norms).  Also stages the exp table.
 // Returns the status for the stamp (uniform across the work-group).
+template <int NT = BLOCK>
 __device__ __forceinline__ int lazy_norms(const LdsLayout &L, ngmix_gauss2d *gm,
                                           int ng)
 {
@@ -80,14 +81,14 @@ __device__ __forceinline__ int lazy_norms(const LdsLayout &L, ngmix_gauss2d *gm,
     __syncthreads();
     const bool need = ng > 0 && gm[0].norm_set == 0;
     if (need) {
-        for (int g = tid; g < ng; g += BLOCK) {
+        for (int g = tid; g < ng; g += NT) {
             ngmix_gauss2d t = gm[g];
             int st = gauss_set_norm(t);
             if (st) atomicMin(&L.ctl[0], g);
         }
         __syncthreads();
         const int first_fail = L.ctl[0];
-        for (int g = tid; g < ng; g += BLOCK) {
+        for (int g = tid; g < ng; g += NT) {
             if (g < first_fail) {
                 ngmix_gauss2d t = gm[g];
                 gauss_set_norm(t);
@@ -271,20 +272,30 @@ __global__ __launch_bounds__(BLOCK) void pixpass_grid_kernel(
 }
 
 // ===========================================================================
-// FUSED kernel: same results to rounding (<= ~1e-13 relative per pixel for
-// ordinary ellipticities; north_star tolerance 1e-10), about half the VALU
-// instructions of the exact kernel, which is what bounds this path.
+// FUSED kernels (default): ONE WAVE PER STAMP.
 //
-//  * chi2 with FMAs; when every gaussian of the stamp has the same centre
+// Same results as the exact kernels to rounding (<= ~1e-13 of the stamp's peak
+// per pixel; north_star tolerance 1e-10) at about a third of the instructions:
+//
+//  * every VALU instruction costs the same issue slot on CDNA (fp64 FMA runs
+//    at full rate), so the design minimises instructions per pixel-gaussian
+//    pair and per stamp, not flops;
+//  * a 64-thread work-group (one wave) owns a stamp: no barriers, one set of
+//    per-stamp overheads instead of four, 32 stamps in flight per CU;
+//  * chi2/2 with FMAs; when every gaussian of the stamp has the same centre
 //    (object (x) centred psf) dv^2, du^2, dv*du are formed once per pixel and
-//    each gaussian costs 3 FMAs;
-//  * the gates 0 <= chi2 < 25 and chi2 >= 20 are single unsigned compares on
-//    the high word of chi2 -- exactly the reference's predicate when the form
-//    is positive definite (chi2 is then never -0.0; negative, NaN and inf fail
-//    the unsigned compare as they fail the reference's); W(20) == 1 exactly;
-//  * Horner with FMAs, pnorm*area folded into the accumulation;
-//  * tile-outer / gaussian-inner: one tile's state in registers, the mask of
-//    gaussians whose chi2<25 box touches the tile comes from one ballot.
+//    each gaussian costs 3 instructions;
+//  * the gate 0 <= chi2 < 25 is one unsigned compare on the high word of
+//    chi2/2 -- exactly the reference's predicate when the form is positive
+//    definite (chi2 is then never -0.0; negative, NaN and inf fail it as they
+//    fail the reference's);
+//  * the fexp cell index comes out of the low word of y + 1.5*2^52 (no
+//    conversions), Horner with one v_fma_f64 per step, coefficients in SGPRs;
+//  * per-tile records (coordinates, byte offset) are staged once in LDS, so
+//    the tile loop has no index arithmetic; the masks of gaussians whose
+//    chi2<25 box touches each tile come from one ballot per 64/ngauss tiles;
+//  * FUSED_PF tiles of val/ierr are in flight per wave in rotating register
+//    sets (no LDS staging of pixels, 8 waves per SIMD).
 // The summation order over gaussians (index order) and the gate semantics
 // are the reference's; only the rounding of individual operations differs.
 // ===========================================================================
@@ -296,85 +307,24 @@ struct GaussFused {
 };
 static_assert(sizeof(GaussFused) == 64, "GaussFused");
 
-// One record per 8x8 tile of the stamp, staged in LDS by the work-group and
-// read back by the wave that owns the tile with two broadcast ds_read_b128:
-// everything the tile loop needs without scalar index arithmetic.
-constexpr int FUSED_PF = 3;                         // tiles in flight per wave
-constexpr int FUSED_SENTINELS = FUSED_PF * NWAVES;  // look-ahead past the last tile
+constexpr int FUSED_PF = 3;                // tiles in flight per wave
+constexpr int FUSED_SENTINELS = FUSED_PF;  // look-ahead past the last tile
 
+// One record per 8x8 tile of the stamp, staged in LDS and read back with
+// broadcast ds_reads: everything the tile loop needs without index arithmetic.
 struct TileEnt {
-    double bv, bu;   // (v - cen_row, u - cen_col) of the tile's first pixel
+    double bv, bu;   // (v, u) of the tile's first pixel
     int off;         // byte offset of the tile's first pixel inside the stamp
     int r0, c0;      // its row / column (r0 == nrow marks a sentinel)
     int pad;
 };
 static_assert(sizeof(TileEnt) == 32, "TileEnt");
 
-__device__ __forceinline__ int stage_gaussians_fused(const LdsLayout &L,
-                                                     ngmix_gauss2d *gm, int ng,
-                                                     const ngmix_jacobian &jac,
-                                                     double area, bool want_box,
-                                                     int nrow, int ncol)
-{
-    const int st = lazy_norms(L, gm, ng);
-    if (st != NGMIX_OK) return st;
-    // the fused evaluator indexes the table by n = round(chi2/2): exp(-n)
-    if (threadIdx.x < 16) L.tab[threadIdx.x] = c_exp_table[15 - threadIdx.x];
-    GaussFused *gf = (GaussFused *)L.gl;
-    const double row0 = ng > 0 ? gm[0].row : 0.0, col0 = ng > 0 ? gm[0].col : 0.0;
-    for (int g = threadIdx.x; g < ng; g += BLOCK) {
-        const ngmix_gauss2d t = gm[g];
-        GaussFused r;
-        r.a = 0.5 * t.dcc;   // exact scalings: y == 0.5 * chi2 bit for bit
-        r.b = 0.5 * t.drr;
-        r.c = -t.drc;
-        r.pa = t.pnorm * area;
-        r.row = t.row;
-        r.col = t.col;
-        r.box = want_box ? gauss_pixel_box(t, jac) : full_box();
-        gf[g] = r;
-        if (!(t.row == row0 && t.col == col0)) L.ctl[2] = 0;
-        const double detq = t.dcc * t.drr - t.drc * t.drc;
-        if (!(t.dcc > 0.0 && t.drr > 0.0 && detq > 0.0)) L.ctl[3] = 0;
-    }
-    __syncthreads();
-    // tile records (coordinates relative to the shared centre when there is
-    // one), followed by NWAVES sentinels so the look-ahead never leaves them
-    const int ntx = (ncol + TILE_W - 1) / TILE_W;
-    const int nty = (nrow + TILE_H - 1) / TILE_H;
-    const int ntiles = ntx * nty;
-    const bool fast = L.ctl[2] != 0 && L.ctl[3] != 0;
-    const double cr = fast ? row0 : 0.0, cc = fast ? col0 : 0.0;
-    TileEnt *te = (TileEnt *)L.tb;
-    for (int T = threadIdx.x; T < ntiles + FUSED_SENTINELS; T += BLOCK) {
-        TileEnt e;
-        if (T < ntiles) {
-            const int ty = T / ntx, tx = T - ty * ntx;
-            e.r0 = ty * TILE_H;
-            e.c0 = tx * TILE_W;
-            const double rd = (double)e.r0 - jac.row0, cd = (double)e.c0 - jac.col0;
-            e.bv = fma(jac.dvdrow, rd, jac.dvdcol * cd) - cr;
-            e.bu = fma(jac.dudrow, rd, jac.dudcol * cd) - cc;
-            e.off = (e.r0 * ncol + e.c0) * 8;
-        } else {
-            e.r0 = nrow;
-            e.c0 = ncol;
-            e.bv = 0.0;
-            e.bu = 0.0;
-            e.off = 0;
-        }
-        e.pad = 0;
-        te[T] = e;
-    }
-    __syncthreads();
-    return NGMIX_OK;
-}
-
 // fexp(-y) for 0 <= y < 12.5, y = chi2/2 (fastexp_nb.py:223-262).
 // n = round-to-nearest(y) comes out of the low word of y + 1.5*2^52; the
 // reference takes ival = trunc(-y - 0.5) = -n except on exact ties
 // y = k + 0.5 with k even, where it uses the neighbouring cell of its
-// C2-continuous piecewise polynomial (a 1-ulp difference).
+// C2-continuous piecewise polynomial (a 1-ulp difference).  tabr[n] = exp(-n).
 __device__ __forceinline__ double fexp_neg_fused(double y, const double *tabr)
 {
     constexpr double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
@@ -391,32 +341,32 @@ __device__ __forceinline__ double fexp_neg_fused(double y, const double *tabr)
     return tv * p;
 }
 
-// Each wave walks its tiles (T = wave, wave + 4, ...) with one tile's state in
-// registers and the next tile's val/ierr loads already in flight, so 7-8
-// waves per SIMD hide the HBM latency without staging pixels through LDS.
-// All per-tile quantities come from the TileEnt records; the mask of
-// gaussians whose chi2<25 box touches the tile comes from one ballot.
-// FAST = every gaussian of the stamp is positive definite and shares one
-// centre: dv^2, du^2, dv*du are formed once per pixel.
-template <int OP, bool FAST>
-__device__ __forceinline__ void fused_tiles(
-    const LdsLayout &L, const GaussFused *gf, int ng, const ngmix_stamp &st,
-    const double *__restrict__ sval, const double *__restrict__ sierr, bool masked,
-    double *out, int64_t out_base, const ngmix_jacobian &jac, double &acc_ll,
-    double &acc_sn, double &acc_sd)
+// The tile loop of one stamp.  FAST = every gaussian of the stamp is positive
+// definite and shares one centre.
+template <int OP, bool MASKED, bool FAST>
+__device__ __forceinline__ void wave_tiles(
+    const LdsLayout &L, const GaussFused *gf, const TileEnt *te, int ng,
+    const ngmix_stamp &st, const double *__restrict__ sval,
+    const double *__restrict__ sierr, bool masked, double *out, int64_t out_base,
+    const ngmix_jacobian &jac, double &acc_ll, double &acc_sn, double &acc_sd)
 {
     constexpr bool kNeedsVal = (OP == OP_LOGLIKE || OP == OP_FDIFF);
     constexpr bool kNeedsIerr = (OP != OP_RENDER_FAST);
-    const int lane = lane_id(), w = wave_id();
+    const int lane = threadIdx.x;
     const int lrow = lane / TILE_W, lcol = lane % TILE_W;
     const int nrow = st.nrow, ncol = st.ncol;
     const int ntx = (ncol + TILE_W - 1) / TILE_W;
     const int nty = (nrow + TILE_H - 1) / TILE_H;
     const int ntiles = ntx * nty;
-    const TileEnt *te = (const TileEnt *)L.tb;
-    // lane-constant parts: offset inside a tile, in (v,u) and in bytes
-    const double olv = fma(jac.dvdrow, (double)lrow, jac.dvdcol * (double)lcol);
-    const double olu = fma(jac.dudrow, (double)lrow, jac.dudcol * (double)lcol);
+    // every tile is complete: no per-lane bounds tests
+    const bool full = ((nrow | ncol) & (TILE_W - 1)) == 0;
+    // lane-constant parts: offset inside a tile in (v,u), minus the shared
+    // centre when there is one, and in bytes
+    const double cen_row = FAST ? gf[0].row : 0.0, cen_col = FAST ? gf[0].col : 0.0;
+    const double olv =
+        fma(jac.dvdrow, (double)lrow, jac.dvdcol * (double)lcol) - cen_row;
+    const double olu =
+        fma(jac.dudrow, (double)lrow, jac.dudcol * (double)lcol) - cen_col;
     const unsigned lane_off = (unsigned)(lrow * ncol + lcol) * 8u;
     const int rlim = nrow - lrow, clim = ncol - lcol;  // in bounds: r0 < rlim, c0 < clim
     const char *bval = (const char *)sval;
@@ -424,58 +374,79 @@ __device__ __forceinline__ void fused_tiles(
     char *bimg = (char *)(out + st.pix_off);   // render: the stamp's image
     char *bfd = (char *)(out + out_base);      // fdiff: the stamp's residuals
 
-    // When (tiles of this wave) x (gaussians) <= 64, one ballot before the loop
-    // tests every (tile, gaussian) box pair: lane = k*ng + g.  The per-tile
-    // mask is then a scalar shift of that 64-bit word.
-    const int my_tiles = (ntiles - w + NWAVES - 1) / NWAVES;
-    const bool premask = ng > 0 && ng <= 32 && my_tiles * ng <= WAVE;
-    unsigned long long allmask = 0ull;
-    if (premask) {
-        const int k = lane / ng, g = lane - k * ng;
-        const int Tk = (k < my_tiles) ? w + k * NWAVES : ntiles;  // else a sentinel
-        const int r0k = te[Tk].r0, c0k = te[Tk].c0;
-        const PixBox box = gf[g].box;
-        const bool hit = (k < my_tiles) & (r0k <= box.rmax) &
-                         (r0k + TILE_H - 1 >= box.rmin) & (c0k <= box.cmax) &
-                         (c0k + TILE_W - 1 >= box.cmin);
-        allmask = __ballot(hit);
+    // (tile, gaussian) box tests, CH tiles per ballot: lane = k*ng + g holds
+    // gaussian g's box and tests it against tile T + k
+    const bool chunked = ng <= 32;
+    const int CH = chunked ? WAVE / ng : 0;
+    const unsigned ngmask = chunked ? (unsigned)((1ull << ng) - 1ull) : 0u;
+    int k_l = 0;
+    PixBox mybox = full_box();
+    bool lane_valid = false;
+    if (chunked) {
+        k_l = lane / ng;
+        lane_valid = k_l < CH;
+        mybox = gf[lane - k_l * ng].box;
+        mybox.rmin -= TILE_H - 1;
+        mybox.cmin -= TILE_W - 1;
     }
+    unsigned long long allmask = 0ull;
+    int kc = 0;
 
-    // issue the loads of tile Tn of this wave (a sentinel past the last tile
-    // loads nothing); lanes outside the stamp carry val = ierr = 0
+    // issue the loads of tile Tn (a sentinel past the last tile loads
+    // nothing); lanes outside the stamp carry val = ierr = 0
     auto prefetch = [&](int Tn, bool &inb_n, double &nval, double &nierr) {
-        const int r0n = te[Tn].r0, c0n = te[Tn].c0, offn = te[Tn].off;
-        inb_n = (r0n < rlim) & (c0n < clim);
-        nval = 0.0;
-        nierr = 0.0;
-        if (inb_n) {
-            const unsigned off2 = lane_off + (unsigned)offn;
-            if (kNeedsVal) nval = *(const double *)(bval + off2);
-            if (kNeedsIerr) nierr = *(const double *)(bierr + off2);
-            if (OP == OP_RENDER_FAST) nval = *(const double *)(bimg + off2);
+        if (full) {
+            inb_n = true;
+            if (Tn < ntiles) {
+                const unsigned off2 = lane_off + (unsigned)te[Tn].off;
+                if (kNeedsVal) nval = *(const double *)(bval + off2);
+                if (kNeedsIerr) nierr = *(const double *)(bierr + off2);
+                if (OP == OP_RENDER_FAST) nval = *(const double *)(bimg + off2);
+            }
+        } else {
+            const int r0n = te[Tn].r0, c0n = te[Tn].c0;
+            inb_n = (r0n < rlim) & (c0n < clim);
+            nval = 0.0;
+            nierr = 0.0;
+            if (inb_n) {
+                const unsigned off2 = lane_off + (unsigned)te[Tn].off;
+                if (kNeedsVal) nval = *(const double *)(bval + off2);
+                if (kNeedsIerr) nierr = *(const double *)(bierr + off2);
+                if (OP == OP_RENDER_FAST) nval = *(const double *)(bimg + off2);
+            }
         }
     };
+
     // one tile: evaluate the gaussians that can reach it, accumulate / store
     auto compute = [&](int Tc, bool inb, double pval, double pierr) {
-        const TileEnt cur = te[Tc];
-        const double v = cur.bv + olv, u = cur.bu + olu;  // centre-relative if FAST
+        const double v = te[Tc].bv + olv, u = te[Tc].bu + olu;
         double dv = v, du = u;
         double v2 = dv * dv, u2 = du * du, vu = dv * du;
         double model = 0.0;
 
         for (int g0 = 0; g0 < ng; g0 += 32) {
             unsigned gmask;
-            if (premask) {
-                gmask = (unsigned)allmask & (unsigned)((1ull << ng) - 1ull);
+            if (chunked) {
+                if (kc == 0) {
+                    int Tk = Tc + k_l;
+                    if (Tk > ntiles) Tk = ntiles;  // a sentinel
+                    const int r0k = te[Tk].r0, c0k = te[Tk].c0;
+                    const bool hit = lane_valid & (r0k <= mybox.rmax) &
+                                     (r0k >= mybox.rmin) & (c0k <= mybox.cmax) &
+                                     (c0k >= mybox.cmin);
+                    allmask = __ballot(hit);
+                }
+                gmask = (unsigned)allmask & ngmask;
                 allmask >>= ng;
+                kc = (kc + 1 == CH) ? 0 : kc + 1;
             } else {
-                // lane g tests gaussian g's box against this tile (branch-free)
+                // lane g tests gaussian g0+g's box against this tile
+                const int r0 = te[Tc].r0, c0 = te[Tc].c0;
                 const int gi = (lane < 32 && g0 + lane < ng) ? g0 + lane : g0;
                 const PixBox box = gf[gi].box;
-                const bool hit = (lane < 32) & (g0 + lane < ng) & (cur.r0 <= box.rmax) &
-                                 (cur.r0 >= box.rmin - (TILE_H - 1)) &
-                                 (cur.c0 <= box.cmax) &
-                                 (cur.c0 >= box.cmin - (TILE_W - 1));
+                const bool hit = (lane < 32) & (g0 + lane < ng) & (r0 <= box.rmax) &
+                                 (r0 >= box.rmin - (TILE_H - 1)) & (c0 <= box.cmax) &
+                                 (c0 >= box.cmin - (TILE_W - 1));
                 gmask = (unsigned)__ballot(hit);
             }
             while (gmask) {
@@ -491,9 +462,7 @@ __device__ __forceinline__ void fused_tiles(
                     vu = dv * du;
                 }
                 const double y = fma(ga, v2, fma(gb, u2, gc * vu));  // chi2/2
-                // 0 <= chi2 < 25  <=>  y in [+0, 12.5): for positive definite
-                // forms one unsigned compare of the high word (negative, NaN
-                // and inf fail it as they fail the reference's predicate)
+                // 0 <= chi2 < 25  <=>  y in [+0, 12.5)
                 const bool pass = FAST ? ((unsigned)__double2hiint(y) < 0x40290000u)
                                        : (y < 12.5 && y >= 0.0);
                 if (pass) {
@@ -515,7 +484,7 @@ __device__ __forceinline__ void fused_tiles(
         if (OP == OP_LOGLIKE || OP == OP_S2N) {
             // lanes outside the stamp have ierr == 0 and add exactly 0; so do
             // zero-weight pixels, except that a masked pixel may hold a
-            // non-finite val, hence the select on masked stamps
+            // non-finite val, hence the select in the MASKED kernels
             const double ivar = pierr * pierr;
             const double mi = model * ivar;
             double t_ll = 0.0, t_sn = 0.0;
@@ -525,20 +494,16 @@ __device__ __forceinline__ void fused_tiles(
                 t_sn = fma(pval, mi, acc_sn);
             }
             const double t_sd = fma(model, mi, acc_sd);
-            if (!masked) {
-                acc_ll = t_ll;
-                acc_sn = t_sn;
-                acc_sd = t_sd;
-            } else if (pierr > 0.0) {
+            if (!MASKED || !masked || pierr > 0.0) {
                 acc_ll = t_ll;
                 acc_sn = t_sn;
                 acc_sd = t_sd;
             }
-        } else if (inb) {
-            const unsigned off = lane_off + (unsigned)cur.off;
+        } else if (full || inb) {
+            const unsigned off = lane_off + (unsigned)te[Tc].off;
             if (OP == OP_RENDER_FAST) {
                 *(double *)(bimg + off) = pval + model;
-            } else if (!masked) {
+            } else if (!MASKED || !masked) {
                 *(double *)(bfd + off) = (model - pval) * pierr;
             } else if (pierr > 0.0) {
                 const int rank = kept_rank(L.cmask, L.cpre, (int)(off >> 3));
@@ -547,36 +512,36 @@ __device__ __forceinline__ void fused_tiles(
         }
     };
 
-    // PF tiles of this wave are in flight while one is being evaluated: the
-    // kernel is bound by HBM latency x bytes in flight, not by arithmetic.
-    // The register sets rotate by unrolling, not by copying.
-    int T = w;
-    bool in0, in1, in2, in3;
-    double va0, va1, va2, va3, ie0, ie1, ie2, ie3;
-    prefetch(T, in0, va0, ie0);
-    prefetch(T + NWAVES, in1, va1, ie1);
-    prefetch(T + 2 * NWAVES, in2, va2, ie2);
+    // FUSED_PF tiles are in flight while one is evaluated; the register sets
+    // rotate by unrolling, not by copying
+    int T = 0;
+    bool in0 = true, in1 = true, in2 = true, in3 = true;
+    double va0 = 0.0, va1 = 0.0, va2 = 0.0, va3 = 0.0;
+    double ie0 = 0.0, ie1 = 0.0, ie2 = 0.0, ie3 = 0.0;
+    prefetch(0, in0, va0, ie0);
+    prefetch(1, in1, va1, ie1);
+    prefetch(2, in2, va2, ie2);
     while (T < ntiles) {
-        prefetch(T + 3 * NWAVES, in3, va3, ie3);
+        prefetch(T + 3, in3, va3, ie3);
         compute(T, in0, va0, ie0);
-        T += NWAVES;
+        T++;
         if (T >= ntiles) break;
-        prefetch(T + 3 * NWAVES, in0, va0, ie0);
+        prefetch(T + 3, in0, va0, ie0);
         compute(T, in1, va1, ie1);
-        T += NWAVES;
+        T++;
         if (T >= ntiles) break;
-        prefetch(T + 3 * NWAVES, in1, va1, ie1);
+        prefetch(T + 3, in1, va1, ie1);
         compute(T, in2, va2, ie2);
-        T += NWAVES;
+        T++;
         if (T >= ntiles) break;
-        prefetch(T + 3 * NWAVES, in2, va2, ie2);
+        prefetch(T + 3, in2, va2, ie2);
         compute(T, in3, va3, ie3);
-        T += NWAVES;
+        T++;
     }
 }
 
-template <int OP>
-__global__ __launch_bounds__(BLOCK) void pixpass_fused_kernel(
+template <int OP, bool MASKED>
+__global__ __launch_bounds__(WAVE) void pixpass_wave_kernel(
     const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
     const double *__restrict__ ierr, const ngmix_jacobian *__restrict__ jacs,
     ngmix_gauss2d *gmix, double *out, const int64_t *__restrict__ out_start,
@@ -584,7 +549,8 @@ __global__ __launch_bounds__(BLOCK) void pixpass_fused_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LdsLayout L = carve(smem, max_ngauss, nchunks_cap, tile_cap);
-    const GaussFused *gf = (const GaussFused *)L.gl;
+    GaussFused *gf = (GaussFused *)L.gl;
+    TileEnt *te = (TileEnt *)L.tb;
 
     const int s = blockIdx.x;
     const ngmix_stamp st = stamps[s];
@@ -596,31 +562,73 @@ __global__ __launch_bounds__(BLOCK) void pixpass_fused_kernel(
     const double *sierr = ierr + st.pix_off;
     const bool izw = (st.flags & NGMIX_STAMP_IGNORE_ZERO_WEIGHT) != 0;
     constexpr bool kNeedsVal = (OP == OP_LOGLIKE || OP == OP_FDIFF);
-    constexpr bool kNeedsIerr = (OP != OP_RENDER_FAST);
     const double area = jac.scale * jac.scale;
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
 
-    const int stcode = stage_gaussians_fused(L, gm, ng, jac, area, !no_skip, nrow, ncol);
+    // ---- stage: norms (lazily, as the reference), gaussians, tile records
+    const int stcode = lazy_norms<WAVE>(L, gm, ng);
     if (stcode != NGMIX_OK) {
-        if (tid == 0) status[s] = stcode;
+        if (lane == 0) status[s] = stcode;
         return;
     }
+    // the fused evaluator indexes the table by n = round(chi2/2): exp(-n)
+    if (lane < 16) L.tab[lane] = c_exp_table[15 - lane];
+    const double row0 = ng > 0 ? gm[0].row : 0.0, col0 = ng > 0 ? gm[0].col : 0.0;
+    for (int g = lane; g < ng; g += WAVE) {
+        const ngmix_gauss2d t = gm[g];
+        GaussFused r;
+        r.a = 0.5 * t.dcc;   // exact scalings: y == 0.5 * chi2 bit for bit
+        r.b = 0.5 * t.drr;
+        r.c = -t.drc;
+        r.pa = t.pnorm * area;
+        r.row = t.row;
+        r.col = t.col;
+        r.box = no_skip ? full_box() : gauss_pixel_box(t, jac);
+        gf[g] = r;
+        if (!(t.row == row0 && t.col == col0)) L.ctl[2] = 0;
+        const double detq = t.dcc * t.drr - t.drc * t.drc;
+        if (!(t.dcc > 0.0 && t.drr > 0.0 && detq > 0.0)) L.ctl[3] = 0;
+    }
+    const int ntx = (ncol + TILE_W - 1) / TILE_W;
+    const int nty = (nrow + TILE_H - 1) / TILE_H;
+    const int ntiles = ntx * nty;
+    for (int T = lane; T < ntiles + FUSED_SENTINELS; T += WAVE) {
+        TileEnt e;
+        if (T < ntiles) {
+            const int ty = T / ntx, tx = T - ty * ntx;
+            e.r0 = ty * TILE_H;
+            e.c0 = tx * TILE_W;
+            const double rd = (double)e.r0 - jac.row0, cd = (double)e.c0 - jac.col0;
+            e.bv = fma(jac.dvdrow, rd, jac.dvdcol * cd);
+            e.bu = fma(jac.dudrow, rd, jac.dudcol * cd);
+            e.off = (e.r0 * ncol + e.c0) * 8;
+        } else {
+            e.r0 = nrow;
+            e.c0 = ncol;
+            e.bv = 0.0;
+            e.bu = 0.0;
+            e.off = 0;
+        }
+        e.pad = 0;
+        te[T] = e;
+    }
+    __syncthreads();  // one wave: orders the LDS writes above, no s_barrier
     const bool fast = L.ctl[2] != 0 && L.ctl[3] != 0;
-    const bool masked = kNeedsIerr && izw && st.npix_kept != npix;
-    if (OP == OP_FDIFF && masked) build_rank_tables(L.cmask, L.cpre, sierr, npix);
+    const bool masked = MASKED && izw && st.npix_kept != npix;
+    if (OP == OP_FDIFF && masked) build_rank_tables<WAVE>(L.cmask, L.cpre, sierr, npix);
     const int64_t out_base = (OP == OP_FDIFF) ? out_start[s] : 0;
 
     double acc_ll = 0.0, acc_sn = 0.0, acc_sd = 0.0;
     if (ng > 0) {
         if (fast)
-            fused_tiles<OP, true>(L, gf, ng, st, sval, sierr, masked, out, out_base,
-                                  jac, acc_ll, acc_sn, acc_sd);
+            wave_tiles<OP, MASKED, true>(L, gf, te, ng, st, sval, sierr, masked, out,
+                                         out_base, jac, acc_ll, acc_sn, acc_sd);
         else
-            fused_tiles<OP, false>(L, gf, ng, st, sval, sierr, masked, out, out_base,
-                                   jac, acc_ll, acc_sn, acc_sd);
+            wave_tiles<OP, MASKED, false>(L, gf, te, ng, st, sval, sierr, masked, out,
+                                          out_base, jac, acc_ll, acc_sn, acc_sd);
     } else if (OP != OP_RENDER_FAST) {
         // an empty mixture: model == 0 everywhere
-        for (int p = tid; p < npix; p += BLOCK) {
+        for (int p = lane; p < npix; p += WAVE) {
             const double pv = kNeedsVal ? sval[p] : 0.0, pe = sierr[p];
             if (masked && !(pe > 0.0)) continue;
             if (OP == OP_LOGLIKE) acc_ll = fma(pv * pv, pe * pe, acc_ll);
@@ -632,25 +640,24 @@ __global__ __launch_bounds__(BLOCK) void pixpass_fused_kernel(
     }
 
     if (OP == OP_LOGLIKE) {
-        double v[3] = {acc_ll, acc_sn, acc_sd};
-        block_sum<3>(v, L.red);
-        if (tid == 0) {
-            out[4 * (int64_t)s + 0] = v[0] * -0.5;
-            out[4 * (int64_t)s + 1] = v[1];
-            out[4 * (int64_t)s + 2] = v[2];
+        const double ll = wave_total(acc_ll), sn = wave_total(acc_sn),
+                     sd = wave_total(acc_sd);
+        if (lane == 0) {
+            out[4 * (int64_t)s + 0] = ll * -0.5;  // gmix_nb.py:872
+            out[4 * (int64_t)s + 1] = sn;
+            out[4 * (int64_t)s + 2] = sd;
             // the number of listed pixels is a property of the stamp
             out[4 * (int64_t)s + 3] = (double)(izw ? st.npix_kept : npix);
             status[s] = NGMIX_OK;
         }
     } else if (OP == OP_S2N) {
-        double v[1] = {acc_sd};
-        block_sum<1>(v, L.red);
-        if (tid == 0) {
-            out[s] = v[0];
+        const double sd = wave_total(acc_sd);
+        if (lane == 0) {
+            out[s] = sd;
             status[s] = NGMIX_OK;
         }
     } else {
-        if (tid == 0) status[s] = NGMIX_OK;
+        if (lane == 0) status[s] = NGMIX_OK;
     }
 }
 
@@ -682,18 +689,22 @@ static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
         return NGMIX_ERR_BAD_ARG;
     }
     const int no_skip = (b->flags & NGMIX_BATCH_NO_SKIP) ? 1 : 0;
-    // per-tile records: ntiles <= npix/8 + 1 for any stamp shape, + sentinels
-    int a_tc = b->max_npix / 8 + 1 + FUSED_SENTINELS;
+    // per-tile records of the fused kernels: exact when the batch carries its
+    // largest stamp shape, else ntiles <= npix/8 + 1 holds for any shape
+    int a_tc = b->max_npix / 8 + 1;
+    if (b->max_nrow > 0 && b->max_ncol > 0)
+        a_tc = ((b->max_nrow + TILE_H - 1) / TILE_H) * ((b->max_ncol + TILE_W - 1) / TILE_W);
+    a_tc += FUSED_SENTINELS;
     // the true-exp render has no cut and no fused form
     const bool exact = (b->flags & NGMIX_BATCH_EXACT) || OP == OP_RENDER_EXACT ||
                        a_tc > FUSED_TILE_CAP;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)b->nstamps), block(BLOCK);
     const ngmix_stamp *a_stamps = b->stamps;
     const double *a_val = b->val, *a_ierr = b->ierr;
     const ngmix_jacobian *a_jac = b->jac;
     int a_ng = max_ng, a_nc = nchunks_cap, a_ns = no_skip;
     if (exact) {
+        dim3 grid((unsigned)b->nstamps), block(BLOCK);
         const bool k4 = pick_k(b->max_npix) == 4;
         const void *kern = k4 ? (const void *)pixpass_grid_kernel<OP, 4>
                               : (const void *)pixpass_grid_kernel<OP, 9>;
@@ -706,7 +717,10 @@ static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
         return NGMIX_OK;
     }
     constexpr int FOP = (OP == OP_RENDER_EXACT) ? OP_RENDER_FAST : OP;
-    const void *kern = (const void *)pixpass_fused_kernel<FOP>;
+    // zero-weight pixels only matter to the kernels that read ierr
+    const bool mk = b->any_masked && FOP != OP_RENDER_FAST;
+    const void *kern = mk ? (const void *)pixpass_wave_kernel<FOP, true>
+                          : (const void *)pixpass_wave_kernel<FOP, false>;
     const size_t flds = lds_bytes(max_ng, nchunks_cap, a_tc);
     if (flds > 160 * 1024) {
         set_last_error_msg("stamp needs more than 160 KiB of LDS");
@@ -715,6 +729,7 @@ static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
     if (flds > 64 * 1024)
         NGMIX_HIP_CHECK(hipFuncSetAttribute(
             kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+    dim3 grid((unsigned)b->nstamps), block(WAVE);
     void *args[] = {&a_stamps, &a_val, &a_ierr, &a_jac, &gmix, &out, &out_start,
                     &status, &a_ng, &a_nc, &a_ns, &a_tc};
     NGMIX_HIP_CHECK(hipLaunchKernel(kern, grid, block, args, flds, s));
