@@ -265,7 +265,7 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": "pixpass_%s_kernel<%s>" % (
-                    "grid" if args.exact else "fused", dominant),
+                    "grid" if args.exact else "wave", dominant),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -20,6 +20,13 @@
 namespace ngmix {
 
 __constant__ double c_exp_table[16] = NGMIX_EXP_TABLE;
+// exp5_smooth coefficients c0..c5 (fastexp_nb.py:252-258) followed by the
+// apodisation constants 10, -15, 6: read with scalar loads so that they live
+// in SGPRs and every Horner step is a single v_fma_f64 v, v, v, s
+__constant__ double c_fexp_coef[9] = {
+    1.0000011318561302, 0.999993601071577,   0.49992478810274166,
+    0.16674612720799442, 0.042330947141114836, 0.008197933236258961,
+    10.0, -15.0, 6.0};
 
 enum PassOp { OP_LOGLIKE = 0, OP_FDIFF = 1, OP_RENDER_FAST = 2,
               OP_RENDER_EXACT = 3, OP_S2N = 4 };
@@ -312,6 +319,10 @@ constexpr int FUSED_SENTINELS = FUSED_PF;  // look-ahead past the last tile
 
 // One record per 8x8 tile of the stamp, staged in LDS and read back with
 // broadcast ds_reads: everything the tile loop needs without index arithmetic.
+// Tile shape (template TW): 8x8 for the kernels that only read (fewest
+// (tile, gaussian) pairs survive the box test: they are instruction bound);
+// 4 rows x 16 columns for render, whose read-modify-write stream is HBM bound
+// and wants whole 128-byte lines per wave access.
 struct TileEnt {
     double bv, bu;   // (v, u) of the tile's first pixel
     int off;         // byte offset of the tile's first pixel inside the stamp
@@ -320,12 +331,75 @@ struct TileEnt {
 };
 static_assert(sizeof(TileEnt) == 32, "TileEnt");
 
+// Untracked loads for the look-ahead of the FULL tile loop.  hipcc counts its
+// own memory operations but is conservative across loop back-edges and
+// branches (it drains to vmcnt(0) once per trip); these loads are invisible to
+// it and are waited for by wait_vm<N>, N = number of such loads issued AFTER
+// the one needed (loads complete in order).  Compiler-issued memory
+// operations in between only make the wait conservative, never unsafe.
+__device__ __forceinline__ void gload_f64(double &dst, const void *base, unsigned off)
+{
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base));
+}
+
+// The same load issued with EXEC = 0 when `on` (wave-uniform) is false: no
+// memory request, dst untouched, but the instruction is still issued and
+// counted -- so the number of loads behind any given one stays a constant and
+// the register is never the target of a compiler-made copy (a branch around an
+// asm load would make dst a phi of "loaded" and "old", and a copy of a
+// register whose data has not landed yet reads garbage).
+__device__ __forceinline__ void gload_f64_if(double &dst, const void *base,
+                                             unsigned off, bool on)
+{
+    const int m = __builtin_amdgcn_readfirstlane(on ? -1 : 0);
+    unsigned long long save;
+    asm volatile(
+        "s_mov_b64 %1, exec\n\t"
+        "s_and_b32 exec_lo, exec_lo, %3\n\t"
+        "s_and_b32 exec_hi, exec_hi, %3\n\t"
+        "global_load_dwordx2 %0, %2, %4\n\t"
+        "s_mov_b64 exec, %1"
+        : "+v"(dst), "=&s"(save)
+        : "v"(off), "s"(m), "s"(base));
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm(double &a, double &b)
+{
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+
+struct FexpCoef {
+    double c0, c1, c2, c3, c4, c5, w10, wm15, w6;
+    int c5lo, c5hi, w6lo, w6hi;
+};
+
+__device__ __forceinline__ FexpCoef load_fexp_coef()
+{
+    // the index is opaque to the compiler (always 0), so the values stay
+    // loaded SGPRs instead of being re-materialised as literals in VGPRs
+    const double *c = c_fexp_coef + __builtin_amdgcn_readfirstlane(blockIdx.x >> 31);
+    FexpCoef k;
+    k.c0 = c[0]; k.c1 = c[1]; k.c2 = c[2]; k.c3 = c[3]; k.c4 = c[4]; k.c5 = c[5];
+    k.w10 = c[6]; k.wm15 = c[7]; k.w6 = c[8];
+    // a VOP3 instruction reads at most one SGPR pair: the multiplicands of the
+    // two-constant steps live in VGPRs (opaque moves, so they stay there)
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+                 : "=v"(k.c5lo), "=v"(k.c5hi)
+                 : "s"(__double2loint(c[5])), "s"(__double2hiint(c[5])));
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+                 : "=v"(k.w6lo), "=v"(k.w6hi)
+                 : "s"(__double2loint(c[8])), "s"(__double2hiint(c[8])));
+    return k;
+}
+
 // fexp(-y) for 0 <= y < 12.5, y = chi2/2 (fastexp_nb.py:223-262).
 // n = round-to-nearest(y) comes out of the low word of y + 1.5*2^52; the
 // reference takes ival = trunc(-y - 0.5) = -n except on exact ties
 // y = k + 0.5 with k even, where it uses the neighbouring cell of its
 // C2-continuous piecewise polynomial (a 1-ulp difference).  tabr[n] = exp(-n).
-__device__ __forceinline__ double fexp_neg_fused(double y, const double *tabr)
+__device__ __forceinline__ double fexp_neg_fused(double y, const double *tabr,
+                                                 const FexpCoef &k)
 {
     constexpr double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
     const double t = y + MAGIC;
@@ -333,33 +407,39 @@ __device__ __forceinline__ double fexp_neg_fused(double y, const double *tabr)
     const double nd = t - MAGIC;
     const double f = nd - y;  // = x - ival of the reference, x = -y
     const double tv = tabr[n];
-    double p = fma_sconst(f, 0.008197933236258961, 0.042330947141114836);
-    p = fma_sconst(f, p, 0.16674612720799442);
-    p = fma_sconst(f, p, 0.49992478810274166);
-    p = fma_sconst(f, p, 0.999993601071577);
-    p = fma_sconst(f, p, 1.0000011318561302);
+    double p = fma(f, __hiloint2double(k.c5hi, k.c5lo), k.c4);
+    p = fma(f, p, k.c3);
+    p = fma(f, p, k.c2);
+    p = fma(f, p, k.c1);
+    p = fma(f, p, k.c0);
     return tv * p;
 }
 
 // The tile loop of one stamp.  FAST = every gaussian of the stamp is positive
 // definite and shares one centre.
-template <int OP, bool MASKED, bool FAST>
+template <int OP, bool MASKED, bool FAST, bool FULL, int TW>
 __device__ __forceinline__ void wave_tiles(
     const LdsLayout &L, const GaussFused *gf, const TileEnt *te, int ng,
     const ngmix_stamp &st, const double *__restrict__ sval,
     const double *__restrict__ sierr, bool masked, double *out, int64_t out_base,
-    const ngmix_jacobian &jac, double &acc_ll, double &acc_sn, double &acc_sd)
+    const ngmix_jacobian &jac, double (&pv)[FUSED_PF], double (&pe)[FUSED_PF],
+    double &acc_ll, double &acc_sn, double &acc_sd)
 {
     constexpr bool kNeedsVal = (OP == OP_LOGLIKE || OP == OP_FDIFF);
     constexpr bool kNeedsIerr = (OP != OP_RENDER_FAST);
+    constexpr int TH = WAVE / TW;  // tile = TH rows x TW columns = one wave
     const int lane = threadIdx.x;
-    const int lrow = lane / TILE_W, lcol = lane % TILE_W;
+    const int lrow = lane / TW, lcol = lane % TW;
     const int nrow = st.nrow, ncol = st.ncol;
-    const int ntx = (ncol + TILE_W - 1) / TILE_W;
-    const int nty = (nrow + TILE_H - 1) / TILE_H;
+    const int ntx = (ncol + TW - 1) / TW;
+    const int nty = (nrow + TH - 1) / TH;
     const int ntiles = ntx * nty;
-    // every tile is complete: no per-lane bounds tests
-    const bool full = ((nrow | ncol) & (TILE_W - 1)) == 0;
+    // FULL: every tile is complete -- no per-lane bounds tests, and every
+    // load / store is unconditional so that the compiler can count them:
+    // waiting for tile T's data is then s_waitcnt vmcnt(ops issued since),
+    // which leaves the look-ahead loads in flight (a branch around a memory
+    // instruction makes the count unknown and forces vmcnt(0))
+    constexpr bool full = FULL;
     // lane-constant parts: offset inside a tile in (v,u), minus the shared
     // centre when there is one, and in bytes
     const double cen_row = FAST ? gf[0].row : 0.0, cen_col = FAST ? gf[0].col : 0.0;
@@ -386,23 +466,24 @@ __device__ __forceinline__ void wave_tiles(
         k_l = lane / ng;
         lane_valid = k_l < CH;
         mybox = gf[lane - k_l * ng].box;
-        mybox.rmin -= TILE_H - 1;
-        mybox.cmin -= TILE_W - 1;
+        mybox.rmin -= TH - 1;
+        mybox.cmin -= TW - 1;
     }
     unsigned long long allmask = 0ull;
     int kc = 0;
+    const FexpCoef K = load_fexp_coef();
 
     // issue the loads of tile Tn (a sentinel past the last tile loads
     // nothing); lanes outside the stamp carry val = ierr = 0
     auto prefetch = [&](int Tn, bool &inb_n, double &nval, double &nierr) {
         if (full) {
             inb_n = true;
-            if (Tn < ntiles) {
-                const unsigned off2 = lane_off + (unsigned)te[Tn].off;
-                if (kNeedsVal) nval = *(const double *)(bval + off2);
-                if (kNeedsIerr) nierr = *(const double *)(bierr + off2);
-                if (OP == OP_RENDER_FAST) nval = *(const double *)(bimg + off2);
-            }
+            // past the last tile: issued with EXEC = 0 (te[] has sentinels)
+            const bool on = Tn < ntiles;
+            const unsigned off2 = lane_off + (unsigned)te[Tn].off;
+            if (kNeedsVal) gload_f64_if(nval, bval, off2, on);
+            if (kNeedsIerr) gload_f64_if(nierr, bierr, off2, on);
+            if (OP == OP_RENDER_FAST) gload_f64_if(nval, bimg, off2, on);
         } else {
             const int r0n = te[Tn].r0, c0n = te[Tn].c0;
             inb_n = (r0n < rlim) & (c0n < clim);
@@ -418,7 +499,9 @@ __device__ __forceinline__ void wave_tiles(
     };
 
     // one tile: evaluate the gaussians that can reach it, accumulate / store
-    auto compute = [&](int Tc, bool inb, double pval, double pierr) {
+    constexpr int kLoadsPerTile = (kNeedsVal ? 1 : 0) + (kNeedsIerr ? 1 : 0) +
+                                  (OP == OP_RENDER_FAST ? 1 : 0);
+    auto compute = [&](int Tc, bool inb, double &pval, double &pierr) {
         const double v = te[Tc].bv + olv, u = te[Tc].bu + olu;
         double dv = v, du = u;
         double v2 = dv * dv, u2 = du * du, vu = dv * du;
@@ -428,7 +511,8 @@ __device__ __forceinline__ void wave_tiles(
             unsigned gmask;
             if (chunked) {
                 if (kc == 0) {
-                    int Tk = Tc + k_l;
+                    int Tk;  // = Tc + k_l; asm so that it is not hoisted out
+                    asm volatile("v_add_u32 %0, %1, %2" : "=v"(Tk) : "s"(Tc), "v"(k_l));
                     if (Tk > ntiles) Tk = ntiles;  // a sentinel
                     const int r0k = te[Tk].r0, c0k = te[Tk].c0;
                     const bool hit = lane_valid & (r0k <= mybox.rmax) &
@@ -445,8 +529,8 @@ __device__ __forceinline__ void wave_tiles(
                 const int gi = (lane < 32 && g0 + lane < ng) ? g0 + lane : g0;
                 const PixBox box = gf[gi].box;
                 const bool hit = (lane < 32) & (g0 + lane < ng) & (r0 <= box.rmax) &
-                                 (r0 >= box.rmin - (TILE_H - 1)) & (c0 <= box.cmax) &
-                                 (c0 >= box.cmin - (TILE_W - 1));
+                                 (r0 >= box.rmin - (TH - 1)) & (c0 <= box.cmax) &
+                                 (c0 >= box.cmin - (TW - 1));
                 gmask = (unsigned)__ballot(hit);
             }
             while (gmask) {
@@ -466,14 +550,15 @@ __device__ __forceinline__ void wave_tiles(
                 const bool pass = FAST ? ((unsigned)__double2hiint(y) < 0x40290000u)
                                        : (y < 12.5 && y >= 0.0);
                 if (pass) {
-                    double e = fexp_neg_fused(y, L.tab);
+                    double e = fexp_neg_fused(y, L.tab, K);
                     const bool band = FAST ? ((unsigned)__double2hiint(y) >= 0x40240000u)
                                            : (y > 10.0);
                     if (band) {
                         // apod_window with FMAs (fastexp_nb.py:97-117);
                         // W(chi2 == 20) == 1 exactly
                         const double au = (12.5 - y) * 0.4;
-                        const double aq = fma_sconst(au, fma(au, 6.0, -15.0), 10.0);
+                        const double aq =
+                            fma(au, fma(au, __hiloint2double(K.w6hi, K.w6lo), K.wm15), K.w10);
                         e *= (au * au) * (au * aq);
                     }
                     model = fma(gpa, e, model);
@@ -481,6 +566,10 @@ __device__ __forceinline__ void wave_tiles(
             }
         }
 
+        // this tile's val / ierr: FUSED_PF younger tiles stay in flight (the
+        // look-ahead past the last tile is issued with EXEC = 0 and completes
+        // in order like any other load)
+        if (full) wait_vm<FUSED_PF * kLoadsPerTile>(pval, pierr);
         if (OP == OP_LOGLIKE || OP == OP_S2N) {
             // lanes outside the stamp have ierr == 0 and add exactly 0; so do
             // zero-weight pixels, except that a masked pixel may hold a
@@ -514,13 +603,18 @@ __device__ __forceinline__ void wave_tiles(
 
     // FUSED_PF tiles are in flight while one is evaluated; the register sets
     // rotate by unrolling, not by copying
+    // (FULL stamps: the first FUSED_PF tiles were requested by the kernel
+    // before the gaussians were staged)
+    static_assert(FUSED_PF == 3, "the rotation below is written for 3 tiles in flight");
     int T = 0;
     bool in0 = true, in1 = true, in2 = true, in3 = true;
-    double va0 = 0.0, va1 = 0.0, va2 = 0.0, va3 = 0.0;
-    double ie0 = 0.0, ie1 = 0.0, ie2 = 0.0, ie3 = 0.0;
-    prefetch(0, in0, va0, ie0);
-    prefetch(1, in1, va1, ie1);
-    prefetch(2, in2, va2, ie2);
+    double va0 = pv[0], va1 = pv[1], va2 = pv[2], va3 = 0.0;
+    double ie0 = pe[0], ie1 = pe[1], ie2 = pe[2], ie3 = 0.0;
+    if (!full) {
+        prefetch(0, in0, va0, ie0);
+        prefetch(1, in1, va1, ie1);
+        prefetch(2, in2, va2, ie2);
+    }
     while (T < ntiles) {
         prefetch(T + 3, in3, va3, ie3);
         compute(T, in0, va0, ie0);
@@ -540,7 +634,7 @@ __device__ __forceinline__ void wave_tiles(
     }
 }
 
-template <int OP, bool MASKED>
+template <int OP, bool MASKED, int TW>
 __global__ __launch_bounds__(WAVE) void pixpass_wave_kernel(
     const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
     const double *__restrict__ ierr, const ngmix_jacobian *__restrict__ jacs,
@@ -565,7 +659,55 @@ __global__ __launch_bounds__(WAVE) void pixpass_wave_kernel(
     const double area = jac.scale * jac.scale;
     const int lane = threadIdx.x;
 
-    // ---- stage: norms (lazily, as the reference), gaussians, tile records
+    // ---- stage 1: tile records (need only the stamp shape and jacobian)
+    constexpr int TH = WAVE / TW;
+    const int ntx = (ncol + TW - 1) / TW;
+    const int nty = (nrow + TH - 1) / TH;
+    const int ntiles = ntx * nty;
+    for (int T = lane; T < ntiles + FUSED_SENTINELS; T += WAVE) {
+        TileEnt e;
+        if (T < ntiles) {
+            const int ty = T / ntx, tx = T - ty * ntx;
+            e.r0 = ty * TH;
+            e.c0 = tx * TW;
+            const double rd = (double)e.r0 - jac.row0, cd = (double)e.c0 - jac.col0;
+            e.bv = fma(jac.dvdrow, rd, jac.dvdcol * cd);
+            e.bu = fma(jac.dudrow, rd, jac.dudcol * cd);
+            e.off = (e.r0 * ncol + e.c0) * 8;
+        } else {
+            e.r0 = nrow;
+            e.c0 = ncol;
+            e.bv = 0.0;
+            e.bu = 0.0;
+            e.off = 0;
+        }
+        e.pad = 0;
+        te[T] = e;
+    }
+    __syncthreads();  // one wave: orders the LDS writes above, no s_barrier
+
+    // ---- request the first tiles now: they fly while the gaussians are staged
+    const bool full = (nrow % TH) == 0 && (ncol % TW) == 0;
+    double pv[FUSED_PF], pe[FUSED_PF];
+#pragma unroll
+    for (int t = 0; t < FUSED_PF; t++) {
+        pv[t] = 0.0;
+        pe[t] = 0.0;
+    }
+    if (full && ng > 0 && ntiles > 0) {
+        const unsigned lane_off = (unsigned)((lane / TW) * ncol + lane % TW) * 8u;
+#pragma unroll
+        for (int t = 0; t < FUSED_PF; t++) {
+            const bool on = t < ntiles;
+            const unsigned off = lane_off + (unsigned)te[t].off;
+            if (kNeedsVal) gload_f64_if(pv[t], (const char *)sval, off, on);
+            if (OP != OP_RENDER_FAST) gload_f64_if(pe[t], (const char *)sierr, off, on);
+            if (OP == OP_RENDER_FAST)
+                gload_f64_if(pv[t], (const char *)(out + st.pix_off), off, on);
+        }
+    }
+
+    // ---- stage 2: norms (lazily, as the reference) and gaussian records
     const int stcode = lazy_norms<WAVE>(L, gm, ng);
     if (stcode != NGMIX_OK) {
         if (lane == 0) status[s] = stcode;
@@ -589,30 +731,7 @@ __global__ __launch_bounds__(WAVE) void pixpass_wave_kernel(
         const double detq = t.dcc * t.drr - t.drc * t.drc;
         if (!(t.dcc > 0.0 && t.drr > 0.0 && detq > 0.0)) L.ctl[3] = 0;
     }
-    const int ntx = (ncol + TILE_W - 1) / TILE_W;
-    const int nty = (nrow + TILE_H - 1) / TILE_H;
-    const int ntiles = ntx * nty;
-    for (int T = lane; T < ntiles + FUSED_SENTINELS; T += WAVE) {
-        TileEnt e;
-        if (T < ntiles) {
-            const int ty = T / ntx, tx = T - ty * ntx;
-            e.r0 = ty * TILE_H;
-            e.c0 = tx * TILE_W;
-            const double rd = (double)e.r0 - jac.row0, cd = (double)e.c0 - jac.col0;
-            e.bv = fma(jac.dvdrow, rd, jac.dvdcol * cd);
-            e.bu = fma(jac.dudrow, rd, jac.dudcol * cd);
-            e.off = (e.r0 * ncol + e.c0) * 8;
-        } else {
-            e.r0 = nrow;
-            e.c0 = ncol;
-            e.bv = 0.0;
-            e.bu = 0.0;
-            e.off = 0;
-        }
-        e.pad = 0;
-        te[T] = e;
-    }
-    __syncthreads();  // one wave: orders the LDS writes above, no s_barrier
+    __syncthreads();
     const bool fast = L.ctl[2] != 0 && L.ctl[3] != 0;
     const bool masked = MASKED && izw && st.npix_kept != npix;
     if (OP == OP_FDIFF && masked) build_rank_tables<WAVE>(L.cmask, L.cpre, sierr, npix);
@@ -620,12 +739,22 @@ __global__ __launch_bounds__(WAVE) void pixpass_wave_kernel(
 
     double acc_ll = 0.0, acc_sn = 0.0, acc_sd = 0.0;
     if (ng > 0) {
-        if (fast)
-            wave_tiles<OP, MASKED, true>(L, gf, te, ng, st, sval, sierr, masked, out,
-                                         out_base, jac, acc_ll, acc_sn, acc_sd);
+        if (fast && full)
+            wave_tiles<OP, MASKED, true, true, TW>(L, gf, te, ng, st, sval, sierr, masked,
+                                               out, out_base, jac, pv, pe, acc_ll,
+                                               acc_sn, acc_sd);
+        else if (fast)
+            wave_tiles<OP, MASKED, true, false, TW>(L, gf, te, ng, st, sval, sierr, masked,
+                                                out, out_base, jac, pv, pe, acc_ll,
+                                                acc_sn, acc_sd);
+        else if (full)
+            wave_tiles<OP, MASKED, false, true, TW>(L, gf, te, ng, st, sval, sierr, masked,
+                                                out, out_base, jac, pv, pe, acc_ll,
+                                                acc_sn, acc_sd);
         else
-            wave_tiles<OP, MASKED, false>(L, gf, te, ng, st, sval, sierr, masked, out,
-                                          out_base, jac, acc_ll, acc_sn, acc_sd);
+            wave_tiles<OP, MASKED, false, false, TW>(L, gf, te, ng, st, sval, sierr,
+                                                 masked, out, out_base, jac, pv, pe,
+                                                 acc_ll, acc_sn, acc_sd);
     } else if (OP != OP_RENDER_FAST) {
         // an empty mixture: model == 0 everywhere
         for (int p = lane; p < npix; p += WAVE) {
@@ -692,8 +821,10 @@ static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
     // per-tile records of the fused kernels: exact when the batch carries its
     // largest stamp shape, else ntiles <= npix/8 + 1 holds for any shape
     int a_tc = b->max_npix / 8 + 1;
+    constexpr int TW = (OP == OP_RENDER_FAST || OP == OP_RENDER_EXACT) ? 16 : 8;
+    constexpr int TH = WAVE / TW;
     if (b->max_nrow > 0 && b->max_ncol > 0)
-        a_tc = ((b->max_nrow + TILE_H - 1) / TILE_H) * ((b->max_ncol + TILE_W - 1) / TILE_W);
+        a_tc = ((b->max_nrow + TH - 1) / TH) * ((b->max_ncol + TW - 1) / TW);
     a_tc += FUSED_SENTINELS;
     // the true-exp render has no cut and no fused form
     const bool exact = (b->flags & NGMIX_BATCH_EXACT) || OP == OP_RENDER_EXACT ||
@@ -719,8 +850,8 @@ static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
     constexpr int FOP = (OP == OP_RENDER_EXACT) ? OP_RENDER_FAST : OP;
     // zero-weight pixels only matter to the kernels that read ierr
     const bool mk = b->any_masked && FOP != OP_RENDER_FAST;
-    const void *kern = mk ? (const void *)pixpass_wave_kernel<FOP, true>
-                          : (const void *)pixpass_wave_kernel<FOP, false>;
+    const void *kern = mk ? (const void *)pixpass_wave_kernel<FOP, true, TW>
+                          : (const void *)pixpass_wave_kernel<FOP, false, TW>;
     const size_t flds = lds_bytes(max_ng, nchunks_cap, a_tc);
     if (flds > 160 * 1024) {
         set_last_error_msg("stamp needs more than 160 KiB of LDS");

@@ -43,8 +43,8 @@ for k, cs in sorted(acc.items()):
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         fetch = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"])
         write = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
-        name = {"pixpass_fused_kernel<0>": "loglike",
-                "pixpass_fused_kernel<2>": "render"}.get(k)
+        name = {"pixpass_wave_kernel<0, false>": "loglike",
+                "pixpass_wave_kernel<2, false>": "render"}.get(k)
         if name:
             traffic[name + "_hbm_bytes_per_launch"] = 2 * fetch * 1024 + write * 1024
             traffic[name + "_fetch_size_kb"] = fetch
