@@ -57,17 +57,17 @@ struct EmShared {
 
 // M-step: gmix_set_from_sums{,_fixcen,_fixcov,_fluxonly}
 // (em_nb.py:284-354, 587-655, 954-1000, 1200-1241); tot[] holds, per object
-// gaussian, [pnew, vsum, usum, u2sum, uvsum, v2sum]
-__device__ __forceinline__ int em_mstep(int kind, ngmix_gauss2d *gmix, int ngauss,
-                                        const ngmix_gauss2d *psf, int npsf,
-                                        ngmix_gauss2d *conv, const double *tot)
+// gaussian, [pnew, vsum, usum, u2sum, uvsum, v2sum].  The psf moments
+// (gmix_get_moms) and centre / flux (gmix_get_cen) are passed in: the psf
+// does not change during a run.
+__device__ __forceinline__ int em_mstep_psf(int kind, ngmix_gauss2d *gmix, int ngauss,
+                                            const ngmix_gauss2d *psf, int npsf,
+                                            ngmix_gauss2d *conv, const double *tot,
+                                            double psf_irr, double psf_irc,
+                                            double psf_icc, double rowcen,
+                                            double colcen, double ipsum)
 {
     const double minval = 1.0e-4;
-    double psf_irr = 0.0, psf_irc = 0.0, psf_icc = 0.0;
-    if (kind == NGMIX_EM_FULL || kind == NGMIX_EM_FIXCEN) {
-        const int st = gmix_moms(psf, npsf, psf_irr, psf_irc, psf_icc);
-        if (st) return st;
-    }
     for (int i = 0; i < ngauss; i++) {
         const double *ts = tot + 6 * i;
         ngmix_gauss2d &gauss = gmix[i];
@@ -109,23 +109,42 @@ __device__ __forceinline__ int em_mstep(int kind, ngmix_gauss2d *gmix, int ngaus
         gauss_set(gauss, p, v, u, irr, irc, icc);
     }
     // gmix_convolve_fill + gmix_set_norms on the convolved mixture
-    double rowcen, colcen, psum;
-    int st = gmix_cen(psf, npsf, rowcen, colcen, psum);
-    if (st) return st;
-    const double ipsum = 1.0 / psum;
     int itot = 0;
     for (int io = 0; io < ngauss; io++)
         for (int ip = 0; ip < npsf; ip++)
             convolve_component(gmix[io], psf[ip], rowcen, colcen, ipsum, conv[itot++]);
     for (int i = 0; i < ngauss * npsf; i++) {
-        st = gauss_set_norm(conv[i]);
+        const int st = gauss_set_norm(conv[i]);
         if (st) return st;
     }
     return NGMIX_OK;
 }
 
+__device__ __forceinline__ int em_mstep(int kind, ngmix_gauss2d *gmix, int ngauss,
+                                        const ngmix_gauss2d *psf, int npsf,
+                                        ngmix_gauss2d *conv, const double *tot)
+{
+    double psf_irr = 0.0, psf_irc = 0.0, psf_icc = 0.0;
+    if (kind == NGMIX_EM_FULL || kind == NGMIX_EM_FIXCEN) {
+        const int st = gmix_moms(psf, npsf, psf_irr, psf_irc, psf_icc);
+        if (st) return st;
+    }
+    // a zero-flux psf raises in gmix_get_cen only after the object gaussians
+    // have been set; nothing of that partial state is observable
+    double rowcen, colcen, psum;
+    const int st = gmix_cen(psf, npsf, rowcen, colcen, psum);
+    if (st) {
+        // reproduce the reference's partial update before the raise
+        em_mstep_psf(kind, gmix, ngauss, psf, 0, conv, tot, psf_irr, psf_irc, psf_icc,
+                     0.0, 0.0, 0.0);
+        return st;
+    }
+    return em_mstep_psf(kind, gmix, ngauss, psf, npsf, conv, tot, psf_irr, psf_irc,
+                        psf_icc, rowcen, colcen, 1.0 / psum);
+}
+
 // NG: compile-time bound on the number of object gaussians (register arrays)
-template <class Src, int PPT, int NG>
+template <class Src, int NT, int PPT, int NG>
 __device__ __forceinline__ void em_body(const Src &src, int kind,
                                         const ngmix_em_conf conf, double sky_in,
                                         ngmix_gauss2d *gmix_io, int ngauss,
@@ -145,18 +164,18 @@ __device__ __forceinline__ void em_body(const Src &src, int kind,
     EmConv *ce = (EmConv *)(conv + nconv);
     double *tot = (double *)(ce + nconv);
 
-    PixCache<Src, BLOCK, PPT> cache;
+    PixCache<Src, NT, PPT> cache;
     cache.fill(src);
     int my_n = 0;
     cache.for_each(src, [&](double, double, double, double, double, int) { my_n++; });
     double cnt[1] = {(double)my_n};
 
     if (tid < 16) sh.tab[tid] = c_exp_table_e[tid];
-    for (int i = tid; i < ngauss; i += BLOCK) gmix[i] = gmix_io[i];
-    for (int i = tid; i < npsf; i += BLOCK) psf[i] = psf_io[i];
-    for (int i = tid; i < nconv; i += BLOCK) conv[i] = conv_io[i];
+    for (int i = tid; i < ngauss; i += NT) gmix[i] = gmix_io[i];
+    for (int i = tid; i < npsf; i += NT) psf[i] = psf_io[i];
+    for (int i = tid; i < nconv; i += NT) conv[i] = conv_io[i];
     __syncthreads();
-    group_sum<BLOCK, 1>(cnt, sh.red_scratch, sh.red_out);
+    group_sum<NT, 1>(cnt, sh.red_scratch, sh.red_out);
     const double npix = sh.red_out[0];
     __syncthreads();
 
@@ -188,7 +207,7 @@ __device__ __forceinline__ void em_body(const Src &src, int kind,
 
     for (int it = 0; it < conf.maxiter && !sh.stop; it++) {
         // set_logtau_logdet + the evaluation view of the convolved mixture
-        for (int i = tid; i < nconv; i += BLOCK) {
+        for (int i = tid; i < nconv; i += NT) {
             EmConv c;
             c.e = make_eval(conv[i]);
             c.logtau = use_logl ? log(conv[i].p) : 0.0;
@@ -274,7 +293,7 @@ __device__ __forceinline__ void em_body(const Src &src, int kind,
         });
 
         const int anybad = __syncthreads_or(bad);
-        group_sum<BLOCK, NV>(acc, sh.red_scratch, sh.red_out);
+        group_sum<NT, NV>(acc, sh.red_scratch, sh.red_out);
 
         if (tid == 0) {
             if (anybad) {
@@ -325,13 +344,13 @@ __device__ __forceinline__ void em_body(const Src &src, int kind,
     // write back.  The reference zeroes norm_set of the pre-psf mixture on a
     // normal exit (em_nb.py:125); on an exception it has no chance to.
     if (sh.status == NGMIX_OK)
-        for (int i = tid; i < ngauss; i += BLOCK) gmix[i].norm_set = 0;
+        for (int i = tid; i < ngauss; i += NT) gmix[i].norm_set = 0;
     __syncthreads();
-    for (int i = tid; i < ngauss; i += BLOCK) gmix_io[i] = gmix[i];
-    for (int i = tid; i < nconv; i += BLOCK) conv_io[i] = conv[i];
+    for (int i = tid; i < ngauss; i += NT) gmix_io[i] = gmix[i];
+    for (int i = tid; i < nconv; i += NT) conv_io[i] = conv[i];
     if (sums_io) {
         const EmLayout L = em_layout(kind);
-        for (int i = tid; i < ngauss; i += BLOCK) {
+        for (int i = tid; i < ngauss; i += NT) {
             double *ts = sums_io + (size_t)i * L.stride;
             const double *t = tot + 6 * i;
             ts[L.pnew] = t[0];
@@ -353,6 +372,358 @@ __device__ __forceinline__ void em_body(const Src &src, int kind,
     }
 }
 
+// ===========================================================================
+// One WAVE per stamp (stamps of <= 16*64 pixels, <= 3 object gaussians).
+//
+// The 40-500 iterations of a stamp are a serial chain of {pixel pass, 6*ng+2
+// sums, O(ng) scalar M-step}; a 256-thread work-group idles three waves (and
+// pays three barriers) during the scalar part of every iteration.  Here a
+// stamp is one wave: v, u, val of its <= 16 pixels per lane stay in
+// registers, there are no barriers, and the SIMD is shared by independent
+// stamps.  The pixel pass is written for instruction count (every VALU
+// instruction costs one issue slot on CDNA, fp64 included): FMA contraction,
+// chi2/2 form with the magic-number fexp cell index, reciprocals by
+// v_rcp_f64 + two Newton steps instead of IEEE division sequences (the
+// reference divides per pixel three times: em_nb.py:240,255-256), and the
+// sums are reduced through a transposed LDS tile instead of 6*ng+2 shuffle
+// trees.  Results agree with the reference to rounding (the tests ask
+// 1e-10 on the mixtures and the exact iteration count).
+// ===========================================================================
+
+struct EmConvF {
+    double row, col;
+    double a, b, c;   // y = chi2/2 = a v2 + b u2 + c uv
+    double pa;        // pnorm * area
+    double K;         // logtau - 0.5*logdet
+    double pad;
+};
+static_assert(sizeof(EmConvF) == 64, "EmConvF");
+
+// 1/x to <= 1 ulp for normal x (x == 0 -> inf, as the reference's division)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+constexpr int EM_RED_STRIDE = 66;  // doubles per row of the reduction tile
+
+template <int NV>
+struct EmWaveShared {
+    double tab[16];    // exp(i), i = -15..0  (zero-weight fill, apodised evaluator)
+    double tabr[16];   // exp(-n), n = 0..15  (fused evaluator)
+    double red[NV * EM_RED_STRIDE];
+    double tot[NV];
+    double sky, frac_diff, elogL_last, p_last;
+    double psf_irr, psf_irc, psf_icc, psf_row, psf_col, psf_ipsum;
+    int numiter, stop, status, pad;
+};
+
+// the sum of each of the NV per-lane values over the wave, left in tot[k]:
+// lane (k, j) adds the j-th segment of row k of the transposed tile, the
+// segments are then folded with log2 shuffles.  Fixed order.
+template <int NV>
+__device__ __forceinline__ void em_wave_reduce(const double (&acc)[NV], double *red,
+                                               double *tot)
+{
+    constexpr int NVP = NV <= 2 ? 2 : NV <= 4 ? 4 : NV <= 8 ? 8 : NV <= 16 ? 16 : 32;
+    constexpr int SEGS = WAVE / NVP;   // lanes per value
+    constexpr int SEGLEN = WAVE / SEGS;
+    static_assert(NV <= 32, "em_wave_reduce: too many sums");
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NV; k++) red[k * EM_RED_STRIDE + lane] = acc[k];
+    __syncthreads();
+    const int k = lane % NVP, j = lane / NVP;
+    double s = 0.0;
+    if (k < NV) {
+        const double *row = red + k * EM_RED_STRIDE + j * SEGLEN;
+#pragma unroll
+        for (int i = 0; i < SEGLEN; i++) s += row[i];
+    }
+#pragma unroll
+    for (int off = SEGS / 2; off > 0; off >>= 1) s += __shfl_down(s, off * NVP, WAVE);
+    if (j == 0 && k < NV) tot[k] = s;
+    __syncthreads();
+}
+
+// sky + model at one zero-weight pixel (fill_zero_weight_pixels, em_nb.py:
+// 1297-1315: the apodised evaluator).  Rare: kept out of line.
+__device__ __noinline__ double em_fill_value(const ngmix_gauss2d *conv, int nconv,
+                                             double v, double u, double area,
+                                             double sky, const double *tab)
+{
+    double m = 0.0;
+    for (int i = 0; i < nconv; i++)
+        m += gauss_eval_fast(make_eval(conv[i]), v, u, area, tab);
+    return sky + m;
+}
+
+// KIND, the number of object gaussians NG and (NPSF1) a one-gaussian psf are
+// compile-time: the pixel pass is straight-line code
+template <int PPT, int KIND, int NG, bool NPSF1>
+__device__ __forceinline__ void em_wave_body(
+    const GridSrc &src, const ngmix_em_conf conf, double sky_in,
+    ngmix_gauss2d *gmix_io, ngmix_gauss2d *psf_io, int npsf_rt,
+    ngmix_gauss2d *conv_io, int fill_zero_weight, double *out3, int32_t *status,
+    EmWaveShared<6 * NG + 2> &sh, char *dyn, const double *coef)
+{
+    constexpr int NV = 6 * NG + 2;
+    constexpr int kind = KIND;
+    constexpr int ngauss = NG;
+    const int npsf = NPSF1 ? 1 : npsf_rt;
+    const int lane = threadIdx.x;
+    const int nconv = ngauss * npsf;
+    ngmix_gauss2d *gmix = (ngmix_gauss2d *)dyn;
+    ngmix_gauss2d *psf = gmix + ngauss;
+    ngmix_gauss2d *conv = psf + npsf;
+    EmConvF *ce = (EmConvF *)(conv + nconv);
+
+    // ---- the stamp, once from HBM, into registers
+    const int n = src.count();
+    double pv[PPT], pu[PPT], pval[PPT];
+    unsigned kept = 0u, zw = 0u;
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        const int p = lane + k * WAVE;
+        pv[k] = pu[k] = pval[k] = 0.0;
+        if (p < n) {
+            double a, ierr;
+            if (src.load(p, pv[k], pu[k], a, pval[k], ierr)) {
+                kept |= 1u << k;
+                if (ierr <= 0.0) zw |= 1u << k;
+            }
+        }
+    }
+    const double area = src.area;
+    const double npix = (double)wave_sum_int(__popc(kept));  // lane 0
+
+    if (lane < 16) {
+        sh.tab[lane] = c_exp_table_e[lane];
+        sh.tabr[lane] = c_exp_table_e[15 - lane];
+    }
+    for (int i = lane; i < ngauss; i += WAVE) gmix[i] = gmix_io[i];
+    for (int i = lane; i < npsf; i += WAVE) psf[i] = psf_io[i];
+    for (int i = lane; i < nconv; i += WAVE) conv[i] = conv_io[i];
+    __syncthreads();
+
+    constexpr bool use_cen = (kind == NGMIX_EM_FULL || kind == NGMIX_EM_FIXCOV);
+    constexpr bool use_cov = (kind == NGMIX_EM_FULL || kind == NGMIX_EM_FIXCEN);
+    constexpr bool use_logl = (kind != NGMIX_EM_FLUXONLY);
+
+    if (lane == 0) {
+        sh.status = NGMIX_OK;
+        sh.stop = 0;
+        sh.sky = sky_in;
+        sh.frac_diff = 0.0;  // unbound in the reference until first assigned
+        sh.elogL_last = -9999.9e9;
+        sh.numiter = 0;
+        // gmix_set_norms(gmix_conv), em_nb.py:59
+        for (int i = 0; i < nconv; i++) {
+            const int st = gauss_set_norm(conv[i]);
+            if (st) {
+                sh.status = st;
+                sh.stop = 1;
+                break;
+            }
+        }
+        double pl = 0.0;
+        for (int i = 0; i < ngauss; i++) pl += gmix[i].p;
+        sh.p_last = pl;  // em_nb.py:1059 (fluxonly)
+        // the psf is constant over the iterations: its moments and centre
+        // (gmix_get_moms / gmix_get_cen in every gmix_set_from_sums of the
+        // reference) give the same values every time
+        sh.psf_irr = sh.psf_irc = sh.psf_icc = 0.0;
+        if (!sh.stop && use_cov) {
+            const int st = gmix_moms(psf, npsf, sh.psf_irr, sh.psf_irc, sh.psf_icc);
+            if (st) {
+                // raised inside the first M-step in the reference: numiter 0
+                sh.pad = st;
+                sh.stop = 2;
+            }
+        }
+        if (sh.stop == 0 || sh.stop == 2) {
+            double psum;
+            const int st = gmix_cen(psf, npsf, sh.psf_row, sh.psf_col, psum);
+            if (st) {
+                sh.pad = st;
+                sh.stop = 2;
+            } else {
+                sh.psf_ipsum = 1.0 / psum;
+            }
+        }
+    }
+    __syncthreads();
+    // stop == 2: the first M-step would raise; the reference gets there only
+    // if maxiter > 0 and the first E-step does not raise first
+    const FexpCoef K = load_fexp_coef(coef);
+
+    for (int it = 0; it < conf.maxiter && sh.stop != 1; it++) {
+        // set_logtau_logdet + the evaluation view of the convolved mixture
+        for (int i = lane; i < nconv; i += WAVE) {
+            const ngmix_gauss2d g = conv[i];
+            EmConvF c;
+            c.row = g.row;
+            c.col = g.col;
+            c.a = 0.5 * g.dcc;
+            c.b = 0.5 * g.drr;
+            c.c = -g.drc;
+            c.pa = g.pnorm * area;
+            c.K = use_logl ? log(g.p) - 0.5 * log(g.det) : 0.0;
+            c.pad = 0.0;
+            ce[i] = c;
+        }
+        __syncthreads();
+        const double sky = sh.sky;
+
+        // fill_zero_weight_pixels overwrites val of the zero-weight pixels
+        // with sky + model, as the reference does in its pixel copy
+        if (fill_zero_weight && __ballot(zw != 0u) != 0ull) {
+#pragma unroll
+            for (int k = 0; k < PPT; k++)
+                if (zw & (1u << k))
+                    pval[k] = em_fill_value(conv, nconv, pv[k], pu[k], area, sky, sh.tab);
+        }
+
+        double acc[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++) acc[k] = 0.0;
+        bool bad = false;
+
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            if (!(kept & (1u << k))) continue;
+            const double v = pv[k], u = pu[k];
+            const double val_pix = pval[k];
+            double gi[NG], tv[NG], tu[NG], tv2[NG], tuv[NG], tu2[NG];
+            double gsum = 0.0, logL = 0.0;
+#pragma unroll
+            for (int ii = 0; ii < NG; ii++) {
+                gi[ii] = tv[ii] = tu[ii] = tv2[ii] = tuv[ii] = tu2[ii] = 0.0;
+                {
+                    for (int i = ii * npsf; i < (ii + 1) * npsf; i++) {
+                        const EmConvF c = ce[i];
+                        const double vdiff = v - c.row;
+                        const double udiff = u - c.col;
+                        const double u2 = udiff * udiff;
+                        const double v2 = vdiff * vdiff;
+                        const double uv = udiff * vdiff;
+                        const double y = fma(c.a, v2, fma(c.b, u2, c.c * uv));
+                        // hard cut: chi2 < 25 and chi2 >= 0 (em_nb.py:222-227)
+                        if (y < 12.5 && y >= 0.0) {
+                            const double val = c.pa * fexp_neg_fused(y, sh.tabr, K);
+                            gi[ii] += val;
+                            gsum += val;
+                            if (use_cen) {
+                                tv[ii] = fma(v, val, tv[ii]);
+                                tu[ii] = fma(u, val, tu[ii]);
+                            }
+                            if (use_cov) {
+                                tv2[ii] = fma(v2, val, tv2[ii]);
+                                tuv[ii] = fma(uv, val, tuv[ii]);
+                                tu2[ii] = fma(u2, val, tu2[ii]);
+                            }
+                            if (use_logl) logL = fma(val, c.K - y, logL);
+                        }
+                    }
+                }
+            }
+            if (use_logl) logL = (gsum == 0.0) ? 0.0 : logL * fast_rcp(gsum);
+            const double gtot = gsum + sky;
+            if (gtot == 0.0) {
+                bad = true;  // GMixRangeError('gtot == 0')
+                continue;
+            }
+            const double factor = val_pix * fast_rcp(gtot);
+            acc[6 * NG + 0] += logL;
+            acc[6 * NG + 1] = fma(sky, factor, acc[6 * NG + 1]);
+#pragma unroll
+            for (int ii = 0; ii < NG; ii++) {
+                {
+                    acc[6 * ii + 0] = fma(gi[ii], factor, acc[6 * ii + 0]);
+                    if (use_cen) {
+                        acc[6 * ii + 2] = fma(tu[ii], factor, acc[6 * ii + 2]);
+                        acc[6 * ii + 1] = fma(tv[ii], factor, acc[6 * ii + 1]);
+                    }
+                    if (use_cov) {
+                        acc[6 * ii + 3] = fma(tu2[ii], factor, acc[6 * ii + 3]);
+                        acc[6 * ii + 4] = fma(tuv[ii], factor, acc[6 * ii + 4]);
+                        acc[6 * ii + 5] = fma(tv2[ii], factor, acc[6 * ii + 5]);
+                    }
+                }
+            }
+        }
+
+        const bool anybad = __ballot(bad) != 0ull;
+        em_wave_reduce<NV>(acc, sh.red, sh.tot);
+
+        if (lane == 0) {
+            if (anybad) {
+                sh.status = NGMIX_ERR_GTOT_ZERO;
+                sh.stop = 1;
+            } else if (sh.stop == 2) {
+                sh.status = sh.pad;  // the psf has no flux: the M-step raises
+                sh.stop = 1;
+            } else {
+                const double elogL = sh.tot[6 * NG + 0];
+                const double skysum = sh.tot[6 * NG + 1];
+                const int st = em_mstep_psf(kind, gmix, ngauss, psf, npsf, conv, sh.tot,
+                                            sh.psf_irr, sh.psf_irc, sh.psf_icc,
+                                            sh.psf_row, sh.psf_col, sh.psf_ipsum);
+                if (st) {
+                    sh.status = st;
+                    sh.stop = 1;
+                } else {
+                    if (conf.vary_sky) sh.sky = skysum / npix;
+                    sh.numiter = it + 1;
+                    if (kind == NGMIX_EM_FLUXONLY) {
+                        double psum = 0.0;
+                        for (int i = 0; i < ngauss; i++) psum += gmix[i].p;
+                        if (sh.numiter >= conf.miniter) {
+                            if (sh.p_last == 0.0) {
+                                sh.status = NGMIX_ERR_ZERO_DIV;
+                                sh.stop = 1;
+                            } else {
+                                sh.frac_diff = fabs(psum / sh.p_last - 1);
+                                if (sh.frac_diff < conf.tol) sh.stop = 1;
+                            }
+                        }
+                        sh.p_last = psum;
+                    } else {
+                        if (sh.numiter >= conf.miniter) {
+                            if (elogL == 0.0) {
+                                sh.status = NGMIX_ERR_ELOGL_ZERO;
+                                sh.stop = 1;
+                            } else {
+                                sh.frac_diff = fabs((elogL - sh.elogL_last) / elogL);
+                                if (sh.frac_diff < conf.tol) sh.stop = 1;
+                            }
+                        }
+                        sh.elogL_last = elogL;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // write back.  The reference zeroes norm_set of the pre-psf mixture on a
+    // normal exit (em_nb.py:125); on an exception it has no chance to.
+    if (sh.status == NGMIX_OK)
+        for (int i = lane; i < ngauss; i += WAVE) gmix[i].norm_set = 0;
+    __syncthreads();
+    for (int i = lane; i < ngauss; i += WAVE) gmix_io[i] = gmix[i];
+    for (int i = lane; i < nconv; i += WAVE) conv_io[i] = conv[i];
+    if (lane == 0) {
+        out3[0] = (double)sh.numiter;
+        out3[1] = sh.frac_diff;
+        out3[2] = sh.sky;
+        if (status) *status = sh.status;
+    }
+}
+
 static size_t em_dyn_lds(int ngauss, int npsf)
 {
     const size_t nconv = (size_t)ngauss * npsf;
@@ -360,8 +731,8 @@ static size_t em_dyn_lds(int ngauss, int npsf)
            6 * (size_t)ngauss * 8 + 64;
 }
 
-template <int PPT, int NG>
-__global__ __launch_bounds__(BLOCK) void em_grid_kernel(
+template <int NT, int PPT, int NG>
+__global__ __launch_bounds__(NT) void em_grid_kernel(
     int kind, ngmix_em_conf conf, const ngmix_stamp *stamps, const double *val,
     const double *ierr, const ngmix_jacobian *jacs, ngmix_gauss2d *gmix, int ngauss,
     ngmix_gauss2d *gmix_psf, int npsf, ngmix_gauss2d *gmix_conv,
@@ -379,12 +750,103 @@ __global__ __launch_bounds__(BLOCK) void em_grid_kernel(
     src.nrow = st.nrow;
     src.ncol = st.ncol;
     src.izw = (st.flags & NGMIX_STAMP_IGNORE_ZERO_WEIGHT) != 0;
-    em_body<GridSrc, PPT, NG>(src, kind, conf, sky_in[s],
+    em_body<GridSrc, NT, PPT, NG>(src, kind, conf, sky_in[s],
                               gmix + (size_t)s * ngauss, ngauss,
                               gmix_psf + (size_t)s * npsf, npsf,
                               gmix_conv + (size_t)s * ngauss * npsf, nullptr,
                               fill_zero_weight, out + 3 * (size_t)s,
                               status ? status + s : nullptr, nullptr, sh, dyn);
+}
+
+__constant__ double c_fexp_coef_e[9] = NGMIX_FEXP_COEF;
+
+template <int PPT, int KIND, int NG, bool NPSF1>
+__global__ __launch_bounds__(WAVE) void em_wave_kernel(
+    ngmix_em_conf conf, const ngmix_stamp *stamps, const double *val,
+    const double *ierr, const ngmix_jacobian *jacs, ngmix_gauss2d *gmix,
+    ngmix_gauss2d *gmix_psf, int npsf, ngmix_gauss2d *gmix_conv,
+    const double *sky_in, int fill_zero_weight, double *out, int32_t *status)
+{
+    __shared__ EmWaveShared<6 * NG + 2> sh;
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    const int s = blockIdx.x;
+    const ngmix_stamp st = stamps[s];
+    GridSrc src;
+    src.val = val + st.pix_off;
+    src.ierr = ierr + st.pix_off;
+    src.jac = jacs[s];
+    src.area = src.jac.scale * src.jac.scale;
+    src.nrow = st.nrow;
+    src.ncol = st.ncol;
+    src.izw = (st.flags & NGMIX_STAMP_IGNORE_ZERO_WEIGHT) != 0;
+    em_wave_body<PPT, KIND, NG, NPSF1>(
+        src, conf, sky_in[s], gmix + (size_t)s * NG, gmix_psf + (size_t)s * npsf, npsf,
+        gmix_conv + (size_t)s * NG * npsf, fill_zero_weight, out + 3 * (size_t)s,
+        status ? status + s : nullptr, sh, dyn, c_fexp_coef_e);
+}
+
+template <int KIND, int NG>
+static void em_wave_launch(const ngmix_em_conf *conf, const ngmix_batch *b,
+                           ngmix_gauss2d *gmix, ngmix_gauss2d *psf, int npsf,
+                           ngmix_gauss2d *conv, const double *sky_in, int fzw,
+                           double *out, int32_t *status, hipStream_t s)
+{
+    constexpr int PPT = 16;
+    const size_t nconv = (size_t)NG * npsf;
+    const size_t lds = (NG + npsf + nconv) * sizeof(ngmix_gauss2d) +
+                       nconv * sizeof(EmConvF) + 64;
+    if (npsf == 1)
+        hipLaunchKernelGGL((em_wave_kernel<PPT, KIND, NG, true>),
+                           dim3((unsigned)b->nstamps), dim3(WAVE), lds, s, *conf,
+                           b->stamps, b->val, b->ierr, b->jac, gmix, psf, npsf, conv,
+                           sky_in, fzw, out, status);
+    else
+        hipLaunchKernelGGL((em_wave_kernel<PPT, KIND, NG, false>),
+                           dim3((unsigned)b->nstamps), dim3(WAVE), lds, s, *conf,
+                           b->stamps, b->val, b->ierr, b->jac, gmix, psf, npsf, conv,
+                           sky_in, fzw, out, status);
+}
+
+template <int KIND>
+static void em_wave_launch_ng(const ngmix_em_conf *conf, const ngmix_batch *b,
+                              ngmix_gauss2d *gmix, int ngauss, ngmix_gauss2d *psf,
+                              int npsf, ngmix_gauss2d *conv, const double *sky_in,
+                              int fzw, double *out, int32_t *status, hipStream_t s)
+{
+    if (ngauss == 1)
+        em_wave_launch<KIND, 1>(conf, b, gmix, psf, npsf, conv, sky_in, fzw, out, status, s);
+    else if (ngauss == 2)
+        em_wave_launch<KIND, 2>(conf, b, gmix, psf, npsf, conv, sky_in, fzw, out, status, s);
+    else
+        em_wave_launch<KIND, 3>(conf, b, gmix, psf, npsf, conv, sky_in, fzw, out, status, s);
+}
+
+// stamps of <= 16*64 pixels, 1..3 object gaussians
+static int em_wave_dispatch(int kind, const ngmix_em_conf *conf, const ngmix_batch *b,
+                            ngmix_gauss2d *gmix, int ngauss, ngmix_gauss2d *psf,
+                            int npsf, ngmix_gauss2d *conv, const double *sky_in,
+                            int fzw, double *out, int32_t *status, hipStream_t s)
+{
+    switch (kind) {
+    case NGMIX_EM_FULL:
+        em_wave_launch_ng<NGMIX_EM_FULL>(conf, b, gmix, ngauss, psf, npsf, conv, sky_in,
+                                         fzw, out, status, s);
+        break;
+    case NGMIX_EM_FIXCEN:
+        em_wave_launch_ng<NGMIX_EM_FIXCEN>(conf, b, gmix, ngauss, psf, npsf, conv,
+                                           sky_in, fzw, out, status, s);
+        break;
+    case NGMIX_EM_FIXCOV:
+        em_wave_launch_ng<NGMIX_EM_FIXCOV>(conf, b, gmix, ngauss, psf, npsf, conv,
+                                           sky_in, fzw, out, status, s);
+        break;
+    default:
+        em_wave_launch_ng<NGMIX_EM_FLUXONLY>(conf, b, gmix, ngauss, psf, npsf, conv,
+                                             sky_in, fzw, out, status, s);
+        break;
+    }
+    NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
 }
 
 template <int NG>
@@ -398,24 +860,24 @@ __global__ __launch_bounds__(BLOCK) void em_list_kernel(
     ListSrc src;
     src.pix = pixels;
     src.n = n;
-    em_body<ListSrc, 0, NG>(src, kind, conf, conf.sky, gmix, ngauss, gmix_psf, npsf,
+    em_body<ListSrc, BLOCK, 0, NG>(src, kind, conf, conf.sky, gmix, ngauss, gmix_psf, npsf,
                             gmix_conv, sums, fill_zero_weight, out3, status, pixels,
                             sh, dyn);
 }
 
-template <int PPT, int NG>
+template <int NT, int PPT, int NG>
 static void em_grid_launch(int kind, const ngmix_em_conf *conf, const ngmix_batch *b,
                            ngmix_gauss2d *gmix, int ngauss, ngmix_gauss2d *psf,
                            int npsf, ngmix_gauss2d *conv, const double *sky_in,
                            int fzw, double *out, int32_t *status, hipStream_t s)
 {
-    hipLaunchKernelGGL((em_grid_kernel<PPT, NG>), dim3((unsigned)b->nstamps),
-                       dim3(BLOCK), em_dyn_lds(ngauss, npsf), s, kind, *conf,
+    hipLaunchKernelGGL((em_grid_kernel<NT, PPT, NG>), dim3((unsigned)b->nstamps),
+                       dim3(NT), em_dyn_lds(ngauss, npsf), s, kind, *conf,
                        b->stamps, b->val, b->ierr, b->jac, gmix, ngauss, psf, npsf,
                        conv, sky_in, fzw, out, status);
 }
 
-template <int PPT>
+template <int NT, int PPT>
 static int em_grid_dispatch_ng(int kind, const ngmix_em_conf *conf,
                                const ngmix_batch *b, ngmix_gauss2d *gmix, int ngauss,
                                ngmix_gauss2d *psf, int npsf, ngmix_gauss2d *conv,
@@ -423,8 +885,8 @@ static int em_grid_dispatch_ng(int kind, const ngmix_em_conf *conf,
                                int32_t *status, hipStream_t s)
 {
 #define NGMIX_EM_CASE(N)                                                          \
-    em_grid_launch<PPT, N>(kind, conf, b, gmix, ngauss, psf, npsf, conv, sky_in, \
-                           fzw, out, status, s)
+    em_grid_launch<NT, PPT, N>(kind, conf, b, gmix, ngauss, psf, npsf, conv,    \
+                               sky_in, fzw, out, status, s)
     if (ngauss <= 1) NGMIX_EM_CASE(1);
     else if (ngauss <= 2) NGMIX_EM_CASE(2);
     else if (ngauss <= 3) NGMIX_EM_CASE(3);
@@ -447,14 +909,24 @@ int launch_em_grid(int kind, const ngmix_em_conf *conf, const ngmix_batch *b,
 {
     if (b->nstamps <= 0) return NGMIX_OK;
     if (kind < 0 || kind > 3 || ngauss < 1 || npsf < 1) return NGMIX_ERR_BAD_ARG;
-    if (b->max_npix <= 4 * BLOCK)
-        return em_grid_dispatch_ng<4>(kind, conf, b, gmix, ngauss, psf, npsf, conv,
-                                      sky_in, fzw, out, status, s);
-    if (b->max_npix <= 9 * BLOCK && ngauss <= 3)
-        return em_grid_dispatch_ng<9>(kind, conf, b, gmix, ngauss, psf, npsf, conv,
-                                      sky_in, fzw, out, status, s);
-    return em_grid_dispatch_ng<0>(kind, conf, b, gmix, ngauss, psf, npsf, conv,
-                                  sky_in, fzw, out, status, s);
+    // one wave per stamp while the stamp fits the registers of one wave (no
+    // barriers, no idle waves during the scalar M-step); tuning hook
+    // NGMIX_EM_NT=64|256 forces the threads per stamp
+    int nt = 0;
+    if (const char *e = getenv("NGMIX_EM_NT")) nt = atoi(e);
+    const int np = b->max_npix;
+    if (nt == 0) nt = (np <= 16 * WAVE && ngauss <= 3) ? WAVE : BLOCK;
+    if (nt == WAVE && np <= 16 * WAVE && ngauss <= 3)
+        return em_wave_dispatch(kind, conf, b, gmix, ngauss, psf, npsf, conv, sky_in,
+                                fzw, out, status, s);
+    if (np <= 4 * BLOCK)
+        return em_grid_dispatch_ng<BLOCK, 4>(kind, conf, b, gmix, ngauss, psf, npsf,
+                                             conv, sky_in, fzw, out, status, s);
+    if (np <= 9 * BLOCK && ngauss <= 3)
+        return em_grid_dispatch_ng<BLOCK, 9>(kind, conf, b, gmix, ngauss, psf, npsf,
+                                             conv, sky_in, fzw, out, status, s);
+    return em_grid_dispatch_ng<BLOCK, 0>(kind, conf, b, gmix, ngauss, psf, npsf, conv,
+                                         sky_in, fzw, out, status, s);
 }
 
 int launch_em_list(int kind, const ngmix_em_conf *conf, ngmix_pixel *pixels,

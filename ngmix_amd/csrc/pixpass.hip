@@ -23,10 +23,7 @@ __constant__ double c_exp_table[16] = NGMIX_EXP_TABLE;
 // exp5_smooth coefficients c0..c5 (fastexp_nb.py:252-258) followed by the
 // apodisation constants 10, -15, 6: read with scalar loads so that they live
 // in SGPRs and every Horner step is a single v_fma_f64 v, v, v, s
-__constant__ double c_fexp_coef[9] = {
-    1.0000011318561302, 0.999993601071577,   0.49992478810274166,
-    0.16674612720799442, 0.042330947141114836, 0.008197933236258961,
-    10.0, -15.0, 6.0};
+__constant__ double c_fexp_coef[9] = NGMIX_FEXP_COEF;
 
 enum PassOp { OP_LOGLIKE = 0, OP_FDIFF = 1, OP_RENDER_FAST = 2,
               OP_RENDER_EXACT = 3, OP_S2N = 4 };
@@ -369,52 +366,6 @@ __device__ __forceinline__ void wait_vm(double &a, double &b)
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
 
-struct FexpCoef {
-    double c0, c1, c2, c3, c4, c5, w10, wm15, w6;
-    int c5lo, c5hi, w6lo, w6hi;
-};
-
-__device__ __forceinline__ FexpCoef load_fexp_coef()
-{
-    // the index is opaque to the compiler (always 0), so the values stay
-    // loaded SGPRs instead of being re-materialised as literals in VGPRs
-    const double *c = c_fexp_coef + __builtin_amdgcn_readfirstlane(blockIdx.x >> 31);
-    FexpCoef k;
-    k.c0 = c[0]; k.c1 = c[1]; k.c2 = c[2]; k.c3 = c[3]; k.c4 = c[4]; k.c5 = c[5];
-    k.w10 = c[6]; k.wm15 = c[7]; k.w6 = c[8];
-    // a VOP3 instruction reads at most one SGPR pair: the multiplicands of the
-    // two-constant steps live in VGPRs (opaque moves, so they stay there)
-    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
-                 : "=v"(k.c5lo), "=v"(k.c5hi)
-                 : "s"(__double2loint(c[5])), "s"(__double2hiint(c[5])));
-    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
-                 : "=v"(k.w6lo), "=v"(k.w6hi)
-                 : "s"(__double2loint(c[8])), "s"(__double2hiint(c[8])));
-    return k;
-}
-
-// fexp(-y) for 0 <= y < 12.5, y = chi2/2 (fastexp_nb.py:223-262).
-// n = round-to-nearest(y) comes out of the low word of y + 1.5*2^52; the
-// reference takes ival = trunc(-y - 0.5) = -n except on exact ties
-// y = k + 0.5 with k even, where it uses the neighbouring cell of its
-// C2-continuous piecewise polynomial (a 1-ulp difference).  tabr[n] = exp(-n).
-__device__ __forceinline__ double fexp_neg_fused(double y, const double *tabr,
-                                                 const FexpCoef &k)
-{
-    constexpr double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
-    const double t = y + MAGIC;
-    const int n = __double2loint(t);
-    const double nd = t - MAGIC;
-    const double f = nd - y;  // = x - ival of the reference, x = -y
-    const double tv = tabr[n];
-    double p = fma(f, __hiloint2double(k.c5hi, k.c5lo), k.c4);
-    p = fma(f, p, k.c3);
-    p = fma(f, p, k.c2);
-    p = fma(f, p, k.c1);
-    p = fma(f, p, k.c0);
-    return tv * p;
-}
-
 // The tile loop of one stamp.  FAST = every gaussian of the stamp is positive
 // definite and shares one centre.
 template <int OP, bool MASKED, bool FAST, bool FULL, int TW>
@@ -471,7 +422,7 @@ __device__ __forceinline__ void wave_tiles(
     }
     unsigned long long allmask = 0ull;
     int kc = 0;
-    const FexpCoef K = load_fexp_coef();
+    const FexpCoef K = load_fexp_coef(c_fexp_coef);
 
     // issue the loads of tile Tn (a sentinel past the last tile loads
     // nothing); lanes outside the stamp carry val = ierr = 0
