@@ -350,6 +350,67 @@ int ngmix_deriv_images_batch(const ngmix_batch *batch, const double *gpars,
                              const double *dcov, double *out,
                              const int64_t *out_start, void *stream);
 
+/* ======================================================================
+ * (3) BATCHED LEVENBERG-MARQUARDT (gauss / exp / dev, analytic jacobian)
+ *
+ * The reference runs one scipy.optimize.leastsq (MINPACK lmder) per object:
+ * Fitter.go -> run_leastsq -> leastsqbound (ngmix/fitting/fitters.py:64-112,
+ * leastsqbound.py:33-155,289-552) calling back into FitModel.calc_fdiff /
+ * calc_jacobian (results.py:439-570) once per evaluation.  These entry
+ * points advance N such fits in lock step, two launches per LM step:
+ * ngmix_lm_eval_batch (objective + jacobian at every object's trial point,
+ * reduced on chip to the 28 normal-equation sums per stamp) and
+ * ngmix_lm_advance_batch (one step of the lmder logic per object).
+ * ====================================================================== */
+#define NGMIX_LM_NPMAX 8  /* parameters per object: 5 shape + up to 3 band fluxes */
+#define NGMIX_LM_NSUM 28  /* per stamp: J^T J upper triangle (21) | J^T f (6) | f.f */
+
+#define NGMIX_LM_PHASE_INIT 0
+#define NGMIX_LM_PHASE_TRIAL 1
+#define NGMIX_LM_PHASE_DONE 2
+
+/* one fit: lmder's loop variables, re-entrant (layout used by host and device) */
+typedef struct {
+    double x[NGMIX_LM_NPMAX];     /* last accepted point */
+    double xt[NGMIX_LM_NPMAX];    /* trial point to evaluate next */
+    double diag[NGMIX_LM_NPMAX];
+    double R[NGMIX_LM_NPMAX * NGMIX_LM_NPMAX]; /* pivoted factor of the jacobian
+                                      at x, upper triangle (MINPACK's fjac) */
+    double qtf[NGMIX_LM_NPMAX];
+    double step[NGMIX_LM_NPMAX];
+    double fnorm, xnorm, delta, par, gnorm, pnorm;
+    double ftol, xtol, gtol, factor;
+    int32_t ipvt[NGMIX_LM_NPMAX]; /* 0-based */
+    int32_t n, iter, nfev, njev, info, phase, maxfev, pad;
+} ngmix_lm_state;
+
+/* HOST: initialise nobj states from the guesses x0 (nobj, npars) */
+int ngmix_lm_init(ngmix_lm_state *states, int64_t nobj, int npars,
+                  const double *x0, double ftol, double xtol, double gtol,
+                  int maxfev, double factor);
+/* HOST: consume one evaluation per object -- ff (nobj,), g (nobj, NPMAX),
+   A (nobj, NPMAX*NPMAX) at states[i].xt -- and advance; returns the number
+   of fits still running.  The same code the device kernel runs; exists for
+   small problems and for testing the iteration against MINPACK on the CPU. */
+int64_t ngmix_lm_advance_host(ngmix_lm_state *states, int64_t nobj,
+                              const double *ff, const double *g, const double *A);
+/* DEVICE: evaluate every stamp of every running fit at its object's trial
+   point.  states: device array; stamp_obj (nstamps,) object of each stamp or
+   NULL (stamp i = object i); stamp_band (nstamps,) or NULL (band 0); psf:
+   nstamps*npsf gauss2d records or NULL with npsf = 0; sums: (nstamps, 28);
+   status: per stamp (NGMIX_ERR_G_RANGE: model out of range at the trial
+   point, sums then carry ff = +inf like the reference's LOWVAL residuals) */
+int ngmix_lm_eval_batch(const ngmix_batch *batch, int model,
+                        const ngmix_lm_state *states, const int32_t *stamp_obj,
+                        const int32_t *stamp_band, const ngmix_gauss2d *psf,
+                        int npsf, double *sums, int32_t *status, void *stream);
+/* DEVICE: fold stamps obj_start[i]..obj_start[i+1] (NULL: stamp i) into
+   object i's normal equations and advance its state; *nactive (device int32,
+   may be NULL) receives the number of fits still running */
+int ngmix_lm_advance_batch(ngmix_lm_state *states, int64_t nobj,
+                           const int64_t *obj_start, const int32_t *stamp_band,
+                           const double *sums, int32_t *nactive, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

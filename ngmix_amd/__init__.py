@@ -42,5 +42,7 @@ from . import fitting  # noqa: F401
 from . import runners  # noqa: F401
 from . import bootstrap  # noqa: F401
 from . import batch  # noqa: F401
+from . import lm_batch  # noqa: F401
+from .lm_batch import LMBatchFitter  # noqa: F401
 
 __version__ = "0.1.0"

@@ -91,6 +91,23 @@ def moments_result_dtype(nmom):
     ], align=True)
 
 
+LM_NPMAX = 8
+LM_NSUM = 28
+LM_PHASE_DONE = 2
+# ngmix_lm_state (include/ngmix_hip.h): one re-entrant lmder iteration
+LM_STATE_DTYPE = np.dtype([
+    ("x", "f8", LM_NPMAX), ("xt", "f8", LM_NPMAX), ("diag", "f8", LM_NPMAX),
+    ("R", "f8", (LM_NPMAX, LM_NPMAX)), ("qtf", "f8", LM_NPMAX),
+    ("step", "f8", LM_NPMAX),
+    ("fnorm", "f8"), ("xnorm", "f8"), ("delta", "f8"), ("par", "f8"),
+    ("gnorm", "f8"), ("pnorm", "f8"),
+    ("ftol", "f8"), ("xtol", "f8"), ("gtol", "f8"), ("factor", "f8"),
+    ("ipvt", "i4", LM_NPMAX),
+    ("n", "i4"), ("iter", "i4"), ("nfev", "i4"), ("njev", "i4"), ("info", "i4"),
+    ("phase", "i4"), ("maxfev", "i4"), ("pad", "i4"),
+], align=True)
+
+
 class Batch(ctypes.Structure):
     """ngmix_batch: host struct of device pointers"""
     _fields_ = [
@@ -166,6 +183,12 @@ SIGNATURES = {
     "ngmix_em_batch": (_i32, [_i32, _vp, _pb, _vp, _i32, _vp, _i32, _vp, _vp,
                               _i32, _vp, _vp, _vp]),
     "ngmix_deriv_images_batch": (_i32, [_pb, _vp, _vp, _vp, _vp, _vp]),
+    # batched Levenberg-Marquardt
+    "ngmix_lm_init": (_i32, [_vp, _i64, _i32, _vp, _f64, _f64, _f64, _i32, _f64]),
+    "ngmix_lm_advance_host": (_i64, [_vp, _i64, _vp, _vp, _vp]),
+    "ngmix_lm_eval_batch": (_i32, [_pb, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
+                                   _vp]),
+    "ngmix_lm_advance_batch": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
 }
 
 

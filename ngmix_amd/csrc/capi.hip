@@ -11,6 +11,7 @@
 
 #include "common.hpp"
 #include "launch.hpp"
+#include "lm_core.hpp"
 #include "launch_iter.hpp"
 
 namespace ngmix {
@@ -536,6 +537,48 @@ int ngmix_deriv_images_batch(const ngmix_batch *batch, const double *gpars,
                              const int64_t *out_start, void *stream)
 {
     return launch_deriv_grid(batch, gpars, dcov, out, out_start, (hipStream_t)stream);
+}
+
+int ngmix_lm_init(ngmix_lm_state *states, int64_t nobj, int npars, const double *x0,
+                  double ftol, double xtol, double gtol, int maxfev, double factor)
+{
+    if (npars < 1 || npars > NGMIX_LM_NPMAX || nobj < 0) {
+        set_last_error_msg("ngmix_lm_init: npars must be 1..NGMIX_LM_NPMAX");
+        return NGMIX_ERR_BAD_ARG;
+    }
+    for (int64_t i = 0; i < nobj; i++)
+        lmcore::lm_init(states[i], npars, x0 + i * npars, ftol, xtol, gtol, maxfev,
+                        factor);
+    return NGMIX_OK;
+}
+
+int64_t ngmix_lm_advance_host(ngmix_lm_state *states, int64_t nobj, const double *ff,
+                              const double *g, const double *A)
+{
+    int64_t running = 0;
+    for (int64_t i = 0; i < nobj; i++) {
+        lmcore::lm_advance(states[i], ff[i], g + i * NGMIX_LM_NPMAX,
+                           A + i * NGMIX_LM_NPMAX * NGMIX_LM_NPMAX);
+        if (states[i].phase != NGMIX_LM_PHASE_DONE) running++;
+    }
+    return running;
+}
+
+int ngmix_lm_eval_batch(const ngmix_batch *batch, int model,
+                        const ngmix_lm_state *states, const int32_t *stamp_obj,
+                        const int32_t *stamp_band, const ngmix_gauss2d *psf, int npsf,
+                        double *sums, int32_t *status, void *stream)
+{
+    return launch_lm_eval(batch, model, states, stamp_obj, stamp_band, psf, npsf, sums,
+                          status, (hipStream_t)stream);
+}
+
+int ngmix_lm_advance_batch(ngmix_lm_state *states, int64_t nobj,
+                           const int64_t *obj_start, const int32_t *stamp_band,
+                           const double *sums, int32_t *nactive, void *stream)
+{
+    return launch_lm_advance(states, nobj, obj_start, stamp_band, sums, nactive,
+                             (hipStream_t)stream);
 }
 
 }  // extern "C"

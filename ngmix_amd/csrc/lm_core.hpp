@@ -1,0 +1,456 @@
+// lm_core.hpp -- a re-entrant Levenberg-Marquardt iteration with the decision
+// logic of MINPACK's lmder (the routine scipy.optimize.leastsq runs when it is
+// given Dfun, which is what the reference's Fitter does for gauss/exp/dev:
+// ngmix/fitting/leastsqbound.py:445-447,485-493, fitters.py:93-97).
+//
+// MINPACK is callback driven: it owns the loop and calls the objective.  Here
+// the loop is turned inside out so that N independent fits advance in lock
+// step, one objective/jacobian kernel launch per step for all of them: the
+// caller evaluates, at the trial point the state asks for,
+//
+//     ff = |f|^2,   g = J^T f,   A = J^T J          (n <= LM_NPMAX parameters)
+//
+// and lm_advance() consumes them and either finishes the fit or asks for the
+// next trial point.  lmder works on the pivoted QR of J (R, ipvt, Q^T f);
+// R is the pivoted Cholesky factor of A and the first n entries of Q^T f are
+// R^-T P^T g, so the whole algorithm -- qrfac's pivot rule, the scaled
+// gradient test, lmpar with qrsolv, the trust region update, the four
+// convergence tests -- runs from (A, g, ff) and follows MINPACK's path up to
+// the rounding of the factorisation (cond(J)^2 instead of cond(J)).  The
+// jacobian is evaluated at every trial point, not only at accepted ones: one
+// launch per step instead of two; nfev / njev still count what lmder counts.
+//
+// Everything is host+device so the same code is tested on the CPU against
+// scipy.optimize.leastsq (tests/test_lm_core.py).
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#ifndef NGMIX_HD
+#define NGMIX_HD __host__ __device__ __forceinline__
+#endif
+
+#include "../../include/ngmix_hip.h"
+
+#define LM_NPMAX NGMIX_LM_NPMAX
+#define LM_PHASE_INIT NGMIX_LM_PHASE_INIT    /* waiting for the evaluation at x0 */
+#define LM_PHASE_TRIAL NGMIX_LM_PHASE_TRIAL  /* waiting for the evaluation at xt */
+#define LM_PHASE_DONE NGMIX_LM_PHASE_DONE
+
+typedef ngmix_lm_state lm_state;
+
+namespace lmcore {
+
+constexpr double EPSMCH = 2.220446049250313e-16;
+constexpr double DWARF = 2.2250738585072014e-308;
+
+NGMIX_HD double enorm(int n, const double *x)
+{
+    // MINPACK's enorm guards against over/underflow with three accumulators;
+    // the quantities here (parameter steps, scaled gradients) are far from
+    // either limit, where it reduces to this
+    double s = 0.0;
+    for (int i = 0; i < n; i++) s += x[i] * x[i];
+    return sqrt(s);
+}
+
+// Pivoted Cholesky of A = J^T J with qrfac's pivot rule (largest remaining
+// column norm first): A P = (QR)^T (QR) P  ->  R^T R = P^T A P.
+// Returns R (upper, n x n in an LM_NPMAX-strided array), ipvt, and
+// acnorm[j] = |J[:, j]|.
+NGMIX_HD void factor_normal(int n, const double *A, double *R, int32_t *ipvt,
+                            double *acnorm)
+{
+    double S[LM_NPMAX * LM_NPMAX];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) S[i * LM_NPMAX + j] = A[i * LM_NPMAX + j];
+    for (int j = 0; j < n; j++) {
+        ipvt[j] = j;
+        const double d = A[j * LM_NPMAX + j];
+        acnorm[j] = d > 0.0 ? sqrt(d) : 0.0;
+    }
+    for (int i = 0; i < LM_NPMAX * LM_NPMAX; i++) R[i] = 0.0;
+    // S is kept in the permuted order: row/col k of S <-> parameter ipvt[k]
+    for (int k = 0; k < n; k++) {
+        int kmax = k;
+        for (int j = k + 1; j < n; j++)
+            if (S[j * LM_NPMAX + j] > S[kmax * LM_NPMAX + kmax]) kmax = j;
+        if (kmax != k) {
+            for (int i = 0; i < n; i++) {
+                const double t = S[i * LM_NPMAX + k];
+                S[i * LM_NPMAX + k] = S[i * LM_NPMAX + kmax];
+                S[i * LM_NPMAX + kmax] = t;
+            }
+            for (int j = 0; j < n; j++) {
+                const double t = S[k * LM_NPMAX + j];
+                S[k * LM_NPMAX + j] = S[kmax * LM_NPMAX + j];
+                S[kmax * LM_NPMAX + j] = t;
+            }
+            for (int i = 0; i < k; i++) {
+                const double t = R[i * LM_NPMAX + k];
+                R[i * LM_NPMAX + k] = R[i * LM_NPMAX + kmax];
+                R[i * LM_NPMAX + kmax] = t;
+            }
+            const int32_t ti = ipvt[k];
+            ipvt[k] = ipvt[kmax];
+            ipvt[kmax] = ti;
+        }
+        const double d = S[k * LM_NPMAX + k];
+        if (!(d > 0.0)) {
+            // rank deficient: the remaining columns are (numerically) in the
+            // span of the first k; qrfac leaves rdiag = 0 there
+            for (int j = k; j < n; j++) R[k * LM_NPMAX + j] = 0.0;
+            for (int kk = k + 1; kk < n; kk++)
+                for (int j = kk; j < n; j++) R[kk * LM_NPMAX + j] = 0.0;
+            return;
+        }
+        const double rkk = sqrt(d);
+        R[k * LM_NPMAX + k] = rkk;
+        for (int j = k + 1; j < n; j++) R[k * LM_NPMAX + j] = S[k * LM_NPMAX + j] / rkk;
+        for (int i = k + 1; i < n; i++)
+            for (int j = i; j < n; j++) {
+                const double v = S[i * LM_NPMAX + j] -
+                                 R[k * LM_NPMAX + i] * R[k * LM_NPMAX + j];
+                S[i * LM_NPMAX + j] = v;
+                S[j * LM_NPMAX + i] = v;
+            }
+    }
+}
+
+// first n components of Q^T f:  R^T qtf = P^T g
+NGMIX_HD void qtf_from_gradient(int n, const double *R, const int32_t *ipvt,
+                                const double *g, double *qtf)
+{
+    for (int j = 0; j < n; j++) {
+        double s = g[ipvt[j]];
+        for (int i = 0; i < j; i++) s -= R[i * LM_NPMAX + j] * qtf[i];
+        const double rjj = R[j * LM_NPMAX + j];
+        qtf[j] = rjj != 0.0 ? s / rjj : 0.0;
+    }
+}
+
+// MINPACK qrsolv.  r: n x n with the upper triangle holding R; on output the
+// strict lower triangle holds the strict upper triangle of S transposed and
+// sdiag the diagonal of S.
+NGMIX_HD void qrsolv(int n, double *r, const int32_t *ipvt, const double *diag,
+                     const double *qtb, double *x, double *sdiag, double *wa)
+{
+    for (int j = 0; j < n; j++) {
+        for (int i = j; i < n; i++) r[i * LM_NPMAX + j] = r[j * LM_NPMAX + i];
+        x[j] = r[j * LM_NPMAX + j];
+        wa[j] = qtb[j];
+    }
+    for (int j = 0; j < n; j++) {
+        const int l = ipvt[j];
+        if (diag[l] != 0.0) {
+            for (int k = j; k < n; k++) sdiag[k] = 0.0;
+            sdiag[j] = diag[l];
+            double qtbpj = 0.0;
+            for (int k = j; k < n; k++) {
+                if (sdiag[k] == 0.0) continue;
+                double cs, sn;
+                const double rkk = r[k * LM_NPMAX + k];
+                if (fabs(rkk) < fabs(sdiag[k])) {
+                    const double cotan = rkk / sdiag[k];
+                    sn = 0.5 / sqrt(0.25 + 0.25 * (cotan * cotan));
+                    cs = sn * cotan;
+                } else {
+                    const double tn = sdiag[k] / rkk;
+                    cs = 0.5 / sqrt(0.25 + 0.25 * (tn * tn));
+                    sn = cs * tn;
+                }
+                r[k * LM_NPMAX + k] = cs * rkk + sn * sdiag[k];
+                double temp = cs * wa[k] + sn * qtbpj;
+                qtbpj = -sn * wa[k] + cs * qtbpj;
+                wa[k] = temp;
+                for (int i = k + 1; i < n; i++) {
+                    temp = cs * r[i * LM_NPMAX + k] + sn * sdiag[i];
+                    sdiag[i] = -sn * r[i * LM_NPMAX + k] + cs * sdiag[i];
+                    r[i * LM_NPMAX + k] = temp;
+                }
+            }
+        }
+        sdiag[j] = r[j * LM_NPMAX + j];
+        r[j * LM_NPMAX + j] = x[j];
+    }
+    int nsing = n;
+    for (int j = 0; j < n; j++) {
+        if (sdiag[j] == 0.0 && nsing == n) nsing = j;
+        if (nsing < n) wa[j] = 0.0;
+    }
+    for (int k = 0; k < nsing; k++) {
+        const int j = nsing - 1 - k;
+        double sum = 0.0;
+        for (int i = j + 1; i < nsing; i++) sum += r[i * LM_NPMAX + j] * wa[i];
+        wa[j] = (wa[j] - sum) / sdiag[j];
+    }
+    for (int j = 0; j < n; j++) x[ipvt[j]] = wa[j];
+}
+
+// MINPACK lmpar.  r is modified as qrsolv leaves it (upper triangle intact).
+NGMIX_HD void lmpar(int n, double *r, const int32_t *ipvt, const double *diag,
+                    const double *qtb, double delta, double &par, double *x,
+                    double *sdiag)
+{
+    double wa1[LM_NPMAX], wa2[LM_NPMAX];
+    // gauss-newton direction
+    int nsing = n;
+    for (int j = 0; j < n; j++) {
+        wa1[j] = qtb[j];
+        if (r[j * LM_NPMAX + j] == 0.0 && nsing == n) nsing = j;
+        if (nsing < n) wa1[j] = 0.0;
+    }
+    for (int k = 0; k < nsing; k++) {
+        const int j = nsing - 1 - k;
+        wa1[j] /= r[j * LM_NPMAX + j];
+        const double temp = wa1[j];
+        for (int i = 0; i < j; i++) wa1[i] -= r[i * LM_NPMAX + j] * temp;
+    }
+    for (int j = 0; j < n; j++) x[ipvt[j]] = wa1[j];
+
+    int iter = 0;
+    for (int j = 0; j < n; j++) wa2[j] = diag[j] * x[j];
+    double dxnorm = enorm(n, wa2);
+    double fp = dxnorm - delta;
+    if (fp <= 0.1 * delta) {
+        par = 0.0;
+        return;
+    }
+    // lower bound
+    double parl = 0.0;
+    if (nsing >= n) {
+        for (int j = 0; j < n; j++) {
+            const int l = ipvt[j];
+            wa1[j] = diag[l] * (wa2[l] / dxnorm);
+        }
+        for (int j = 0; j < n; j++) {
+            double sum = 0.0;
+            for (int i = 0; i < j; i++) sum += r[i * LM_NPMAX + j] * wa1[i];
+            wa1[j] = (wa1[j] - sum) / r[j * LM_NPMAX + j];
+        }
+        const double temp = enorm(n, wa1);
+        parl = ((fp / delta) / temp) / temp;
+    }
+    // upper bound
+    for (int j = 0; j < n; j++) {
+        double sum = 0.0;
+        for (int i = 0; i <= j; i++) sum += r[i * LM_NPMAX + j] * qtb[i];
+        wa1[j] = sum / diag[ipvt[j]];
+    }
+    const double gnorm = enorm(n, wa1);
+    double paru = gnorm / delta;
+    if (paru == 0.0) paru = DWARF / fmin(delta, 0.1);
+    par = fmax(par, parl);
+    par = fmin(par, paru);
+    if (par == 0.0) par = gnorm / dxnorm;
+
+    for (;;) {
+        iter++;
+        if (par == 0.0) par = fmax(DWARF, 0.001 * paru);
+        double temp = sqrt(par);
+        for (int j = 0; j < n; j++) wa1[j] = temp * diag[j];
+        qrsolv(n, r, ipvt, wa1, qtb, x, sdiag, wa2);
+        for (int j = 0; j < n; j++) wa2[j] = diag[j] * x[j];
+        dxnorm = enorm(n, wa2);
+        temp = fp;
+        fp = dxnorm - delta;
+        if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) ||
+            iter == 10)
+            break;
+        // newton correction
+        for (int j = 0; j < n; j++) {
+            const int l = ipvt[j];
+            wa1[j] = diag[l] * (wa2[l] / dxnorm);
+        }
+        for (int j = 0; j < n; j++) {
+            wa1[j] /= sdiag[j];
+            temp = wa1[j];
+            for (int i = j + 1; i < n; i++) wa1[i] -= r[i * LM_NPMAX + j] * temp;
+        }
+        temp = enorm(n, wa1);
+        const double parc = ((fp / delta) / temp) / temp;
+        if (fp > 0.0) parl = fmax(parl, par);
+        if (fp < 0.0) paru = fmin(paru, par);
+        par = fmax(parl, par + parc);
+    }
+}
+
+// lmpar on the stored factor, trial point, and the quantities the ratio test
+// needs afterwards (lmder: the body of the inner loop up to the evaluation)
+NGMIX_HD void propose(lm_state &s)
+{
+    const int n = s.n;
+    double r[LM_NPMAX * LM_NPMAX], sdiag[LM_NPMAX], p[LM_NPMAX], wa3[LM_NPMAX];
+    for (int i = 0; i < LM_NPMAX * LM_NPMAX; i++) r[i] = s.R[i];
+    lmpar(n, r, s.ipvt, s.diag, s.qtf, s.delta, s.par, p, sdiag);
+    for (int j = 0; j < n; j++) {
+        s.step[j] = -p[j];
+        s.xt[j] = s.x[j] + s.step[j];
+        wa3[j] = s.diag[j] * s.step[j];
+    }
+    s.pnorm = enorm(n, wa3);
+    if (s.iter == 1) s.delta = fmin(s.delta, s.pnorm);
+}
+
+// the outer-loop head of lmder at the point whose normal equations are
+// (A, g): factor, scale, gradient test, then the first proposal.
+// Returns true when the fit has terminated (info set).
+NGMIX_HD bool new_jacobian(lm_state &s, const double *A, const double *g)
+{
+    const int n = s.n;
+    double acnorm[LM_NPMAX];
+    s.njev++;
+    factor_normal(n, A, s.R, s.ipvt, acnorm);
+    if (s.iter == 1) {
+        double wa3[LM_NPMAX];
+        for (int j = 0; j < n; j++) {
+            s.diag[j] = acnorm[j];
+            if (acnorm[j] == 0.0) s.diag[j] = 1.0;
+            wa3[j] = s.diag[j] * s.x[j];
+        }
+        s.xnorm = enorm(n, wa3);
+        s.delta = s.factor * s.xnorm;
+        if (s.delta == 0.0) s.delta = s.factor;
+    }
+    qtf_from_gradient(n, s.R, s.ipvt, g, s.qtf);
+    // norm of the scaled gradient
+    s.gnorm = 0.0;
+    if (s.fnorm != 0.0) {
+        for (int j = 0; j < n; j++) {
+            const int l = s.ipvt[j];
+            if (acnorm[l] == 0.0) continue;
+            double sum = 0.0;
+            for (int i = 0; i <= j; i++) sum += s.R[i * LM_NPMAX + j] * (s.qtf[i] / s.fnorm);
+            s.gnorm = fmax(s.gnorm, fabs(sum / acnorm[l]));
+        }
+    }
+    if (s.gnorm <= s.gtol) {
+        s.info = 4;
+        s.phase = LM_PHASE_DONE;
+        return true;
+    }
+    for (int j = 0; j < n; j++) s.diag[j] = fmax(s.diag[j], acnorm[j]);
+    propose(s);
+    return false;
+}
+
+NGMIX_HD void lm_init(lm_state &s, int n, const double *x0, double ftol, double xtol,
+                      double gtol, int maxfev, double factor)
+{
+    s.n = n;
+    for (int j = 0; j < LM_NPMAX; j++) {
+        s.x[j] = j < n ? x0[j] : 0.0;
+        s.xt[j] = s.x[j];
+        s.diag[j] = 0.0;
+        s.qtf[j] = 0.0;
+        s.step[j] = 0.0;
+        s.ipvt[j] = j;
+    }
+    for (int i = 0; i < LM_NPMAX * LM_NPMAX; i++) s.R[i] = 0.0;
+    s.fnorm = s.xnorm = s.delta = s.par = s.gnorm = s.pnorm = 0.0;
+    s.ftol = ftol;
+    s.xtol = xtol;
+    s.gtol = gtol;
+    s.factor = factor;
+    s.maxfev = maxfev;
+    s.iter = 1;
+    s.nfev = s.njev = 0;
+    s.info = 0;
+    s.phase = LM_PHASE_INIT;
+    s.pad = 0;
+}
+
+// Consume the evaluation at s.xt:  ff = |f|^2, g = J^T f, A = J^T J
+// (A, g in LM_NPMAX-strided / LM_NPMAX-long arrays).  ff may be +inf (the
+// model was out of range at xt: the reference's calc_fdiff returns -inf
+// residuals there); A and g are then ignored.
+NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g, const double *A)
+{
+    const int n = s.n;
+    if (s.phase == LM_PHASE_DONE) return;
+    if (s.phase == LM_PHASE_INIT) {
+        // lmder: fvec at the starting point, then the outer loop
+        s.nfev = 1;
+        s.fnorm = sqrt(ff);
+        s.par = 0.0;
+        s.iter = 1;
+        if (!(s.fnorm < INFINITY)) {
+            // nothing to linearise: MINPACK would carry infs through
+            s.info = 0;
+            s.phase = LM_PHASE_DONE;
+            return;
+        }
+        s.phase = LM_PHASE_TRIAL;
+        new_jacobian(s, A, g);
+        return;
+    }
+
+    // ---- LM_PHASE_TRIAL: the rest of lmder's inner loop
+    s.nfev++;
+    const double fnorm1 = sqrt(ff);
+    double actred = -1.0;
+    if (0.1 * fnorm1 < s.fnorm) {
+        const double t = fnorm1 / s.fnorm;
+        actred = 1.0 - t * t;
+    }
+    // predicted reduction and directional derivative
+    double wa3[LM_NPMAX];
+    for (int j = 0; j < n; j++) wa3[j] = 0.0;
+    for (int j = 0; j < n; j++) {
+        const double temp = s.step[s.ipvt[j]];
+        for (int i = 0; i <= j; i++) wa3[i] += s.R[i * LM_NPMAX + j] * temp;
+    }
+    const double temp1 = enorm(n, wa3) / s.fnorm;
+    const double temp2 = (sqrt(s.par) * s.pnorm) / s.fnorm;
+    const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+    const double dirder = -(temp1 * temp1 + temp2 * temp2);
+    double ratio = 0.0;
+    if (prered != 0.0) ratio = actred / prered;
+    // update the step bound
+    if (ratio <= 0.25) {
+        double temp = 0.5;
+        if (actred < 0.0) temp = 0.5 * dirder / (dirder + 0.5 * actred);
+        if (0.1 * fnorm1 >= s.fnorm || temp < 0.1) temp = 0.1;
+        s.delta = temp * fmin(s.delta, s.pnorm / 0.1);
+        s.par = s.par / temp;
+    } else if (s.par == 0.0 || ratio >= 0.75) {
+        s.delta = s.pnorm / 0.5;
+        s.par = 0.5 * s.par;
+    }
+    const bool accepted = ratio >= 1.0e-4;
+    if (accepted) {
+        double w[LM_NPMAX];
+        for (int j = 0; j < n; j++) {
+            s.x[j] = s.xt[j];
+            w[j] = s.diag[j] * s.x[j];
+        }
+        s.xnorm = enorm(n, w);
+        s.fnorm = fnorm1;
+        s.iter++;
+    }
+    // convergence tests
+    int info = 0;
+    if (fabs(actred) <= s.ftol && prered <= s.ftol && 0.5 * ratio <= 1.0) info = 1;
+    if (s.delta <= s.xtol * s.xnorm) info = 2;
+    if (fabs(actred) <= s.ftol && prered <= s.ftol && 0.5 * ratio <= 1.0 && info == 2)
+        info = 3;
+    if (info == 0) {
+        // termination and stringent tolerances
+        if (s.nfev >= s.maxfev) info = 5;
+        if (fabs(actred) <= EPSMCH && prered <= EPSMCH && 0.5 * ratio <= 1.0) info = 6;
+        if (s.delta <= EPSMCH * s.xnorm) info = 7;
+        if (s.gnorm <= EPSMCH) info = 8;
+    }
+    if (info != 0) {
+        s.info = info;
+        s.phase = LM_PHASE_DONE;
+        return;
+    }
+    if (accepted)
+        new_jacobian(s, A, g);  // the trial point's jacobian is the new one
+    else
+        propose(s);             // same factor, smaller region
+}
+
+}  // namespace lmcore

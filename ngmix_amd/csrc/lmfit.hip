@@ -1,0 +1,376 @@
+// lmfit.hip -- batched Levenberg-Marquardt for the simple models
+// (gauss / exp / dev, optionally psf-convolved): SURVEY.md 8(f)-1.
+//
+// Reference path being replaced, per object and per function evaluation:
+// Fitter.go -> scipy leastsq (MINPACK lmder) -> FitModel.calc_fdiff /
+// calc_jacobian (ngmix/fitting/results.py:439-570) -> fill_fdiff
+// (gmix_nb.py:877-900) and deriv_images (derivs_nb.py:40-127) per observation.
+//
+// Here N fits advance in lock step, two launches per LM step for all of them:
+//
+//   lm_eval_kernel   one WAVE per stamp: fills the model mixture from the
+//                    object's trial parameters, convolves it with the stamp's
+//                    psf, evaluates value + 5 derivative images per pixel in
+//                    registers (never written to HBM) and accumulates the
+//                    stamp's normal equations  A = J^T J (21), g = J^T f (6),
+//                    ff = |f|^2  -- 28 doubles out per stamp, 16 B/pixel in.
+//   lm_advance_kernel  one THREAD per object: folds the object's stamps
+//                    (epochs / bands) into its (5+nband)-parameter system and
+//                    runs one step of the lmder logic (lm_core.hpp).
+#include "device_utils.hpp"
+#include "launch.hpp"
+#include "lm_core.hpp"
+
+
+namespace ngmix {
+
+__constant__ ModelTables c_tables_lm = NGMIX_MODEL_TABLES;
+__constant__ double c_exp_table_lm[16] = NGMIX_EXP_TABLE;
+__constant__ double c_fexp_coef_lm[9] = NGMIX_FEXP_COEF;
+
+constexpr int LM_NSUM = NGMIX_LM_NSUM;  // 21 + 6 + 1
+
+// one composed gaussian, staged in LDS
+struct DerivGauss {
+    double row, col;
+    double w11, w12, w22;  // Q = Sigma^-1
+    double pa;             // norm * area
+    double d[3][3];        // halved d(irr,irc,icc)/d(g1,g2,T), middle entry doubled
+    double trh[3];         // tr(Q dSigma_a) / 2
+    PixBox box;
+};
+static_assert(sizeof(DerivGauss) == 160, "DerivGauss");
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_shr_zero(double x)
+{
+    // row_shr within each row of 16 lanes; lanes without a source read 0
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// sum of x over each row of 16 lanes, valid in the row's last lane
+__device__ __forceinline__ double row16_sum(double x)
+{
+    x += dpp_row_shr_zero<0x111>(x);
+    x += dpp_row_shr_zero<0x112>(x);
+    x += dpp_row_shr_zero<0x114>(x);
+    x += dpp_row_shr_zero<0x118>(x);
+    return x;
+}
+
+struct LmEvalShared {
+    double tabr[16];
+    double red[LM_NSUM * 4];
+    int ctl[4];
+};
+
+__global__ __launch_bounds__(WAVE) void lm_eval_kernel(
+    const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
+    const double *__restrict__ ierr, const ngmix_jacobian *__restrict__ jacs,
+    int model, int ng0, const lm_state *__restrict__ states,
+    const int32_t *__restrict__ stamp_obj, const int32_t *__restrict__ stamp_band,
+    const ngmix_gauss2d *__restrict__ psf, int npsf, double *__restrict__ sums,
+    int32_t *__restrict__ status, int no_skip)
+{
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    __shared__ LmEvalShared sh;
+    DerivGauss *dg = (DerivGauss *)dyn;
+
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int obj = stamp_obj ? stamp_obj[s] : s;
+    const lm_state &state = states[obj];
+    if (state.phase == LM_PHASE_DONE) return;  // this object has finished
+    const int band = stamp_band ? stamp_band[s] : 0;
+    const ngmix_stamp st = stamps[s];
+    const ngmix_jacobian jac = jacs[s];
+    const int nrow = st.nrow, ncol = st.ncol;
+    const double area = jac.scale * jac.scale;
+    const bool izw = (st.flags & NGMIX_STAMP_IGNORE_ZERO_WEIGHT) != 0;
+    const bool masked = izw && st.npix_kept != nrow * ncol;
+    double *out = sums + (size_t)s * LM_NSUM;
+
+    // ---- the composed mixture and its derivative data at the trial point
+    double p[6];
+    for (int k = 0; k < 5; k++) p[k] = state.xt[k];
+    p[5] = state.xt[5 + band];
+    const double g1 = p[2], g2 = p[3], T = p[4], flux = p[5];
+    const int npsf1 = npsf > 0 ? npsf : 1;
+    const int G = ng0 * npsf1;
+    int bad = 0;
+    if (T == 0.0 || flux == 0.0) bad = 1;  // results.py:527-531
+    FillCtx c;
+    if (fill_prepare(c_tables_lm, model, ng0, p, nullptr, c) != NGMIX_OK) bad = 1;
+    double rowcen = 0.0, colcen = 0.0, ipsum = 1.0;
+    const ngmix_gauss2d *q = psf ? psf + (size_t)s * npsf : nullptr;
+    if (npsf > 0) {
+        double psum;
+        if (gmix_cen(q, npsf, rowcen, colcen, psum) != NGMIX_OK) bad = 1;
+        else ipsum = 1.0 / psum;
+    }
+    if (lane < 16) sh.tabr[lane] = c_exp_table_lm[15 - lane];
+    if (!bad) {
+        // d(e1, e2)/d(g1, g2) for e = 2 g / (1 + g^2)  (results.py:985-992)
+        const double gsq = g1 * g1 + g2 * g2;
+        const double f = 2.0 / (1.0 + gsq);
+        const double dfac = -f / (1.0 + gsq);
+        const double de1dg1 = f + 2.0 * g1 * g1 * dfac;
+        const double de1dg2 = 2.0 * g1 * g2 * dfac;
+        const double de2dg1 = de1dg2;
+        const double de2dg2 = f + 2.0 * g2 * g2 * dfac;
+        for (int i = lane; i < G; i += WAVE) {
+            const int io = i / npsf1, ip = i - io * npsf1;
+            ngmix_gauss2d g0, gc;
+            fill_component(c_tables_lm, c, p, io, g0);
+            if (npsf > 0) convolve_component(g0, q[ip], rowcen, colcen, ipsum, gc);
+            else gc = g0;
+            if (gauss_set_norm(gc) != NGMIX_OK) bad = 1;
+            DerivGauss r;
+            r.row = gc.row;
+            r.col = gc.col;
+            r.w11 = gc.dcc;   // icc / det
+            r.w12 = -gc.drc;  // -irc / det
+            r.w22 = gc.drr;   // irr / det
+            r.pa = gc.pnorm * area;
+            const double Tk = g0.irr + g0.icc;
+            const double dc[3][3] = {
+                {-0.5 * Tk * de1dg1, 0.5 * Tk * de2dg1, 0.5 * Tk * de1dg1},
+                {-0.5 * Tk * de1dg2, 0.5 * Tk * de2dg2, 0.5 * Tk * de1dg2},
+                {g0.irr / T, g0.irc / T, g0.icc / T}};
+            for (int a = 0; a < 3; a++) {
+                r.d[a][0] = 0.5 * dc[a][0];
+                r.d[a][1] = dc[a][1];
+                r.d[a][2] = 0.5 * dc[a][2];
+                r.trh[a] = 0.5 * (r.w11 * dc[a][0] + 2.0 * r.w12 * dc[a][1] +
+                                  r.w22 * dc[a][2]);
+            }
+            r.box = no_skip ? full_box() : gauss_pixel_box(gc, jac);
+            dg[i] = r;
+        }
+    }
+    if (__ballot(bad != 0) != 0ull) {
+        // out of range at the trial point: calc_fdiff's LOWVAL vector
+        if (lane == 0) {
+            for (int k = 0; k < LM_NSUM - 1; k++) out[k] = 0.0;
+            out[LM_NSUM - 1] = INFINITY;
+            if (status) status[s] = NGMIX_ERR_G_RANGE;
+        }
+        return;
+    }
+    __syncthreads();
+
+    // ---- pixel pass: 8x8 tiles, value + 5 derivatives per pixel in registers
+    const FexpCoef K = load_fexp_coef(c_fexp_coef_lm);
+    const int lrow = lane / TILE_W, lcol = lane % TILE_W;
+    const int ntx = (ncol + TILE_W - 1) / TILE_W;
+    const int nty = (nrow + TILE_H - 1) / TILE_H;
+    const double *sval = val + st.pix_off;
+    const double *sierr = ierr + st.pix_off;
+    const double iflux = 1.0 / flux;
+
+    double acc[LM_NSUM];
+#pragma unroll
+    for (int k = 0; k < LM_NSUM; k++) acc[k] = 0.0;
+
+    auto load_tile = [&](int ty, int tx, double &pv, double &pe) {
+        const int row = ty * TILE_H + lrow, col = tx * TILE_W + lcol;
+        pv = 0.0;
+        pe = 0.0;
+        if (ty < nty && row < nrow && col < ncol) {
+            pv = sval[row * ncol + col];
+            pe = sierr[row * ncol + col];
+        }
+    };
+
+    int ty = 0, tx = 0;
+    double nval, nierr;
+    load_tile(ty, tx, nval, nierr);
+    while (ty < nty) {
+        const double pval = nval, pierr = nierr;
+        int ty2 = ty, tx2 = tx + 1;
+        if (tx2 == ntx) {
+            tx2 = 0;
+            ty2++;
+        }
+        load_tile(ty2, tx2, nval, nierr);
+
+        const int r0 = ty * TILE_H, c0 = tx * TILE_W;
+        const double rowd = (double)(r0 + lrow) - jac.row0;
+        const double cold = (double)(c0 + lcol) - jac.col0;
+        const double v = fma(jac.dvdrow, rowd, jac.dvdcol * cold);
+        const double u = fma(jac.dudrow, rowd, jac.dudcol * cold);
+        double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0, o4 = 0.0, o5 = 0.0;
+
+        for (int gb = 0; gb < G; gb += WAVE) {
+            // lane g tests gaussian gb+g's chi2<25 box against this tile
+            const int gi = gb + lane < G ? gb + lane : gb;
+            const PixBox box = dg[gi].box;
+            const bool hit = (gb + lane < G) & (r0 <= box.rmax) &
+                             (r0 + TILE_H - 1 >= box.rmin) & (c0 <= box.cmax) &
+                             (c0 + TILE_W - 1 >= box.cmin);
+            unsigned long long gmask = __ballot(hit);
+            while (gmask) {
+                const int g = gb + __builtin_ctzll(gmask);
+                gmask &= gmask - 1ull;
+                const DerivGauss &D = dg[g];
+                const double dv = v - D.row, du = u - D.col;
+                const double qv = fma(D.w11, dv, D.w12 * du);
+                const double qu = fma(D.w12, dv, D.w22 * du);
+                const double y = 0.5 * fma(dv, qv, du * qu);  // chi2 / 2
+                // derivs_nb.py:104-105: chi2 >= 25 or chi2 < 0 -> skip
+                if (y < 12.5 && y >= 0.0) {
+                    double e = D.pa * fexp_neg_fused(y, sh.tabr, K);
+                    double ec = e;
+                    if (y > 10.0) {
+                        // W and W - 2 W' of the apodisation (fastexp_nb.py:97-135)
+                        const double au = (12.5 - y) * 0.4;
+                        const double aq = fma(au, fma(au, K.w6, K.wm15), K.w10);
+                        const double w = (au * au) * (au * aq);
+                        const double umu = au * (1.0 - au);
+                        // -2 W' = 60 * 0.2 * umu^2
+                        ec = e * fma(12.0 * umu, umu, w);
+                        e *= w;
+                    }
+                    o0 += e;
+                    o1 = fma(ec, qv, o1);
+                    o2 = fma(ec, qu, o2);
+                    const double qvv = qv * qv, qvu = qv * qu, quu = qu * qu;
+                    const double q0 = fma(qvv, D.d[0][0], fma(qvu, D.d[0][1], quu * D.d[0][2]));
+                    const double q1 = fma(qvv, D.d[1][0], fma(qvu, D.d[1][1], quu * D.d[1][2]));
+                    const double q2 = fma(qvv, D.d[2][0], fma(qvu, D.d[2][1], quu * D.d[2][2]));
+                    o3 = fma(ec, q0, fma(-e, D.trh[0], o3));
+                    o4 = fma(ec, q1, fma(-e, D.trh[1], o4));
+                    o5 = fma(ec, q2, fma(-e, D.trh[2], o5));
+                }
+            }
+        }
+
+        // residual and jacobian row of this pixel (results.py:556-563); lanes
+        // outside the stamp and zero-weight pixels have ierr == 0
+        if (!masked || pierr > 0.0) {
+            const double f = (o0 - pval) * pierr;
+            double J[6];
+            J[0] = o1 * pierr;
+            J[1] = o2 * pierr;
+            J[2] = o3 * pierr;
+            J[3] = o4 * pierr;
+            J[4] = o5 * pierr;
+            J[5] = o0 * (pierr * iflux);
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = a; b < 6; b++) {
+                    acc[k] = fma(J[a], J[b], acc[k]);
+                    k++;
+                }
+#pragma unroll
+            for (int a = 0; a < 6; a++) acc[21 + a] = fma(J[a], f, acc[21 + a]);
+            acc[27] = fma(f, f, acc[27]);
+        }
+        ty = ty2;
+        tx = tx2;
+    }
+
+    // ---- 28 sums over the wave: DPP inside rows of 16, then 4 partials in LDS
+#pragma unroll
+    for (int k = 0; k < LM_NSUM; k++) {
+        const double r = row16_sum(acc[k]);
+        if ((lane & 15) == 15) sh.red[k * 4 + (lane >> 4)] = r;
+    }
+    __syncthreads();
+    if (lane < LM_NSUM) {
+        const double *r = sh.red + lane * 4;
+        out[lane] = ((r[0] + r[1]) + r[2]) + r[3];
+    }
+    if (lane == 0 && status) status[s] = NGMIX_OK;
+}
+
+// One thread per object: gather its stamps' sums into the (5+nband)-parameter
+// normal equations and advance the LM state.
+__global__ __launch_bounds__(BLOCK) void lm_advance_kernel(
+    lm_state *states, int64_t nobj, const int64_t *__restrict__ obj_start,
+    const int32_t *__restrict__ stamp_band, const double *__restrict__ sums,
+    int32_t *nactive)
+{
+    const int64_t o = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+    if (o >= nobj) return;
+    lm_state s = states[o];
+    if (s.phase == LM_PHASE_DONE) return;
+    double A[LM_NPMAX * LM_NPMAX], g[LM_NPMAX];
+    for (int i = 0; i < LM_NPMAX * LM_NPMAX; i++) A[i] = 0.0;
+    for (int i = 0; i < LM_NPMAX; i++) g[i] = 0.0;
+    double ff = 0.0;
+    const int64_t s0 = obj_start ? obj_start[o] : o;
+    const int64_t s1 = obj_start ? obj_start[o + 1] : o + 1;
+    for (int64_t st = s0; st < s1; st++) {
+        const double *v = sums + st * LM_NSUM;
+        const int band = stamp_band ? stamp_band[st] : 0;
+        int k = 0;
+        for (int a = 0; a < 6; a++) {
+            const int ga = a < 5 ? a : 5 + band;
+            for (int b = a; b < 6; b++) {
+                const int gb = b < 5 ? b : 5 + band;
+                A[ga * LM_NPMAX + gb] += v[k];
+                if (ga != gb) A[gb * LM_NPMAX + ga] += v[k];
+                k++;
+            }
+            g[ga] += v[21 + a];
+        }
+        ff += v[27];
+    }
+    lmcore::lm_advance(s, ff, g, A);
+    states[o] = s;
+    if (s.phase != LM_PHASE_DONE && nactive) atomicAdd(nactive, 1);
+}
+
+int launch_lm_eval(const ngmix_batch *b, int model, const lm_state *states,
+                   const int32_t *stamp_obj, const int32_t *stamp_band,
+                   const ngmix_gauss2d *psf, int npsf, double *sums, int32_t *status,
+                   hipStream_t s)
+{
+    if (b->nstamps <= 0) return NGMIX_OK;
+    int ng0;
+    switch (model) {
+    case NGMIX_MODEL_GAUSS: ng0 = 1; break;
+    case NGMIX_MODEL_EXP: ng0 = 6; break;
+    case NGMIX_MODEL_DEV: ng0 = 10; break;
+    default:
+        set_last_error_msg("lm_eval: the analytic jacobian exists for gauss, exp, dev");
+        return NGMIX_ERR_BAD_ARG;
+    }
+    if (npsf < 0) return NGMIX_ERR_BAD_ARG;
+    const size_t lds = (size_t)ng0 * (npsf > 0 ? npsf : 1) * sizeof(DerivGauss);
+    if (lds > 96 * 1024) {
+        set_last_error_msg("lm_eval: too many composed gaussians for LDS");
+        return NGMIX_ERR_BAD_ARG;
+    }
+    if (lds > 48 * 1024)
+        NGMIX_HIP_CHECK(hipFuncSetAttribute(
+            (const void *)lm_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+            (int)lds));
+    const int no_skip = (b->flags & NGMIX_BATCH_NO_SKIP) ? 1 : 0;
+    hipLaunchKernelGGL(lm_eval_kernel, dim3((unsigned)b->nstamps), dim3(WAVE), lds, s,
+                       b->stamps, b->val, b->ierr, b->jac, model, ng0, states,
+                       stamp_obj, stamp_band, psf, npsf, sums, status, no_skip);
+    NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
+}
+
+int launch_lm_advance(lm_state *states, int64_t nobj, const int64_t *obj_start,
+                      const int32_t *stamp_band, const double *sums, int32_t *nactive,
+                      hipStream_t s)
+{
+    if (nobj <= 0) return NGMIX_OK;
+    if (nactive) NGMIX_HIP_CHECK(hipMemsetAsync(nactive, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(lm_advance_kernel, dim3((unsigned)((nobj + BLOCK - 1) / BLOCK)),
+                       dim3(BLOCK), 0, s, states, nobj, obj_start, stamp_band, sums,
+                       nactive);
+    NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
+}
+
+}  // namespace ngmix

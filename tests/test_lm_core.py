@@ -1,0 +1,194 @@
+"""
+The re-entrant Levenberg-Marquardt iteration (ngmix_amd/csrc/lm_core.hpp)
+against MINPACK itself: scipy.optimize.leastsq with Dfun is lmder, the routine
+the reference's Fitter runs for gauss/exp/dev (ngmix/fitting/leastsqbound.py:
+445-447, fitters.py:93-97).  The core is driven from the normal equations
+(|f|^2, J^T f, J^T J) through the host entry points of the C ABI, so this runs
+without a GPU; the device kernel runs the same code.
+"""
+import numpy as np
+import pytest
+from scipy.optimize import leastsq
+
+from ngmix_amd import _lib
+
+NP = _lib.LM_NPMAX
+
+
+def run_lm(func, jac, x0, ftol=1e-5, xtol=1e-5, gtol=0.0, maxfev=4000,
+           factor=100.0, maxrounds=10000):
+    """drive one fit through ngmix_lm_init / ngmix_lm_advance_host"""
+    L = _lib.lib()
+    x0 = np.ascontiguousarray(x0, dtype="f8").reshape(1, -1)
+    n = x0.shape[1]
+    st = np.zeros(1, dtype=_lib.LM_STATE_DTYPE)
+    assert L.ngmix_lm_init(_lib.ptr(st), 1, n, _lib.ptr(x0), ftol, xtol, gtol,
+                           maxfev, factor) == 0
+    rounds = 0
+    while st["phase"][0] != _lib.LM_PHASE_DONE:
+        xt = st["xt"][0, :n].copy()
+        f = func(xt)
+        J = jac(xt)
+        ff = np.array([np.dot(f, f)])
+        g = np.zeros((1, NP))
+        A = np.zeros((1, NP, NP))
+        g[0, :n] = J.T @ f
+        A[0, :n, :n] = J.T @ J
+        L.ngmix_lm_advance_host(_lib.ptr(st), 1, _lib.ptr(ff), _lib.ptr(g),
+                                _lib.ptr(A))
+        rounds += 1
+        assert rounds < maxrounds
+    return st[0]
+
+
+def cov_from_state(st):
+    """what scipy.optimize.leastsq derives from fjac / ipvt"""
+    n = int(st["n"])
+    R = st["R"][:n, :n]
+    perm = np.eye(n)[st["ipvt"][:n]]
+    Rp = np.triu(R) @ perm
+    return np.linalg.inv(Rp.T @ Rp)
+
+
+def problems():
+    rng = np.random.RandomState(31)
+    t = np.linspace(0.0, 4.0, 40)
+
+    # 1. exponential decay + offset
+    ytrue = 3.0 * np.exp(-1.3 * t) + 0.5
+    y = ytrue + 0.01 * rng.normal(size=t.size)
+
+    def f1(p):
+        return p[0] * np.exp(-p[1] * t) + p[2] - y
+
+    def j1(p):
+        e = np.exp(-p[1] * t)
+        return np.stack([e, -p[0] * t * e, np.ones_like(t)], axis=1)
+
+    yield "expdecay", f1, j1, np.array([1.0, 0.5, 0.0])
+    yield "expdecay_far", f1, j1, np.array([10.0, 3.0, -2.0])
+
+    # 2. a gaussian profile with very different parameter scales
+    xx = np.linspace(-5, 5, 101)
+    yg = 250.0 * np.exp(-0.5 * (xx - 0.3) ** 2 / 1.7 ** 2) + 0.5 * rng.normal(size=xx.size)
+
+    def f2(p):
+        return p[0] * np.exp(-0.5 * (xx - p[1]) ** 2 / p[2] ** 2) - yg
+
+    def j2(p):
+        e = np.exp(-0.5 * (xx - p[1]) ** 2 / p[2] ** 2)
+        return np.stack([e, p[0] * e * (xx - p[1]) / p[2] ** 2,
+                         p[0] * e * (xx - p[1]) ** 2 / p[2] ** 3], axis=1)
+
+    yield "gaussprof", f2, j2, np.array([100.0, -0.5, 1.0])
+
+    # 3. Rosenbrock as least squares (a curved valley: many rejected steps)
+    def f3(p):
+        return np.array([10.0 * (p[1] - p[0] ** 2), 1.0 - p[0]])
+
+    def j3(p):
+        return np.array([[-20.0 * p[0], 10.0], [-1.0, 0.0]])
+
+    yield "rosenbrock", f3, j3, np.array([-1.2, 1.0])
+
+    # 4. six parameters: sum of two exponentials + line
+    yy = (2.0 * np.exp(-0.7 * t) + 1.0 * np.exp(-3.0 * t) + 0.2 + 0.05 * t +
+          0.002 * rng.normal(size=t.size))
+
+    def f4(p):
+        return (p[0] * np.exp(-p[1] * t) + p[2] * np.exp(-p[3] * t) + p[4] +
+                p[5] * t - yy)
+
+    def j4(p):
+        e1, e2 = np.exp(-p[1] * t), np.exp(-p[3] * t)
+        return np.stack([e1, -p[0] * t * e1, e2, -p[2] * t * e2, np.ones_like(t), t],
+                        axis=1)
+
+    yield "twoexp", f4, j4, np.array([1.5, 0.5, 1.5, 2.0, 0.0, 0.0])
+
+
+@pytest.mark.parametrize("case", list(problems()), ids=lambda c: c[0])
+@pytest.mark.parametrize("tol", [1e-5, 1.49012e-8])
+def test_lm_core_follows_minpack(case, tol):
+    name, func, jac, x0 = case
+    xs, cov, info, mesg, ier = leastsq(func, x0, Dfun=jac, full_output=1, ftol=tol,
+                                       xtol=tol, maxfev=4000)
+    st = run_lm(func, jac, x0, ftol=tol, xtol=tol)
+    n = x0.size
+    x = st["x"][:n]
+    # the same iteration path: same termination code and evaluation counts
+    assert int(st["info"]) == ier, (name, st["info"], ier, mesg)
+    assert int(st["nfev"]) == info["nfev"], name
+    assert int(st["njev"]) == info["njev"], name
+    scale = np.maximum(np.abs(xs), 1e-3)
+    assert np.all(np.abs(x - xs) <= 1e-7 * scale), (name, x, xs)
+    f = func(x)
+    np.testing.assert_allclose(st["fnorm"], np.sqrt(np.dot(f, f)), rtol=1e-12)
+    if cov is not None:
+        np.testing.assert_allclose(cov_from_state(st), cov, rtol=1e-5, atol=0)
+
+
+def test_lm_core_maxfev_and_batch():
+    """maxfev -> info 5; several fits in one call advance independently"""
+    cases = list(problems())
+    name, func, jac, x0 = cases[3]  # rosenbrock needs > 5 evaluations
+    st = run_lm(func, jac, x0, maxfev=5)
+    assert int(st["info"]) == 5 and int(st["nfev"]) == 5
+    _, _, _, _, ier = leastsq(func, x0, Dfun=jac, full_output=1, ftol=1e-5,
+                              xtol=1e-5, maxfev=5)
+    assert ier == 5
+
+    # a batch of three-parameter fits from different starts
+    L = _lib.lib()
+    _, f1, j1, _ = cases[0]
+    starts = np.array([[1.0, 0.5, 0.0], [2.0, 1.0, 0.3], [5.0, 2.0, 1.0]])
+    st = np.zeros(3, dtype=_lib.LM_STATE_DTYPE)
+    L.ngmix_lm_init(_lib.ptr(st), 3, 3, _lib.ptr(starts), 1e-5, 1e-5, 0.0, 4000, 100.0)
+    running = 3
+    while running:
+        ff = np.zeros(3)
+        g = np.zeros((3, NP))
+        A = np.zeros((3, NP, NP))
+        for i in range(3):
+            xt = st["xt"][i, :3]
+            f, J = f1(xt), j1(xt)
+            ff[i] = f @ f
+            g[i, :3] = J.T @ f
+            A[i, :3, :3] = J.T @ J
+        running = L.ngmix_lm_advance_host(_lib.ptr(st), 3, _lib.ptr(ff), _lib.ptr(g),
+                                          _lib.ptr(A))
+    for i in range(3):
+        xs, ier = leastsq(f1, starts[i], Dfun=j1, ftol=1e-5, xtol=1e-5, maxfev=4000)
+        assert int(st["info"][i]) == ier
+        np.testing.assert_allclose(st["x"][i, :3], xs, rtol=1e-7)
+
+
+def test_lm_core_out_of_range_trial():
+    """ff = +inf at a trial point is a rejected step, as MINPACK treats the
+    reference's -inf residual vector (results.py:463-464)"""
+    cases = list(problems())
+    _, func, jac, x0 = cases[0]
+
+    def fwall(p):
+        f = func(p)
+        if p[1] > 1.2:  # forbid part of the path: the true b is 1.3
+            return np.full_like(f, np.inf)
+        return f
+
+    L = _lib.lib()
+    x0 = x0.reshape(1, -1)
+    st = np.zeros(1, dtype=_lib.LM_STATE_DTYPE)
+    L.ngmix_lm_init(_lib.ptr(st), 1, 3, _lib.ptr(x0), 1e-5, 1e-5, 0.0, 200, 100.0)
+    while st["phase"][0] != _lib.LM_PHASE_DONE:
+        xt = st["xt"][0, :3].copy()
+        f, J = fwall(xt), jac(xt)
+        ff = np.array([np.inf if not np.all(np.isfinite(f)) else f @ f])
+        g = np.zeros((1, NP))
+        A = np.zeros((1, NP, NP))
+        if np.isfinite(ff[0]):
+            g[0, :3] = J.T @ f
+            A[0, :3, :3] = J.T @ J
+        L.ngmix_lm_advance_host(_lib.ptr(st), 1, _lib.ptr(ff), _lib.ptr(g), _lib.ptr(A))
+    assert st["x"][0, 1] <= 1.2
+    assert np.isfinite(st["fnorm"][0])
+    assert int(st["info"][0]) in (1, 2, 3, 5)
