@@ -37,6 +37,34 @@ from .gmix import get_model_num
 
 __all__ = ["LMBatchFitter"]
 
+
+def _upper_inverse(R):
+    """inverse of a batch (N, n, n) of upper triangular matrices"""
+    n = R.shape[1]
+    X = np.zeros_like(R)
+    for j in range(n):
+        X[:, j, j] = 1.0 / R[:, j, j]
+        for i in range(j - 1, -1, -1):
+            acc = np.einsum("nk,nk->n", R[:, i, i + 1:j + 1], X[:, i + 1:j + 1, j])
+            X[:, i, j] = -acc / R[:, i, i]
+    return X
+
+
+def _has_negative_pivot(S):
+    """for a batch of symmetric matrices: does LDL^T (no pivoting) meet a
+    negative pivot, i.e. does the matrix have a negative eigenvalue"""
+    A = S.copy()
+    n = A.shape[1]
+    neg = np.zeros(A.shape[0], dtype=bool)
+    with np.errstate(all="ignore"):
+        for k in range(n):
+            d = A[:, k, k]
+            neg |= d < 0
+            safe = np.where(d != 0, d, 1.0)
+            col = A[:, k + 1:, k] / safe[:, None]
+            A[:, k + 1:, k + 1:] -= col[:, :, None] * A[:, None, k, k + 1:]
+    return neg
+
 SIMPLE_ANALYTIC_MODELS = ("gauss", "exp", "dev")
 
 
@@ -112,7 +140,7 @@ class LMBatchFitter(object):
             float(fp.get("factor", 100.0))), "ngmix_lm_init")
         maxfev = int(states["maxfev"][0])
 
-        d_states = torch.from_numpy(states.view(np.uint8).reshape(nobj, -1).copy()).to(dev)
+        d_states = torch.from_numpy(states.view(np.uint8).reshape(nobj, -1)).to(dev)
         d_sobj = torch.from_numpy(sobj).to(dev)
         d_sband = torch.from_numpy(sband).to(dev)
         d_start = torch.from_numpy(obj_start).to(dev)
@@ -122,6 +150,9 @@ class LMBatchFitter(object):
         b = stamps._batch(1)
         modnum = get_model_num(self.model)
         rounds = 0
+        import time
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
         with torch.cuda.device(dev):
             while True:
                 _lib.check(L.ngmix_lm_eval_batch(
@@ -139,7 +170,10 @@ class LMBatchFitter(object):
                         break
                 if rounds > maxfev + 2:
                     raise RuntimeError("batched LM did not terminate")
-        states = d_states.cpu().numpy().reshape(-1).view(_lib.LM_STATE_DTYPE).copy()
+        torch.cuda.synchronize(dev)
+        # seconds in the lock-step loop (kernels + one 4-byte readback per round)
+        self.loop_seconds = time.perf_counter() - t0
+        states = d_states.cpu().numpy().reshape(-1).view(_lib.LM_STATE_DTYPE)
         self.rounds = rounds
         res = self._package(states, npars, stamps, obj_start)
         self._add_stats(res, stamps, psf, sobj, sband, obj_start, nband)
@@ -163,19 +197,19 @@ class LMBatchFitter(object):
         flags[hard] |= 2 ** (ier[hard] - 5)
         ok = ~(notfinite | hard)
 
-        # cov_x as scipy.optimize.leastsq forms it from fjac / ipvt
-        R = np.triu(st["R"][:, :n, :n])
-        perm = np.eye(n)[st["ipvt"][:, :n]]          # (nobj, n, n)
-        Rp = R @ perm
-        rtr = np.transpose(Rp, (0, 2, 1)) @ Rp
-        diagR = np.abs(np.diagonal(R, axis1=1, axis2=2))
-        singular = ok & (~np.isfinite(rtr).all(axis=(1, 2)) |
-                         (diagR.min(axis=1) == 0.0))
+        # cov_x as scipy.optimize.leastsq forms it from fjac / ipvt:
+        # inv((R P^T)^T (R P^T)) = P R^-1 R^-T P^T, by back substitution
+        R = st["R"][:, :n, :n]
+        diagR = np.diagonal(R, axis1=1, axis2=2)
+        singular = ok & ((diagR == 0.0).any(axis=1) | ~np.isfinite(R).all(axis=(1, 2)))
         good = ok & ~singular
-        safe = rtr.copy()
-        safe[~good] = np.eye(n)
         with np.errstate(all="ignore"):
-            inv = np.linalg.inv(safe)
+            Rinv = _upper_inverse(np.where(good[:, None, None], R, np.eye(n)))
+            cov_piv = Rinv @ np.transpose(Rinv, (0, 2, 1))
+        ipvt = st["ipvt"][:, :n].astype(np.int64)
+        rows = np.arange(nobj)[:, None, None]
+        inv = np.empty_like(cov_piv)
+        inv[rows, ipvt[:, :, None], ipvt[:, None, :]] = cov_piv
         badinv = good & ~np.isfinite(inv).all(axis=(1, 2))
         singular |= badinv
         good &= ~badinv
@@ -190,26 +224,24 @@ class LMBatchFitter(object):
         good &= ~zero_dof
         with np.errstate(all="ignore"):
             s_sq = st["fnorm"] ** 2 / dof
-        pc = pcov0 * s_sq[:, None, None]
-        # _test_cov (leastsqbound.py:158-184)
+        pc = inv * s_sq[:, None, None]
+        # _test_cov (leastsqbound.py:158-184): a negative eigenvalue of the
+        # symmetric matrix <=> a negative pivot of its LDL^T (inertia)
         cflags = np.zeros(nobj, dtype=np.int64)
         finite = np.isfinite(pc).all(axis=(1, 2))
-        tmp = pc.copy()
-        tmp[~(good & finite)] = np.eye(n)
-        eig = np.linalg.eigvals(tmp)
+        tmp = np.where((good & finite)[:, None, None], pc, np.eye(n))
         cflags[good & ~finite] |= EIG_NOTFINITE
-        cflags[good & finite & (eig.real < 0).any(axis=1)] |= LM_NEG_COV_EIG
+        cflags[good & finite & _has_negative_pivot(tmp)] |= LM_NEG_COV_EIG
         d = np.diagonal(tmp, axis1=1, axis2=2)
         cflags[good & finite & (d < 0).any(axis=1)] |= LM_NEG_COV_DIAG
         flags |= np.where(good, cflags, 0)
         pcov[good] = pc[good]
         goodcov = good & (cflags == 0)
         with np.errstate(invalid="ignore"):
-            perr[goodcov] = np.sqrt(np.diagonal(pc, axis1=1, axis2=2))[goodcov]
+            perr[goodcov] = np.sqrt(d)[goodcov]
 
         bad_pars = notfinite | hard
         pars[bad_pars] = PDEF
-        pcov0[~good & ~zero_dof] = CDEF
         return {
             "model": self.model,
             "flags": flags,
