@@ -367,6 +367,27 @@ class StampBatch(object):
         _lib.check(st, "ngmix_loglike_batch")
         return out, status
 
+    def loglike_objects(self, gm, obj_start, out=None, status=None, exact=False):
+        """
+        get_loglike summed over the observations (epochs / bands) of each
+        object, as FitModel.calc_lnprob does (results.py:142-210): stamps
+        obj_start[i] .. obj_start[i+1] belong to object i.  One launch over all
+        (object, epoch) stamps plus a fixed-order segmented sum on the device.
+        Returns (per_object (nobj, 4), per_stamp (N, 4), status).
+        """
+        torch = _torch()
+        per_stamp, status = self.loglike(gm, out=out, status=status, exact=exact)
+        obj_start = np.asarray(obj_start, dtype=np.int64)
+        lengths = np.diff(obj_start)
+        assert obj_start[0] == 0 and obj_start[-1] == self.n and np.all(lengths > 0)
+        if np.all(lengths == lengths[0]):
+            per_obj = per_stamp.reshape(-1, int(lengths[0]), 4).sum(dim=1)
+        else:
+            per_obj = torch.segment_reduce(
+                per_stamp, "sum", lengths=torch.from_numpy(lengths).to(self.device),
+                axis=0)
+        return per_obj, per_stamp, status
+
     def fill_fdiff(self, gm, fdiff=None, fdiff_start=None, status=None,
                    no_skip=False, exact=False):
         """

@@ -465,3 +465,62 @@ def test_full_size_properties(exact):
         np.testing.assert_allclose(outh[i, :3], res[:3], rtol=1e-10, atol=0)
         # ierr**2 then sqrt is not always the identity: compare fdiff to rounding
         np.testing.assert_allclose(fdh[i], rfd, rtol=1e-12, atol=1e-12)
+
+
+def test_multi_epoch_bdf_loglike_vs_oracle():
+    """BASELINE config 5 in small: objects with several 64x64 epochs (sub-pixel
+    jacobian offsets per epoch, as ngmix/tests/_sims.py:150-159), 16-gaussian
+    'bdf' (x) 1-gaussian psf, loglike summed over the epochs of each object"""
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    from oracle import oracle as ora
+    rng = np.random.RandomState(99)
+    nobj, nepoch, dim, scale = 3, 4, 64, 0.263
+    ns = nobj * nepoch
+    pars = np.zeros((nobj, 7))
+    pars[:, 0:2] = rng.uniform(-0.3, 0.3, size=(nobj, 2)) * scale
+    pars[:, 2:4] = rng.normal(scale=0.08, size=(nobj, 2))
+    pars[:, 4] = rng.uniform(0.5, 2.0, size=nobj)
+    pars[:, 5] = rng.uniform(0.2, 0.8, size=nobj)   # fracdev
+    pars[:, 6] = rng.uniform(100, 400, size=nobj)
+    spars = np.repeat(pars, nepoch, axis=0)
+    jac = np.zeros((ns, 8))
+    for s in range(ns):
+        jac[s] = [(dim - 1) / 2 + rng.uniform(-0.5, 0.5),
+                  (dim - 1) / 2 + rng.uniform(-0.5, 0.5), scale, 0.0, 0.0, scale,
+                  scale ** 2, scale]
+    psfpars = np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (ns, 1))
+    gm0, st0 = GMixBatch.from_pars(spars, "bdf")
+    psf, _ = GMixBatch.from_pars(psfpars, "gauss")
+    gm, _ = gm0.convolve(psf)
+    assert gm.ngauss == 16 and int(st0.abs().sum()) == 0
+    geom = StampBatch.from_images(np.zeros((ns, dim, dim)), None, jac)
+    truth, _ = geom.render(gm)
+    images = truth.cpu().numpy().reshape(ns, dim, dim) + 0.05 * rng.normal(size=(ns, dim, dim))
+    weights = np.full((ns, dim, dim), 400.0)
+    sb = StampBatch.from_images(images, weights, jac)
+    obj_start = np.arange(nobj + 1) * nepoch
+    per_obj, per_stamp, status = sb.loglike_objects(gm, obj_start)
+    assert int(status.abs().sum()) == 0
+    per_obj = per_obj.cpu().numpy()
+    gmh = gm.to_numpy()
+    ref = np.zeros((nobj, 4))
+    for s in range(ns):
+        g = np.zeros(16, dtype=ora.GAUSS2D_DTYPE)
+        for name in ora.GAUSS2D_DTYPE.names:
+            g[name] = gmh[s][name]
+        j = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+        j[0] = tuple(jac[s])
+        st, res = ora.get_loglike(g, ora.make_pixels(images[s], weights[s], j, True))
+        assert st == 0
+        ref[s // nepoch] += res
+    np.testing.assert_allclose(per_obj[:, 0], ref[:, 0], rtol=1e-10)
+    np.testing.assert_allclose(per_obj[:, 1:3], ref[:, 1:3], rtol=1e-10)
+    assert np.all(per_obj[:, 3] == ref[:, 3])
+    # ragged epochs per object take the segmented path
+    rag_start = np.array([0, 3, 8, 12])
+    per_obj2, _, _ = sb.loglike_objects(gm, rag_start)
+    ps = per_stamp.cpu().numpy()
+    for i in range(3):
+        np.testing.assert_allclose(per_obj2.cpu().numpy()[i],
+                                   ps[rag_start[i]:rag_start[i + 1]].sum(axis=0),
+                                   rtol=1e-14)
