@@ -41,6 +41,10 @@ from . import em  # noqa: F401
 from . import fitting  # noqa: F401
 from . import runners  # noqa: F401
 from . import bootstrap  # noqa: F401
+from . import gaussmom  # noqa: F401
+from .gaussmom import GaussMom, GaussMomBatch  # noqa: F401
+from . import psfflux  # noqa: F401
+from .psfflux import PSFFluxFitter  # noqa: F401
 from . import batch  # noqa: F401
 from . import lm_batch  # noqa: F401
 from .lm_batch import LMBatchFitter  # noqa: F401
