@@ -224,7 +224,7 @@ class LMBatchFitter(object):
         good &= ~zero_dof
         with np.errstate(all="ignore"):
             s_sq = st["fnorm"] ** 2 / dof
-        pc = inv * s_sq[:, None, None]
+            pc = inv * s_sq[:, None, None]
         # _test_cov (leastsqbound.py:158-184): a negative eigenvalue of the
         # symmetric matrix <=> a negative pivot of its LDL^T (inertia)
         cflags = np.zeros(nobj, dtype=np.int64)
