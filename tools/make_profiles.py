@@ -25,7 +25,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         continue
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0].replace("void ngmix::", "")
-        if "pixpass" in k or "admom" in k or "em_grid" in k:
+        if "pixpass" in k or "admom" in k or "em_" in k or "lm_" in k:
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 
 lines = ["# rocprofv3 --pmc passes (tools/run_prof.sh), mean per launch, "
@@ -43,12 +43,39 @@ for k, cs in sorted(acc.items()):
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         fetch = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"])
         write = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
-        name = {"pixpass_wave_kernel<0, false>": "loglike",
-                "pixpass_wave_kernel<2, false>": "render"}.get(k)
+        name = {"pixpass_wave_kernel<0, false, 8>": "loglike",
+                "pixpass_wave_kernel<2, false, 16>": "render"}.get(k)
         if name:
             traffic[name + "_hbm_bytes_per_launch"] = 2 * fetch * 1024 + write * 1024
             traffic[name + "_fetch_size_kb"] = fetch
             traffic[name + "_write_size_kb"] = write
+# kernel-trace --stats of the bench command itself and of the other configs'
+# drivers, trimmed to this library's kernels
+for sub, name in (("bench_stats", "bench"), ("iter_stats", "iter"), ("lm_stats", "lm")):
+    f = os.path.join(src, sub, "run_kernel_stats.csv")
+    if not os.path.exists(f):
+        continue
+    rows = list(csv.reader(open(f)))
+    keep = [rows[0]] + [r for r in rows[1:] if "ngmix::" in r[0]]
+    with open(os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, name)), "w") as fo:
+        csv.writer(fo, quoting=csv.QUOTE_ALL).writerows(keep)
+    lines.append("# rocprofv3 --kernel-trace --stats -- %s (ngmix kernels): calls, average ns"
+                 % {"bench": "python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline",
+                    "iter": "python3 tools/bench_iter.py 200000 3",
+                    "lm": "python3 tools/bench_lm.py 100000 0"}[name])
+    for r in keep[1:]:
+        lines.append("%-60s calls %5s avg %12.0f ns" % (
+            r[0].split("(")[0].replace("void ngmix::", "")[:60], r[1], float(r[3])))
+bj = os.path.join(src, "bench.json")
+if os.path.exists(bj):
+    shutil.copy(bj, os.path.join(out, "%s_bench.json" % tag))
+for logname in ("iter.log", "lm.log"):
+    f = os.path.join(src, logname)
+    if os.path.exists(f):
+        txt = [l for l in open(f).read().splitlines()
+               if l.startswith(("admom", "em_run", "batched LM", "   mean"))]
+        lines.append("# %s" % logname)
+        lines.extend(txt)
 open(os.path.join(out, "%s_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print("\n".join(lines[:60]))

@@ -1,0 +1,20 @@
+#!/bin/bash
+# every rocprofv3 artefact committed under profiles/ for one round.
+# usage (GPU box): bash tools/run_prof_all.sh <tag>
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+# 1. pixel-pass kernels: stats + PMC passes on the C2 workload
+bash $ROOT/tools/run_prof.sh $TAG 100000 > $OUT/run_prof.log 2>&1
+cd /tmp && export TMPDIR=/tmp
+# 2. the bench command itself (kernel stats must agree with bench.py's HIP-event timing)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -o run -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_stats.log
+# 3. iterative kernels and batched LM
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/iter_stats -o run -- python3 $ROOT/tools/bench_iter.py 200000 3 > $OUT/iter.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lm_stats -o run -- python3 $ROOT/tools/bench_lm.py 100000 0 > $OUT/lm.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_iter -o run -- python3 $ROOT/tools/bench_iter.py 100000 1 > $OUT/pmc_iter.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_lm -o run -- python3 $ROOT/tools/bench_lm.py 100000 0 > $OUT/pmc_lm.log 2>&1
+cd $ROOT
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+ls $OUT
