@@ -57,6 +57,13 @@ extern "C" {
 #define NGMIX_FLAG_NONPOS_SIZE 8
 #define NGMIX_FLAG_LOW_DET 16
 #define NGMIX_FLAG_MAXITER 32
+/* LM result flags (ngmix/flags.py:14-20) */
+#define NGMIX_FLAG_LM_SINGULAR_MATRIX (1 << 9)
+#define NGMIX_FLAG_LM_NEG_COV_EIG (1 << 10)
+#define NGMIX_FLAG_LM_NEG_COV_DIAG (1 << 11)
+#define NGMIX_FLAG_LM_FUNC_NOTFINITE (1 << 12)
+#define NGMIX_FLAG_EIG_NOTFINITE (1 << 13)
+#define NGMIX_FLAG_ZERO_DOF (1 << 15)
 
 /* ---- model ids (ngmix/gmix/gmix.py:1100-1110) -------------------------- */
 #define NGMIX_MODEL_FULL 0
@@ -410,6 +417,15 @@ int ngmix_lm_eval_batch(const ngmix_batch *batch, int model,
 int ngmix_lm_advance_batch(ngmix_lm_state *states, int64_t nobj,
                            const int64_t *obj_start, const int32_t *stamp_band,
                            const double *sums, int32_t *nactive, void *stream);
+
+/* DEVICE: package every fit as run_leastsq does (leastsqbound.py:33-155):
+   rec is (nobj, 4 + 2n + 2n^2) doubles per object, n = states[i].n:
+   [flags, nfev, ier, dof | pars (n) | pars_err (n) | pars_cov0 (n,n) |
+   pars_cov (n,n)]; npix_obj (nobj,) = pixels in the object's residual vector;
+   pdef / cdef = the reference's PDEF / CDEF sentinels (defaults.py:10-11) */
+int ngmix_lm_finalize_batch(const ngmix_lm_state *states, int64_t nobj,
+                            const int64_t *npix_obj, double pdef, double cdef,
+                            double *rec, void *stream);
 
 #ifdef __cplusplus
 }

@@ -581,4 +581,12 @@ int ngmix_lm_advance_batch(ngmix_lm_state *states, int64_t nobj,
                              (hipStream_t)stream);
 }
 
+int ngmix_lm_finalize_batch(const ngmix_lm_state *states, int64_t nobj,
+                            const int64_t *npix_obj, double pdef, double cdef,
+                            double *rec, void *stream)
+{
+    return launch_lm_finalize(states, nobj, npix_obj, pdef, cdef, rec,
+                              (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -49,4 +49,8 @@ int launch_lm_advance(ngmix_lm_state *states, int64_t nobj, const int64_t *obj_s
                       const int32_t *stamp_band, const double *sums, int32_t *nactive,
                       hipStream_t s);
 
+int launch_lm_finalize(const ngmix_lm_state *states, int64_t nobj,
+                       const int64_t *npix_obj, double pdef, double cdef, double *rec,
+                       hipStream_t s);
+
 }  // namespace ngmix

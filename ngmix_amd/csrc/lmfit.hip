@@ -327,6 +327,121 @@ __global__ __launch_bounds__(BLOCK) void lm_advance_kernel(
     if (s.phase != LM_PHASE_DONE && nactive) atomicAdd(nactive, 1);
 }
 
+// run_leastsq's packaging (leastsqbound.py:33-155) for one fit per thread:
+// cov_x as scipy.optimize.leastsq forms it from fjac / ipvt
+// (inv((R P^T)^T (R P^T)) = P R^-1 R^-T P^T by back substitution), scaled by
+// sum(fdiff^2)/dof; flags from ier and the covariance sanity tests.
+// rec (nobj, 4 + n + 2 n^2 + n doubles):
+//   [flags, nfev, ier, dof | pars n | pars_err n | cov0 n*n | cov n*n]
+__global__ __launch_bounds__(BLOCK) void lm_finalize_kernel(
+    const lm_state *__restrict__ states, int64_t nobj,
+    const int64_t *__restrict__ npix_obj, double pdef, double cdef, double *rec)
+{
+    const int64_t o = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+    if (o >= nobj) return;
+    const lm_state &s = states[o];
+    const int n = s.n;
+    double *r = rec + o * (4 + 2 * (int64_t)n + 2 * (int64_t)n * n);
+    double *pars = r + 4, *perr = pars + n, *cov0 = perr + n, *cov = cov0 + n * n;
+    int flags = 0;
+    const int ier = s.info;
+    const long long dof = (long long)npix_obj[o] - n;
+    for (int i = 0; i < n; i++) {
+        pars[i] = s.x[i];
+        perr[i] = cdef;
+    }
+    for (int i = 0; i < n * n; i++) cov0[i] = cov[i] = cdef;
+    if (ier == 0) {
+        flags |= NGMIX_FLAG_LM_FUNC_NOTFINITE;
+        for (int i = 0; i < n; i++) pars[i] = pdef;
+    } else if (ier > 4) {
+        flags |= 1 << (ier - 5);
+        for (int i = 0; i < n; i++) pars[i] = pdef;
+    } else {
+        // R^-1 (upper triangular), in the pivoted order
+        double X[LM_NPMAX * LM_NPMAX];
+        bool singular = false;
+        for (int j = 0; j < n; j++) {
+            const double d = s.R[j * LM_NPMAX + j];
+            if (d == 0.0 || !(fabs(d) < INFINITY)) singular = true;
+        }
+        if (!singular) {
+            for (int i = 0; i < LM_NPMAX * LM_NPMAX; i++) X[i] = 0.0;
+            for (int j = 0; j < n; j++) {
+                X[j * LM_NPMAX + j] = 1.0 / s.R[j * LM_NPMAX + j];
+                for (int i = j - 1; i >= 0; i--) {
+                    double acc = 0.0;
+                    for (int k = i + 1; k <= j; k++)
+                        acc += s.R[i * LM_NPMAX + k] * X[k * LM_NPMAX + j];
+                    X[i * LM_NPMAX + j] = -acc / s.R[i * LM_NPMAX + i];
+                }
+            }
+            for (int a = 0; a < n; a++)
+                for (int b = 0; b < n; b++) {
+                    double acc = 0.0;
+                    for (int k = (a > b ? a : b); k < n; k++)
+                        acc += X[a * LM_NPMAX + k] * X[b * LM_NPMAX + k];
+                    cov0[s.ipvt[a] * n + s.ipvt[b]] = acc;
+                    if (!(fabs(acc) < INFINITY)) singular = true;
+                }
+        }
+        if (singular) {
+            flags |= NGMIX_FLAG_LM_SINGULAR_MATRIX;
+            for (int i = 0; i < n * n; i++) cov0[i] = cdef;
+        } else if (dof == 0) {
+            flags |= NGMIX_FLAG_ZERO_DOF;
+        } else {
+            const double s_sq = s.fnorm * s.fnorm / (double)dof;
+            bool finite = true;
+            for (int i = 0; i < n * n; i++) {
+                cov[i] = cov0[i] * s_sq;
+                if (!(fabs(cov[i]) < INFINITY)) finite = false;
+            }
+            int cflags = 0;
+            if (!finite) {
+                cflags |= NGMIX_FLAG_EIG_NOTFINITE;
+            } else {
+                // a negative eigenvalue <=> a negative pivot of LDL^T (inertia)
+                double A[LM_NPMAX * LM_NPMAX];
+                for (int a = 0; a < n; a++)
+                    for (int b = 0; b < n; b++) A[a * LM_NPMAX + b] = cov[a * n + b];
+                bool neg = false, negdiag = false;
+                for (int a = 0; a < n; a++)
+                    if (cov[a * n + a] < 0.0) negdiag = true;
+                for (int k = 0; k < n; k++) {
+                    const double d = A[k * LM_NPMAX + k];
+                    if (d < 0.0) neg = true;
+                    const double safe = d != 0.0 ? d : 1.0;
+                    for (int a = k + 1; a < n; a++) {
+                        const double c = A[a * LM_NPMAX + k] / safe;
+                        for (int b = k + 1; b < n; b++)
+                            A[a * LM_NPMAX + b] -= c * A[k * LM_NPMAX + b];
+                    }
+                }
+                if (neg) cflags |= NGMIX_FLAG_LM_NEG_COV_EIG;
+                if (negdiag) cflags |= NGMIX_FLAG_LM_NEG_COV_DIAG;
+            }
+            flags |= cflags;
+            if (cflags == 0)
+                for (int a = 0; a < n; a++) perr[a] = sqrt(cov[a * n + a]);
+        }
+    }
+    r[0] = (double)flags;
+    r[1] = ier == 0 ? -1.0 : (double)s.nfev;
+    r[2] = (double)ier;
+    r[3] = (double)dof;
+}
+
+int launch_lm_finalize(const lm_state *states, int64_t nobj, const int64_t *npix_obj,
+                       double pdef, double cdef, double *rec, hipStream_t s)
+{
+    if (nobj <= 0) return NGMIX_OK;
+    hipLaunchKernelGGL(lm_finalize_kernel, dim3((unsigned)((nobj + BLOCK - 1) / BLOCK)),
+                       dim3(BLOCK), 0, s, states, nobj, npix_obj, pdef, cdef, rec);
+    NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
+}
+
 int launch_lm_eval(const ngmix_batch *b, int model, const lm_state *states,
                    const int32_t *stamp_obj, const int32_t *stamp_band,
                    const ngmix_gauss2d *psf, int npsf, double *sums, int32_t *status,

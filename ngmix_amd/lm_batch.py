@@ -13,6 +13,9 @@ device for every object at once:
                             trial point, reduced on chip to J^T J, J^T f, |f|^2
     ngmix_lm_advance_batch  one lmder step per object
 
+    ngmix_lm_finalize_batch run_leastsq's packaging per object (cov_x from
+                            R / ipvt, chi2/dof scaling, flags)
+
 and the results are packaged exactly as run_leastsq / FitModel.set_fit_result
 package one fit: flags, nfev, ier, pars, pars_err, pars_cov0, pars_cov, and for
 flags == 0 lnprob, s2n_numer, s2n_denom, npix, chi2per, dof, s2n_w, s2n, g,
@@ -29,41 +32,10 @@ import numpy as np
 from . import _lib
 from .batch import GMixBatch, _dptr, _stream, _torch
 from .defaults import PDEF, CDEF, DEFAULT_LM_PARS
-from .flags import (
-    ZERO_DOF, LM_SINGULAR_MATRIX, LM_NEG_COV_EIG, LM_NEG_COV_DIAG, EIG_NOTFINITE,
-    LM_FUNC_NOTFINITE,
-)
 from .gmix import get_model_num
 
 __all__ = ["LMBatchFitter"]
 
-
-def _upper_inverse(R):
-    """inverse of a batch (N, n, n) of upper triangular matrices"""
-    n = R.shape[1]
-    X = np.zeros_like(R)
-    for j in range(n):
-        X[:, j, j] = 1.0 / R[:, j, j]
-        for i in range(j - 1, -1, -1):
-            acc = np.einsum("nk,nk->n", R[:, i, i + 1:j + 1], X[:, i + 1:j + 1, j])
-            X[:, i, j] = -acc / R[:, i, i]
-    return X
-
-
-def _has_negative_pivot(S):
-    """for a batch of symmetric matrices: does LDL^T (no pivoting) meet a
-    negative pivot, i.e. does the matrix have a negative eigenvalue"""
-    A = S.copy()
-    n = A.shape[1]
-    neg = np.zeros(A.shape[0], dtype=bool)
-    with np.errstate(all="ignore"):
-        for k in range(n):
-            d = A[:, k, k]
-            neg |= d < 0
-            safe = np.where(d != 0, d, 1.0)
-            col = A[:, k + 1:, k] / safe[:, None]
-            A[:, k + 1:, k + 1:] -= col[:, :, None] * A[:, None, k, k + 1:]
-    return neg
 
 SIMPLE_ANALYTIC_MODELS = ("gauss", "exp", "dev")
 
@@ -173,88 +145,40 @@ class LMBatchFitter(object):
         torch.cuda.synchronize(dev)
         # seconds in the lock-step loop (kernels + one 4-byte readback per round)
         self.loop_seconds = time.perf_counter() - t0
-        states = d_states.cpu().numpy().reshape(-1).view(_lib.LM_STATE_DTYPE)
+        self._d_states = d_states
         self.rounds = rounds
-        res = self._package(states, npars, stamps, obj_start)
+        # run_leastsq's packaging, one thread per fit (ngmix_lm_finalize_batch)
+        n = npars
+        npix_obj = np.add.reduceat(stamps.npix_kept.astype(np.int64), obj_start[:-1])
+        d_npix = torch.from_numpy(npix_obj).to(dev)
+        width = 4 + 2 * n + 2 * n * n
+        d_rec = torch.empty((nobj, width), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.ngmix_lm_finalize_batch(
+                _dptr(d_states), nobj, _dptr(d_npix), float(PDEF), float(CDEF),
+                _dptr(d_rec), _stream()), "ngmix_lm_finalize_batch")
+        rec = d_rec.cpu().numpy()
+        njev = d_states.view(torch.int32).reshape(nobj, -1)[
+            :, _lib.LM_STATE_DTYPE.fields["njev"][1] // 4].cpu().numpy()
+        res = {
+            "model": self.model,
+            "flags": rec[:, 0].astype(np.int64),
+            "nfev": rec[:, 1].astype(np.int64),
+            "njev": njev.astype(np.int64),
+            "ier": rec[:, 2].astype(np.int64),
+            "pars": rec[:, 4:4 + n].copy(),
+            "pars_err": rec[:, 4 + n:4 + 2 * n].copy(),
+            "pars_cov0": rec[:, 4 + 2 * n:4 + 2 * n + n * n].reshape(nobj, n, n).copy(),
+            "pars_cov": rec[:, 4 + 2 * n + n * n:].reshape(nobj, n, n).copy(),
+            "npix": npix_obj,
+            "dof": rec[:, 3].astype(np.int64),
+        }
         self._add_stats(res, stamps, psf, sobj, sband, obj_start, nband)
         return res
 
-    # ------------------------------------------------------------------
-    def _package(self, st, npars, stamps, obj_start):
-        """run_leastsq's packaging (leastsqbound.py:33-155), vectorised"""
-        nobj = st.size
-        n = npars
-        ier = st["info"].astype(np.int64)
-        pars = st["x"][:, :n].copy()
-        flags = np.zeros(nobj, dtype=np.int64)
-        pcov0 = np.full((nobj, n, n), CDEF)
-        pcov = np.full((nobj, n, n), CDEF)
-        perr = np.full((nobj, n), CDEF)
-
-        notfinite = ier == 0                     # no finite starting residual
-        flags[notfinite] |= LM_FUNC_NOTFINITE
-        hard = ier > 4
-        flags[hard] |= 2 ** (ier[hard] - 5)
-        ok = ~(notfinite | hard)
-
-        # cov_x as scipy.optimize.leastsq forms it from fjac / ipvt:
-        # inv((R P^T)^T (R P^T)) = P R^-1 R^-T P^T, by back substitution
-        R = st["R"][:, :n, :n]
-        diagR = np.diagonal(R, axis1=1, axis2=2)
-        singular = ok & ((diagR == 0.0).any(axis=1) | ~np.isfinite(R).all(axis=(1, 2)))
-        good = ok & ~singular
-        with np.errstate(all="ignore"):
-            Rinv = _upper_inverse(np.where(good[:, None, None], R, np.eye(n)))
-            cov_piv = Rinv @ np.transpose(Rinv, (0, 2, 1))
-        ipvt = st["ipvt"][:, :n].astype(np.int64)
-        rows = np.arange(nobj)[:, None, None]
-        inv = np.empty_like(cov_piv)
-        inv[rows, ipvt[:, :, None], ipvt[:, None, :]] = cov_piv
-        badinv = good & ~np.isfinite(inv).all(axis=(1, 2))
-        singular |= badinv
-        good &= ~badinv
-        flags[singular] |= LM_SINGULAR_MATRIX
-        pcov0[good] = inv[good]
-
-        # pars_cov = pars_cov0 * sum(fdiff^2) / dof at the solution
-        npix_obj = np.add.reduceat(stamps.npix_kept.astype(np.int64), obj_start[:-1])
-        dof = npix_obj - n
-        zero_dof = good & (dof == 0)
-        flags[zero_dof] |= ZERO_DOF
-        good &= ~zero_dof
-        with np.errstate(all="ignore"):
-            s_sq = st["fnorm"] ** 2 / dof
-            pc = inv * s_sq[:, None, None]
-        # _test_cov (leastsqbound.py:158-184): a negative eigenvalue of the
-        # symmetric matrix <=> a negative pivot of its LDL^T (inertia)
-        cflags = np.zeros(nobj, dtype=np.int64)
-        finite = np.isfinite(pc).all(axis=(1, 2))
-        tmp = np.where((good & finite)[:, None, None], pc, np.eye(n))
-        cflags[good & ~finite] |= EIG_NOTFINITE
-        cflags[good & finite & _has_negative_pivot(tmp)] |= LM_NEG_COV_EIG
-        d = np.diagonal(tmp, axis1=1, axis2=2)
-        cflags[good & finite & (d < 0).any(axis=1)] |= LM_NEG_COV_DIAG
-        flags |= np.where(good, cflags, 0)
-        pcov[good] = pc[good]
-        goodcov = good & (cflags == 0)
-        with np.errstate(invalid="ignore"):
-            perr[goodcov] = np.sqrt(d)[goodcov]
-
-        bad_pars = notfinite | hard
-        pars[bad_pars] = PDEF
-        return {
-            "model": self.model,
-            "flags": flags,
-            "nfev": np.where(notfinite, -1, st["nfev"].astype(np.int64)),
-            "njev": st["njev"].astype(np.int64),
-            "ier": ier,
-            "pars": pars,
-            "pars_err": perr,
-            "pars_cov0": pcov0,
-            "pars_cov": pcov,
-            "npix": npix_obj,
-            "dof": dof,
-        }
+    def states(self):
+        """the raw ngmix_lm_state records of the last go() (debugging)"""
+        return self._d_states.cpu().numpy().reshape(-1).view(_lib.LM_STATE_DTYPE)
 
     def _add_stats(self, res, stamps, psf, sobj, sband, obj_start, nband):
         """FitModel.set_fit_result (results.py:45-72, 398-408, 1079-1109) for
