@@ -772,7 +772,7 @@ static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
     // per-tile records of the fused kernels: exact when the batch carries its
     // largest stamp shape, else ntiles <= npix/8 + 1 holds for any shape
     int a_tc = b->max_npix / 8 + 1;
-    constexpr int TW = (OP == OP_RENDER_FAST || OP == OP_RENDER_EXACT) ? 16 : 8;
+    constexpr int TW = (OP == OP_RENDER_FAST || OP == OP_RENDER_EXACT || OP == OP_FDIFF) ? 16 : 8;
     constexpr int TH = WAVE / TW;
     if (b->max_nrow > 0 && b->max_ncol > 0)
         a_tc = ((b->max_nrow + TH - 1) / TH) * ((b->max_ncol + TW - 1) / TW);

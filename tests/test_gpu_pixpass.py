@@ -268,7 +268,13 @@ def _oracle_eval(gmrow, image, weight, jac, izw):
 @pytest.mark.parametrize("exact", [True, False], ids=["exact", "fused"])
 @pytest.mark.parametrize("dims,ngauss", [((48, 48), 6), ((32, 32), 1),
                                          ((25, 25), 3), ((64, 64), 16),
-                                         ((7, 50), 2), ((70, 9), 4)])
+                                         ((7, 50), 2), ((70, 9), 4),
+                                         # more than 32 gaussians: per-tile ballots
+                                         ((40, 56), 40), ((48, 48), 33),
+                                         # fewer tiles than the look-ahead depth
+                                         ((8, 16), 2), ((4, 16), 1), ((8, 8), 3),
+                                         # many tiles per wave, complete tiles
+                                         ((96, 112), 5)])
 def test_batch_random_vs_oracle(dims, ngauss, exact):
     """seeded random batches, sheared jacobians, masks: batch kernels == oracle"""
     from ngmix_amd.batch import StampBatch, GMixBatch
