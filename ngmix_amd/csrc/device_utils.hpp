@@ -144,6 +144,39 @@ __device__ __forceinline__ double wave_total(double x)
     return readlane_f64(x, 63);
 }
 
+// ---- many sums per wave through a transposed LDS tile ------------------------
+// The sum of each of the NV per-lane values over the 64 lanes of a ONE-WAVE
+// work-group, left in tot[k] (LDS): lane (k, j) adds the j-th segment of row k
+// of the tile, the segments are then folded with log2 shuffles.  Fixed order.
+// ~NVP + 3 log2(64/NVP) VALU instructions in all, against ~34 per value for
+// a DPP tree; red: NV * WAVE_RED_STRIDE doubles, tot: NV doubles.
+constexpr int WAVE_RED_STRIDE = 66;  // doubles per row (spreads the banks)
+
+template <int NV>
+__device__ __forceinline__ void wave_reduce_lds(const double (&acc)[NV], double *red,
+                                                double *tot)
+{
+    constexpr int NVP = NV <= 2 ? 2 : NV <= 4 ? 4 : NV <= 8 ? 8 : NV <= 16 ? 16 : 32;
+    constexpr int SEGS = WAVE / NVP;   // lanes per value
+    constexpr int SEGLEN = WAVE / SEGS;
+    static_assert(NV <= 32, "wave_reduce_lds: too many sums");
+    const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int k = 0; k < NV; k++) red[k * WAVE_RED_STRIDE + lane] = acc[k];
+    __syncthreads();
+    const int k = lane % NVP, j = lane / NVP;
+    double s = 0.0;
+    if (k < NV) {
+        const double *row = red + k * WAVE_RED_STRIDE + j * SEGLEN;
+#pragma unroll
+        for (int i = 0; i < SEGLEN; i++) s += row[i];
+    }
+#pragma unroll
+    for (int off = SEGS / 2; off > 0; off >>= 1) s += __shfl_down(s, off * NVP, WAVE);
+    if (j == 0 && k < NV) tot[k] = s;
+    __syncthreads();
+}
+
 __device__ __forceinline__ int wave_sum_int(int x)
 {
 #pragma unroll

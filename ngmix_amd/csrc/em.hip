@@ -408,46 +408,16 @@ __device__ __forceinline__ double fast_rcp(double x)
     return r;
 }
 
-constexpr int EM_RED_STRIDE = 66;  // doubles per row of the reduction tile
-
 template <int NV>
 struct EmWaveShared {
     double tab[16];    // exp(i), i = -15..0  (zero-weight fill, apodised evaluator)
     double tabr[16];   // exp(-n), n = 0..15  (fused evaluator)
-    double red[NV * EM_RED_STRIDE];
+    double red[NV * WAVE_RED_STRIDE];
     double tot[NV];
     double sky, frac_diff, elogL_last, p_last;
     double psf_irr, psf_irc, psf_icc, psf_row, psf_col, psf_ipsum;
     int numiter, stop, status, pad;
 };
-
-// the sum of each of the NV per-lane values over the wave, left in tot[k]:
-// lane (k, j) adds the j-th segment of row k of the transposed tile, the
-// segments are then folded with log2 shuffles.  Fixed order.
-template <int NV>
-__device__ __forceinline__ void em_wave_reduce(const double (&acc)[NV], double *red,
-                                               double *tot)
-{
-    constexpr int NVP = NV <= 2 ? 2 : NV <= 4 ? 4 : NV <= 8 ? 8 : NV <= 16 ? 16 : 32;
-    constexpr int SEGS = WAVE / NVP;   // lanes per value
-    constexpr int SEGLEN = WAVE / SEGS;
-    static_assert(NV <= 32, "em_wave_reduce: too many sums");
-    const int lane = threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < NV; k++) red[k * EM_RED_STRIDE + lane] = acc[k];
-    __syncthreads();
-    const int k = lane % NVP, j = lane / NVP;
-    double s = 0.0;
-    if (k < NV) {
-        const double *row = red + k * EM_RED_STRIDE + j * SEGLEN;
-#pragma unroll
-        for (int i = 0; i < SEGLEN; i++) s += row[i];
-    }
-#pragma unroll
-    for (int off = SEGS / 2; off > 0; off >>= 1) s += __shfl_down(s, off * NVP, WAVE);
-    if (j == 0 && k < NV) tot[k] = s;
-    __syncthreads();
-}
 
 // sky + model at one zero-weight pixel (fill_zero_weight_pixels, em_nb.py:
 // 1297-1315: the apodised evaluator).  Rare: kept out of line.
@@ -657,7 +627,7 @@ __device__ __forceinline__ void em_wave_body(
         }
 
         const bool anybad = __ballot(bad) != 0ull;
-        em_wave_reduce<NV>(acc, sh.red, sh.tot);
+        wave_reduce_lds<NV>(acc, sh.red, sh.tot);
 
         if (lane == 0) {
             if (anybad) {

@@ -15,6 +15,7 @@
 namespace ngmix {
 
 __constant__ double c_exp_table_m[16] = NGMIX_EXP_TABLE;
+__constant__ double c_fexp_coef_m[9] = NGMIX_FEXP_COEF;
 
 // ===========================================================================
 // weighted sums
@@ -580,7 +581,7 @@ __device__ __forceinline__ void admom_body(const Src &src,
 // weighted sum ignores them without a branch; wsum uses the kept bit.
 
 struct AdmomFusedShared {
-    double tab[16];
+    double tab[16];    // exp(-n), n = 0..15 (fused evaluator)
     double slots[2][NWAVES][32];
     int iscratch[NWAVES + 4];
 };
@@ -589,9 +590,15 @@ struct AdmomFusedShared {
 
 template <int NT, int NV>
 __device__ __forceinline__ void group_total(double (&a)[NV],
-                                            double (*slots)[NWAVES][32], int &phase)
+                                            double (*slots)[NWAVES][32], int &phase,
+                                            double *red = nullptr, double *tot = nullptr)
 {
     constexpr int NW = NT / WAVE;
+    // (a transposed LDS tile -- wave_reduce_lds, as the EM kernel uses -- was
+    // 1.7x SLOWER here: this loop is a short serial chain per iteration and the
+    // LDS round trips cost more latency than the DPP trees cost issue slots)
+    (void)red;
+    (void)tot;
 #pragma unroll
     for (int i = 0; i < NV; i++) a[i] = wave_total(a[i]);
     if (NW > 1) {
@@ -630,11 +637,11 @@ __device__ __forceinline__ int group_sum_int(int x, int *scratch)
 
 // gauss2d_eval_pixel_fast with FMAs on a precomputed chi2; pa = pnorm*area
 __device__ __forceinline__ double weight_fused(double chi2, double pa,
-                                               const double *tab)
+                                               const double *tabr, const FexpCoef &K)
 {
     double w = 0.0;
     if (chi2 < MAX_CHI2 && chi2 >= 0.0) {
-        double e = fexp_fused(-0.5 * chi2, tab);
+        double e = fexp_neg_fused(0.5 * chi2, tabr, K);
         if (chi2 > APOD_CHI2) {
             const double au = (MAX_CHI2 - chi2) * APOD_IWIDTH;
             const double aq = fma(au, fma(au, 6.0, -15.0), 10.0);
@@ -675,7 +682,8 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
             }
         }
     }
-    if (tid < 16) sh.tab[tid] = c_exp_table_m[tid];
+    if (tid < 16) sh.tab[tid] = c_exp_table_m[15 - tid];  // exp(-n)
+    const FexpCoef K = load_fexp_coef(c_fexp_coef_m);
     const int last_pos = group_max_int<NT>(my_last, sh.iscratch);
     const int has_zero = group_max_int<NT>(my_zero, sh.iscratch);
     const int npix = group_sum_int<NT>(__popc(kept), sh.iscratch);
@@ -719,7 +727,7 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
                 const double vd = pv[k] - row, ud = pu[k] - col;
                 const double chi2 =
                     fma(dcc * vd, vd, fma(drr * ud, ud, (mdrc2 * vd) * ud));
-                const double wdata = weight_fused(chi2, pa, sh.tab) * pval[k];
+                const double wdata = weight_fused(chi2, pa, sh.tab, K) * pval[k];
                 a[0] = fma(wdata, pv[k], a[0]);
                 a[1] = fma(wdata, pu[k], a[1]);
                 a[2] += wdata;
@@ -759,7 +767,7 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
                 const double vd = pv[k] - row, ud = pu[k] - col;
                 const double vv = vd * vd, uu = ud * ud, vu = vd * ud;
                 const double chi2 = fma(dcc, vv, fma(drr, uu, mdrc2 * vu));
-                const double weight = weight_fused(chi2, pa, sh.tab);
+                const double weight = weight_fused(chi2, pa, sh.tab, K);
                 const double wdata = weight * pval[k];
                 a[0] = fma(wdata, pv[k], a[0]);
                 a[1] = fma(wdata, pu[k], a[1]);
@@ -877,7 +885,7 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
                 for (int i = 0; i < 7; i++) res_io[0].F[i] = F[i];
             }
             if (want_cov) {
-                const double weight = weight_fused(chi2, used_pa, sh.tab);
+                const double weight = weight_fused(chi2, used_pa, sh.tab, K);
                 double w2var = 0.0;
                 if ((kept >> k) & 1u) {
                     const double ierr = src.ierr[p];
