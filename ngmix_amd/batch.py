@@ -454,12 +454,17 @@ class StampBatch(object):
         return out, status
 
     # ------------------------------------------------ moments / iterative ops
-    def weighted_sums(self, wt, maxrad, nmom=6, res=None, status=None):
+    def weighted_sums(self, wt, maxrad, nmom=6, res=None, status=None, exact=False):
         """
         get_weighted_sums / get_higher_order_weighted_sums per stamp
         (gmix_nb.py:681-821); wt must have its norms set.  res: (N, nbytes/8)
         float64 tensor of result records, ADDED into (zeros when None).
         Returns (res, status); view res with records_to_numpy(res, dtype).
+
+        exact=False (default): register accumulators and a fixed-order tree
+        (sums agree with the reference to summation-order rounding);
+        exact=True: every sum accumulated in the reference's sequential pixel
+        order (bit-identical to the seam form, ~60x slower).
         """
         torch = _torch()
         assert wt.n == self.n and nmom in (6, 17)
@@ -471,7 +476,7 @@ class StampBatch(object):
         maxrad = _as_device_f64(np.broadcast_to(np.asarray(maxrad, dtype="f8"),
                                                 (self.n,)).copy(), self.device) \
             if not isinstance(maxrad, torch.Tensor) else maxrad
-        b = self._batch(wt.ngauss)
+        b = self._batch(wt.ngauss, False, exact)
         with torch.cuda.device(self.device):
             st = _lib.lib().ngmix_weighted_sums_batch(
                 ctypes.byref(b), _dptr(wt.data), _dptr(res), nmom, _dptr(maxrad),

@@ -34,29 +34,7 @@ __device__ __forceinline__ double wave_sum(double x)
     return x;
 }
 
-// a*b + c with the constant c taken from a scalar register pair: one
-// v_fma_f64 per Horner step (left to itself hipcc keeps the coefficients in
-// VGPRs and emits v_mov_b64 + v_fmac_f64, two issue slots per step)
-__device__ __forceinline__ double fma_sconst(double a, double b, double c)
-{
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
-    return r;
-}
-
-__device__ __forceinline__ double fexp_fused(double x, const double *tab)
-{
-    const int ival = (int)(x - 0.5);
-    const double f = x - (double)ival;
-    double p = fma_sconst(f, 0.008197933236258961, 0.042330947141114836);
-    p = fma_sconst(f, p, 0.16674612720799442);
-    p = fma_sconst(f, p, 0.49992478810274166);
-    p = fma_sconst(f, p, 0.999993601071577);
-    p = fma_sconst(f, p, 1.0000011318561302);
-    return tab[ival + 15] * p;
-}
-
-// ---- the fused fexp evaluator (pixpass.hip, em.hip) ------------------------
+// ---- the fused fexp evaluator (pixpass.hip, moments.hip, em.hip, lmfit.hip) ------------------------
 // exp5_smooth coefficients c0..c5 (fastexp_nb.py:252-258) followed by the
 // apodisation constants 10, -15, 6: read with scalar loads so that they live
 // in SGPRs and every Horner step is a single v_fma_f64 v, v, v, s

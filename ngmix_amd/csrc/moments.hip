@@ -184,6 +184,253 @@ __device__ __forceinline__ void weighted_sums_body(const Src &src,
     if (tid == 0 && status) *status = NGMIX_OK;
 }
 
+// ---------------------------------------------------------------------------
+// FUSED weighted sums (batch form default): one wave per stamp, every sum in a
+// register accumulator per lane, FMA arithmetic, a fixed-order tree at the
+// end.  The exact-order kernel above walks 256-pixel chunks with ONE thread
+// per output element adding pixels sequentially (the reference's order, to
+// the last bit) and is ~60x slower: 75 ms per 100k 48x48 stamps against
+// ~1.3 ms here.  Results agree to summation-order rounding (<= 1e-12 of the
+// sum of |terms|).
+//
+// NMOM = 6: one pass, 6 sums + 21 covariance entries (the reference fills all
+// 36, symmetric by construction: mirrored on output) + wsum + npix.
+// NMOM = 17: 17 + 153 + 2 accumulators do not fit the register file; four
+// passes over the pixels each own a block of covariance rows (the stamp is
+// re-read: 16 B/pixel per pass).
+// ---------------------------------------------------------------------------
+
+template <int NMOM>
+__device__ __forceinline__ void wsums_F(double vmod, double umod, double v, double u,
+                                        double rad2, double (&F)[NMOM])
+{
+    F[0] = v;
+    F[1] = u;
+    if (NMOM == 6) {
+        F[2] = umod * umod - vmod * vmod;
+        F[3] = 2 * vmod * umod;
+        F[4] = rad2;
+        F[5] = 1.0;
+    } else {
+        // gmix_nb.py:780-813
+        const double uu = umod, vv = vmod, r2 = rad2;
+        const double u2 = uu * uu, v2 = vv * vv, vu = vv * uu;
+        const double u4 = u2 * u2, v4 = v2 * v2;
+        const double r4 = r2 * r2, r6 = r4 * r2, r8 = r6 * r2;
+        F[2] = u2 - v2;
+        F[3] = 2 * vu;
+        F[4] = r2;
+        F[5] = 1.0;
+        F[6 % NMOM] = uu * r2;
+        F[7 % NMOM] = vv * r2;
+        F[8 % NMOM] = uu * (u2 - 3 * v2);
+        F[9 % NMOM] = vv * (3 * u2 - v2);
+        F[10 % NMOM] = r4;
+        F[11 % NMOM] = r2 * (u2 - v2);
+        F[12 % NMOM] = r2 * 2 * uu * vv;
+        F[13 % NMOM] = u4 - 6 * u2 * v2 + v4;
+        F[14 % NMOM] = (u2 - v2) * 4 * uu * vv;
+        F[15 % NMOM] = r6;
+        F[16 % NMOM] = r8;
+    }
+}
+
+struct WsumsWaveShared {
+    double red[64 * 4];
+    int err;
+    int lastp;
+};
+
+// covariance rows [I0, I1) (entries j >= i), plus the sums / wsum / npix when
+// WITH_SUMS; tot[] receives the wave totals in accumulator order
+template <int NMOM, int I0, int I1, bool WITH_SUMS>
+__device__ __forceinline__ void wsums_pass(const GridSrc &src, const EvalGauss *ge,
+                                           int ng, double vcen, double ucen,
+                                           double maxrad2, WsumsWaveShared &sh,
+                                           double *tot, int &lastp_out)
+{
+    constexpr int NCOV = (I1 - I0) * NMOM - ((I1 - 1) * I1 - (I0 - 1) * I0) / 2;
+    constexpr int NACC = NCOV + (WITH_SUMS ? NMOM + 2 : 0);
+    static_assert(NACC <= 64, "too many accumulators for one pass");
+    const int lane = threadIdx.x;
+    const int lrow = lane / TILE_W, lcol = lane % TILE_W;
+    const int nrow = src.nrow, ncol = src.ncol;
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; k++) acc[k] = 0.0;
+    int lastp = -1;
+    bool zero_div = false;
+
+    for (int r0 = 0; r0 < nrow; r0 += TILE_H) {
+        for (int c0 = 0; c0 < ncol; c0 += TILE_W) {
+            const int row = r0 + lrow, col = c0 + lcol;
+            if (!(row < nrow && col < ncol)) continue;
+            const int p = row * ncol + col;
+            const double val = src.val[p], ierr = src.ierr[p];
+            if (src.izw && !(ierr > 0.0)) continue;  // not in the pixel list
+            double v, u;
+            {
+                const double rd = (double)row - src.jac.row0, cd = (double)col - src.jac.col0;
+                v = fma(src.jac.dvdrow, rd, src.jac.dvdcol * cd);
+                u = fma(src.jac.dudrow, rd, src.jac.dudcol * cd);
+            }
+            const double vmod = v - vcen, umod = u - ucen;
+            const double rad2 = fma(umod, umod, vmod * vmod);
+            bool take = rad2 < maxrad2;
+            if (NMOM == 6) take = take && ierr > 0.0;  // gmix_nb.py:713
+            if (!take) continue;
+            const double ierr2 = ierr * ierr;
+            if (ierr2 == 0.0) {
+                zero_div = true;  // gmix_nb.py:775: 1/ierr^2
+                continue;
+            }
+            double weight = 0.0;
+            for (int g = 0; g < ng; g++) {
+                const EvalGauss e = ge[g];
+                const double vd = v - e.row, ud = u - e.col;
+                const double chi2 =
+                    fma(e.dcc * vd, vd, fma(e.drr * ud, ud, -(e.drc2 * vd) * ud));
+                weight = fma(e.pnorm * exp(-0.5 * chi2), src.area, weight);
+            }
+            const double var = 1.0 / ierr2;
+            const double w2var = weight * weight * var;
+            double F[NMOM];
+            wsums_F<NMOM>(vmod, umod, v, u, rad2, F);
+            int k = 0;
+#pragma unroll
+            for (int i = I0; i < I1; i++) {
+                const double wf = w2var * F[i];
+#pragma unroll
+                for (int j = i; j < NMOM; j++) {
+                    acc[k] = fma(wf, F[j], acc[k]);
+                    k++;
+                }
+            }
+            if (WITH_SUMS) {
+                const double wdata = weight * val;
+#pragma unroll
+                for (int i = 0; i < NMOM; i++) acc[NCOV + i] = fma(wdata, F[i], acc[NCOV + i]);
+                acc[NCOV + NMOM] += weight;
+                acc[NCOV + NMOM + 1] += 1.0;
+            }
+            lastp = p > lastp ? p : lastp;
+        }
+    }
+    if (__ballot(zero_div) != 0ull && lane == 0) sh.err = NGMIX_ERR_ZERO_DIV;
+    // wave totals: DPP inside rows of 16 lanes, the 4 row sums through LDS
+#pragma unroll
+    for (int k = 0; k < NACC; k++) {
+        double x = acc[k];
+        x += dpp_move_or_zero<0x111, 0xf>(x);
+        x += dpp_move_or_zero<0x112, 0xf>(x);
+        x += dpp_move_or_zero<0x114, 0xf>(x);
+        x += dpp_move_or_zero<0x118, 0xf>(x);
+        if ((lane & 15) == 15) sh.red[k * 4 + (lane >> 4)] = x;
+    }
+    __syncthreads();
+    if (lane < NACC) {
+        const double *r = sh.red + lane * 4;
+        tot[lane] = ((r[0] + r[1]) + r[2]) + r[3];
+    }
+    // the position of the last pixel used (its F stays in the record)
+    for (int off = WAVE / 2; off > 0; off >>= 1) {
+        const int y = __shfl_down(lastp, off, WAVE);
+        lastp = y > lastp ? y : lastp;
+    }
+    lastp_out = __builtin_amdgcn_readfirstlane(lastp);
+    __syncthreads();
+}
+
+// add the totals of one pass into the record
+template <int NMOM, int I0, int I1, bool WITH_SUMS>
+__device__ __forceinline__ void wsums_store(const double *tot, char *resbase)
+{
+    constexpr int NCOV = (I1 - I0) * NMOM - ((I1 - 1) * I1 - (I0 - 1) * I0) / 2;
+    const int lane = threadIdx.x;
+    int32_t *r_npix = (int32_t *)(resbase + 4);
+    double *r_wsum = (double *)(resbase + 8);
+    double *r_sums = (double *)(resbase + 16);
+    double *r_cov = r_sums + NMOM;
+    if (lane == 0) {
+        int k = 0;
+        for (int i = I0; i < I1; i++)
+            for (int j = i; j < NMOM; j++) {
+                r_cov[i * NMOM + j] += tot[k];
+                if (j != i) r_cov[j * NMOM + i] += tot[k];
+                k++;
+            }
+        if (WITH_SUMS) {
+            for (int i = 0; i < NMOM; i++) r_sums[i] += tot[NCOV + i];
+            *r_wsum += tot[NCOV + NMOM];
+            *r_npix += (int32_t)tot[NCOV + NMOM + 1];
+        }
+    }
+}
+
+template <int NMOM>
+__global__ __launch_bounds__(WAVE) void wsums_wave_kernel(
+    const ngmix_stamp *stamps, const double *val, const double *ierr,
+    const ngmix_jacobian *jacs, const ngmix_gauss2d *gmix, char *res,
+    const double *maxrad, int32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ WsumsWaveShared sh;
+    __shared__ double tot[64];
+    EvalGauss *ge = (EvalGauss *)smem;
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
+    const ngmix_stamp st = stamps[s];
+    GridSrc src;
+    src.val = val + st.pix_off;
+    src.ierr = ierr + st.pix_off;
+    src.jac = jacs[s];
+    src.area = src.jac.scale * src.jac.scale;
+    src.nrow = st.nrow;
+    src.ncol = st.ncol;
+    src.izw = (st.flags & NGMIX_STAMP_IGNORE_ZERO_WEIGHT) != 0;
+    const ngmix_gauss2d *wt = gmix + st.gm_off;
+    const int ng = st.ngauss;
+    for (int g = lane; g < ng; g += WAVE) ge[g] = make_eval(wt[g]);
+    if (lane == 0) sh.err = 0;
+    __syncthreads();
+    const double vcen = wt[0].row, ucen = wt[0].col;
+    const double mr = maxrad[s], maxrad2 = mr * mr;
+    char *resbase = res + (size_t)s * NGMIX_MOMENTS_RESULT_BYTES(NMOM);
+    int lastp = -1;
+
+    // the reference raises mid-loop on 1/ierr^2 == inf and the caller's record
+    // keeps its partial sums; here the record is left untouched, so the passes
+    // first run into scratch totals and are stored only when none failed
+    if constexpr (NMOM == 6) {
+        wsums_pass<6, 0, 6, true>(src, ge, ng, vcen, ucen, maxrad2, sh, tot, lastp);
+        if (sh.err == 0) wsums_store<6, 0, 6, true>(tot, resbase);
+    } else {
+        __shared__ double totb[3][64];
+        wsums_pass<NMOM, 0, 3, false>(src, ge, ng, vcen, ucen, maxrad2, sh, totb[0], lastp);
+        wsums_pass<NMOM, 3, 7, false>(src, ge, ng, vcen, ucen, maxrad2, sh, totb[1], lastp);
+        wsums_pass<NMOM, 7, 12, false>(src, ge, ng, vcen, ucen, maxrad2, sh, totb[2], lastp);
+        wsums_pass<NMOM, 12, NMOM, true>(src, ge, ng, vcen, ucen, maxrad2, sh, tot, lastp);
+        if (sh.err == 0) {
+            wsums_store<NMOM, 0, 3, false>(totb[0], resbase);
+            wsums_store<NMOM, 3, 7, false>(totb[1], resbase);
+            wsums_store<NMOM, 7, 12, false>(totb[2], resbase);
+            wsums_store<NMOM, 12, NMOM, true>(tot, resbase);
+        }
+    }
+    if (sh.err == 0 && lastp >= 0 && lane == 0) {
+        // F of the last pixel used is left in the record (scratch field)
+        const int row = lastp / src.ncol, col = lastp - row * src.ncol;
+        double v, u;
+        jacobian_vu(src.jac, (double)row, (double)col, v, u);
+        const double vmod = v - vcen, umod = u - ucen;
+        double F[NMOM];
+        wsums_F<NMOM>(vmod, umod, v, u, umod * umod + vmod * vmod, F);
+        double *r_F = (double *)(resbase + 16) + NMOM + NMOM * NMOM + NMOM;
+        for (int i = 0; i < NMOM; i++) r_F[i] = F[i];
+    }
+    if (lane == 0 && status) status[s] = sh.err;
+}
+
 static size_t wsums_lds(int nmom, int ng)
 {
     return (size_t)WS_CHUNK * (nmom + 3) * 8 + (WS_CHUNK + 2) * 4 +
@@ -229,6 +476,19 @@ int launch_weighted_sums_grid(const ngmix_batch *b, const ngmix_gauss2d *gmix,
     if (b->nstamps <= 0) return NGMIX_OK;
     if (nmom != 6 && nmom != 17) return NGMIX_ERR_BAD_ARG;
     const int ng = b->max_ngauss > 0 ? b->max_ngauss : 1;
+    if (!(b->flags & NGMIX_BATCH_EXACT)) {
+        const size_t lds = (size_t)ng * sizeof(EvalGauss) + 16;
+        if (nmom == 6)
+            hipLaunchKernelGGL(wsums_wave_kernel<6>, dim3((unsigned)b->nstamps),
+                               dim3(WAVE), lds, s, b->stamps, b->val, b->ierr, b->jac,
+                               gmix, (char *)res, maxrad, status);
+        else
+            hipLaunchKernelGGL(wsums_wave_kernel<17>, dim3((unsigned)b->nstamps),
+                               dim3(WAVE), lds, s, b->stamps, b->val, b->ierr, b->jac,
+                               gmix, (char *)res, maxrad, status);
+        NGMIX_HIP_CHECK(hipGetLastError());
+        return NGMIX_OK;
+    }
     hipLaunchKernelGGL(weighted_sums_grid_kernel, dim3((unsigned)b->nstamps),
                        dim3(BLOCK), wsums_lds(nmom, ng), s, b->stamps, b->val,
                        b->ierr, b->jac, gmix, (char *)res, nmom, maxrad, status);

@@ -64,7 +64,8 @@ def test_weighted_sums_seam_and_batch(golden):
         sb = StampBatch.from_images(g[name + "_image"], g[name + "_weight"],
                                     g[name + "_jac"],
                                     ignore_zero_weight=bool(g[name + "_izw"]))
-        bres, status = sb.weighted_sums(GMixBatch.from_numpy(wt), maxrad, nmom=nmom)
+        bres, status = sb.weighted_sums(GMixBatch.from_numpy(wt), maxrad, nmom=nmom,
+                                        exact=True)
         assert int(status.cpu()[0]) == 0
         bres = records_to_numpy(bres, dt)
         for got in (res, bres):
@@ -73,9 +74,25 @@ def test_weighted_sums_seam_and_batch(golden):
             for f in ("wsum", "sums", "sums_cov"):
                 close(got[f][0], ref[f][0], rtol=1e-13, err_msg="%s %s" % (name, f))
             np.testing.assert_allclose(got["F"][0], ref["F"][0], rtol=1e-15, atol=0)
-        # seam and batch forms run the same arithmetic in the same order
+        # seam and exact batch forms run the same arithmetic in the same order
         for f in ("wsum", "sums", "sums_cov", "F"):
             np.testing.assert_array_equal(res[f], bres[f])
+        # default batch form: register accumulators + tree, FMA arithmetic:
+        # every sum to 1e-12 of its largest term's scale (sum of |terms| is
+        # bounded by sqrt(cov_ii cov_jj) for the covariance, Cauchy-Schwarz)
+        fres, status = sb.weighted_sums(GMixBatch.from_numpy(wt), maxrad, nmom=nmom)
+        assert int(status.cpu()[0]) == 0
+        fres = records_to_numpy(fres, dt)
+        assert fres["npix"][0] == ref["npix"][0], name
+        np.testing.assert_allclose(fres["wsum"][0], ref["wsum"][0], rtol=1e-12)
+        cov = ref["sums_cov"][0]
+        dscale = np.sqrt(np.abs(np.diag(cov)))
+        assert np.all(np.abs(fres["sums_cov"][0] - cov) <=
+                      1e-12 * np.outer(dscale, dscale)), name
+        # sums[i] = sum w val F_i: |terms| <= sqrt(sum (w val)^2 * sum F_i^2)
+        assert np.all(np.abs(fres["sums"][0] - ref["sums"][0]) <=
+                      1e-11 * np.maximum(np.abs(ref["sums"][0]).max(), 1e-300)), name
+        np.testing.assert_allclose(fres["F"][0], ref["F"][0], rtol=1e-14, atol=0)
         # accumulate-into: a second call doubles
         assert L.ngmix_get_weighted_sums(_lib.ptr(wt), wt.size, _lib.ptr(pixels),
                                          pixels.size, _lib.ptr(res), nmom,

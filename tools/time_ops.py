@@ -43,3 +43,31 @@ for name, nbytes, fn in ops:
     t = timeit(fn)
     res.append("%s %.4f ms %.2f TB/s" % (name, t, nbytes * n / t / 1e9))
 print(os.environ.get("NGMIX_HIP_LIB", "default")[-24:], " | ".join(res))
+
+# weighted sums (GaussMom's kernel) and deriv_images on the same stamps
+import numpy as np  # noqa: E402
+from ngmix_amd.batch import GMixBatch  # noqa: E402
+from ngmix_amd import _lib  # noqa: E402
+
+wt, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.6, 1.0], (n, 1)), "gauss",
+                            device=dev)
+wt.set_norms()
+maxrad = np.full(n, 100.0 * np.sqrt(0.3))
+res = []
+for nmom in (6, 17):
+    nd = _lib.moments_result_dtype(nmom).itemsize // 8
+    r = torch.zeros((n, nd), dtype=torch.float64, device=dev)
+    t = timeit(lambda: sb.weighted_sums(wt, maxrad, nmom=nmom, res=r, status=status))
+    nbytes = 16 * 2304 + nd * 8 * 2
+    res.append("wsums%d %.4f ms %.2f TB/s" % (nmom, t, nbytes * n / t / 1e9))
+gmh = gm.to_numpy()
+gpars = np.stack([gmh[k] for k in ("p", "row", "col", "irr", "irc", "icc")], axis=-1)
+gpars = np.ascontiguousarray(gpars.reshape(-1, 6))
+dcov = np.tile(np.eye(3)[None] * 0.1, (gpars.shape[0], 1, 1))
+dgp = torch.from_numpy(gpars).to(dev)
+ddc = torch.from_numpy(dcov).to(dev)
+dout = torch.zeros(6 * sb.total_pix, dtype=torch.float64, device=dev)
+ostart = torch.from_numpy(np.arange(n, dtype=np.int64) * 6 * 2304).to(dev)
+t = timeit(lambda: sb.deriv_images(dgp, ddc, 6, out=dout, out_start=ostart), reps=5)
+res.append("deriv_images %.4f ms %.2f TB/s" % (t, (6 * 2 * 8 * 2304) * n / t / 1e9))
+print(" | ".join(res))
