@@ -408,11 +408,12 @@ __device__ __forceinline__ double fast_rcp(double x)
     return r;
 }
 
-template <int NV>
+template <int NT, int NV>
 struct EmWaveShared {
     double tab[16];    // exp(i), i = -15..0  (zero-weight fill, apodised evaluator)
     double tabr[16];   // exp(-n), n = 0..15  (fused evaluator)
-    double red[NV * WAVE_RED_STRIDE];
+    double red[NV * (NT + 2)];
+    double part[NV * 16];
     double tot[NV];
     double sky, frac_diff, elogL_last, p_last;
     double psf_irr, psf_irc, psf_icc, psf_row, psf_col, psf_ipsum;
@@ -431,14 +432,56 @@ __device__ __noinline__ double em_fill_value(const ngmix_gauss2d *conv, int ncon
     return sky + m;
 }
 
+// The sum of each of NV per-thread values over an NT-thread work-group (NT = 64,
+// 128, 256), left in tot[k]: the values go through a transposed LDS tile, NV*S
+// threads each add one segment of one row, NV threads fold the S partials.
+// Fixed order.  One wave: wave_reduce_lds (no barriers).
+template <int NT, int NV>
+__device__ __forceinline__ void em_group_reduce(const double (&acc)[NV], double *red,
+                                                double *part, double *tot)
+{
+    if constexpr (NT == WAVE) {
+        wave_reduce_lds<NV>(acc, red, tot);
+    } else {
+    constexpr int STRIDE = NT + 2;
+    // segments per value: the largest power of two with NV*S <= NT, at most 16
+    constexpr int Q = NT / NV;
+    constexpr int S = Q >= 16 ? 16 : Q >= 8 ? 8 : Q >= 4 ? 4 : 2;
+    static_assert(NV * S <= NT && NT % S == 0, "em_group_reduce sizing");
+    constexpr int SEGLEN = NT / S;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NV; k++) red[k * STRIDE + tid] = acc[k];
+    __syncthreads();
+    if (tid < NV * S) {
+        const int k = tid / S, j = tid - k * S;
+        const double *row = red + k * STRIDE + j * SEGLEN;
+        double s = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < SEGLEN; i++) s += row[i];
+        part[k * 16 + j] = s;
+    }
+    __syncthreads();
+    if (tid < NV) {
+        const double *r = part + tid * 16;
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < S; j++) s += r[j];
+        tot[tid] = s;
+    }
+    __syncthreads();
+    }
+}
+
 // KIND, the number of object gaussians NG and (NPSF1) a one-gaussian psf are
-// compile-time: the pixel pass is straight-line code
-template <int PPT, int KIND, int NG, bool NPSF1>
+// compile-time: the pixel pass is straight-line code.  NT threads per stamp
+// (1, 2 or 4 waves), PPT pixels per thread in registers.
+template <int NT, int PPT, int KIND, int NG, bool NPSF1>
 __device__ __forceinline__ void em_wave_body(
     const GridSrc &src, const ngmix_em_conf conf, double sky_in,
     ngmix_gauss2d *gmix_io, ngmix_gauss2d *psf_io, int npsf_rt,
     ngmix_gauss2d *conv_io, int fill_zero_weight, double *out3, int32_t *status,
-    EmWaveShared<6 * NG + 2> &sh, char *dyn, const double *coef)
+    EmWaveShared<NT, 6 * NG + 2> &sh, char *dyn, const double *coef)
 {
     constexpr int NV = 6 * NG + 2;
     constexpr int kind = KIND;
@@ -457,7 +500,7 @@ __device__ __forceinline__ void em_wave_body(
     unsigned kept = 0u, zw = 0u;
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
-        const int p = lane + k * WAVE;
+        const int p = lane + k * NT;
         pv[k] = pu[k] = pval[k] = 0.0;
         if (p < n) {
             double a, ierr;
@@ -468,15 +511,23 @@ __device__ __forceinline__ void em_wave_body(
         }
     }
     const double area = src.area;
-    const double npix = (double)wave_sum_int(__popc(kept));  // lane 0
+    double cnt[1] = {(double)__popc(kept)};
 
     if (lane < 16) {
         sh.tab[lane] = c_exp_table_e[lane];
         sh.tabr[lane] = c_exp_table_e[15 - lane];
     }
-    for (int i = lane; i < ngauss; i += WAVE) gmix[i] = gmix_io[i];
-    for (int i = lane; i < npsf; i += WAVE) psf[i] = psf_io[i];
-    for (int i = lane; i < nconv; i += WAVE) conv[i] = conv_io[i];
+    {
+        double pad[6 * NG + 2];
+#pragma unroll
+        for (int k = 0; k < 6 * NG + 2; k++) pad[k] = k == 0 ? cnt[0] : 0.0;
+        em_group_reduce<NT, 6 * NG + 2>(pad, sh.red, sh.part, sh.tot);
+    }
+    const double npix = sh.tot[0];
+    __syncthreads();
+    for (int i = lane; i < ngauss; i += NT) gmix[i] = gmix_io[i];
+    for (int i = lane; i < npsf; i += NT) psf[i] = psf_io[i];
+    for (int i = lane; i < nconv; i += NT) conv[i] = conv_io[i];
     __syncthreads();
 
     constexpr bool use_cen = (kind == NGMIX_EM_FULL || kind == NGMIX_EM_FIXCOV);
@@ -532,7 +583,7 @@ __device__ __forceinline__ void em_wave_body(
 
     for (int it = 0; it < conf.maxiter && sh.stop != 1; it++) {
         // set_logtau_logdet + the evaluation view of the convolved mixture
-        for (int i = lane; i < nconv; i += WAVE) {
+        for (int i = lane; i < nconv; i += NT) {
             const ngmix_gauss2d g = conv[i];
             EmConvF c;
             c.row = g.row;
@@ -550,7 +601,7 @@ __device__ __forceinline__ void em_wave_body(
 
         // fill_zero_weight_pixels overwrites val of the zero-weight pixels
         // with sky + model, as the reference does in its pixel copy
-        if (fill_zero_weight && __ballot(zw != 0u) != 0ull) {
+        if (fill_zero_weight && zw != 0u) {
 #pragma unroll
             for (int k = 0; k < PPT; k++)
                 if (zw & (1u << k))
@@ -626,8 +677,8 @@ __device__ __forceinline__ void em_wave_body(
             }
         }
 
-        const bool anybad = __ballot(bad) != 0ull;
-        wave_reduce_lds<NV>(acc, sh.red, sh.tot);
+        const bool anybad = __syncthreads_or(bad ? 1 : 0) != 0;
+        em_group_reduce<NT, NV>(acc, sh.red, sh.part, sh.tot);
 
         if (lane == 0) {
             if (anybad) {
@@ -682,10 +733,10 @@ __device__ __forceinline__ void em_wave_body(
     // write back.  The reference zeroes norm_set of the pre-psf mixture on a
     // normal exit (em_nb.py:125); on an exception it has no chance to.
     if (sh.status == NGMIX_OK)
-        for (int i = lane; i < ngauss; i += WAVE) gmix[i].norm_set = 0;
+        for (int i = lane; i < ngauss; i += NT) gmix[i].norm_set = 0;
     __syncthreads();
-    for (int i = lane; i < ngauss; i += WAVE) gmix_io[i] = gmix[i];
-    for (int i = lane; i < nconv; i += WAVE) conv_io[i] = conv[i];
+    for (int i = lane; i < ngauss; i += NT) gmix_io[i] = gmix[i];
+    for (int i = lane; i < nconv; i += NT) conv_io[i] = conv[i];
     if (lane == 0) {
         out3[0] = (double)sh.numiter;
         out3[1] = sh.frac_diff;
@@ -730,14 +781,14 @@ __global__ __launch_bounds__(NT) void em_grid_kernel(
 
 __constant__ double c_fexp_coef_e[9] = NGMIX_FEXP_COEF;
 
-template <int PPT, int KIND, int NG, bool NPSF1>
-__global__ __launch_bounds__(WAVE) void em_wave_kernel(
+template <int NT, int PPT, int KIND, int NG, bool NPSF1>
+__global__ __launch_bounds__(NT) void em_wave_kernel(
     ngmix_em_conf conf, const ngmix_stamp *stamps, const double *val,
     const double *ierr, const ngmix_jacobian *jacs, ngmix_gauss2d *gmix,
     ngmix_gauss2d *gmix_psf, int npsf, ngmix_gauss2d *gmix_conv,
     const double *sky_in, int fill_zero_weight, double *out, int32_t *status)
 {
-    __shared__ EmWaveShared<6 * NG + 2> sh;
+    __shared__ EmWaveShared<NT, 6 * NG + 2> sh;
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     const int s = blockIdx.x;
     const ngmix_stamp st = stamps[s];
@@ -749,32 +800,50 @@ __global__ __launch_bounds__(WAVE) void em_wave_kernel(
     src.nrow = st.nrow;
     src.ncol = st.ncol;
     src.izw = (st.flags & NGMIX_STAMP_IGNORE_ZERO_WEIGHT) != 0;
-    em_wave_body<PPT, KIND, NG, NPSF1>(
+    em_wave_body<NT, PPT, KIND, NG, NPSF1>(
         src, conf, sky_in[s], gmix + (size_t)s * NG, gmix_psf + (size_t)s * npsf, npsf,
         gmix_conv + (size_t)s * NG * npsf, fill_zero_weight, out + 3 * (size_t)s,
         status ? status + s : nullptr, sh, dyn, c_fexp_coef_e);
 }
 
+template <int NT, int PPT, int KIND, int NG>
+static void em_wave_launch_nt(const ngmix_em_conf *conf, const ngmix_batch *b,
+                              ngmix_gauss2d *gmix, ngmix_gauss2d *psf, int npsf,
+                              ngmix_gauss2d *conv, const double *sky_in, int fzw,
+                              double *out, int32_t *status, hipStream_t s)
+{
+    const size_t nconv = (size_t)NG * npsf;
+    const size_t lds = (NG + npsf + nconv) * sizeof(ngmix_gauss2d) +
+                       nconv * sizeof(EmConvF) + 64;
+    if (npsf == 1)
+        hipLaunchKernelGGL((em_wave_kernel<NT, PPT, KIND, NG, true>),
+                           dim3((unsigned)b->nstamps), dim3(NT), lds, s, *conf,
+                           b->stamps, b->val, b->ierr, b->jac, gmix, psf, npsf, conv,
+                           sky_in, fzw, out, status);
+    else
+        hipLaunchKernelGGL((em_wave_kernel<NT, PPT, KIND, NG, false>),
+                           dim3((unsigned)b->nstamps), dim3(NT), lds, s, *conf,
+                           b->stamps, b->val, b->ierr, b->jac, gmix, psf, npsf, conv,
+                           sky_in, fzw, out, status);
+}
+
+// one wave up to 32x32 pixels, two up to 45x45, four up to 64x64
 template <int KIND, int NG>
 static void em_wave_launch(const ngmix_em_conf *conf, const ngmix_batch *b,
                            ngmix_gauss2d *gmix, ngmix_gauss2d *psf, int npsf,
                            ngmix_gauss2d *conv, const double *sky_in, int fzw,
                            double *out, int32_t *status, hipStream_t s)
 {
-    constexpr int PPT = 16;
-    const size_t nconv = (size_t)NG * npsf;
-    const size_t lds = (NG + npsf + nconv) * sizeof(ngmix_gauss2d) +
-                       nconv * sizeof(EmConvF) + 64;
-    if (npsf == 1)
-        hipLaunchKernelGGL((em_wave_kernel<PPT, KIND, NG, true>),
-                           dim3((unsigned)b->nstamps), dim3(WAVE), lds, s, *conf,
-                           b->stamps, b->val, b->ierr, b->jac, gmix, psf, npsf, conv,
-                           sky_in, fzw, out, status);
+    const int np = b->max_npix;
+    if (np <= 16 * WAVE)
+        em_wave_launch_nt<WAVE, 16, KIND, NG>(conf, b, gmix, psf, npsf, conv, sky_in, fzw,
+                                              out, status, s);
+    else if (np <= 16 * 2 * WAVE)
+        em_wave_launch_nt<2 * WAVE, 16, KIND, NG>(conf, b, gmix, psf, npsf, conv, sky_in,
+                                                  fzw, out, status, s);
     else
-        hipLaunchKernelGGL((em_wave_kernel<PPT, KIND, NG, false>),
-                           dim3((unsigned)b->nstamps), dim3(WAVE), lds, s, *conf,
-                           b->stamps, b->val, b->ierr, b->jac, gmix, psf, npsf, conv,
-                           sky_in, fzw, out, status);
+        em_wave_launch_nt<BLOCK, 16, KIND, NG>(conf, b, gmix, psf, npsf, conv, sky_in,
+                                               fzw, out, status, s);
 }
 
 template <int KIND>
@@ -791,7 +860,7 @@ static void em_wave_launch_ng(const ngmix_em_conf *conf, const ngmix_batch *b,
         em_wave_launch<KIND, 3>(conf, b, gmix, psf, npsf, conv, sky_in, fzw, out, status, s);
 }
 
-// stamps of <= 16*64 pixels, 1..3 object gaussians
+// stamps of <= 16*256 pixels (64x64), 1..3 object gaussians
 static int em_wave_dispatch(int kind, const ngmix_em_conf *conf, const ngmix_batch *b,
                             ngmix_gauss2d *gmix, int ngauss, ngmix_gauss2d *psf,
                             int npsf, ngmix_gauss2d *conv, const double *sky_in,
@@ -885,8 +954,8 @@ int launch_em_grid(int kind, const ngmix_em_conf *conf, const ngmix_batch *b,
     int nt = 0;
     if (const char *e = getenv("NGMIX_EM_NT")) nt = atoi(e);
     const int np = b->max_npix;
-    if (nt == 0) nt = (np <= 16 * WAVE && ngauss <= 3) ? WAVE : BLOCK;
-    if (nt == WAVE && np <= 16 * WAVE && ngauss <= 3)
+    if (nt == 0) nt = (np <= 16 * BLOCK && ngauss <= 3) ? WAVE : BLOCK;
+    if (nt == WAVE && np <= 16 * BLOCK && ngauss <= 3)
         return em_wave_dispatch(kind, conf, b, gmix, ngauss, psf, npsf, conv, sky_in,
                                 fzw, out, status, s);
     if (np <= 4 * BLOCK)

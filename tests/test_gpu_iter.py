@@ -375,3 +375,55 @@ def test_deriv_images_masked_layout(golden):
     keep = (w[1] > 0).ravel()
     nk = int(keep.sum())
     np.testing.assert_array_equal(out[6 * n0:].reshape(6, nk), full[:, keep])
+
+
+@pytest.mark.parametrize("dim,kind", [(40, 0), (48, 0), (48, 2), (64, 1), (33, 3)])
+def test_em_multi_wave_vs_reference_order_kernel(dim, kind):
+    """stamps above 32x32 run the fused EM body on 2 or 4 waves; the 256-thread
+    reference-order kernel (NGMIX_EM_NT=256) is the check: same iteration
+    count, mixtures to 1e-9"""
+    import os
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    rng = np.random.RandomState(100 + dim + kind)
+    n, scale = 6, 0.263
+    pars = np.zeros((n, 6))
+    pars[:, 0:2] = rng.uniform(-0.5, 0.5, size=(n, 2)) * scale
+    pars[:, 2:4] = rng.normal(scale=0.05, size=(n, 2))
+    pars[:, 4] = rng.uniform(0.5, 1.2, size=n)
+    pars[:, 5] = rng.uniform(50, 200, size=n)
+    cen = (dim - 1) / 2.0
+    jac = np.array([cen, cen, scale, 0.0, 0.0, scale, scale ** 2, scale])
+    gm_true, _ = GMixBatch.from_pars(pars, "gauss")
+    geom = StampBatch.from_images(np.zeros((n, dim, dim)), None, jac)
+    truth, _ = geom.render(gm_true)
+    sky = 0.05
+    images = truth.cpu().numpy().reshape(n, dim, dim) + sky + \
+        0.002 * rng.normal(size=(n, dim, dim))
+    weights = np.full((n, dim, dim), 1.0 / 0.002 ** 2)
+    weights[1, 5, 7] = 0.0
+    sb = StampBatch.from_images(images, weights, jac)
+    guess = pars.copy()
+    guess[:, 4] = (pars[:, 4] - 0.27) * rng.uniform(0.9, 1.1, size=n)
+    guess[:, 5] = pars[:, 5] * scale ** 2 * rng.uniform(0.9, 1.1, size=n)
+    psfpars = np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (n, 1))
+    results = []
+    for env in (None, "256"):
+        if env is None:
+            os.environ.pop("NGMIX_EM_NT", None)
+        else:
+            os.environ["NGMIX_EM_NT"] = env
+        try:
+            gm0, _ = GMixBatch.from_pars(guess, "gauss")
+            psf, _ = GMixBatch.from_pars(psfpars, "gauss")
+            out, status, conv = sb.em(gm0, psf, sky=sky, kind=kind, miniter=20,
+                                      maxiter=200, tol=1e-6, fill_zero_weight=True)
+            assert int(status.abs().sum()) == 0
+            results.append((out.cpu().numpy(), gm0.to_numpy(), conv.to_numpy()))
+        finally:
+            os.environ.pop("NGMIX_EM_NT", None)
+    (o1, g1, c1), (o2, g2, c2) = results
+    np.testing.assert_array_equal(o1[:, 0], o2[:, 0])
+    np.testing.assert_allclose(o1[:, 2], o2[:, 2], rtol=1e-9)
+    for f in ("p", "row", "col", "irr", "irc", "icc"):
+        np.testing.assert_allclose(g1[f], g2[f], rtol=1e-9, atol=1e-11, err_msg=f)
+        np.testing.assert_allclose(c1[f], c2[f], rtol=1e-9, atol=1e-11, err_msg=f)

@@ -1,6 +1,6 @@
 """config-4-like timing of the iterative kernels: N 32x32 stamps,
 round-ish gaussian (x) gaussian psf objects; admom and 1-gaussian em_run.
-python tools/bench_iter.py [nstamps] [reps]"""
+python tools/bench_iter.py [nstamps] [reps] [dim]"""
 import os
 import sys
 import time
@@ -14,7 +14,8 @@ from ngmix_amd.batch import StampBatch, GMixBatch, records_to_numpy  # noqa: E40
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-dim, scale = 32, 0.263
+dim = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+scale = 0.263
 rng = np.random.RandomState(5)
 pars = np.zeros((n, 6))
 pars[:, 0:2] = rng.uniform(-0.5, 0.5, size=(n, 2)) * scale
@@ -22,7 +23,7 @@ pars[:, 2:4] = rng.normal(scale=0.05, size=(n, 2))
 pars[:, 4] = rng.uniform(0.3, 0.9, size=n) + 0.27
 pars[:, 5] = rng.uniform(50, 200, size=n)
 gm_true, _ = GMixBatch.from_pars(pars, "gauss")
-jac = np.array([15.5, 15.5, scale, 0, 0, scale, scale ** 2, scale])
+jac = np.array([(dim - 1) / 2, (dim - 1) / 2, scale, 0, 0, scale, scale ** 2, scale])
 geom = StampBatch(None, None, torch.from_numpy(np.tile(jac, (n, 1))).cuda(),
                   np.full(n, dim), np.full(n, dim),
                   np.arange(n, dtype=np.int64) * dim * dim, True)
