@@ -31,6 +31,12 @@ int launch_em_list(int kind, const ngmix_em_conf *conf, ngmix_pixel *pixels,
                    ngmix_gauss2d *psf, int npsf, ngmix_gauss2d *conv, int fzw,
                    double *out3, int32_t *status, hipStream_t s);
 
+// em_wave.hip: stamps of <= 64x64 pixels, 1..3 object gaussians
+int launch_em_wave(int kind, const ngmix_em_conf *conf, const ngmix_batch *b,
+                   ngmix_gauss2d *gmix, int ngauss, ngmix_gauss2d *psf, int npsf,
+                   ngmix_gauss2d *conv, const double *sky_in, int fzw, double *out,
+                   int32_t *status, hipStream_t s);
+
 // derivs.hip
 int launch_deriv_list(const double *gpars, const double *dcov, int ng,
                       const double *vv, const double *uu, const double *area,
