@@ -141,3 +141,42 @@ def test_batch_out_of_range_start_and_masked():
     assert res["npix"][4] == 32 * 32 - 4 * 12
     pull = (res["pars"][okmask] - pars[okmask]) / res["pars_err"][okmask]
     assert np.all(np.abs(pull) < 6.0)
+
+
+def test_bootstrap_batch_recovers_truth():
+    """psf admom -> guess admom -> batched LM, everything on the device"""
+    from ngmix_amd.pipeline import bootstrap_batch
+    rng = np.random.RandomState(77)
+    n, dim, scale, noise = 200, 40, 0.263, 0.01
+    pars = np.zeros((n, 6))
+    pars[:, 0:2] = rng.uniform(-0.5, 0.5, size=(n, 2)) * scale
+    pars[:, 2:4] = rng.normal(scale=0.1, size=(n, 2))
+    pars[:, 4] = rng.uniform(0.3, 1.0, size=n)
+    pars[:, 5] = rng.uniform(50.0, 200.0, size=n)
+    psf_T = rng.uniform(0.22, 0.32, size=n)
+    psf_pars = np.zeros((n, 6))
+    psf_pars[:, 2:4] = rng.normal(scale=0.02, size=(n, 2))
+    psf_pars[:, 4] = psf_T
+    psf_pars[:, 5] = 1.0
+    cen = (dim - 1) / 2.0
+    jac = np.array([cen, cen, scale, 0.0, 0.0, scale, scale ** 2, scale])
+    gm0, _ = GMixBatch.from_pars(pars, "exp")
+    psf, _ = GMixBatch.from_pars(psf_pars, "gauss")
+    gm, _ = gm0.convolve(psf)
+    geom = StampBatch.from_images(np.zeros((n, dim, dim)), None, jac)
+    truth, _ = geom.render(gm)
+    images = truth.cpu().numpy().reshape(n, dim, dim) + noise * rng.normal(size=(n, dim, dim))
+    sb = StampBatch.from_images(images, np.full((n, dim, dim), 1.0 / noise ** 2), jac)
+    pdim = 25
+    pjac = np.array([12.0, 12.0, scale, 0.0, 0.0, scale, scale ** 2, scale])
+    pgeom = StampBatch.from_images(np.zeros((n, pdim, pdim)), None, pjac)
+    pim, _ = pgeom.render(psf)
+    pimages = pim.cpu().numpy().reshape(n, pdim, pdim) + 1e-5 * rng.normal(size=(n, pdim, pdim))
+    psb = StampBatch.from_images(pimages, np.full((n, pdim, pdim), 1e10), pjac)
+    res = bootstrap_batch(sb, psb, model="exp", psf_Tguess=0.3)
+    assert np.all(res["psf_flags"] == 0)
+    np.testing.assert_allclose(res["psf_T"], psf_T, rtol=2e-3)
+    assert np.all(res["flags"] == 0)
+    pull = (res["pars"] - pars) / res["pars_err"]
+    assert np.all(np.abs(pull) < 6.0)
+    assert 0.7 < np.sqrt((pull ** 2).mean()) < 1.3
