@@ -256,6 +256,19 @@ class StampBatch(object):
         _lib.check(st, "ngmix_weight_to_ierr_batch")
         return cls(dval, ierr, _as_device_f64(jac, dev), nrow, ncol, off, izw)
 
+    @classmethod
+    def from_observations_geometry(cls, obs_list, device=None):
+        """shapes and jacobians only (no pixel data): every pixel of every
+        stamp is listed -- for render / deriv_images over full frames"""
+        dev = _require_cuda(device)
+        nrow = np.array([o.image.shape[0] for o in obs_list], dtype=np.int32)
+        ncol = np.array([o.image.shape[1] for o in obs_list], dtype=np.int32)
+        npix = nrow.astype(np.int64) * ncol
+        off = np.concatenate([[0], np.cumsum(npix)[:-1]]).astype(np.int64)
+        jac = np.stack([o.jacobian.get_data().view(np.float64).reshape(8)
+                        for o in obs_list])
+        return cls(None, None, _as_device_f64(jac, dev), nrow, ncol, off, False)
+
     @staticmethod
     def _jacobian_tensor(jacobians, n, nrow, ncol, dev):
         if jacobians is None:

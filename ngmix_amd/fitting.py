@@ -40,7 +40,7 @@ LOGGER = logging.getLogger(__name__)
 
 SIMPLE_ANALYTIC_MODELS = ("gauss", "exp", "dev")
 # relative step for differencing the (smooth) prior rows of the jacobian
-STEP_PRIOR = 1.0e-7
+STEP_PRIOR = 1.0e-8  # results.py:935
 
 
 # ---------------------------------------------------------------------------
@@ -655,10 +655,6 @@ class Fitter(object):
         self.prior = prior
         self.model = gmix_mod.get_model_num(model)
         self.model_name = gmix_mod.get_model_name(self.model)
-        if use_noise_image:
-            raise NotImplementedError(
-                "use_noise_image (noise-power sandwich covariance) is outside "
-                "the pixel hot path this build covers")
         self.use_noise_image = use_noise_image
         self.analytic_jacobian = analytic_jacobian
         self.fit_pars = (fit_pars.copy() if fit_pars is not None
@@ -674,6 +670,10 @@ class Fitter(object):
         result = run_leastsq(fit_model.calc_fdiff, guess=guess,
                              n_prior_pars=fit_model.n_prior_pars,
                              bounds=fit_model.bounds, Dfun=dfun, **self.fit_pars)
+        if self.use_noise_image:
+            # noise-power sandwich covariance (fitters.py:108-109)
+            from .noise_cov import apply_noise_cov
+            apply_noise_cov(fit_model=fit_model, result=result)
         fit_model.set_fit_result(result)
         return fit_model
 

@@ -63,6 +63,40 @@ def main():
     out["tf_gmix_pars"] = gm.get_full_pars()
     for k in ("flags", "chi2per", "dof", "flux", "flux_err"):
         out["tf_" + k] = res[k]
+    # ---- noise-power sandwich covariance (ngmix/fitting/noise_cov.py)
+    from scipy.ndimage import uniform_filter
+    ol = ngmix.ObsList()
+    truth = [0.03, -0.02, 0.06, -0.04, 0.5, 90.0]
+    for e in range(2):
+        ejac = ngmix.DiagonalJacobian(row=15.0 + 0.3 * e, col=15.5 - 0.2 * e, scale=SCALE)
+        egm = ngmix.GMixModel(truth, "exp").convolve(psf_gm)
+        sigma = 0.03
+        # stationary correlated noise: smoothed white noise, same for the
+        # image's noise and the attached independent realisation
+        nz = [uniform_filter(rng.normal(size=(32, 32)), size=3, mode="wrap") * sigma * 3
+              for _ in range(2)]
+        im = egm.make_image((32, 32), jacobian=ejac, fast_exp=True) + nz[0]
+        wt = np.full((32, 32), 1.0 / sigma ** 2)
+        eobs = ngmix.Observation(im, weight=wt, jacobian=ejac, psf=psf_obs, noise=nz[1])
+        ol.append(eobs)
+        out["nc_e%d_image" % e] = im
+        out["nc_e%d_weight" % e] = wt
+        out["nc_e%d_noise" % e] = nz[1]
+        out["nc_e%d_jac" % e] = ejac.get_data().copy()
+    guess = np.array(truth) * (1.0 + 0.05 * rng.uniform(-1, 1, size=6))
+    out["nc_guess"] = guess
+    for tag, uni in (("nc_plain", False), ("nc_sandwich", True)):
+        res = ngmix.fitting.Fitter(model="exp", use_noise_image=uni).go(obs=ol, guess=guess)
+        for k in ("flags", "nfev", "ier"):
+            out[tag + "_" + k] = res[k]
+        for k in ("pars", "pars_err", "pars_cov", "pars_cov0"):
+            out[tag + "_" + k] = np.array(res[k])
+    # the same sandwich with central-difference derivative images
+    from ngmix.fitting import noise_cov as ncmod
+    fm = ngmix.fitting.results.FitModel(obs=ol, model="exp", guess=guess)
+    fd = ncmod._dmodel_images(fit_model=fm, pars=out["nc_sandwich_pars"], band=0,
+                              obs=ol[0], kpars=list(range(6)), force_fd=True)
+    out["nc_fd_images_e0"] = np.array(fd)
     np.savez_compressed(OUT, **out)
     print("wrote %s (%.1f kB)" % (OUT, os.path.getsize(OUT) / 1e3))
 

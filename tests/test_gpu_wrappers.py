@@ -76,3 +76,52 @@ def test_psf_flux(golden):
     assert res["flags"] == int(g["tf_flags"])
     for k in ("chi2per", "dof", "flux", "flux_err"):
         np.testing.assert_allclose(res[k], float(g["tf_" + k]), rtol=1e-9)
+
+
+def _nc_obslist(g):
+    psf = ngmix.Observation(g["psf_image"], jacobian=_jac(g["psf_jac"]),
+                            gmix=ngmix.GMix(pars=g["psf_pars"]))
+    ol = ngmix.ObsList()
+    for e in range(2):
+        pre = "nc_e%d_" % e
+        ol.append(ngmix.Observation(g[pre + "image"], weight=g[pre + "weight"],
+                                    jacobian=_jac(g[pre + "jac"]), psf=psf,
+                                    noise=g[pre + "noise"]))
+    return ol
+
+
+def test_noise_cov_sandwich(golden):
+    """Fitter(use_noise_image=True): the noise-power sandwich covariance of the
+    reference (noise_cov.py) on two epochs with stationary correlated noise"""
+    g = golden("extra")
+    ol = _nc_obslist(g)
+    for tag, uni in (("nc_plain", False), ("nc_sandwich", True)):
+        res = ngmix.fitting.Fitter(model="exp", use_noise_image=uni).go(
+            obs=ol, guess=g["nc_guess"])
+        assert res["flags"] == int(g[tag + "_flags"]) == 0
+        assert res["nfev"] == int(g[tag + "_nfev"])
+        np.testing.assert_allclose(res["pars"], g[tag + "_pars"], rtol=1e-7, atol=1e-9)
+        refcov = g[tag + "_pars_cov"]
+        sig = np.sqrt(np.diag(refcov))
+        assert np.all(np.abs(res["pars_cov"] - refcov) <=
+                      1e-5 * np.abs(refcov) + 1e-8 * np.outer(sig, sig)), tag
+        np.testing.assert_allclose(res["pars_err"], g[tag + "_pars_err"], rtol=1e-5)
+    # correlated noise: the sandwich errors are well above the chi2-scaled ones
+    assert np.all(g["nc_sandwich_pars_err"] > 2 * g["nc_plain_pars_err"])
+
+
+def test_noise_cov_central_difference_images(golden):
+    from ngmix_amd import noise_cov
+    from ngmix_amd.fitting import FitModel
+    g = golden("extra")
+    ol = _nc_obslist(g)
+    fm = FitModel(obs=ol, model="exp", guess=g["nc_guess"])
+    ims = noise_cov._dmodel_images_all(fm, g["nc_sandwich_pars"], force_fd=True)[0]
+    ref = g["nc_fd_images_e0"]
+    for a in range(6):
+        np.testing.assert_allclose(ims[a], ref[a], rtol=1e-6,
+                                   atol=1e-7 * np.abs(ref[a]).max())
+    # and the analytic images agree with them to the accuracy of the differences
+    ana = noise_cov._dmodel_images_all(fm, g["nc_sandwich_pars"])[0]
+    for a in range(6):
+        assert np.abs(ana[a] - ref[a]).max() <= 2e-4 * np.abs(ref[a]).max()
