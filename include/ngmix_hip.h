@@ -370,11 +370,20 @@ int ngmix_deriv_images_batch(const ngmix_batch *batch, const double *gpars,
  * ngmix_lm_advance_batch (one step of the lmder logic per object).
  * ====================================================================== */
 #define NGMIX_LM_NPMAX 8  /* parameters per object: 5 shape + up to 3 band fluxes */
-#define NGMIX_LM_NSUM 28  /* per stamp: J^T J upper triangle (21) | J^T f (6) | f.f */
+/* per stamp sums over its nloc local parameters (the shared shape parameters
+   followed by the flux of the stamp's band): J^T J upper triangle | J^T f | f.f */
+#define NGMIX_LM_NSUMS(nloc) ((nloc) * ((nloc) + 1) / 2 + (nloc) + 1)
+#define NGMIX_LM_NSUM NGMIX_LM_NSUMS(6) /* gauss / turb / exp / dev: 28 */
 
-#define NGMIX_LM_PHASE_INIT 0
-#define NGMIX_LM_PHASE_TRIAL 1
+#define NGMIX_LM_PHASE_INIT 0   /* wants |f|^2, J^T f, J^T J at xt (= the guess) */
+#define NGMIX_LM_PHASE_TRIAL 1  /* wants |f|^2 at xt (analytic mode: and J^T f, J^T J) */
 #define NGMIX_LM_PHASE_DONE 2
+#define NGMIX_LM_PHASE_JAC 3    /* forward-difference mode: wants J^T f, J^T J at xt (= x) */
+
+/* ngmix_lm_state.mode */
+#define NGMIX_LM_MODE_ANALYTIC 0 /* lmder; the jacobian comes with every evaluation */
+#define NGMIX_LM_MODE_FD 1       /* lmdif: forward-difference jacobian only at accepted
+                                    points, its n evaluations counted in nfev */
 
 /* one fit: lmder's loop variables, re-entrant (layout used by host and device) */
 typedef struct {
@@ -388,13 +397,14 @@ typedef struct {
     double fnorm, xnorm, delta, par, gnorm, pnorm;
     double ftol, xtol, gtol, factor;
     int32_t ipvt[NGMIX_LM_NPMAX]; /* 0-based */
-    int32_t n, iter, nfev, njev, info, phase, maxfev, pad;
+    int32_t n, iter, nfev, njev, info, phase, maxfev, mode;
 } ngmix_lm_state;
 
-/* HOST: initialise nobj states from the guesses x0 (nobj, npars) */
+/* HOST: initialise nobj states from the guesses x0 (nobj, npars);
+   mode = NGMIX_LM_MODE_* */
 int ngmix_lm_init(ngmix_lm_state *states, int64_t nobj, int npars,
                   const double *x0, double ftol, double xtol, double gtol,
-                  int maxfev, double factor);
+                  int maxfev, double factor, int mode);
 /* HOST: consume one evaluation per object -- ff (nobj,), g (nobj, NPMAX),
    A (nobj, NPMAX*NPMAX) at states[i].xt -- and advance; returns the number
    of fits still running.  The same code the device kernel runs; exists for
@@ -402,12 +412,17 @@ int ngmix_lm_init(ngmix_lm_state *states, int64_t nobj, int npars,
 int64_t ngmix_lm_advance_host(ngmix_lm_state *states, int64_t nobj,
                               const double *ff, const double *g, const double *A);
 /* DEVICE: evaluate every stamp of every running fit at its object's trial
-   point.  states: device array; stamp_obj (nstamps,) object of each stamp or
-   NULL (stamp i = object i); stamp_band (nstamps,) or NULL (band 0); psf:
-   nstamps*npsf gauss2d records or NULL with npsf = 0; sums: (nstamps, 28);
-   status: per stamp (NGMIX_ERR_G_RANGE: model out of range at the trial
-   point, sums then carry ff = +inf like the reference's LOWVAL residuals) */
-int ngmix_lm_eval_batch(const ngmix_batch *batch, int model,
+   point.  fd = 0: residuals + analytic jacobian (gauss, exp, dev; states in
+   NGMIX_LM_MODE_ANALYTIC); fd = 1: residuals, plus MINPACK's forward-difference
+   jacobian when the object's phase asks for one (gauss, turb, exp, dev, bdf,
+   bd; states in NGMIX_LM_MODE_FD).  states: device array; stamp_obj (nstamps,)
+   object of each stamp or NULL (stamp i = object i); stamp_band (nstamps,) or
+   NULL (band 0); psf: nstamps*npsf gauss2d records or NULL with npsf = 0;
+   sums: (nstamps, NGMIX_LM_NSUMS(nloc)), nloc = the model's npars (6, bdf 7,
+   bd 8); status: per stamp (NGMIX_ERR_G_RANGE: model out of range at the
+   trial point, sums then carry ff = +inf like the reference's LOWVAL
+   residuals) */
+int ngmix_lm_eval_batch(const ngmix_batch *batch, int model, int fd,
                         const ngmix_lm_state *states, const int32_t *stamp_obj,
                         const int32_t *stamp_band, const ngmix_gauss2d *psf,
                         int npsf, double *sums, int32_t *status, void *stream);
@@ -416,7 +431,8 @@ int ngmix_lm_eval_batch(const ngmix_batch *batch, int model,
    may be NULL) receives the number of fits still running */
 int ngmix_lm_advance_batch(ngmix_lm_state *states, int64_t nobj,
                            const int64_t *obj_start, const int32_t *stamp_band,
-                           const double *sums, int32_t *nactive, void *stream);
+                           const double *sums, int nloc, int32_t *nactive,
+                           void *stream);
 
 /* DEVICE: package every fit as run_leastsq does (leastsqbound.py:33-155):
    rec is (nobj, 4 + 2n + 2n^2) doubles per object, n = states[i].n:

@@ -94,6 +94,9 @@ def moments_result_dtype(nmom):
 LM_NPMAX = 8
 LM_NSUM = 28
 LM_PHASE_DONE = 2
+LM_PHASE_JAC = 3
+LM_MODE_ANALYTIC = 0
+LM_MODE_FD = 1
 # ngmix_lm_state (include/ngmix_hip.h): one re-entrant lmder iteration
 LM_STATE_DTYPE = np.dtype([
     ("x", "f8", LM_NPMAX), ("xt", "f8", LM_NPMAX), ("diag", "f8", LM_NPMAX),
@@ -104,7 +107,7 @@ LM_STATE_DTYPE = np.dtype([
     ("ftol", "f8"), ("xtol", "f8"), ("gtol", "f8"), ("factor", "f8"),
     ("ipvt", "i4", LM_NPMAX),
     ("n", "i4"), ("iter", "i4"), ("nfev", "i4"), ("njev", "i4"), ("info", "i4"),
-    ("phase", "i4"), ("maxfev", "i4"), ("pad", "i4"),
+    ("phase", "i4"), ("maxfev", "i4"), ("mode", "i4"),
 ], align=True)
 
 
@@ -184,11 +187,11 @@ SIGNATURES = {
                               _i32, _vp, _vp, _vp]),
     "ngmix_deriv_images_batch": (_i32, [_pb, _vp, _vp, _vp, _vp, _vp]),
     # batched Levenberg-Marquardt
-    "ngmix_lm_init": (_i32, [_vp, _i64, _i32, _vp, _f64, _f64, _f64, _i32, _f64]),
+    "ngmix_lm_init": (_i32, [_vp, _i64, _i32, _vp, _f64, _f64, _f64, _i32, _f64, _i32]),
     "ngmix_lm_advance_host": (_i64, [_vp, _i64, _vp, _vp, _vp]),
-    "ngmix_lm_eval_batch": (_i32, [_pb, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
-                                   _vp]),
-    "ngmix_lm_advance_batch": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "ngmix_lm_eval_batch": (_i32, [_pb, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp,
+                                   _vp, _vp]),
+    "ngmix_lm_advance_batch": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp]),
     "ngmix_lm_finalize_batch": (_i32, [_vp, _i64, _vp, _f64, _f64, _vp, _vp]),
 }
 

@@ -540,7 +540,8 @@ int ngmix_deriv_images_batch(const ngmix_batch *batch, const double *gpars,
 }
 
 int ngmix_lm_init(ngmix_lm_state *states, int64_t nobj, int npars, const double *x0,
-                  double ftol, double xtol, double gtol, int maxfev, double factor)
+                  double ftol, double xtol, double gtol, int maxfev, double factor,
+                  int mode)
 {
     if (npars < 1 || npars > NGMIX_LM_NPMAX || nobj < 0) {
         set_last_error_msg("ngmix_lm_init: npars must be 1..NGMIX_LM_NPMAX");
@@ -548,7 +549,7 @@ int ngmix_lm_init(ngmix_lm_state *states, int64_t nobj, int npars, const double 
     }
     for (int64_t i = 0; i < nobj; i++)
         lmcore::lm_init(states[i], npars, x0 + i * npars, ftol, xtol, gtol, maxfev,
-                        factor);
+                        factor, mode);
     return NGMIX_OK;
 }
 
@@ -564,20 +565,21 @@ int64_t ngmix_lm_advance_host(ngmix_lm_state *states, int64_t nobj, const double
     return running;
 }
 
-int ngmix_lm_eval_batch(const ngmix_batch *batch, int model,
+int ngmix_lm_eval_batch(const ngmix_batch *batch, int model, int fd,
                         const ngmix_lm_state *states, const int32_t *stamp_obj,
                         const int32_t *stamp_band, const ngmix_gauss2d *psf, int npsf,
                         double *sums, int32_t *status, void *stream)
 {
-    return launch_lm_eval(batch, model, states, stamp_obj, stamp_band, psf, npsf, sums,
-                          status, (hipStream_t)stream);
+    return launch_lm_eval(batch, model, fd, states, stamp_obj, stamp_band, psf, npsf,
+                          sums, status, (hipStream_t)stream);
 }
 
 int ngmix_lm_advance_batch(ngmix_lm_state *states, int64_t nobj,
                            const int64_t *obj_start, const int32_t *stamp_band,
-                           const double *sums, int32_t *nactive, void *stream)
+                           const double *sums, int nloc, int32_t *nactive,
+                           void *stream)
 {
-    return launch_lm_advance(states, nobj, obj_start, stamp_band, sums, nactive,
+    return launch_lm_advance(states, nobj, obj_start, stamp_band, sums, nloc, nactive,
                              (hipStream_t)stream);
 }
 

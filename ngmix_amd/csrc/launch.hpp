@@ -41,13 +41,13 @@ int launch_set_norms(ngmix_gauss2d *gmix, int ngauss, int64_t nstamps,
                      int32_t *status, hipStream_t s);
 
 // lmfit.hip
-int launch_lm_eval(const ngmix_batch *b, int model, const ngmix_lm_state *states,
+int launch_lm_eval(const ngmix_batch *b, int model, int fd, const ngmix_lm_state *states,
                    const int32_t *stamp_obj, const int32_t *stamp_band,
                    const ngmix_gauss2d *psf, int npsf, double *sums, int32_t *status,
                    hipStream_t s);
 int launch_lm_advance(ngmix_lm_state *states, int64_t nobj, const int64_t *obj_start,
-                      const int32_t *stamp_band, const double *sums, int32_t *nactive,
-                      hipStream_t s);
+                      const int32_t *stamp_band, const double *sums, int nloc,
+                      int32_t *nactive, hipStream_t s);
 
 int launch_lm_finalize(const ngmix_lm_state *states, int64_t nobj,
                        const int64_t *npix_obj, double pdef, double cdef, double *rec,

@@ -16,9 +16,14 @@
 // R^-T P^T g, so the whole algorithm -- qrfac's pivot rule, the scaled
 // gradient test, lmpar with qrsolv, the trust region update, the four
 // convergence tests -- runs from (A, g, ff) and follows MINPACK's path up to
-// the rounding of the factorisation (cond(J)^2 instead of cond(J)).  The
-// jacobian is evaluated at every trial point, not only at accepted ones: one
-// launch per step instead of two; nfev / njev still count what lmder counts.
+// the rounding of the factorisation (cond(J)^2 instead of cond(J)).
+//
+// Two modes.  ANALYTIC (lmder): the jacobian is evaluated at every trial
+// point, not only at accepted ones -- one launch per step instead of two; nfev
+// / njev still count what lmder counts.  FD (lmdif, what the reference runs for
+// the models without analytic derivatives): a trial wants only |f|^2; after an
+// accepted step the state asks (phase JAC) for the forward-difference jacobian
+// at the new point and charges its n evaluations to nfev as fdjac2 does.
 //
 // Everything is host+device so the same code is tested on the CPU against
 // scipy.optimize.leastsq (tests/test_lm_core.py).
@@ -37,6 +42,7 @@
 #define LM_PHASE_INIT NGMIX_LM_PHASE_INIT    /* waiting for the evaluation at x0 */
 #define LM_PHASE_TRIAL NGMIX_LM_PHASE_TRIAL  /* waiting for the evaluation at xt */
 #define LM_PHASE_DONE NGMIX_LM_PHASE_DONE
+#define LM_PHASE_JAC NGMIX_LM_PHASE_JAC     /* FD mode: waiting for the jacobian at x */
 
 typedef ngmix_lm_state lm_state;
 
@@ -336,7 +342,8 @@ NGMIX_HD bool new_jacobian(lm_state &s, const double *A, const double *g)
 }
 
 NGMIX_HD void lm_init(lm_state &s, int n, const double *x0, double ftol, double xtol,
-                      double gtol, int maxfev, double factor)
+                      double gtol, int maxfev, double factor,
+                      int mode = NGMIX_LM_MODE_ANALYTIC)
 {
     s.n = n;
     for (int j = 0; j < LM_NPMAX; j++) {
@@ -358,7 +365,7 @@ NGMIX_HD void lm_init(lm_state &s, int n, const double *x0, double ftol, double 
     s.nfev = s.njev = 0;
     s.info = 0;
     s.phase = LM_PHASE_INIT;
-    s.pad = 0;
+    s.mode = mode;
 }
 
 // Consume the evaluation at s.xt:  ff = |f|^2, g = J^T f, A = J^T J
@@ -369,9 +376,17 @@ NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g, const double *
 {
     const int n = s.n;
     if (s.phase == LM_PHASE_DONE) return;
+    if (s.phase == LM_PHASE_JAC) {
+        // lmdif: the forward-difference jacobian at the accepted point cost
+        // n evaluations (fdjac2); then the outer-loop head
+        s.nfev += n;
+        s.phase = LM_PHASE_TRIAL;
+        new_jacobian(s, A, g);
+        return;
+    }
     if (s.phase == LM_PHASE_INIT) {
-        // lmder: fvec at the starting point, then the outer loop
-        s.nfev = 1;
+        // lmder / lmdif: fvec at the starting point, then the outer loop
+        s.nfev = s.mode == NGMIX_LM_MODE_FD ? 1 + n : 1;
         s.fnorm = sqrt(ff);
         s.par = 0.0;
         s.iter = 1;
@@ -447,10 +462,15 @@ NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g, const double *
         s.phase = LM_PHASE_DONE;
         return;
     }
-    if (accepted)
+    if (!accepted) {
+        propose(s);  // same factor, smaller region
+    } else if (s.mode == NGMIX_LM_MODE_FD) {
+        // ask for the jacobian at the new point
+        for (int j = 0; j < n; j++) s.xt[j] = s.x[j];
+        s.phase = LM_PHASE_JAC;
+    } else {
         new_jacobian(s, A, g);  // the trial point's jacobian is the new one
-    else
-        propose(s);             // same factor, smaller region
+    }
 }
 
 }  // namespace lmcore

@@ -289,17 +289,20 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
     if (lane == 0 && status) status[s] = NGMIX_OK;
 }
 
-// One thread per object: gather its stamps' sums into the (5+nband)-parameter
-// normal equations and advance the LM state.
+// One thread per object: gather its stamps' sums into the (nloc-1+nband)-
+// parameter normal equations and advance the LM state.  A stamp's sums are
+// [J^T J upper triangle | J^T f | f.f] over its nloc LOCAL parameters: the
+// shared shape parameters followed by the flux of the stamp's band.
 __global__ __launch_bounds__(BLOCK) void lm_advance_kernel(
     lm_state *states, int64_t nobj, const int64_t *__restrict__ obj_start,
-    const int32_t *__restrict__ stamp_band, const double *__restrict__ sums,
+    const int32_t *__restrict__ stamp_band, const double *__restrict__ sums, int nloc,
     int32_t *nactive)
 {
     const int64_t o = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
     if (o >= nobj) return;
     lm_state s = states[o];
     if (s.phase == LM_PHASE_DONE) return;
+    const int ntri = nloc * (nloc + 1) / 2, nsum = ntri + nloc + 1;
     double A[LM_NPMAX * LM_NPMAX], g[LM_NPMAX];
     for (int i = 0; i < LM_NPMAX * LM_NPMAX; i++) A[i] = 0.0;
     for (int i = 0; i < LM_NPMAX; i++) g[i] = 0.0;
@@ -307,24 +310,248 @@ __global__ __launch_bounds__(BLOCK) void lm_advance_kernel(
     const int64_t s0 = obj_start ? obj_start[o] : o;
     const int64_t s1 = obj_start ? obj_start[o + 1] : o + 1;
     for (int64_t st = s0; st < s1; st++) {
-        const double *v = sums + st * LM_NSUM;
+        const double *v = sums + st * nsum;
         const int band = stamp_band ? stamp_band[st] : 0;
         int k = 0;
-        for (int a = 0; a < 6; a++) {
-            const int ga = a < 5 ? a : 5 + band;
-            for (int b = a; b < 6; b++) {
-                const int gb = b < 5 ? b : 5 + band;
+        for (int a = 0; a < nloc; a++) {
+            const int ga = a < nloc - 1 ? a : nloc - 1 + band;
+            for (int b = a; b < nloc; b++) {
+                const int gb = b < nloc - 1 ? b : nloc - 1 + band;
                 A[ga * LM_NPMAX + gb] += v[k];
                 if (ga != gb) A[gb * LM_NPMAX + ga] += v[k];
                 k++;
             }
-            g[ga] += v[21 + a];
+            g[ga] += v[ntri + a];
         }
-        ff += v[27];
+        ff += v[ntri + nloc];
     }
     lmcore::lm_advance(s, ff, g, A);
     states[o] = s;
     if (s.phase != LM_PHASE_DONE && nactive) atomicAdd(nactive, 1);
+}
+
+// ===========================================================================
+// Forward-difference evaluation (the models without analytic derivatives:
+// turb, bdf, bd -- and any model on request): MINPACK's fdjac2 inside the
+// pixel pass.  A stamp evaluates, per pixel and in registers, the model at the
+// trial point and (when its object asks for a jacobian: phases INIT / JAC) at
+// the NLOC points x + h_j e_j, h_j = sqrt(eps) |x_j| (sqrt(eps) when x_j == 0),
+// and accumulates J^T J, J^T f, |f|^2 with J_j = (f(x + h_j e_j) - f(x)) / h_j.
+// One pass over the pixels does the work of fdjac2's NLOC + 1 residual vectors.
+// ===========================================================================
+
+struct FdGauss {
+    double row, col, a, b, c, pa;  // y = chi2/2 = a dv^2 + b du^2 + c dv du
+};
+static_assert(sizeof(FdGauss) == 48, "FdGauss");
+
+template <int NLOC>
+__global__ __launch_bounds__(WAVE) void lm_eval_fd_kernel(
+    const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
+    const double *__restrict__ ierr, const ngmix_jacobian *__restrict__ jacs,
+    int model, int ng0, const lm_state *__restrict__ states,
+    const int32_t *__restrict__ stamp_obj, const int32_t *__restrict__ stamp_band,
+    const ngmix_gauss2d *__restrict__ psf, int npsf, double *__restrict__ sums,
+    int32_t *__restrict__ status, int no_skip)
+{
+    constexpr int NTRI = NLOC * (NLOC + 1) / 2;
+    constexpr int NSUM = NTRI + NLOC + 1;
+    constexpr int NSETS = NLOC + 1;
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    __shared__ double tabr[16];
+    __shared__ double red[NSUM * 4];
+
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int obj = stamp_obj ? stamp_obj[s] : s;
+    const lm_state &state = states[obj];
+    if (state.phase == LM_PHASE_DONE) return;
+    const bool want_jac = state.phase != LM_PHASE_TRIAL;
+    const int nsets = want_jac ? NSETS : 1;
+    const int band = stamp_band ? stamp_band[s] : 0;
+    const ngmix_stamp st = stamps[s];
+    const ngmix_jacobian jac = jacs[s];
+    const int nrow = st.nrow, ncol = st.ncol;
+    const double area = jac.scale * jac.scale;
+    const bool izw = (st.flags & NGMIX_STAMP_IGNORE_ZERO_WEIGHT) != 0;
+    const bool masked = izw && st.npix_kept != nrow * ncol;
+    double *out = sums + (size_t)s * NSUM;
+    const int npsf1 = npsf > 0 ? npsf : 1;
+    const int G = ng0 * npsf1;
+    FdGauss *ev = (FdGauss *)dyn;                    // [NSETS][G]
+    PixBox *boxes = (PixBox *)(ev + NSETS * G);      // [G], from the base set
+
+    // local parameters and the fdjac2 steps
+    double p0[NLOC], ih[NLOC];
+    constexpr double EPS = 1.4901161193847656e-08;  // sqrt(machine epsilon)
+#pragma unroll
+    for (int k = 0; k < NLOC; k++) {
+        p0[k] = state.xt[k < NLOC - 1 ? k : NLOC - 1 + band];
+        double h = EPS * fabs(p0[k]);
+        if (h == 0.0) h = EPS;
+        ih[k] = 1.0 / h;
+    }
+    double rowcen = 0.0, colcen = 0.0, ipsum = 1.0;
+    const ngmix_gauss2d *q = psf ? psf + (size_t)s * npsf : nullptr;
+    int bad = 0;
+    if (npsf > 0) {
+        double psum;
+        if (gmix_cen(q, npsf, rowcen, colcen, psum) != NGMIX_OK) bad = 1;
+        else ipsum = 1.0 / psum;
+    }
+    if (lane < 16) tabr[lane] = c_exp_table_lm[15 - lane];
+    for (int w = lane; w < nsets * G && !bad; w += WAVE) {
+        const int k = w / G, i = w - k * G;
+        double p[NLOC];
+#pragma unroll
+        for (int j = 0; j < NLOC; j++) {
+            p[j] = p0[j];
+            if (j == k - 1) {
+                double h = EPS * fabs(p0[j]);
+                if (h == 0.0) h = EPS;
+                p[j] = p0[j] + h;
+            }
+        }
+        FillCtx c;
+        if (fill_prepare(c_tables_lm, model, ng0, p, nullptr, c) != NGMIX_OK) {
+            bad = 1;
+            break;
+        }
+        const int io = i / npsf1, ip = i - io * npsf1;
+        ngmix_gauss2d g0, gc;
+        fill_component(c_tables_lm, c, p, io, g0);
+        if (npsf > 0) convolve_component(g0, q[ip], rowcen, colcen, ipsum, gc);
+        else gc = g0;
+        if (gauss_set_norm(gc) != NGMIX_OK) {
+            bad = 1;
+            break;
+        }
+        FdGauss r;
+        r.row = gc.row;
+        r.col = gc.col;
+        r.a = 0.5 * gc.dcc;
+        r.b = 0.5 * gc.drr;
+        r.c = -gc.drc;
+        r.pa = gc.pnorm * area;
+        ev[k * G + i] = r;
+        if (k == 0) boxes[i] = no_skip ? full_box() : gauss_pixel_box(gc, jac);
+    }
+    if (__ballot(bad != 0) != 0ull) {
+        // out of range at (or one step from) the trial point: LOWVAL residuals
+        if (lane == 0) {
+            for (int k = 0; k < NSUM - 1; k++) out[k] = 0.0;
+            out[NSUM - 1] = INFINITY;
+            if (status) status[s] = NGMIX_ERR_G_RANGE;
+        }
+        return;
+    }
+    __syncthreads();
+
+    const FexpCoef K = load_fexp_coef(c_fexp_coef_lm);
+    const int lrow = lane / TILE_W, lcol = lane % TILE_W;
+    const int ntx = (ncol + TILE_W - 1) / TILE_W;
+    const int nty = (nrow + TILE_H - 1) / TILE_H;
+    const double *sval = val + st.pix_off;
+    const double *sierr = ierr + st.pix_off;
+
+    double acc[NSUM];
+#pragma unroll
+    for (int k = 0; k < NSUM; k++) acc[k] = 0.0;
+
+    auto load_tile = [&](int ty, int tx, double &pv, double &pe) {
+        const int row = ty * TILE_H + lrow, col = tx * TILE_W + lcol;
+        pv = 0.0;
+        pe = 0.0;
+        if (ty < nty && row < nrow && col < ncol) {
+            pv = sval[row * ncol + col];
+            pe = sierr[row * ncol + col];
+        }
+    };
+
+    int ty = 0, tx = 0;
+    double nval, nierr;
+    load_tile(ty, tx, nval, nierr);
+    while (ty < nty) {
+        const double pval = nval, pierr = nierr;
+        int ty2 = ty, tx2 = tx + 1;
+        if (tx2 == ntx) {
+            tx2 = 0;
+            ty2++;
+        }
+        load_tile(ty2, tx2, nval, nierr);
+
+        const int r0 = ty * TILE_H, c0 = tx * TILE_W;
+        const double rowd = (double)(r0 + lrow) - jac.row0;
+        const double cold = (double)(c0 + lcol) - jac.col0;
+        const double v = fma(jac.dvdrow, rowd, jac.dvdcol * cold);
+        const double u = fma(jac.dudrow, rowd, jac.dudcol * cold);
+        double m[NSETS];
+#pragma unroll
+        for (int k = 0; k < NSETS; k++) m[k] = 0.0;
+
+        for (int gb = 0; gb < G; gb += WAVE) {
+            const int gi = gb + lane < G ? gb + lane : gb;
+            const PixBox box = boxes[gi];
+            const bool hit = (gb + lane < G) & (r0 <= box.rmax) &
+                             (r0 + TILE_H - 1 >= box.rmin) & (c0 <= box.cmax) &
+                             (c0 + TILE_W - 1 >= box.cmin);
+            unsigned long long gmask = __ballot(hit);
+            while (gmask) {
+                const int g = gb + __builtin_ctzll(gmask);
+                gmask &= gmask - 1ull;
+#pragma unroll
+                for (int k = 0; k < NSETS; k++) {
+                    if (k >= nsets) break;
+                    const FdGauss &E = ev[k * G + g];
+                    const double dv = v - E.row, du = u - E.col;
+                    const double y = fma(E.a, dv * dv, fma(E.b, du * du, E.c * (dv * du)));
+                    if (y < 12.5 && y >= 0.0) {
+                        double e = fexp_neg_fused(y, tabr, K);
+                        if (y > 10.0) {
+                            const double au = (12.5 - y) * 0.4;
+                            const double aq = fma(au, fma(au, K.w6, K.wm15), K.w10);
+                            e *= (au * au) * (au * aq);
+                        }
+                        m[k] = fma(E.pa, e, m[k]);
+                    }
+                }
+            }
+        }
+
+        if (!masked || pierr > 0.0) {
+            const double f = (m[0] - pval) * pierr;
+            acc[NSUM - 1] = fma(f, f, acc[NSUM - 1]);
+            if (want_jac) {
+                double J[NLOC];
+#pragma unroll
+                for (int j = 0; j < NLOC; j++) J[j] = (m[j + 1] - m[0]) * (pierr * ih[j]);
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < NLOC; a++)
+#pragma unroll
+                    for (int b = a; b < NLOC; b++) {
+                        acc[k] = fma(J[a], J[b], acc[k]);
+                        k++;
+                    }
+#pragma unroll
+                for (int a = 0; a < NLOC; a++) acc[NTRI + a] = fma(J[a], f, acc[NTRI + a]);
+            }
+        }
+        ty = ty2;
+        tx = tx2;
+    }
+
+#pragma unroll
+    for (int k = 0; k < NSUM; k++) {
+        const double r = row16_sum(acc[k]);
+        if ((lane & 15) == 15) red[k * 4 + (lane >> 4)] = r;
+    }
+    __syncthreads();
+    if (lane < NSUM) {
+        const double *r = red + lane * 4;
+        out[lane] = ((r[0] + r[1]) + r[2]) + r[3];
+    }
+    if (lane == 0 && status) status[s] = NGMIX_OK;
 }
 
 // run_leastsq's packaging (leastsqbound.py:33-155) for one fit per thread:
@@ -442,47 +669,86 @@ int launch_lm_finalize(const lm_state *states, int64_t nobj, const int64_t *npix
     return NGMIX_OK;
 }
 
-int launch_lm_eval(const ngmix_batch *b, int model, const lm_state *states,
+static int model_ngauss_npars(int model, int &ng0, int &nloc)
+{
+    switch (model) {
+    case NGMIX_MODEL_GAUSS: ng0 = 1; nloc = 6; return 0;
+    case NGMIX_MODEL_TURB: ng0 = 3; nloc = 6; return 0;
+    case NGMIX_MODEL_EXP: ng0 = 6; nloc = 6; return 0;
+    case NGMIX_MODEL_DEV: ng0 = 10; nloc = 6; return 0;
+    case NGMIX_MODEL_BDF: ng0 = 16; nloc = 7; return 0;
+    case NGMIX_MODEL_BD: ng0 = 16; nloc = 8; return 0;
+    default: return -1;
+    }
+}
+
+int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *states,
                    const int32_t *stamp_obj, const int32_t *stamp_band,
                    const ngmix_gauss2d *psf, int npsf, double *sums, int32_t *status,
                    hipStream_t s)
 {
     if (b->nstamps <= 0) return NGMIX_OK;
-    int ng0;
-    switch (model) {
-    case NGMIX_MODEL_GAUSS: ng0 = 1; break;
-    case NGMIX_MODEL_EXP: ng0 = 6; break;
-    case NGMIX_MODEL_DEV: ng0 = 10; break;
-    default:
-        set_last_error_msg("lm_eval: the analytic jacobian exists for gauss, exp, dev");
+    int ng0, nloc;
+    if (model_ngauss_npars(model, ng0, nloc) != 0 || npsf < 0) {
+        set_last_error_msg("lm_eval: model must be gauss, turb, exp, dev, bdf or bd");
         return NGMIX_ERR_BAD_ARG;
     }
-    if (npsf < 0) return NGMIX_ERR_BAD_ARG;
-    const size_t lds = (size_t)ng0 * (npsf > 0 ? npsf : 1) * sizeof(DerivGauss);
-    if (lds > 96 * 1024) {
+    const int no_skip = (b->flags & NGMIX_BATCH_NO_SKIP) ? 1 : 0;
+    const int G = ng0 * (npsf > 0 ? npsf : 1);
+    dim3 grid((unsigned)b->nstamps), block(WAVE);
+    if (!fd) {
+        if (!(model == NGMIX_MODEL_GAUSS || model == NGMIX_MODEL_EXP ||
+              model == NGMIX_MODEL_DEV)) {
+            set_last_error_msg("lm_eval: the analytic jacobian exists for gauss, exp, dev");
+            return NGMIX_ERR_BAD_ARG;
+        }
+        const size_t lds = (size_t)G * sizeof(DerivGauss);
+        if (lds > 96 * 1024) {
+            set_last_error_msg("lm_eval: too many composed gaussians for LDS");
+            return NGMIX_ERR_BAD_ARG;
+        }
+        if (lds > 48 * 1024)
+            NGMIX_HIP_CHECK(hipFuncSetAttribute(
+                (const void *)lm_eval_kernel,
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(lm_eval_kernel, grid, block, lds, s, b->stamps, b->val,
+                           b->ierr, b->jac, model, ng0, states, stamp_obj, stamp_band,
+                           psf, npsf, sums, status, no_skip);
+        NGMIX_HIP_CHECK(hipGetLastError());
+        return NGMIX_OK;
+    }
+    const size_t lds = (size_t)(nloc + 1) * G * sizeof(FdGauss) + (size_t)G * sizeof(PixBox);
+    if (lds > 128 * 1024) {
         set_last_error_msg("lm_eval: too many composed gaussians for LDS");
         return NGMIX_ERR_BAD_ARG;
     }
-    if (lds > 48 * 1024)
-        NGMIX_HIP_CHECK(hipFuncSetAttribute(
-            (const void *)lm_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-            (int)lds));
-    const int no_skip = (b->flags & NGMIX_BATCH_NO_SKIP) ? 1 : 0;
-    hipLaunchKernelGGL(lm_eval_kernel, dim3((unsigned)b->nstamps), dim3(WAVE), lds, s,
-                       b->stamps, b->val, b->ierr, b->jac, model, ng0, states,
-                       stamp_obj, stamp_band, psf, npsf, sums, status, no_skip);
+#define NGMIX_FD_LAUNCH(N)                                                              \
+    do {                                                                                \
+        if (lds > 48 * 1024)                                                            \
+            NGMIX_HIP_CHECK(hipFuncSetAttribute(                                        \
+                (const void *)lm_eval_fd_kernel<N>,                                     \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+        hipLaunchKernelGGL(lm_eval_fd_kernel<N>, grid, block, lds, s, b->stamps, b->val, \
+                           b->ierr, b->jac, model, ng0, states, stamp_obj, stamp_band,  \
+                           psf, npsf, sums, status, no_skip);                           \
+    } while (0)
+    if (nloc == 6) NGMIX_FD_LAUNCH(6);
+    else if (nloc == 7) NGMIX_FD_LAUNCH(7);
+    else NGMIX_FD_LAUNCH(8);
+#undef NGMIX_FD_LAUNCH
     NGMIX_HIP_CHECK(hipGetLastError());
     return NGMIX_OK;
 }
 
 int launch_lm_advance(lm_state *states, int64_t nobj, const int64_t *obj_start,
-                      const int32_t *stamp_band, const double *sums, int32_t *nactive,
-                      hipStream_t s)
+                      const int32_t *stamp_band, const double *sums, int nloc,
+                      int32_t *nactive, hipStream_t s)
 {
     if (nobj <= 0) return NGMIX_OK;
+    if (nloc < 2 || nloc > LM_NPMAX) return NGMIX_ERR_BAD_ARG;
     if (nactive) NGMIX_HIP_CHECK(hipMemsetAsync(nactive, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(lm_advance_kernel, dim3((unsigned)((nobj + BLOCK - 1) / BLOCK)),
-                       dim3(BLOCK), 0, s, states, nobj, obj_start, stamp_band, sums,
+                       dim3(BLOCK), 0, s, states, nobj, obj_start, stamp_band, sums, nloc,
                        nactive);
     NGMIX_HIP_CHECK(hipGetLastError());
     return NGMIX_OK;

@@ -21,9 +21,12 @@ package one fit: flags, nfev, ier, pars, pars_err, pars_cov0, pars_cov, and for
 flags == 0 lnprob, s2n_numer, s2n_denom, npix, chi2per, dof, s2n_w, s2n, g,
 g_cov, g_err, T, T_err, flux, flux_err (flux_cov when nband > 1).
 
-Scope: the simple models with an analytic jacobian (gauss, exp, dev:
-results.py SIMPLE_ANALYTIC_MODELS), no prior (prior=None is legal in the
-reference: zero prior rows, no bounds, results.py:354-357).
+Scope: gauss / exp / dev with the analytic jacobian (lmder, as the reference's
+Fitter: results.py SIMPLE_ANALYTIC_MODELS) and gauss / turb / exp / dev / bdf /
+bd with MINPACK's forward differences evaluated inside the pixel pass (lmdif,
+what the reference runs for the models without analytic derivatives); no prior
+(prior=None is legal in the reference: zero prior rows, no bounds,
+results.py:354-357).
 """
 import ctypes
 
@@ -38,6 +41,8 @@ __all__ = ["LMBatchFitter"]
 
 
 SIMPLE_ANALYTIC_MODELS = ("gauss", "exp", "dev")
+# local (per band) parameter count of the models the device kernels fill
+MODEL_NLOC = {"gauss": 6, "turb": 6, "exp": 6, "dev": 6, "bdf": 7, "bd": 8}
 
 
 class LMBatchFitter(object):
@@ -45,23 +50,32 @@ class LMBatchFitter(object):
     fitter = LMBatchFitter(model='exp')
     res = fitter.go(stamps, guess, psf=psf_gmixes)
 
-    model: 'gauss' | 'exp' | 'dev'
+    model: 'gauss' | 'exp' | 'dev' (analytic jacobian, MINPACK lmder, as the
+        reference's Fitter) or 'turb' | 'bdf' | 'bd' (forward differences,
+        MINPACK lmdif, as the reference runs the models without analytic
+        derivatives)
     fit_pars: dict with maxfev / ftol / xtol as for Fitter (defaults
         DEFAULT_LM_PARS, ngmix/defaults.py:17)
+    analytic_jacobian: False forces forward differences for gauss/exp/dev
+        too (Fitter's switch of the same name)
     """
 
-    def __init__(self, model, fit_pars=None):
-        if model not in SIMPLE_ANALYTIC_MODELS:
-            raise ValueError("LMBatchFitter supports %s" % (SIMPLE_ANALYTIC_MODELS,))
+    def __init__(self, model, fit_pars=None, analytic_jacobian=True):
+        if model not in MODEL_NLOC:
+            raise ValueError("LMBatchFitter supports %s" % (tuple(MODEL_NLOC),))
         self.model = model
+        self.nloc = MODEL_NLOC[model]
+        self.fd = not (analytic_jacobian and model in SIMPLE_ANALYTIC_MODELS)
         self.fit_pars = dict(DEFAULT_LM_PARS if fit_pars is None else fit_pars)
 
     def go(self, stamps, guess, psf=None, stamp_obj=None, stamp_band=None,
            check_every=1):
         """
         stamps: StampBatch -- every observation (epoch / band) of every object
-        guess: (nobj, 5 + nband) starting parameters
-            [cen1, cen2, g1, g2, T, flux_band0, ...]
+        guess: (nobj, nshape + nband) starting parameters: the model's shape
+            parameters ([cen1, cen2, g1, g2, T] for gauss/turb/exp/dev, plus
+            fracdev for bdf, plus logTratio and fracdev for bd) followed by
+            one flux per band
         psf: GMixBatch with one mixture per stamp, or None
         stamp_obj: (nstamps,) object index of each stamp, non-decreasing;
             None: stamp i is object i
@@ -74,10 +88,11 @@ class LMBatchFitter(object):
         dev = stamps.device
         guess = np.ascontiguousarray(np.atleast_2d(guess), dtype="f8")
         nobj, npars = guess.shape
-        nband = npars - 5
+        nshape = self.nloc - 1
+        nband = npars - nshape
         if nband < 1 or npars > _lib.LM_NPMAX:
-            raise ValueError("guess must have 5 + nband (1..%d) columns"
-                             % (_lib.LM_NPMAX - 5))
+            raise ValueError("guess must have %d + nband (1..%d) columns"
+                             % (nshape, _lib.LM_NPMAX - nshape))
         ns = stamps.n
         if stamp_obj is None:
             if ns != nobj:
@@ -109,14 +124,16 @@ class LMBatchFitter(object):
             _lib.ptr(states), nobj, npars, _lib.ptr(guess),
             float(fp.get("ftol", 1.49012e-8)), float(fp.get("xtol", 1.49012e-8)),
             float(fp.get("gtol", 0.0)), int(fp.get("maxfev", 100 * (npars + 1))),
-            float(fp.get("factor", 100.0))), "ngmix_lm_init")
+            float(fp.get("factor", 100.0)),
+            _lib.LM_MODE_FD if self.fd else _lib.LM_MODE_ANALYTIC), "ngmix_lm_init")
         maxfev = int(states["maxfev"][0])
 
         d_states = torch.from_numpy(states.view(np.uint8).reshape(nobj, -1)).to(dev)
         d_sobj = torch.from_numpy(sobj).to(dev)
         d_sband = torch.from_numpy(sband).to(dev)
         d_start = torch.from_numpy(obj_start).to(dev)
-        d_sums = torch.zeros((ns, _lib.LM_NSUM), dtype=torch.float64, device=dev)
+        nsum = self.nloc * (self.nloc + 1) // 2 + self.nloc + 1
+        d_sums = torch.zeros((ns, nsum), dtype=torch.float64, device=dev)
         d_status = torch.zeros(ns, dtype=torch.int32, device=dev)
         d_nact = torch.zeros(1, dtype=torch.int32, device=dev)
         b = stamps._batch(1)
@@ -128,19 +145,19 @@ class LMBatchFitter(object):
         with torch.cuda.device(dev):
             while True:
                 _lib.check(L.ngmix_lm_eval_batch(
-                    ctypes.byref(b), modnum, _dptr(d_states), _dptr(d_sobj),
+                    ctypes.byref(b), modnum, int(self.fd), _dptr(d_states), _dptr(d_sobj),
                     _dptr(d_sband), _dptr(psf.data) if psf is not None else None,
                     npsf, _dptr(d_sums), _dptr(d_status), _stream()),
                     "ngmix_lm_eval_batch")
                 _lib.check(L.ngmix_lm_advance_batch(
                     _dptr(d_states), nobj, _dptr(d_start), _dptr(d_sband),
-                    _dptr(d_sums), _dptr(d_nact), _stream()),
+                    _dptr(d_sums), self.nloc, _dptr(d_nact), _stream()),
                     "ngmix_lm_advance_batch")
                 rounds += 1
-                if rounds % check_every == 0 or rounds > maxfev:
+                if rounds % check_every == 0 or rounds > 2 * maxfev:
                     if int(d_nact.item()) == 0:
                         break
-                if rounds > maxfev + 2:
+                if rounds > 2 * maxfev + 4:
                     raise RuntimeError("batched LM did not terminate")
         torch.cuda.synchronize(dev)
         # seconds in the lock-step loop (kernels + one 4-byte readback per round)
@@ -187,13 +204,18 @@ class LMBatchFitter(object):
         nobj = res["flags"].size
         ok = res["flags"] == 0
         pars = res["pars"]
+        nshape = self.nloc - 1
         usable = np.where(ok[:, None], pars, 0.0)
         # a harmless model for failed fits (their statistics are not reported)
         usable[~ok, 4] = 1.0
-        usable[~ok, 5:] = 1.0
-        band_pars = np.empty((stamps.n, 6))
-        band_pars[:, :5] = usable[sobj, :5]
-        band_pars[:, 5] = usable[sobj, 5 + sband]
+        if self.model == "bdf":
+            usable[~ok, 5] = 0.5
+        if self.model == "bd":
+            usable[~ok, 6] = 0.5
+        usable[~ok, nshape:] = 1.0
+        band_pars = np.empty((stamps.n, self.nloc))
+        band_pars[:, :nshape] = usable[sobj, :nshape]
+        band_pars[:, nshape] = usable[sobj, nshape + sband]
         gm0, st0 = GMixBatch.from_pars(band_pars, self.model, device=stamps.device)
         gm = gm0
         if psf is not None:
@@ -223,11 +245,11 @@ class LMBatchFitter(object):
             res["T"] = pars[:, 4].copy()
             res["T_err"] = np.sqrt(pc[:, 4, 4])
             if nband == 1:
-                res["flux"] = pars[:, 5].copy()
-                res["flux_err"] = np.sqrt(pc[:, 5, 5])
+                res["flux"] = pars[:, nshape].copy()
+                res["flux_err"] = np.sqrt(pc[:, nshape, nshape])
             else:
-                res["flux"] = pars[:, 5:].copy()
-                res["flux_cov"] = pc[:, 5:, 5:].copy()
+                res["flux"] = pars[:, nshape:].copy()
+                res["flux_cov"] = pc[:, nshape:, nshape:].copy()
                 res["flux_err"] = np.sqrt(np.diagonal(res["flux_cov"], axis1=1,
                                                       axis2=2))
         del torch

@@ -180,3 +180,61 @@ def test_bootstrap_batch_recovers_truth():
     pull = (res["pars"] - pars) / res["pars_err"]
     assert np.all(np.abs(pull) < 6.0)
     assert 0.7 < np.sqrt((pull ** 2).mean()) < 1.3
+
+
+def _fit_one(model, image, weight, jobj, psf_rec, guess, analytic):
+    pgm = ngmix.GMix(ngauss=1)
+    pgm.get_data()[:] = psf_rec
+    pobs = ngmix.Observation(np.zeros((5, 5)), jacobian=jobj, gmix=pgm)
+    obs = ngmix.Observation(image, weight=weight, jacobian=jobj, psf=pobs)
+    return ngmix.fitting.Fitter(model=model, analytic_jacobian=analytic).go(
+        obs=obs, guess=guess)
+
+
+@pytest.mark.parametrize("model", ["exp", "bdf", "turb"])
+def test_batch_forward_difference_mode(model):
+    """lmdif in lock step (the jacobian by MINPACK's forward differences inside
+    the pixel pass) against the per-object Fitter's scipy lmdif"""
+    rng = np.random.RandomState({"exp": 21, "bdf": 22, "turb": 23}[model])
+    n, dim, scale, noise = 12, 32, 0.263, 0.01
+    base = "exp" if model == "bdf" else model
+    pars, guess, images, weights, jac, sb, psf = _make_objects(n, base, rng, dim=dim)
+    if model == "bdf":
+        # re-simulate as bdf: [cen1, cen2, g1, g2, T, fracdev, flux]
+        fracdev = rng.uniform(0.2, 0.8, size=n)
+        pars = np.column_stack([pars[:, :5], fracdev, pars[:, 5]])
+        gm0, _ = GMixBatch.from_pars(pars, "bdf")
+        gm, _ = gm0.convolve(psf)
+        geom = StampBatch.from_images(np.zeros((n, dim, dim)), None, jac)
+        truth, _ = geom.render(gm)
+        images = truth.cpu().numpy().reshape(n, dim, dim) + noise * rng.normal(size=(n, dim, dim))
+        sb = StampBatch.from_images(images, weights, jac)
+        guess = np.column_stack([guess[:, :5], fracdev * rng.uniform(0.9, 1.1, size=n),
+                                 guess[:, 5]])
+    fitter = LMBatchFitter(model, analytic_jacobian=False)
+    assert fitter.fd
+    res = fitter.go(sb, guess, psf=psf)
+    psf_rec = psf.to_numpy()
+    jobj = ngmix.Jacobian(row=jac[0], col=jac[1], dvdrow=jac[2], dvdcol=jac[3],
+                          dudrow=jac[4], dudcol=jac[5])
+    same_nfev = 0
+    checked = 0
+    for i in range(n):
+        one = _fit_one(model, images[i], weights[i], jobj, psf_rec[i], guess[i], False)
+        if one["flags"] != 0 or res["flags"][i] != 0:
+            # a noisy fracdev can walk out of range; both paths must agree on it
+            assert (one["flags"] != 0) == (res["flags"][i] != 0), i
+            continue
+        checked += 1
+        same_nfev += int(res["nfev"][i] == one["nfev"])
+        err = one["pars_err"]
+        # forward differences: the two paths agree far inside the errors
+        assert np.all(np.abs(res["pars"][i] - one["pars"]) <= 2e-2 * err), (i, model)
+        np.testing.assert_allclose(res["pars_err"][i], err, rtol=2e-2)
+        np.testing.assert_allclose(res["lnprob"][i], one["lnprob"], rtol=1e-4)
+    assert checked >= n - 2
+    assert same_nfev >= checked - 3
+    ok = res["flags"] == 0
+    pull = (res["pars"][ok] - pars[ok]) / res["pars_err"][ok]
+    if model != "bdf":   # fracdev is nearly unconstrained at this S/N
+        assert np.all(np.abs(pull) < 6.0)

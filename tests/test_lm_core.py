@@ -15,25 +15,41 @@ from ngmix_amd import _lib
 NP = _lib.LM_NPMAX
 
 
+def fd_jacobian(func, x, f0):
+    """MINPACK fdjac2 with scipy's default epsfcn (machine epsilon)"""
+    eps = np.sqrt(np.finfo("f8").eps)
+    J = np.zeros((f0.size, x.size))
+    for j in range(x.size):
+        h = eps * abs(x[j])
+        if h == 0.0:
+            h = eps
+        xp = x.copy()
+        xp[j] = x[j] + h
+        J[:, j] = (func(xp) - f0) / h
+    return J
+
+
 def run_lm(func, jac, x0, ftol=1e-5, xtol=1e-5, gtol=0.0, maxfev=4000,
-           factor=100.0, maxrounds=10000):
-    """drive one fit through ngmix_lm_init / ngmix_lm_advance_host"""
+           factor=100.0, maxrounds=10000, mode=0):
+    """drive one fit through ngmix_lm_init / ngmix_lm_advance_host;
+    mode 1: forward differences (jac is ignored)"""
     L = _lib.lib()
     x0 = np.ascontiguousarray(x0, dtype="f8").reshape(1, -1)
     n = x0.shape[1]
     st = np.zeros(1, dtype=_lib.LM_STATE_DTYPE)
     assert L.ngmix_lm_init(_lib.ptr(st), 1, n, _lib.ptr(x0), ftol, xtol, gtol,
-                           maxfev, factor) == 0
+                           maxfev, factor, mode) == 0
     rounds = 0
     while st["phase"][0] != _lib.LM_PHASE_DONE:
         xt = st["xt"][0, :n].copy()
         f = func(xt)
-        J = jac(xt)
         ff = np.array([np.dot(f, f)])
         g = np.zeros((1, NP))
         A = np.zeros((1, NP, NP))
-        g[0, :n] = J.T @ f
-        A[0, :n, :n] = J.T @ J
+        if mode == 0 or st["phase"][0] != 1:   # not a plain trial of FD mode
+            J = jac(xt) if mode == 0 else fd_jacobian(func, xt, f)
+            g[0, :n] = J.T @ f
+            A[0, :n, :n] = J.T @ J
         L.ngmix_lm_advance_host(_lib.ptr(st), 1, _lib.ptr(ff), _lib.ptr(g),
                                 _lib.ptr(A))
         rounds += 1
@@ -128,6 +144,25 @@ def test_lm_core_follows_minpack(case, tol):
         np.testing.assert_allclose(cov_from_state(st), cov, rtol=1e-5, atol=0)
 
 
+@pytest.mark.parametrize("case", list(problems()), ids=lambda c: c[0])
+@pytest.mark.parametrize("tol", [1e-5, 1.49012e-8])
+def test_lm_core_fd_mode_follows_lmdif(case, tol):
+    """forward-difference mode against scipy leastsq without Dfun (lmdif)"""
+    name, func, jac, x0 = case
+    xs, cov, info, mesg, ier = leastsq(func, x0, full_output=1, ftol=tol, xtol=tol,
+                                       maxfev=4000)
+    st = run_lm(func, None, x0, ftol=tol, xtol=tol, mode=1)
+    n = x0.size
+    assert int(st["info"]) == ier, (name, st["info"], ier, mesg)
+    assert int(st["nfev"]) == info["nfev"], name
+    # forward-difference noise times the conditioning of the normal equations
+    # (twoexp is nearly degenerate): iterates agree to 1e-5, counts exactly
+    scale = np.maximum(np.abs(xs), 1e-3)
+    assert np.all(np.abs(st["x"][:n] - xs) <= 1e-5 * scale), (name, st["x"][:n], xs)
+    if cov is not None:
+        np.testing.assert_allclose(cov_from_state(st), cov, rtol=1e-3, atol=0)
+
+
 def test_lm_core_maxfev_and_batch():
     """maxfev -> info 5; several fits in one call advance independently"""
     cases = list(problems())
@@ -143,7 +178,7 @@ def test_lm_core_maxfev_and_batch():
     _, f1, j1, _ = cases[0]
     starts = np.array([[1.0, 0.5, 0.0], [2.0, 1.0, 0.3], [5.0, 2.0, 1.0]])
     st = np.zeros(3, dtype=_lib.LM_STATE_DTYPE)
-    L.ngmix_lm_init(_lib.ptr(st), 3, 3, _lib.ptr(starts), 1e-5, 1e-5, 0.0, 4000, 100.0)
+    L.ngmix_lm_init(_lib.ptr(st), 3, 3, _lib.ptr(starts), 1e-5, 1e-5, 0.0, 4000, 100.0, 0)
     running = 3
     while running:
         ff = np.zeros(3)
@@ -178,7 +213,7 @@ def test_lm_core_out_of_range_trial():
     L = _lib.lib()
     x0 = x0.reshape(1, -1)
     st = np.zeros(1, dtype=_lib.LM_STATE_DTYPE)
-    L.ngmix_lm_init(_lib.ptr(st), 1, 3, _lib.ptr(x0), 1e-5, 1e-5, 0.0, 200, 100.0)
+    L.ngmix_lm_init(_lib.ptr(st), 1, 3, _lib.ptr(x0), 1e-5, 1e-5, 0.0, 200, 100.0, 0)
     while st["phase"][0] != _lib.LM_PHASE_DONE:
         xt = st["xt"][0, :3].copy()
         f, J = fwall(xt), jac(xt)
