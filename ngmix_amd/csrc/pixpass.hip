@@ -14,6 +14,8 @@
 //
 // LIST kernels (seam forms): the reference's AoS pixel / coord arrays,
 // arbitrary coordinates, one thread per pixel.
+#include <type_traits>
+
 #include "device_utils.hpp"
 #include "launch.hpp"
 
@@ -311,8 +313,8 @@ struct GaussFused {
 };
 static_assert(sizeof(GaussFused) == 64, "GaussFused");
 
-constexpr int FUSED_PF = 3;                // tiles in flight per wave
-constexpr int FUSED_SENTINELS = FUSED_PF;  // look-ahead past the last tile
+constexpr int FUSED_PF = 4;         // register sets: tiles requested ahead
+constexpr int FUSED_SENTINELS = 8;  // look-ahead past the last tile
 
 // One record per 8x8 tile of the stamp, staged in LDS and read back with
 // broadcast ds_reads: everything the tile loop needs without index arithmetic.
@@ -452,7 +454,7 @@ __device__ __forceinline__ void wave_tiles(
     // one tile: evaluate the gaussians that can reach it, accumulate / store
     constexpr int kLoadsPerTile = (kNeedsVal ? 1 : 0) + (kNeedsIerr ? 1 : 0) +
                                   (OP == OP_RENDER_FAST ? 1 : 0);
-    auto compute = [&](int Tc, bool inb, double &pval, double &pierr) {
+    auto compute = [&](auto nyounger, int Tc, bool inb, double &pval, double &pierr) {
         const double v = te[Tc].bv + olv, u = te[Tc].bu + olu;
         double dv = v, du = u;
         double v2 = dv * dv, u2 = du * du, vu = dv * du;
@@ -517,10 +519,10 @@ __device__ __forceinline__ void wave_tiles(
             }
         }
 
-        // this tile's val / ierr: FUSED_PF younger tiles stay in flight (the
+        // this tile's val / ierr: the younger tiles stay in flight (the
         // look-ahead past the last tile is issued with EXEC = 0 and completes
         // in order like any other load)
-        if (full) wait_vm<FUSED_PF * kLoadsPerTile>(pval, pierr);
+        if (full) wait_vm<decltype(nyounger)::value * kLoadsPerTile>(pval, pierr);
         if (OP == OP_LOGLIKE || OP == OP_S2N) {
             // lanes outside the stamp have ierr == 0 and add exactly 0; so do
             // zero-weight pixels, except that a masked pixel may hold a
@@ -552,36 +554,39 @@ __device__ __forceinline__ void wave_tiles(
         }
     };
 
-    // FUSED_PF tiles are in flight while one is evaluated; the register sets
-    // rotate by unrolling, not by copying
-    // (FULL stamps: the first FUSED_PF tiles were requested by the kernel
-    // before the gaussians were staged)
-    static_assert(FUSED_PF == 3, "the rotation below is written for 3 tiles in flight");
+    // Four register sets hold tiles T .. T+3; tiles are requested in PAIRS of
+    // neighbours (two 64-byte halves of the same 128-byte lines issued back
+    // to back: with single requests a tile-time apart ~15 % of the second
+    // halves had left L2 and were fetched from HBM again), so 2-3 tiles are
+    // always in flight behind the one being evaluated.  The sets rotate by
+    // unrolling, not by copying.  (FULL stamps: the first four tiles were
+    // requested by the kernel before the gaussians were staged.)
+    static_assert(FUSED_PF == 4, "the rotation below is written for four register sets");
+    using Y3 = std::integral_constant<int, 3>;
+    using Y2 = std::integral_constant<int, 2>;
     int T = 0;
     bool in0 = true, in1 = true, in2 = true, in3 = true;
-    double va0 = pv[0], va1 = pv[1], va2 = pv[2], va3 = 0.0;
-    double ie0 = pe[0], ie1 = pe[1], ie2 = pe[2], ie3 = 0.0;
+    double va0 = pv[0], va1 = pv[1], va2 = pv[2], va3 = pv[3];
+    double ie0 = pe[0], ie1 = pe[1], ie2 = pe[2], ie3 = pe[3];
     if (!full) {
         prefetch(0, in0, va0, ie0);
         prefetch(1, in1, va1, ie1);
         prefetch(2, in2, va2, ie2);
+        prefetch(3, in3, va3, ie3);
     }
     while (T < ntiles) {
-        prefetch(T + 3, in3, va3, ie3);
-        compute(T, in0, va0, ie0);
-        T++;
-        if (T >= ntiles) break;
-        prefetch(T + 3, in0, va0, ie0);
-        compute(T, in1, va1, ie1);
-        T++;
-        if (T >= ntiles) break;
-        prefetch(T + 3, in1, va1, ie1);
-        compute(T, in2, va2, ie2);
-        T++;
-        if (T >= ntiles) break;
-        prefetch(T + 3, in2, va2, ie2);
-        compute(T, in3, va3, ie3);
-        T++;
+        compute(Y3{}, T, in0, va0, ie0);
+        if (T + 1 >= ntiles) break;
+        compute(Y2{}, T + 1, in1, va1, ie1);
+        prefetch(T + 4, in0, va0, ie0);
+        prefetch(T + 5, in1, va1, ie1);
+        if (T + 2 >= ntiles) break;
+        compute(Y3{}, T + 2, in2, va2, ie2);
+        if (T + 3 >= ntiles) break;
+        compute(Y2{}, T + 3, in3, va3, ie3);
+        prefetch(T + 6, in2, va2, ie2);
+        prefetch(T + 7, in3, va3, ie3);
+        T += 4;
     }
 }
 
