@@ -111,6 +111,26 @@ __device__ __forceinline__ double readlane_f64(double x, int lane)
     return __hiloint2double(hi, lo);
 }
 
+// sum over each row of 16 lanes, valid in the row's last lane (4 DPP steps
+// with zero fill, no initialisation moves)
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_shr_bc(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double row16_total(double x)
+{
+    x += dpp_row_shr_bc<0x111>(x);
+    x += dpp_row_shr_bc<0x112>(x);
+    x += dpp_row_shr_bc<0x114>(x);
+    x += dpp_row_shr_bc<0x118>(x);
+    return x;
+}
+
 __device__ __forceinline__ double wave_total(double x)
 {
     x += dpp_move_or_zero<0x111, 0xf>(x);  // row_shr:1
@@ -215,16 +235,32 @@ __device__ __forceinline__ PixBox gauss_pixel_box(const ngmix_gauss2d &g,
     // chi2 = dcc dv^2 + drr du^2 - 2 drc dv du
     const double detq = dcc * drr - drc * drc;
     if (!(dcc > 0.0) || !(drr > 0.0) || !(detq > 0.0)) return full;
-    const double rho2 = (drc * drc) / (dcc * drr);
-    if (!(rho2 < 1.0 - 1.0e-6)) return full;
+    // rho^2 < 1 - 1e-6, without the division
+    if (!(drc * drc < (1.0 - 1.0e-6) * (dcc * drr))) return full;
+    // The box only has to be CONSERVATIVE, so its arithmetic does not need
+    // IEEE divisions / square roots (~25 instructions each, paid by the whole
+    // wave for the few lanes that stage gaussians): v_rcp_f64 / v_rsq_f64 with
+    // one Newton step are good to ~1e-10 relative, far inside the 1e-6
+    // inflation below.
+    auto rcp = [](double x) {
+        double r = __builtin_amdgcn_rcp(x);
+        return fma(fma(-x, r, 1.0), r, r);
+    };
+    auto sqrt_fast = [](double x) {
+        if (!(x > 0.0)) return 0.0;
+        double r = __builtin_amdgcn_rsq(x);          // ~1/sqrt(x)
+        double s = x * r;                            // ~sqrt(x)
+        return fma(fma(-s, s, x), 0.5 * r, s);       // one Newton step
+    };
     // covariance of the form: [[var_v, cov],[cov, var_u]]
-    const double var_v = drr / detq, var_u = dcc / detq, cov = drc / detq;
+    const double idetq = rcp(detq);
+    const double var_v = drr * idetq, var_u = dcc * idetq, cov = drc * idetq;
     // pixel = Jinv (v,u):  dr = ( d*v - b*u)/det ; dc = (-c*v + a*u)/det
     const double a = j.dvdrow, b = j.dvdcol, c = j.dudrow, d = j.dudcol;
     const double det = a * d - b * c;
     const double jn = a * a + b * b + c * c + d * d;
     if (!(fabs(det) > 1.0e-6 * jn) || !(jn > 0.0)) return full;
-    const double idet = 1.0 / det;
+    const double idet = rcp(det);
     const double rr = d * idet, ru = -b * idet;   // dr = rr*v + ru*u
     const double cr = -c * idet, cu = a * idet;   // dc = cr*v + cu*u
     const double var_r = rr * rr * var_v + 2.0 * rr * ru * cov + ru * ru * var_u;
@@ -238,8 +274,8 @@ __device__ __forceinline__ PixBox gauss_pixel_box(const ngmix_gauss2d &g,
     // chi2 given rho2 < 1-1e-6) plus 1e-6 pixel absolute for the rounding of
     // the centre and pixel coordinates; the integer pixels inside
     // [lo, hi] are ceil(lo) .. floor(hi).
-    const double hr = 5.0 * sqrt(var_r) * (1.0 + 1.0e-6) + 1.0e-6;
-    const double hc = 5.0 * sqrt(var_c) * (1.0 + 1.0e-6) + 1.0e-6;
+    const double hr = 5.0 * sqrt_fast(var_r) * (1.0 + 1.0e-6) + 1.0e-6;
+    const double hc = 5.0 * sqrt_fast(var_c) * (1.0 + 1.0e-6) + 1.0e-6;
     const double lo_r = cen_r - hr, hi_r = cen_r + hr;
     const double lo_c = cen_c - hc, hi_c = cen_c + hc;
     const double big = 1.0e9;

@@ -725,8 +725,19 @@ __global__ __launch_bounds__(WAVE) void pixpass_wave_kernel(
     }
 
     if (OP == OP_LOGLIKE) {
-        const double ll = wave_total(acc_ll), sn = wave_total(acc_sn),
-                     sd = wave_total(acc_sd);
+        // DPP inside rows of 16 lanes, the 4 row sums through LDS
+        double *red = L.red;
+        const double r0_ = row16_total(acc_ll), r1_ = row16_total(acc_sn),
+                     r2_ = row16_total(acc_sd);
+        if ((lane & 15) == 15) {
+            red[0 + (lane >> 4)] = r0_;
+            red[4 + (lane >> 4)] = r1_;
+            red[8 + (lane >> 4)] = r2_;
+        }
+        __syncthreads();
+        const double ll = ((red[0] + red[1]) + red[2]) + red[3];
+        const double sn = ((red[4] + red[5]) + red[6]) + red[7];
+        const double sd = ((red[8] + red[9]) + red[10]) + red[11];
         if (lane == 0) {
             out[4 * (int64_t)s + 0] = ll * -0.5;  // gmix_nb.py:872
             out[4 * (int64_t)s + 1] = sn;
