@@ -348,9 +348,9 @@ __device__ __forceinline__ void gload_f64(double &dst, const void *base, unsigne
 // asm load would make dst a phi of "loaded" and "old", and a copy of a
 // register whose data has not landed yet reads garbage).
 __device__ __forceinline__ void gload_f64_if(double &dst, const void *base,
-                                             unsigned off, bool on)
+                                             unsigned off, int on_mask)
 {
-    const int m = __builtin_amdgcn_readfirstlane(on ? -1 : 0);
+    // on_mask: -1 (load) or 0 (EXEC = 0), wave-uniform, in an SGPR
     unsigned long long save;
     asm volatile(
         "s_mov_b64 %1, exec\n\t"
@@ -359,7 +359,24 @@ __device__ __forceinline__ void gload_f64_if(double &dst, const void *base,
         "global_load_dwordx2 %0, %2, %4\n\t"
         "s_mov_b64 exec, %1"
         : "+v"(dst), "=&s"(save)
-        : "v"(off), "s"(m), "s"(base));
+        : "v"(off), "s"(on_mask), "s"(base));
+}
+
+// two loads (val and ierr of one tile) under one EXEC toggle
+__device__ __forceinline__ void gload2_f64_if(double &d0, const void *base0, double &d1,
+                                              const void *base1, unsigned off,
+                                              int on_mask)
+{
+    unsigned long long save;
+    asm volatile(
+        "s_mov_b64 %2, exec\n\t"
+        "s_and_b32 exec_lo, exec_lo, %4\n\t"
+        "s_and_b32 exec_hi, exec_hi, %4\n\t"
+        "global_load_dwordx2 %0, %3, %5\n\t"
+        "global_load_dwordx2 %1, %3, %6\n\t"
+        "s_mov_b64 exec, %2"
+        : "+v"(d0), "+v"(d1), "=&s"(save)
+        : "v"(off), "s"(on_mask), "s"(base0), "s"(base1));
 }
 
 template <int N>
@@ -386,7 +403,7 @@ __device__ __forceinline__ void wave_tiles(
     const int nrow = st.nrow, ncol = st.ncol;
     const int ntx = (ncol + TW - 1) / TW;
     const int nty = (nrow + TH - 1) / TH;
-    const int ntiles = ntx * nty;
+    const int ntiles = __builtin_amdgcn_readfirstlane(ntx * nty);
     // FULL: every tile is complete -- no per-lane bounds tests, and every
     // load / store is unconditional so that the compiler can count them:
     // waiting for tile T's data is then s_waitcnt vmcnt(ops issued since),
@@ -432,11 +449,15 @@ __device__ __forceinline__ void wave_tiles(
         if (full) {
             inb_n = true;
             // past the last tile: issued with EXEC = 0 (te[] has sentinels)
-            const bool on = Tn < ntiles;
+            const int on = __builtin_amdgcn_readfirstlane(-(int)(Tn < ntiles));
             const unsigned off2 = lane_off + (unsigned)te[Tn].off;
-            if (kNeedsVal) gload_f64_if(nval, bval, off2, on);
-            if (kNeedsIerr) gload_f64_if(nierr, bierr, off2, on);
-            if (OP == OP_RENDER_FAST) gload_f64_if(nval, bimg, off2, on);
+            if (kNeedsVal && kNeedsIerr) {
+                gload2_f64_if(nval, bval, nierr, bierr, off2, on);
+            } else {
+                if (kNeedsVal) gload_f64_if(nval, bval, off2, on);
+                if (kNeedsIerr) gload_f64_if(nierr, bierr, off2, on);
+                if (OP == OP_RENDER_FAST) gload_f64_if(nval, bimg, off2, on);
+            }
         } else {
             const int r0n = te[Tn].r0, c0n = te[Tn].c0;
             inb_n = (r0n < rlim) & (c0n < clim);
@@ -654,7 +675,7 @@ __global__ __launch_bounds__(WAVE) void pixpass_wave_kernel(
         const unsigned lane_off = (unsigned)((lane / TW) * ncol + lane % TW) * 8u;
 #pragma unroll
         for (int t = 0; t < FUSED_PF; t++) {
-            const bool on = t < ntiles;
+            const int on = __builtin_amdgcn_readfirstlane(-(int)(t < ntiles));
             const unsigned off = lane_off + (unsigned)te[t].off;
             if (kNeedsVal) gload_f64_if(pv[t], (const char *)sval, off, on);
             if (OP != OP_RENDER_FAST) gload_f64_if(pe[t], (const char *)sierr, off, on);
