@@ -561,6 +561,29 @@ class StampBatch(object):
         _lib.check(st, "ngmix_em_batch")
         return out, status, conv
 
+    def prep_em(self):
+        """
+        the batched prep_obs of the EM fitters (em.py prep_image): every stamp
+        shifted so that its minimum is 0.001*(max-min).  Returns (batch, sky)
+        with batch sharing ierr / jacobians with self and sky an (N,) device
+        tensor, the value em() wants as `sky`.
+        """
+        torch = _torch()
+        if self.n and np.all(self.npix == self.npix[0]):
+            v = self.val.reshape(self.n, -1)
+            vmin, vmax = v.amin(dim=1), v.amax(dim=1)
+            sky = 0.001 * (vmax - vmin) - vmin
+            val = (v + sky[:, None]).reshape(-1)
+        else:
+            lengths = torch.from_numpy(self.npix).to(self.device)
+            vmin = torch.segment_reduce(self.val, "min", lengths=lengths)
+            vmax = torch.segment_reduce(self.val, "max", lengths=lengths)
+            sky = 0.001 * (vmax - vmin) - vmin
+            val = self.val + torch.repeat_interleave(sky, lengths)
+        izw = (self.flags & _lib.STAMP_IGNORE_ZERO_WEIGHT) != 0
+        return StampBatch(val, self.ierr, self.jac, self.nrow, self.ncol,
+                          self.pix_off, izw), sky
+
     def deriv_images(self, gpars, dcov, ngauss, out=None, out_start=None):
         """
         deriv_images per stamp (derivs_nb.py:40-127).  gpars (N*ngauss, 6) and

@@ -4,7 +4,8 @@ batched counterpart of the reference's bootstrap (ngmix/bootstrap.py:67-154:
 fit obs.psf, store its mixture, then run the object fitter from a guess).
 
     1. adaptive moments of every psf stamp        (ngmix_admom_batch)
-       -> one gaussian psf mixture per stamp
+       -> one gaussian psf mixture per stamp; with psf_ngauss > 1 an EM fit
+       of psf_ngauss gaussians from that size     (ngmix_em_batch)
     2. adaptive moments of every object stamp     (ngmix_admom_batch)
        -> centre / shape / size guess, flux guess from the pixel sum
     3. lock-step Levenberg-Marquardt              (LMBatchFitter)
@@ -47,14 +48,67 @@ def _admom_gaussians(stamps, Tguess, rng):
     return wt.to_numpy()[:, 0], rec, status.cpu().numpy()
 
 
+# starting mixtures of the EM psf fit: flux fractions and size factors relative
+# to the adaptive-moments T (a core and wings, as GMixPSFGuesser's em2 / em3
+# tables do in guessers.py:899-950)
+_EM_PSF_GUESS = {
+    1: ([1.0], [1.0]),
+    2: ([0.6, 0.4], [0.58, 1.62]),
+    3: ([0.55, 0.35, 0.10], [0.5, 1.3, 3.0]),
+}
+
+EM_MAXITER = 2 ** 1   # em.py's flag values
+EM_RANGE_ERROR = 2 ** 0
+
+
+def _em_psf(psf_stamps, ngauss, T0, cen, rng, em_pars):
+    """EM fit of ngauss free gaussians to every psf stamp (runners.py
+    PSFRunner + EMFitter on prep_obs images); returns the flux-normalised
+    mixtures (GMixBatch) and per-stamp flags"""
+    import torch
+    n = psf_stamps.n
+    frac, fac = _EM_PSF_GUESS[ngauss]
+    full = np.zeros((n, ngauss, 6))
+    for i in range(ngauss):
+        sig2 = 0.5 * T0 * fac[i]
+        full[:, i, 0] = frac[i] * rng.uniform(0.9, 1.1, size=n)
+        full[:, i, 1:3] = cen + rng.uniform(-0.02, 0.02, size=(n, 2)) * np.sqrt(T0)[:, None]
+        full[:, i, 3] = sig2 * (1.0 + rng.uniform(-0.1, 0.1, size=n))
+        full[:, i, 4] = rng.uniform(-0.05, 0.05, size=n) * sig2
+        full[:, i, 5] = sig2 * (1.0 + rng.uniform(-0.1, 0.1, size=n))
+    gm, _ = GMixBatch.from_pars(full.reshape(n, -1), "full", device=psf_stamps.device,
+                                ngauss=ngauss)
+    delta = np.zeros((n, 6))
+    delta[:, 5] = 1.0
+    nopsf, _ = GMixBatch.from_pars(delta, "gauss", device=psf_stamps.device)
+    skyb, sky = psf_stamps.prep_em()
+    pars = dict(miniter=40, maxiter=500, tol=1.0e-5)
+    pars.update(em_pars or {})
+    out, status, _ = skyb.em(gm, nopsf, sky=sky, **pars)
+    out = out.cpu().numpy()
+    status = status.cpu().numpy()
+    flags = np.where(status != 0, EM_RANGE_ERROR,
+                     np.where(out[:, 0] >= pars["maxiter"], EM_MAXITER, 0))
+    # set_flux(1.0) of the stored psf mixture (em.py:129): p /= sum p per stamp
+    data = gm.data.reshape(n, ngauss, 13)  # a view: edited in place
+    psum = data[:, :, 0].sum(dim=1, keepdim=True)
+    psum = torch.where(psum > 0, psum, torch.ones_like(psum))
+    data[:, :, 0] /= psum
+    gm.set_norms()
+    return gm, flags
+
+
 def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None,
-                    fit_pars=None, rng=None):
+                    fit_pars=None, rng=None, psf_ngauss=1, em_pars=None):
     """
     stamps, psf_stamps: StampBatch of the object images and of their psf images
         (stamp i of one belongs to stamp i of the other)
     model: 'gauss' | 'exp' | 'dev'
     psf_Tguess / Tguess: starting sizes for the adaptive moments (arcsec^2);
         Tguess defaults to 2 * psf_Tguess
+    psf_ngauss: 1: the psf is its adaptive-moments gaussian; 2 or 3: an EM fit
+        of that many free gaussians started from the adaptive-moments size
+        (em_pars: miniter / maxiter / tol of that fit)
 
     Returns a dict: the LMBatchFitter result arrays, plus 'psf_T', 'psf_flags',
     'psf_g', 'guess' (the LM starting points) and 'guess_flags'.
@@ -76,6 +130,11 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
     psf_pars = np.zeros((n, 6))
     psf_pars[:, 2], psf_pars[:, 3], psf_pars[:, 4], psf_pars[:, 5] = pg1, pg2, psf_T, 1.0
     psf_gm, _ = GMixBatch.from_pars(psf_pars, "gauss", device=stamps.device)
+    em_flags = np.zeros(n, dtype=np.int64)
+    if psf_ngauss > 1:
+        cen = np.where(psf_bad[:, None], 0.0, np.stack([pw["row"], pw["col"]], axis=1))
+        psf_gm, em_flags = _em_psf(psf_stamps, psf_ngauss, psf_T, cen, rng, em_pars)
+        psf_bad = psf_bad | (em_flags != 0)
 
     # 2. guess: adaptive moments of the object, psf size taken out
     ow, orec, ost = _admom_gaussians(stamps, Tguess, rng)
@@ -105,6 +164,8 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
     res["psf_T"] = psf_T
     res["psf_g"] = np.stack([pg1, pg2], axis=1)
     res["psf_flags"] = np.where(pst != 0, -1, prec["flags"])
+    res["psf_em_flags"] = em_flags
+    res["psf_gmix"] = psf_gm
     res["guess"] = guess
     res["guess_flags"] = np.where(ost != 0, -1, orec["flags"])
     res["rounds"] = fitter.rounds

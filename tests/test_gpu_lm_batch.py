@@ -182,6 +182,79 @@ def test_bootstrap_batch_recovers_truth():
     assert 0.7 < np.sqrt((pull ** 2).mean()) < 1.3
 
 
+def test_prep_em_matches_prep_image():
+    """the batched sky shift of the EM fitters, uniform and ragged batches"""
+    from ngmix_amd.em import prep_image
+    rng = np.random.RandomState(5)
+    ims = rng.normal(size=(7, 12, 9))
+    sb = StampBatch.from_images(ims, None, None)
+    b2, sky = sb.prep_em()
+    for i in range(7):
+        im, s = prep_image(ims[i])
+        np.testing.assert_allclose(sky[i].item(), s, rtol=1e-14)
+        np.testing.assert_allclose(b2.val.reshape(7, 12, 9)[i].cpu().numpy(), im,
+                                   rtol=0, atol=1e-15)
+    obs = [ngmix.Observation(rng.normal(size=(5 + i, 8 - i))) for i in range(4)]
+    rb = StampBatch.from_observations(obs)
+    b3, sky3 = rb.prep_em()
+    v = b3.val.cpu().numpy()
+    for i, o in enumerate(obs):
+        im, s = prep_image(o.image)
+        np.testing.assert_allclose(sky3[i].item(), s, rtol=1e-14)
+        a = rb.pix_off[i]
+        np.testing.assert_allclose(v[a:a + im.size], im.ravel(), rtol=0, atol=1e-15)
+
+
+def test_bootstrap_batch_with_em_psf():
+    """a two-gaussian psf: the EM psf fit (psf_ngauss=2) removes the size bias
+    the single adaptive-moments gaussian leaves"""
+    from ngmix_amd.pipeline import bootstrap_batch
+    rng = np.random.RandomState(78)
+    n, dim, scale, noise = 150, 40, 0.263, 0.005
+    pars = np.zeros((n, 6))
+    pars[:, 0:2] = rng.uniform(-0.5, 0.5, size=(n, 2)) * scale
+    pars[:, 2:4] = rng.normal(scale=0.1, size=(n, 2))
+    pars[:, 4] = rng.uniform(0.3, 0.8, size=n)
+    pars[:, 5] = rng.uniform(100.0, 200.0, size=n)
+    full = np.zeros((n, 2, 6))
+    Tc = rng.uniform(0.18, 0.24, size=n)
+    full[:, 0, 0], full[:, 1, 0] = 0.7, 0.3
+    full[:, 0, 3] = full[:, 0, 5] = 0.5 * Tc
+    full[:, 1, 3] = full[:, 1, 5] = 0.5 * Tc * 3.0
+    full[:, 1, 4] = 0.02 * Tc
+    psf, _ = GMixBatch.from_pars(full.reshape(n, -1), "full", ngauss=2)
+    psf_T = 0.7 * Tc + 0.3 * 3.0 * Tc
+    cen = (dim - 1) / 2.0
+    jac = np.array([cen, cen, scale, 0.0, 0.0, scale, scale ** 2, scale])
+    gm0, _ = GMixBatch.from_pars(pars, "exp")
+    gm, _ = gm0.convolve(psf)
+    geom = StampBatch.from_images(np.zeros((n, dim, dim)), None, jac)
+    truth, _ = geom.render(gm)
+    images = truth.cpu().numpy().reshape(n, dim, dim) + noise * rng.normal(size=(n, dim, dim))
+    sb = StampBatch.from_images(images, np.full((n, dim, dim), 1.0 / noise ** 2), jac)
+    pdim = 33
+    pjac = np.array([16.0, 16.0, scale, 0.0, 0.0, scale, scale ** 2, scale])
+    pgeom = StampBatch.from_images(np.zeros((n, pdim, pdim)), None, pjac)
+    pim, _ = pgeom.render(psf)
+    pimages = pim.cpu().numpy().reshape(n, pdim, pdim) + 1e-6 * rng.normal(size=(n, pdim, pdim))
+    psb = StampBatch.from_images(pimages, np.full((n, pdim, pdim), 1e12), pjac)
+
+    res2 = bootstrap_batch(sb, psb, model="exp", psf_Tguess=0.3, psf_ngauss=2)
+    assert np.all(res2["psf_em_flags"] == 0)
+    assert np.all(res2["flags"] == 0)
+    fitted = res2["psf_gmix"].to_numpy()
+    np.testing.assert_allclose(fitted["p"].sum(axis=1), 1.0, rtol=1e-12)
+    Tfit = (fitted["p"] * (fitted["irr"] + fitted["icc"])).sum(axis=1)
+    np.testing.assert_allclose(Tfit, psf_T, rtol=0.02)
+    pull2 = (res2["pars"] - pars) / res2["pars_err"]
+    assert np.all(np.abs(pull2) < 6.0)
+    assert np.sqrt((pull2 ** 2).mean()) < 1.4
+    # the one-gaussian psf misses the wings: its T is biased
+    res1 = bootstrap_batch(sb, psb, model="exp", psf_Tguess=0.3, psf_ngauss=1)
+    pull1 = (res1["pars"] - pars) / res1["pars_err"]
+    assert np.abs(pull1[:, 4].mean()) > 2.0 * np.abs(pull2[:, 4].mean()) + 0.5
+
+
 def _fit_one(model, image, weight, jobj, psf_rec, guess, analytic):
     pgm = ngmix.GMix(ngauss=1)
     pgm.get_data()[:] = psf_rec
