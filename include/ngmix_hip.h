@@ -140,6 +140,11 @@ typedef struct {
  * ====================================================================== */
 const char *ngmix_version(void);
 const char *ngmix_last_error(void);
+/* sizeof() of an ABI record by its type name ("ngmix_gauss2d", "ngmix_pixel",
+   "ngmix_coord", "ngmix_jacobian", "ngmix_admom_conf", "ngmix_admom_result",
+   "ngmix_em_conf", "ngmix_stamp", "ngmix_batch", "ngmix_lm_state"), -1 for an
+   unknown name: lets a binding check its own record layouts at load time */
+int64_t ngmix_abi_sizeof(const char *type_name);
 int ngmix_device_count(void);
 int ngmix_set_device(int device);
 /* thin wrappers so a numpy-only host can own device buffers */
@@ -396,15 +401,30 @@ typedef struct {
     double step[NGMIX_LM_NPMAX];
     double fnorm, xnorm, delta, par, gnorm, pnorm;
     double ftol, xtol, gtol, factor;
+    /* leastsqbound's bounds transform (leastsqbound.py:183-262): MINPACK
+       iterates on the unconstrained internal parameters xi / xti; x / xt are
+       their constrained images, the points the model is evaluated at.
+       Without bounds the two coincide. */
+    double xi[NGMIX_LM_NPMAX];    /* internal image of x */
+    double xti[NGMIX_LM_NPMAX];   /* internal image of xt */
+    double lo[NGMIX_LM_NPMAX];    /* lower bounds, -inf: none */
+    double hi[NGMIX_LM_NPMAX];    /* upper bounds, +inf: none */
+    /* forward-difference mode, fdjac2's points: column j of the jacobian is
+       (f(xt with xt[j] := xstep[j]) - f(xt)) / hstep[j] */
+    double xstep[NGMIX_LM_NPMAX];
+    double hstep[NGMIX_LM_NPMAX];
     int32_t ipvt[NGMIX_LM_NPMAX]; /* 0-based */
     int32_t n, iter, nfev, njev, info, phase, maxfev, mode;
+    int32_t bounded, pad_;
 } ngmix_lm_state;
 
 /* HOST: initialise nobj states from the guesses x0 (nobj, npars);
-   mode = NGMIX_LM_MODE_* */
+   mode = NGMIX_LM_MODE_*; lo / hi: (npars,) bounds shared by all the fits
+   (-inf / +inf: none) or NULL, the `bounds` of leastsqbound */
 int ngmix_lm_init(ngmix_lm_state *states, int64_t nobj, int npars,
                   const double *x0, double ftol, double xtol, double gtol,
-                  int maxfev, double factor, int mode);
+                  int maxfev, double factor, int mode, const double *lo,
+                  const double *hi);
 /* HOST: consume one evaluation per object -- ff (nobj,), g (nobj, NPMAX),
    A (nobj, NPMAX*NPMAX) at states[i].xt -- and advance; returns the number
    of fits still running.  The same code the device kernel runs; exists for
@@ -428,20 +448,26 @@ int ngmix_lm_eval_batch(const ngmix_batch *batch, int model, int fd,
                         int npsf, double *sums, int32_t *status, void *stream);
 /* DEVICE: fold stamps obj_start[i]..obj_start[i+1] (NULL: stamp i) into
    object i's normal equations and advance its state; *nactive (device int32,
-   may be NULL) receives the number of fits still running */
+   may be NULL) receives the number of fits still running.  obj_sums (may be
+   NULL): (nobj, NGMIX_LM_NSUMS(n)) further rows of each object's residual
+   vector already reduced over the object's n parameters -- the prior rows at
+   the head of the reference's fdiff (results.py:454, joint_prior.py:86-120);
+   in forward-difference mode their jacobian is by the state's xstep / hstep */
 int ngmix_lm_advance_batch(ngmix_lm_state *states, int64_t nobj,
                            const int64_t *obj_start, const int32_t *stamp_band,
-                           const double *sums, int nloc, int32_t *nactive,
-                           void *stream);
+                           const double *sums, int nloc, const double *obj_sums,
+                           int32_t *nactive, void *stream);
 
 /* DEVICE: package every fit as run_leastsq does (leastsqbound.py:33-155):
    rec is (nobj, 4 + 2n + 2n^2) doubles per object, n = states[i].n:
    [flags, nfev, ier, dof | pars (n) | pars_err (n) | pars_cov0 (n,n) |
    pars_cov (n,n)]; npix_obj (nobj,) = pixels in the object's residual vector;
-   pdef / cdef = the reference's PDEF / CDEF sentinels (defaults.py:10-11) */
+   ff_extra (nobj,) or NULL: the part of |f|^2 that came through obj_sums (the
+   prior rows are left out of chi2/dof, leastsqbound.py:97); pdef / cdef =
+   the reference's PDEF / CDEF sentinels (defaults.py:10-11) */
 int ngmix_lm_finalize_batch(const ngmix_lm_state *states, int64_t nobj,
-                            const int64_t *npix_obj, double pdef, double cdef,
-                            double *rec, void *stream);
+                            const int64_t *npix_obj, const double *ff_extra,
+                            double pdef, double cdef, double *rec, void *stream);
 
 #ifdef __cplusplus
 }

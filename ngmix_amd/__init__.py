@@ -46,6 +46,7 @@ from .gaussmom import GaussMom, GaussMomBatch  # noqa: F401
 from . import psfflux  # noqa: F401
 from .psfflux import PSFFluxFitter  # noqa: F401
 from . import batch  # noqa: F401
+from . import prior_batch  # noqa: F401
 from . import lm_batch  # noqa: F401
 from .lm_batch import LMBatchFitter  # noqa: F401
 from . import pipeline  # noqa: F401

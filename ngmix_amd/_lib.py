@@ -105,9 +105,13 @@ LM_STATE_DTYPE = np.dtype([
     ("fnorm", "f8"), ("xnorm", "f8"), ("delta", "f8"), ("par", "f8"),
     ("gnorm", "f8"), ("pnorm", "f8"),
     ("ftol", "f8"), ("xtol", "f8"), ("gtol", "f8"), ("factor", "f8"),
+    ("xi", "f8", LM_NPMAX), ("xti", "f8", LM_NPMAX),
+    ("lo", "f8", LM_NPMAX), ("hi", "f8", LM_NPMAX),
+    ("xstep", "f8", LM_NPMAX), ("hstep", "f8", LM_NPMAX),
     ("ipvt", "i4", LM_NPMAX),
     ("n", "i4"), ("iter", "i4"), ("nfev", "i4"), ("njev", "i4"), ("info", "i4"),
     ("phase", "i4"), ("maxfev", "i4"), ("mode", "i4"),
+    ("bounded", "i4"), ("pad_", "i4"),
 ], align=True)
 
 
@@ -187,12 +191,14 @@ SIGNATURES = {
                               _i32, _vp, _vp, _vp]),
     "ngmix_deriv_images_batch": (_i32, [_pb, _vp, _vp, _vp, _vp, _vp]),
     # batched Levenberg-Marquardt
-    "ngmix_lm_init": (_i32, [_vp, _i64, _i32, _vp, _f64, _f64, _f64, _i32, _f64, _i32]),
+    "ngmix_abi_sizeof": (_i64, [ctypes.c_char_p]),
+    "ngmix_lm_init": (_i32, [_vp, _i64, _i32, _vp, _f64, _f64, _f64, _i32, _f64, _i32,
+                              _vp, _vp]),
     "ngmix_lm_advance_host": (_i64, [_vp, _i64, _vp, _vp, _vp]),
     "ngmix_lm_eval_batch": (_i32, [_pb, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp,
                                    _vp, _vp]),
-    "ngmix_lm_advance_batch": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp]),
-    "ngmix_lm_finalize_batch": (_i32, [_vp, _i64, _vp, _f64, _f64, _vp, _vp]),
+    "ngmix_lm_advance_batch": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "ngmix_lm_finalize_batch": (_i32, [_vp, _i64, _vp, _vp, _f64, _f64, _vp, _vp]),
 }
 
 

@@ -85,6 +85,26 @@ const char *ngmix_version(void) { return "ngmix_amd 0.1.0 (gfx950)"; }
 
 const char *ngmix_last_error(void) { return g_last_error.c_str(); }
 
+int64_t ngmix_abi_sizeof(const char *type_name)
+{
+    if (!type_name) return -1;
+    const std::string t(type_name);
+#define NGMIX_SIZEOF_CASE(T) \
+    if (t == #T) return (int64_t)sizeof(T)
+    NGMIX_SIZEOF_CASE(ngmix_gauss2d);
+    NGMIX_SIZEOF_CASE(ngmix_pixel);
+    NGMIX_SIZEOF_CASE(ngmix_coord);
+    NGMIX_SIZEOF_CASE(ngmix_jacobian);
+    NGMIX_SIZEOF_CASE(ngmix_admom_conf);
+    NGMIX_SIZEOF_CASE(ngmix_admom_result);
+    NGMIX_SIZEOF_CASE(ngmix_em_conf);
+    NGMIX_SIZEOF_CASE(ngmix_stamp);
+    NGMIX_SIZEOF_CASE(ngmix_batch);
+    NGMIX_SIZEOF_CASE(ngmix_lm_state);
+#undef NGMIX_SIZEOF_CASE
+    return -1;
+}
+
 int ngmix_device_count(void)
 {
     int n = 0;
@@ -541,7 +561,7 @@ int ngmix_deriv_images_batch(const ngmix_batch *batch, const double *gpars,
 
 int ngmix_lm_init(ngmix_lm_state *states, int64_t nobj, int npars, const double *x0,
                   double ftol, double xtol, double gtol, int maxfev, double factor,
-                  int mode)
+                  int mode, const double *lo, const double *hi)
 {
     if (npars < 1 || npars > NGMIX_LM_NPMAX || nobj < 0) {
         set_last_error_msg("ngmix_lm_init: npars must be 1..NGMIX_LM_NPMAX");
@@ -549,7 +569,7 @@ int ngmix_lm_init(ngmix_lm_state *states, int64_t nobj, int npars, const double 
     }
     for (int64_t i = 0; i < nobj; i++)
         lmcore::lm_init(states[i], npars, x0 + i * npars, ftol, xtol, gtol, maxfev,
-                        factor, mode);
+                        factor, mode, lo, hi);
     return NGMIX_OK;
 }
 
@@ -576,18 +596,18 @@ int ngmix_lm_eval_batch(const ngmix_batch *batch, int model, int fd,
 
 int ngmix_lm_advance_batch(ngmix_lm_state *states, int64_t nobj,
                            const int64_t *obj_start, const int32_t *stamp_band,
-                           const double *sums, int nloc, int32_t *nactive,
-                           void *stream)
+                           const double *sums, int nloc, const double *obj_sums,
+                           int32_t *nactive, void *stream)
 {
-    return launch_lm_advance(states, nobj, obj_start, stamp_band, sums, nloc, nactive,
-                             (hipStream_t)stream);
+    return launch_lm_advance(states, nobj, obj_start, stamp_band, sums, nloc, obj_sums,
+                             nactive, (hipStream_t)stream);
 }
 
 int ngmix_lm_finalize_batch(const ngmix_lm_state *states, int64_t nobj,
-                            const int64_t *npix_obj, double pdef, double cdef,
-                            double *rec, void *stream)
+                            const int64_t *npix_obj, const double *ff_extra,
+                            double pdef, double cdef, double *rec, void *stream)
 {
-    return launch_lm_finalize(states, nobj, npix_obj, pdef, cdef, rec,
+    return launch_lm_finalize(states, nobj, npix_obj, ff_extra, pdef, cdef, rec,
                               (hipStream_t)stream);
 }
 

@@ -47,10 +47,10 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const ngmix_lm_state
                    hipStream_t s);
 int launch_lm_advance(ngmix_lm_state *states, int64_t nobj, const int64_t *obj_start,
                       const int32_t *stamp_band, const double *sums, int nloc,
-                      int32_t *nactive, hipStream_t s);
+                      const double *obj_sums, int32_t *nactive, hipStream_t s);
 
 int launch_lm_finalize(const ngmix_lm_state *states, int64_t nobj,
-                       const int64_t *npix_obj, double pdef, double cdef, double *rec,
-                       hipStream_t s);
+                       const int64_t *npix_obj, const double *ff_extra, double pdef,
+                       double cdef, double *rec, hipStream_t s);
 
 }  // namespace ngmix

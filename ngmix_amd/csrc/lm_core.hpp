@@ -282,6 +282,50 @@ NGMIX_HD void lmpar(int n, double *r, const int32_t *ipvt, const double *diag,
     }
 }
 
+// ---- leastsqbound's parameter transforms (leastsqbound.py:183-262) ----------
+NGMIX_HD double i2e(double v, double lo, double hi)
+{
+    const bool has_lo = lo > -INFINITY, has_hi = hi < INFINITY;
+    if (!has_lo && !has_hi) return v;
+    if (!has_hi) return lo - 1.0 + sqrt(v * v + 1.0);
+    if (!has_lo) return hi + 1.0 - sqrt(v * v + 1.0);
+    return lo + ((hi - lo) / 2.0) * (sin(v) + 1.0);
+}
+
+NGMIX_HD double e2i(double x, double lo, double hi)
+{
+    const bool has_lo = lo > -INFINITY, has_hi = hi < INFINITY;
+    if (!has_lo && !has_hi) return x;
+    if (!has_hi) return sqrt((x - lo + 1.0) * (x - lo + 1.0) - 1.0);
+    if (!has_lo) return sqrt((hi - x + 1.0) * (hi - x + 1.0) - 1.0);
+    return asin((2.0 * (x - lo) / (hi - lo)) - 1.0);
+}
+
+NGMIX_HD double i2e_grad(double v, double lo, double hi)
+{
+    const bool has_lo = lo > -INFINITY, has_hi = hi < INFINITY;
+    if (!has_lo && !has_hi) return 1.0;
+    if (!has_hi) return v / sqrt(v * v + 1.0);
+    if (!has_lo) return -v / sqrt(v * v + 1.0);
+    return (hi - lo) * cos(v) / 2.0;
+}
+
+// the external trial point from the internal one, and fdjac2's points
+// (h = sqrt(eps) |x_j|, sqrt(eps) at 0, in the internal parameters)
+NGMIX_HD void set_trial(lm_state &s)
+{
+    constexpr double EPS = 1.4901161193847656e-08;  // sqrt(machine epsilon)
+    for (int j = 0; j < s.n; j++) {
+        s.xt[j] = s.bounded ? i2e(s.xti[j], s.lo[j], s.hi[j]) : s.xti[j];
+        if (s.mode == NGMIX_LM_MODE_FD) {
+            double h = EPS * fabs(s.xti[j]);
+            if (h == 0.0) h = EPS;
+            s.hstep[j] = h;
+            s.xstep[j] = s.bounded ? i2e(s.xti[j] + h, s.lo[j], s.hi[j]) : s.xti[j] + h;
+        }
+    }
+}
+
 // lmpar on the stored factor, trial point, and the quantities the ratio test
 // needs afterwards (lmder: the body of the inner loop up to the evaluation)
 NGMIX_HD void propose(lm_state &s)
@@ -292,9 +336,10 @@ NGMIX_HD void propose(lm_state &s)
     lmpar(n, r, s.ipvt, s.diag, s.qtf, s.delta, s.par, p, sdiag);
     for (int j = 0; j < n; j++) {
         s.step[j] = -p[j];
-        s.xt[j] = s.x[j] + s.step[j];
+        s.xti[j] = s.xi[j] + s.step[j];
         wa3[j] = s.diag[j] * s.step[j];
     }
+    set_trial(s);
     s.pnorm = enorm(n, wa3);
     if (s.iter == 1) s.delta = fmin(s.delta, s.pnorm);
 }
@@ -313,7 +358,7 @@ NGMIX_HD bool new_jacobian(lm_state &s, const double *A, const double *g)
         for (int j = 0; j < n; j++) {
             s.diag[j] = acnorm[j];
             if (acnorm[j] == 0.0) s.diag[j] = 1.0;
-            wa3[j] = s.diag[j] * s.x[j];
+            wa3[j] = s.diag[j] * s.xi[j];
         }
         s.xnorm = enorm(n, wa3);
         s.delta = s.factor * s.xnorm;
@@ -343,17 +388,30 @@ NGMIX_HD bool new_jacobian(lm_state &s, const double *A, const double *g)
 
 NGMIX_HD void lm_init(lm_state &s, int n, const double *x0, double ftol, double xtol,
                       double gtol, int maxfev, double factor,
-                      int mode = NGMIX_LM_MODE_ANALYTIC)
+                      int mode = NGMIX_LM_MODE_ANALYTIC, const double *lo = nullptr,
+                      const double *hi = nullptr)
 {
     s.n = n;
+    s.mode = mode;
+    s.bounded = 0;
+    s.pad_ = 0;
     for (int j = 0; j < LM_NPMAX; j++) {
-        s.x[j] = j < n ? x0[j] : 0.0;
-        s.xt[j] = s.x[j];
+        s.lo[j] = (lo && j < n) ? lo[j] : -INFINITY;
+        s.hi[j] = (hi && j < n) ? hi[j] : INFINITY;
+        if (s.lo[j] > -INFINITY || s.hi[j] < INFINITY) s.bounded = 1;
+    }
+    for (int j = 0; j < LM_NPMAX; j++) {
+        // i0 = e2i(x0); the first evaluation is at i2e(i0) (leastsqbound.py:454)
+        s.xi[j] = j < n ? (s.bounded ? e2i(x0[j], s.lo[j], s.hi[j]) : x0[j]) : 0.0;
+        s.xti[j] = s.xi[j];
+        s.xt[j] = s.xstep[j] = s.hstep[j] = 0.0;
         s.diag[j] = 0.0;
         s.qtf[j] = 0.0;
         s.step[j] = 0.0;
         s.ipvt[j] = j;
     }
+    set_trial(s);
+    for (int j = 0; j < LM_NPMAX; j++) s.x[j] = s.xt[j];
     for (int i = 0; i < LM_NPMAX * LM_NPMAX; i++) s.R[i] = 0.0;
     s.fnorm = s.xnorm = s.delta = s.par = s.gnorm = s.pnorm = 0.0;
     s.ftol = ftol;
@@ -365,17 +423,33 @@ NGMIX_HD void lm_init(lm_state &s, int n, const double *x0, double ftol, double 
     s.nfev = s.njev = 0;
     s.info = 0;
     s.phase = LM_PHASE_INIT;
-    s.mode = mode;
 }
 
 // Consume the evaluation at s.xt:  ff = |f|^2, g = J^T f, A = J^T J
 // (A, g in LM_NPMAX-strided / LM_NPMAX-long arrays).  ff may be +inf (the
 // model was out of range at xt: the reference's calc_fdiff returns -inf
 // residuals there); A and g are then ignored.
-NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g, const double *A)
+NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g_in, const double *A_in)
 {
     const int n = s.n;
     if (s.phase == LM_PHASE_DONE) return;
+    // analytic jacobians are with respect to the external parameters: the
+    // wrapped Dfun of leastsqbound.py:485-489 scales column j by d xt_j / d xti_j
+    // (forward differences are taken in the internal parameters already)
+    double gs[LM_NPMAX], As[LM_NPMAX * LM_NPMAX];
+    const double *g = g_in, *A = A_in;
+    if (s.bounded && s.mode == NGMIX_LM_MODE_ANALYTIC) {
+        double sc[LM_NPMAX];
+        for (int j = 0; j < LM_NPMAX; j++)
+            sc[j] = j < n ? i2e_grad(s.xti[j], s.lo[j], s.hi[j]) : 0.0;
+        for (int j = 0; j < LM_NPMAX; j++) {
+            gs[j] = g_in[j] * sc[j];
+            for (int k = 0; k < LM_NPMAX; k++)
+                As[j * LM_NPMAX + k] = A_in[j * LM_NPMAX + k] * sc[j] * sc[k];
+        }
+        g = gs;
+        A = As;
+    }
     if (s.phase == LM_PHASE_JAC) {
         // lmdif: the forward-difference jacobian at the accepted point cost
         // n evaluations (fdjac2); then the outer-loop head
@@ -391,8 +465,12 @@ NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g, const double *
         s.par = 0.0;
         s.iter = 1;
         if (!(s.fnorm < INFINITY)) {
-            // nothing to linearise: MINPACK would carry infs through
-            s.info = 0;
+            // the guess itself is out of range: the reference hands MINPACK
+            // -inf residuals and a zero jacobian (results.py:463-464,567-568),
+            // for which lmder's gradient test ends the fit at once with
+            // info 4 and a singular factor (-> LM_SINGULAR_MATRIX downstream)
+            s.njev = 1;
+            s.info = 4;
             s.phase = LM_PHASE_DONE;
             return;
         }
@@ -403,7 +481,10 @@ NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g, const double *
 
     // ---- LM_PHASE_TRIAL: the rest of lmder's inner loop
     s.nfev++;
-    const double fnorm1 = sqrt(ff);
+    // an out-of-range trial is a residual vector of -inf in the reference;
+    // MINPACK's enorm of that is NaN (inf/inf in its scaled sums), and the
+    // comparisons below then go the way they go for a NaN
+    const double fnorm1 = ff < INFINITY ? sqrt(ff) : NAN;
     double actred = -1.0;
     if (0.1 * fnorm1 < s.fnorm) {
         const double t = fnorm1 / s.fnorm;
@@ -438,7 +519,8 @@ NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g, const double *
         double w[LM_NPMAX];
         for (int j = 0; j < n; j++) {
             s.x[j] = s.xt[j];
-            w[j] = s.diag[j] * s.x[j];
+            s.xi[j] = s.xti[j];
+            w[j] = s.diag[j] * s.xi[j];
         }
         s.xnorm = enorm(n, w);
         s.fnorm = fnorm1;
@@ -466,7 +548,8 @@ NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g, const double *
         propose(s);  // same factor, smaller region
     } else if (s.mode == NGMIX_LM_MODE_FD) {
         // ask for the jacobian at the new point
-        for (int j = 0; j < n; j++) s.xt[j] = s.x[j];
+        for (int j = 0; j < n; j++) s.xti[j] = s.xi[j];
+        set_trial(s);
         s.phase = LM_PHASE_JAC;
     } else {
         new_jacobian(s, A, g);  // the trial point's jacobian is the new one

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
 __global__ __launch_bounds__(BLOCK) void lm_advance_kernel(
     lm_state *states, int64_t nobj, const int64_t *__restrict__ obj_start,
     const int32_t *__restrict__ stamp_band, const double *__restrict__ sums, int nloc,
-    int32_t *nactive)
+    const double *__restrict__ obj_sums, int32_t *nactive)
 {
     const int64_t o = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
     if (o >= nobj) return;
@@ -324,6 +324,21 @@ __global__ __launch_bounds__(BLOCK) void lm_advance_kernel(
             g[ga] += v[ntri + a];
         }
         ff += v[ntri + nloc];
+    }
+    if (obj_sums) {
+        // rows over the object's own n parameters (the prior rows)
+        const int n = s.n, nt = n * (n + 1) / 2;
+        const double *v = obj_sums + o * (int64_t)(nt + n + 1);
+        int k = 0;
+        for (int a = 0; a < n; a++) {
+            for (int b = a; b < n; b++) {
+                A[a * LM_NPMAX + b] += v[k];
+                if (a != b) A[b * LM_NPMAX + a] += v[k];
+                k++;
+            }
+            g[a] += v[nt + a];
+        }
+        ff += v[nt + n];
     }
     lmcore::lm_advance(s, ff, g, A);
     states[o] = s;
@@ -381,15 +396,15 @@ __global__ __launch_bounds__(WAVE) void lm_eval_fd_kernel(
     FdGauss *ev = (FdGauss *)dyn;                    // [NSETS][G]
     PixBox *boxes = (PixBox *)(ev + NSETS * G);      // [G], from the base set
 
-    // local parameters and the fdjac2 steps
-    double p0[NLOC], ih[NLOC];
-    constexpr double EPS = 1.4901161193847656e-08;  // sqrt(machine epsilon)
+    // local parameters and the fdjac2 points the state prepared (xstep /
+    // hstep: the step is taken in leastsqbound's internal parameters)
+    double p0[NLOC], ps[NLOC], ih[NLOC];
 #pragma unroll
     for (int k = 0; k < NLOC; k++) {
-        p0[k] = state.xt[k < NLOC - 1 ? k : NLOC - 1 + band];
-        double h = EPS * fabs(p0[k]);
-        if (h == 0.0) h = EPS;
-        ih[k] = 1.0 / h;
+        const int gk = k < NLOC - 1 ? k : NLOC - 1 + band;
+        p0[k] = state.xt[gk];
+        ps[k] = state.xstep[gk];
+        ih[k] = 1.0 / state.hstep[gk];
     }
     double rowcen = 0.0, colcen = 0.0, ipsum = 1.0;
     const ngmix_gauss2d *q = psf ? psf + (size_t)s * npsf : nullptr;
@@ -405,12 +420,7 @@ __global__ __launch_bounds__(WAVE) void lm_eval_fd_kernel(
         double p[NLOC];
 #pragma unroll
         for (int j = 0; j < NLOC; j++) {
-            p[j] = p0[j];
-            if (j == k - 1) {
-                double h = EPS * fabs(p0[j]);
-                if (h == 0.0) h = EPS;
-                p[j] = p0[j] + h;
-            }
+            p[j] = (j == k - 1) ? ps[j] : p0[j];
         }
         FillCtx c;
         if (fill_prepare(c_tables_lm, model, ng0, p, nullptr, c) != NGMIX_OK) {
@@ -562,7 +572,8 @@ __global__ __launch_bounds__(WAVE) void lm_eval_fd_kernel(
 //   [flags, nfev, ier, dof | pars n | pars_err n | cov0 n*n | cov n*n]
 __global__ __launch_bounds__(BLOCK) void lm_finalize_kernel(
     const lm_state *__restrict__ states, int64_t nobj,
-    const int64_t *__restrict__ npix_obj, double pdef, double cdef, double *rec)
+    const int64_t *__restrict__ npix_obj, const double *__restrict__ ff_extra,
+    double pdef, double cdef, double *rec)
 {
     const int64_t o = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
     if (o >= nobj) return;
@@ -608,7 +619,13 @@ __global__ __launch_bounds__(BLOCK) void lm_finalize_kernel(
                     double acc = 0.0;
                     for (int k = (a > b ? a : b); k < n; k++)
                         acc += X[a * LM_NPMAX + k] * X[b * LM_NPMAX + k];
-                    cov0[s.ipvt[a] * n + s.ipvt[b]] = acc;
+                    // internal -> external: fjac columns over the transform's
+                    // gradient at the solution (leastsqbound.py:535-538)
+                    const int pa = s.ipvt[a], pb = s.ipvt[b];
+                    if (s.bounded)
+                        acc *= lmcore::i2e_grad(s.xi[pa], s.lo[pa], s.hi[pa]) *
+                               lmcore::i2e_grad(s.xi[pb], s.lo[pb], s.hi[pb]);
+                    cov0[pa * n + pb] = acc;
                     if (!(fabs(acc) < INFINITY)) singular = true;
                 }
         }
@@ -618,7 +635,8 @@ __global__ __launch_bounds__(BLOCK) void lm_finalize_kernel(
         } else if (dof == 0) {
             flags |= NGMIX_FLAG_ZERO_DOF;
         } else {
-            const double s_sq = s.fnorm * s.fnorm / (double)dof;
+            const double s_sq =
+                (s.fnorm * s.fnorm - (ff_extra ? ff_extra[o] : 0.0)) / (double)dof;
             bool finite = true;
             for (int i = 0; i < n * n; i++) {
                 cov[i] = cov0[i] * s_sq;
@@ -660,11 +678,12 @@ __global__ __launch_bounds__(BLOCK) void lm_finalize_kernel(
 }
 
 int launch_lm_finalize(const lm_state *states, int64_t nobj, const int64_t *npix_obj,
-                       double pdef, double cdef, double *rec, hipStream_t s)
+                       const double *ff_extra, double pdef, double cdef, double *rec,
+                       hipStream_t s)
 {
     if (nobj <= 0) return NGMIX_OK;
     hipLaunchKernelGGL(lm_finalize_kernel, dim3((unsigned)((nobj + BLOCK - 1) / BLOCK)),
-                       dim3(BLOCK), 0, s, states, nobj, npix_obj, pdef, cdef, rec);
+                       dim3(BLOCK), 0, s, states, nobj, npix_obj, ff_extra, pdef, cdef, rec);
     NGMIX_HIP_CHECK(hipGetLastError());
     return NGMIX_OK;
 }
@@ -742,14 +761,14 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *stat
 
 int launch_lm_advance(lm_state *states, int64_t nobj, const int64_t *obj_start,
                       const int32_t *stamp_band, const double *sums, int nloc,
-                      int32_t *nactive, hipStream_t s)
+                      const double *obj_sums, int32_t *nactive, hipStream_t s)
 {
     if (nobj <= 0) return NGMIX_OK;
     if (nloc < 2 || nloc > LM_NPMAX) return NGMIX_ERR_BAD_ARG;
     if (nactive) NGMIX_HIP_CHECK(hipMemsetAsync(nactive, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(lm_advance_kernel, dim3((unsigned)((nobj + BLOCK - 1) / BLOCK)),
                        dim3(BLOCK), 0, s, states, nobj, obj_start, stamp_band, sums, nloc,
-                       nactive);
+                       obj_sums, nactive);
     NGMIX_HIP_CHECK(hipGetLastError());
     return NGMIX_OK;
 }

@@ -156,11 +156,16 @@ def leastsqbound(func, x0, args=(), bounds=None, Dfun=None, full_output=0,
         return x, ier
     # R of the final jacobian's QR, rescaled from internal to external pars
     grad = tr.grad(xi)
-    ipvt = infodict["ipvt"]
-    infodict["fjac"] = (infodict["fjac"].T / np.take(grad, ipvt - 1)).T
+    # MINPACK's ipvt is 1-based from the Fortran library and 0-based from the
+    # C translation scipy ships since 1.15; the reference subtracts 1
+    # unconditionally (leastsqbound.py:536-543), which under the newer scipy
+    # rotates the covariance by one parameter.  The permutation itself says
+    # which base it has.
+    ipvt0 = infodict["ipvt"] - infodict["ipvt"].min()
+    infodict["fjac"] = (infodict["fjac"].T / np.take(grad, ipvt0)).T
     cov_x = None
     if ier in (1, 2, 3, 4):
-        perm = np.take(np.eye(n), ipvt - 1, 0)
+        perm = np.take(np.eye(n), ipvt0, 0)
         r = np.triu(np.transpose(infodict["fjac"])[:n, :])
         R = np.dot(r, perm)
         try:

@@ -24,9 +24,11 @@ g_cov, g_err, T, T_err, flux, flux_err (flux_cov when nband > 1).
 Scope: gauss / exp / dev with the analytic jacobian (lmder, as the reference's
 Fitter: results.py SIMPLE_ANALYTIC_MODELS) and gauss / turb / exp / dev / bdf /
 bd with MINPACK's forward differences evaluated inside the pixel pass (lmdif,
-what the reference runs for the models without analytic derivatives); no prior
-(prior=None is legal in the reference: zero prior rows, no bounds,
-results.py:354-357).
+what the reference runs for the models without analytic derivatives).  A
+batch prior (ngmix_amd/prior_batch.py) adds the reference's prior rows to every
+object's residual vector and its bounds run leastsqbound's parameter transform
+inside the iteration; prior=None is legal as in the reference (zero prior rows,
+no bounds, results.py:354-357).
 """
 import ctypes
 
@@ -36,6 +38,8 @@ from . import _lib
 from .batch import GMixBatch, _dptr, _stream, _torch
 from .defaults import PDEF, CDEF, DEFAULT_LM_PARS
 from .gmix import get_model_num
+from .fitting import get_lm_n_prior_pars
+from .prior_batch import bounds_arrays, prior_normal_sums
 
 __all__ = ["LMBatchFitter"]
 
@@ -58,9 +62,12 @@ class LMBatchFitter(object):
         DEFAULT_LM_PARS, ngmix/defaults.py:17)
     analytic_jacobian: False forces forward differences for gauss/exp/dev
         too (Fitter's switch of the same name)
+    prior: a batch prior (prior_batch.PriorSimpleSepBatch, PriorBatchAdapter
+        around a reference-style prior, or anything with their three members)
     """
 
-    def __init__(self, model, fit_pars=None, analytic_jacobian=True):
+    def __init__(self, model, fit_pars=None, analytic_jacobian=True, prior=None):
+        self.prior = prior
         if model not in MODEL_NLOC:
             raise ValueError("LMBatchFitter supports %s" % (tuple(MODEL_NLOC),))
         self.model = model
@@ -119,13 +126,18 @@ class LMBatchFitter(object):
             npsf = psf.ngauss
 
         fp = self.fit_pars
+        lo = hi = None
+        if self.prior is not None and getattr(self.prior, "bounds", None) is not None:
+            lo, hi = bounds_arrays(self.prior.bounds, npars)
         states = np.zeros(nobj, dtype=_lib.LM_STATE_DTYPE)
         _lib.check(L.ngmix_lm_init(
             _lib.ptr(states), nobj, npars, _lib.ptr(guess),
             float(fp.get("ftol", 1.49012e-8)), float(fp.get("xtol", 1.49012e-8)),
             float(fp.get("gtol", 0.0)), int(fp.get("maxfev", 100 * (npars + 1))),
             float(fp.get("factor", 100.0)),
-            _lib.LM_MODE_FD if self.fd else _lib.LM_MODE_ANALYTIC), "ngmix_lm_init")
+            _lib.LM_MODE_FD if self.fd else _lib.LM_MODE_ANALYTIC,
+            _lib.ptr(lo) if lo is not None else None,
+            _lib.ptr(hi) if hi is not None else None), "ngmix_lm_init")
         maxfev = int(states["maxfev"][0])
 
         d_states = torch.from_numpy(states.view(np.uint8).reshape(nobj, -1)).to(dev)
@@ -138,6 +150,14 @@ class LMBatchFitter(object):
         d_nact = torch.zeros(1, dtype=torch.int32, device=dev)
         b = stamps._batch(1)
         modnum = get_model_num(self.model)
+        # float64 view of the state records: the columns a prior needs
+        fields = _lib.LM_STATE_DTYPE.fields
+        sview = d_states.view(torch.float64)
+
+        def col(name):
+            a = fields[name][1] // 8
+            return sview[:, a:a + npars]
+        d_osums = None
         rounds = 0
         import time
         torch.cuda.synchronize(dev)
@@ -149,9 +169,18 @@ class LMBatchFitter(object):
                     _dptr(d_sband), _dptr(psf.data) if psf is not None else None,
                     npsf, _dptr(d_sums), _dptr(d_status), _stream()),
                     "ngmix_lm_eval_batch")
+                if self.prior is not None:
+                    # the prior rows at the same trial points (results.py:454)
+                    if self.fd:
+                        d_osums, _ = prior_normal_sums(
+                            self.prior, col("xt"), col("xstep"), col("hstep"))
+                    else:
+                        d_osums, _ = prior_normal_sums(self.prior, col("xt"))
                 _lib.check(L.ngmix_lm_advance_batch(
                     _dptr(d_states), nobj, _dptr(d_start), _dptr(d_sband),
-                    _dptr(d_sums), self.nloc, _dptr(d_nact), _stream()),
+                    _dptr(d_sums), self.nloc,
+                    _dptr(d_osums) if d_osums is not None else None,
+                    _dptr(d_nact), _stream()),
                     "ngmix_lm_advance_batch")
                 rounds += 1
                 if rounds % check_every == 0 or rounds > 2 * maxfev:
@@ -170,9 +199,26 @@ class LMBatchFitter(object):
         d_npix = torch.from_numpy(npix_obj).to(dev)
         width = 4 + 2 * n + 2 * n * n
         d_rec = torch.empty((nobj, width), dtype=torch.float64, device=dev)
+        d_ffx = None
+        if self.prior is not None:
+            # chi2/dof is over fdiff[n_prior_pars:] (leastsqbound.py:97): the
+            # prior rows are left out -- and, the reference reserving more
+            # slots than PriorSimpleSep fills (results.py:1050-1078 against
+            # joint_prior.py:86-120) while the pixel rows start right after the
+            # filled ones (results.py:454-461), so are the first pixels
+            rows, bad = self.prior.fill_fdiff_batch(col("x"))
+            d_ffx = torch.where(bad, torch.zeros_like(rows[:, 0]),
+                                (rows * rows).sum(dim=1))
+            d_ffx = torch.where(torch.isfinite(d_ffx), d_ffx, torch.zeros_like(d_ffx))
+            nskip = get_lm_n_prior_pars(self.model, nband) - rows.shape[1]
+            if nskip > 0:
+                d_ffx = d_ffx + self._first_pixels_fdiff2(
+                    stamps, psf, col("x"), obj_start, sband, nskip)
+            d_ffx = d_ffx.contiguous()
         with torch.cuda.device(dev):
             _lib.check(L.ngmix_lm_finalize_batch(
-                _dptr(d_states), nobj, _dptr(d_npix), float(PDEF), float(CDEF),
+                _dptr(d_states), nobj, _dptr(d_npix),
+                _dptr(d_ffx) if d_ffx is not None else None, float(PDEF), float(CDEF),
                 _dptr(d_rec), _stream()), "ngmix_lm_finalize_batch")
         rec = d_rec.cpu().numpy()
         njev = d_states.view(torch.int32).reshape(nobj, -1)[
@@ -192,6 +238,63 @@ class LMBatchFitter(object):
         }
         self._add_stats(res, stamps, psf, sobj, sband, obj_start, nband)
         return res
+
+    def _first_pixels_fdiff2(self, stamps, psf, x, obj_start, sband, nskip):
+        """sum of fdiff^2 over the first nskip listed pixels of each object's
+        first stamp at the parameters x (device tensor (nobj, npars)): the rows
+        the reference's chi2/dof leaves out next to the prior's (see go())"""
+        torch = _torch()
+        dev = stamps.device
+        nobj = x.shape[0]
+        nshape = self.nloc - 1
+        s0 = obj_start[:-1]
+        band_pars = torch.empty((nobj, self.nloc), dtype=torch.float64, device=dev)
+        band_pars[:, :nshape] = x[:, :nshape]
+        idx = torch.from_numpy(nshape + sband[s0].astype(np.int64)).to(dev)
+        band_pars[:, nshape] = x.gather(1, idx[:, None])[:, 0]
+        gm, _ = GMixBatch.from_pars(band_pars, self.model, device=dev)
+        d_s0 = torch.from_numpy(s0).to(dev)
+        if psf is not None:
+            pdata = psf.data.reshape(stamps.n, psf.ngauss, 13)[d_s0]
+            gm, _ = gm.convolve(GMixBatch(pdata.reshape(-1, 13).contiguous(), nobj,
+                                          psf.ngauss))
+        gm.set_norms()
+        G = gm.data.reshape(nobj, gm.ngauss, 13)
+        # the first nskip listed pixels of stamp s0 (row-major, weight > 0
+        # when the stamp ignores zero weights)
+        ncol = torch.from_numpy(stamps.ncol[s0].astype(np.int64)).to(dev)
+        off = torch.from_numpy(stamps.pix_off[s0]).to(dev)
+        izw = (stamps.flags[s0] & _lib.STAMP_IGNORE_ZERO_WEIGHT) != 0
+        masked = izw & (stamps.npix_kept[s0] != stamps.npix[s0])
+        first = np.tile(np.arange(nskip, dtype=np.int64), (nobj, 1))
+        if np.any(masked):
+            for o in np.nonzero(masked)[0]:
+                a = int(stamps.pix_off[s0[o]])
+                seg = stamps.ierr[a:a + int(stamps.npix[s0[o]])].cpu().numpy()
+                kept = np.nonzero(seg > 0)[0][:nskip]
+                first[o, :kept.size] = kept
+        first = torch.from_numpy(first).to(dev)
+        jac = stamps.jac[d_s0]
+        out = torch.zeros(nobj, dtype=torch.float64, device=dev)
+        for k in range(nskip):
+            pix = first[:, k]
+            r = (pix // ncol).to(torch.float64)
+            c = (pix % ncol).to(torch.float64)
+            v = jac[:, 2] * (r - jac[:, 0]) + jac[:, 3] * (c - jac[:, 1])
+            u = jac[:, 4] * (r - jac[:, 0]) + jac[:, 5] * (c - jac[:, 1])
+            vd = v[:, None] - G[:, :, 1]
+            ud = u[:, None] - G[:, :, 2]
+            chi2 = G[:, :, 10] * vd * vd + G[:, :, 8] * ud * ud - 2.0 * G[:, :, 9] * vd * ud
+            w = (25.0 - chi2) * 0.2
+            apod = torch.where(chi2 > 20.0, w ** 3 * (10.0 + w * (-15.0 + 6.0 * w)),
+                               torch.ones_like(w))
+            val = torch.where((chi2 < 25.0) & (chi2 >= 0.0),
+                              G[:, :, 12] * torch.exp(-0.5 * chi2) * apod,
+                              torch.zeros_like(chi2))
+            model = val.sum(dim=1) * jac[:, 7] ** 2  # area = scale^2 (jacobian_nb.py:33-40)
+            fd = (model - stamps.val[off + pix]) * stamps.ierr[off + pix]
+            out += fd * fd
+        return out
 
     def states(self):
         """the raw ngmix_lm_state records of the last go() (debugging)"""
@@ -223,6 +326,11 @@ class LMBatchFitter(object):
         out, st1 = stamps.loglike(gm)
         out = out.cpu().numpy()
         lnprob = np.add.reduceat(out[:, 0], obj_start[:-1])
+        if self.prior is not None:
+            # calc_lnprob adds the joint prior (results.py:410-437)
+            lnp = self.prior.get_lnprob_batch(
+                torch.from_numpy(np.ascontiguousarray(usable)).to(stamps.device))
+            lnprob = lnprob + lnp.cpu().numpy()
         s2n_numer = np.add.reduceat(out[:, 1], obj_start[:-1])
         s2n_denom = np.add.reduceat(out[:, 2], obj_start[:-1])
         npix = np.add.reduceat(out[:, 3], obj_start[:-1]).astype(np.int64)

@@ -1,0 +1,257 @@
+"""
+Priors for the batched LM driver (LMBatchFitter(prior=...)).
+
+The reference evaluates a joint prior once per object and evaluation:
+prior.fill_fdiff(pars, fdiff) writes sqrt(-2 ln p) rows at the head of the LM
+residual vector (ngmix/joint_prior.py:86-120, results.py:454,468-484) and
+prior.bounds feeds leastsqbound's parameter transform (results.py:389-396).
+A lock-step batch wants the rows of all N objects at once, so a batch prior is
+any object with
+
+    bounds                        None or [(lo, hi)] * npars, None = unbounded
+    fill_fdiff_batch(pars)        (N, npars) float64 tensor -> (rows, bad):
+                                  rows (N, k) = sqrt(-2 ln p) per prior term,
+                                  bad (N,) bool = the reference would raise
+                                  GMixRangeError there (whole fdiff = -inf)
+    get_lnprob_batch(pars)        (N,) ln p, -inf where bad
+
+evaluated with torch on the device the fit runs on.  PriorSimpleSepBatch is the
+separable joint prior of the reference's PriorSimpleSep built from the
+elementwise terms below; PriorBatchAdapter serves any reference-style prior
+object (fill_fdiff / get_lnprob_scalar / bounds) by looping over the objects
+on the host.
+"""
+import math
+
+import numpy as np
+
+from .gexceptions import GMixRangeError
+
+__all__ = ["GaussianCen", "GPriorBA", "Flat", "TwoSidedErf", "PriorSimpleSepBatch",
+           "PriorBatchAdapter", "prior_normal_sums"]
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class GaussianCen(object):
+    """CenPrior (priors/multivariate.py:24-71): independent gaussians on the
+    two centre offsets"""
+
+    def __init__(self, cen1, cen2, sigma1, sigma2):
+        self.cen1, self.cen2 = float(cen1), float(cen2)
+        self.s2inv1, self.s2inv2 = 1.0 / float(sigma1) ** 2, 1.0 / float(sigma2) ** 2
+
+    def lnprob_sep(self, x1, x2):
+        d1 = self.cen1 - x1
+        d2 = self.cen2 - x2
+        return -0.5 * d1 * d1 * self.s2inv1, -0.5 * d2 * d2 * self.s2inv2
+
+
+class GPriorBA(object):
+    """Bernstein & Armstrong shape prior (priors/shape.py:446-564):
+    ln p = 2 ln(1 - g^2) - g^2 / (2 sigma^2); g^2 >= 1 is a range error"""
+
+    def __init__(self, sigma):
+        self.sig2inv = 1.0 / float(sigma) ** 2
+
+    def lnprob2d(self, g1, g2):
+        torch = _torch()
+        gsq = g1 * g1 + g2 * g2
+        omgsq = 1.0 - gsq
+        bad = omgsq <= 0.0
+        safe = torch.where(bad, torch.ones_like(omgsq), omgsq)
+        return 2.0 * torch.log(safe) - 0.5 * gsq * self.sig2inv, bad
+
+
+class Flat(object):
+    """FlatPrior (priors/priors.py:49-100): ln p = 0 inside [minval, maxval],
+    a range error outside; bounds, if given, go to leastsqbound"""
+
+    def __init__(self, minval, maxval, bounds=None):
+        self.minval, self.maxval = float(minval), float(maxval)
+        self.bounds = bounds
+
+    def lnprob(self, x):
+        torch = _torch()
+        return torch.zeros_like(x), (x < self.minval) | (x > self.maxval)
+
+
+class TwoSidedErf(object):
+    """TwoSidedErf (priors/priors.py:186-251): flat between two error-function
+    edges; p <= 0 gives ln p = -inf (a zero-probability row, not an error)"""
+
+    def __init__(self, minval, width_at_min, maxval, width_at_max, bounds=None):
+        self.minval, self.width_at_min = float(minval), float(width_at_min)
+        self.maxval, self.width_at_max = float(maxval), float(width_at_max)
+        self.bounds = bounds
+
+    def lnprob(self, x):
+        torch = _torch()
+        p = 0.5 * torch.erf((self.maxval - x) / self.width_at_max) + \
+            0.5 * torch.erf((x - self.minval) / self.width_at_min)
+        pos = p > 0.0
+        lnp = torch.where(pos, torch.log(torch.where(pos, p, torch.ones_like(p))),
+                          torch.full_like(p, -math.inf))
+        return lnp, torch.zeros_like(pos)
+
+
+class PriorSimpleSepBatch(object):
+    """
+    PriorSimpleSep (joint_prior.py:10-120) over a batch: rows
+    [cen1, cen2, g, T, F_band...] = sqrt(clip(-2 ln p, 0)) and the bounds of
+    the T and flux terms.
+    """
+
+    def __init__(self, cen_prior, g_prior, T_prior, F_prior):
+        self.cen_prior = cen_prior
+        self.g_prior = g_prior
+        self.T_prior = T_prior
+        self.F_priors = list(F_prior) if isinstance(F_prior, (list, tuple)) else [F_prior]
+        self.nband = len(self.F_priors)
+        bounds = [(None, None)] * 4
+        some = False
+        for p in [self.T_prior] + self.F_priors:
+            b = getattr(p, "bounds", None)
+            if b is not None:
+                some = True
+                bounds.append((b[0], b[1]))
+            else:
+                bounds.append((None, None))
+        self.bounds = bounds if some else None
+
+    def _lnprobs(self, pars):
+        torch = _torch()
+        l1, l2 = self.cen_prior.lnprob_sep(pars[:, 0], pars[:, 1])
+        lg, bad = self.g_prior.lnprob2d(pars[:, 2], pars[:, 3])
+        lT, bT = self.T_prior.lnprob(pars[:, 4])
+        bad = bad | bT
+        cols = [l1, l2, lg, lT]
+        for i, Fp in enumerate(self.F_priors):
+            lF, bF = Fp.lnprob(pars[:, 5 + i])
+            bad = bad | bF
+            cols.append(lF)
+        return torch.stack(cols, dim=1), bad
+
+    def fill_fdiff_batch(self, pars):
+        torch = _torch()
+        lnp, bad = self._lnprobs(pars)
+        rows = torch.sqrt(torch.clamp(-2.0 * lnp, min=0.0))
+        return rows, bad
+
+    def get_lnprob_batch(self, pars):
+        torch = _torch()
+        lnp, bad = self._lnprobs(pars)
+        tot = lnp.sum(dim=1)
+        return torch.where(bad, torch.full_like(tot, -math.inf), tot)
+
+
+class PriorBatchAdapter(object):
+    """
+    a reference-style joint prior (fill_fdiff(pars, fdiff) -> nrows,
+    get_lnprob_scalar(pars), optional .bounds) evaluated object by object on
+    the host: correct for any prior, at one Python call per object and
+    evaluation
+    """
+
+    def __init__(self, prior, max_rows):
+        self.prior = prior
+        self.max_rows = int(max_rows)
+        self.bounds = getattr(prior, "bounds", None)
+
+    def fill_fdiff_batch(self, pars):
+        torch = _torch()
+        p = pars.detach().cpu().numpy()
+        n = p.shape[0]
+        rows = np.zeros((n, self.max_rows))
+        bad = np.zeros(n, dtype=bool)
+        buf = np.zeros(self.max_rows)
+        nrows = self.max_rows
+        for i in range(n):
+            buf[:] = 0.0
+            try:
+                nrows = self.prior.fill_fdiff(p[i], buf)
+                rows[i] = buf
+            except GMixRangeError:
+                bad[i] = True
+        return (torch.from_numpy(rows[:, :nrows].copy()).to(pars.device),
+                torch.from_numpy(bad).to(pars.device))
+
+    def get_lnprob_batch(self, pars):
+        torch = _torch()
+        p = pars.detach().cpu().numpy()
+        out = np.empty(p.shape[0])
+        for i in range(p.shape[0]):
+            try:
+                out[i] = self.prior.get_lnprob_scalar(p[i])
+            except GMixRangeError:
+                out[i] = -np.inf
+        return torch.from_numpy(out).to(pars.device)
+
+
+def bounds_arrays(bounds, npars):
+    """(lo, hi) float64 arrays with -inf / +inf for None"""
+    lo = np.full(npars, -np.inf)
+    hi = np.full(npars, np.inf)
+    if bounds is not None:
+        if len(bounds) != npars:
+            raise ValueError("length of bounds != number of parameters")
+        for i, (a, b) in enumerate(bounds):
+            if a is not None:
+                lo[i] = a
+            if b is not None:
+                hi[i] = b
+    return lo, hi
+
+
+def prior_normal_sums(prior, xt, xstep=None, hstep=None, step_rel=1.0e-8):
+    """
+    The prior rows of N objects at their trial points xt (N, n), reduced to
+    the normal-equation sums ngmix_lm_advance_batch takes as obj_sums:
+    (N, n(n+1)/2 + n + 1) = [J^T J upper triangle | J^T r | r.r].
+
+    The jacobian of the rows is by differences, as in the reference:
+    analytic mode (xstep None): forward steps step_rel * max(1, |x_j|), backward
+    where the forward point is out of range (results.py:572-625); rows that are
+    not finite get zero derivatives.  Forward-difference mode: the state's own
+    fdjac2 points (column j of xt replaced by xstep[:, j], divided by
+    hstep[:, j]), which is what lmdif does to the whole residual vector.
+
+    Returns (sums, ff) with ff (N,) = r.r (+inf where the prior is out of range).
+    """
+    torch = _torch()
+    N, n = xt.shape
+    r0, bad0 = prior.fill_fdiff_batch(xt)
+    k = r0.shape[1]
+    fin0 = torch.isfinite(r0)
+    J = torch.zeros((N, k, n), dtype=torch.float64, device=xt.device)
+    for j in range(n):
+        xp = xt.clone()
+        if xstep is None:
+            step = step_rel * torch.clamp(xt[:, j].abs(), min=1.0)
+            xp[:, j] = xt[:, j] + step
+            rj, badj = prior.fill_fdiff_batch(xp)
+            if bool(badj.any()):
+                xm = xt.clone()
+                xm[:, j] = xt[:, j] - step
+                rm, badm = prior.fill_fdiff_batch(xm)
+                rj = torch.where(badj[:, None], rm, rj)
+                step = torch.where(badj, -step, step)
+                badj = badj & badm
+        else:
+            step = hstep[:, j]
+            xp[:, j] = xstep[:, j]
+            rj, badj = prior.fill_fdiff_batch(xp)
+        good = fin0 & torch.isfinite(rj) & ~badj[:, None] & ~bad0[:, None]
+        d = (rj - r0) / step[:, None]
+        J[:, :, j] = torch.where(good, d, torch.zeros_like(d))
+    rz = torch.where(fin0, r0, torch.zeros_like(r0))
+    A = torch.einsum("nka,nkb->nab", J, J)
+    g = torch.einsum("nka,nk->na", J, rz)
+    ff = (r0 * r0).sum(dim=1)
+    ff = torch.where(bad0, torch.full_like(ff, math.inf), ff)
+    iu = torch.triu_indices(n, n, device=xt.device)
+    sums = torch.cat([A[:, iu[0], iu[1]], g, ff[:, None]], dim=1).contiguous()
+    return sums, ff

@@ -59,6 +59,28 @@ def test_struct_layouts_match_reference():
     assert _lib.moments_result_dtype(17).itemsize == 2736
 
 
+def test_binding_record_sizes_match_the_library():
+    """the numpy / ctypes mirrors of every ABI record against sizeof() in the
+    library itself (ngmix_abi_sizeof)"""
+    import ctypes
+    L = _lib.lib()
+    sizes = {
+        "ngmix_gauss2d": _lib.GAUSS2D_DTYPE.itemsize,
+        "ngmix_pixel": _lib.PIXEL_DTYPE.itemsize,
+        "ngmix_coord": _lib.COORD_DTYPE.itemsize,
+        "ngmix_jacobian": _lib.JACOBIAN_DTYPE.itemsize,
+        "ngmix_admom_conf": _lib.ADMOM_CONF_DTYPE.itemsize,
+        "ngmix_admom_result": _lib.ADMOM_RESULT_DTYPE.itemsize,
+        "ngmix_em_conf": _lib.EM_CONF_DTYPE.itemsize,
+        "ngmix_stamp": _lib.STAMP_DTYPE.itemsize,
+        "ngmix_batch": ctypes.sizeof(_lib.Batch),
+        "ngmix_lm_state": _lib.LM_STATE_DTYPE.itemsize,
+    }
+    for name, size in sizes.items():
+        assert L.ngmix_abi_sizeof(name.encode()) == size, name
+    assert L.ngmix_abi_sizeof(b"no_such_record") == -1
+
+
 FILL_CASES = ["gauss", "exp", "dev", "turb", "bdf", "bd", "coellip", "full",
               "exp_round", "exp_highg"]
 MODEL_IDS = {"full": 0, "gauss": 1, "turb": 2, "exp": 3, "dev": 4, "bdf": 6,

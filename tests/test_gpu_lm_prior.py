@@ -1,0 +1,179 @@
+"""
+Priors and bounds in the batched LM driver (LMBatchFitter(prior=...),
+ngmix_amd/prior_batch.py, the bounds transform in csrc/lm_core.hpp) against
+this package's per-object Fitter given the same prior through the reference's
+interface (prior.fill_fdiff / get_lnprob_scalar / bounds: results.py:389-396,
+454, joint_prior.py:86-120), which runs scipy's MINPACK through leastsqbound.
+"""
+from math import erf, log, sqrt
+
+import numpy as np
+import pytest
+
+import ngmix_amd as ngmix
+from ngmix_amd.batch import StampBatch, GMixBatch
+from ngmix_amd.gexceptions import GMixRangeError
+from ngmix_amd.lm_batch import LMBatchFitter
+from ngmix_amd import prior_batch as pb
+
+pytestmark = pytest.mark.gpu
+
+
+class ScalarSimpleSep(object):
+    """the reference's PriorSimpleSep written out for one object: gaussian
+    centre, BA shape, two-sided-erf or flat T and flux terms"""
+
+    def __init__(self, cen_sigma, g_sigma, T_term, F_term, bounds=None):
+        self.cs2inv = 1.0 / cen_sigma ** 2
+        self.gs2inv = 1.0 / g_sigma ** 2
+        self.T_term, self.F_term = T_term, F_term
+        self.bounds = bounds
+
+    @staticmethod
+    def _term(t, x):
+        if t[0] == "erf":
+            _, mn, wmn, mx, wmx = t
+            p = 0.5 * erf((mx - x) / wmx) + 0.5 * erf((x - mn) / wmn)
+            return log(p) if p > 0 else -np.inf
+        _, mn, mx = t
+        if x < mn or x > mx:
+            raise GMixRangeError("out of range")
+        return 0.0
+
+    def _lnps(self, pars):
+        gsq = pars[2] ** 2 + pars[3] ** 2
+        if 1.0 - gsq <= 0.0:
+            raise GMixRangeError("g too big")
+        return [-0.5 * pars[0] ** 2 * self.cs2inv, -0.5 * pars[1] ** 2 * self.cs2inv,
+                2 * log(1.0 - gsq) - 0.5 * gsq * self.gs2inv,
+                self._term(self.T_term, pars[4]), self._term(self.F_term, pars[5])]
+
+    def fill_fdiff(self, pars, fdiff):
+        lnps = self._lnps(pars)
+        for i, l in enumerate(lnps):
+            fdiff[i] = sqrt(max(-2.0 * l, 0.0))
+        return len(lnps)
+
+    def get_lnprob_scalar(self, pars):
+        return float(sum(self._lnps(pars)))
+
+
+def _batch_prior(cen_sigma, g_sigma, T_term, F_term, bounds=None):
+    def term(t, b):
+        if t[0] == "erf":
+            return pb.TwoSidedErf(*t[1:], bounds=b)
+        return pb.Flat(*t[1:], bounds=b)
+    bT = bounds[4] if bounds is not None else None
+    bF = bounds[5] if bounds is not None else None
+    return pb.PriorSimpleSepBatch(pb.GaussianCen(0.0, 0.0, cen_sigma, cen_sigma),
+                                  pb.GPriorBA(g_sigma), term(T_term, bT),
+                                  term(F_term, bF))
+
+
+def _sim(model, n, seed, noise=0.02, dim=32):
+    rng = np.random.RandomState(seed)
+    scale = 0.263
+    pars = np.zeros((n, 6))
+    pars[:, 0:2] = rng.uniform(-0.3, 0.3, size=(n, 2)) * scale
+    pars[:, 2:4] = rng.normal(scale=0.1, size=(n, 2))
+    pars[:, 4] = rng.uniform(0.3, 0.8, size=n)
+    pars[:, 5] = rng.uniform(20.0, 60.0, size=n)
+    psf_pars = np.array([0.0, 0.0, 0.01, -0.01, 0.27, 1.0])
+    cen = (dim - 1) / 2.0
+    jobj = ngmix.DiagonalJacobian(row=cen, col=cen, scale=scale)
+    pgm = ngmix.GMixModel(psf_pars, "gauss")
+    obs = []
+    for i in range(n):
+        gm = ngmix.GMixModel(pars[i], model).convolve(pgm)
+        im = gm.make_image((dim, dim), jacobian=jobj, fast_exp=True)
+        im += noise * rng.normal(size=im.shape)
+        pobs = ngmix.Observation(np.zeros((5, 5)), jacobian=jobj, gmix=pgm.copy())
+        obs.append(ngmix.Observation(im, weight=np.full(im.shape, 1.0 / noise ** 2),
+                                     jacobian=jobj, psf=pobs))
+    guess = pars * (1.0 + 0.05 * rng.uniform(-1, 1, size=pars.shape))
+    guess[:, 0:2] = pars[:, 0:2] + 0.02 * rng.uniform(-1, 1, size=(n, 2))
+    psf = GMixBatch.from_numpy(np.stack([pgm.get_data().copy()] * n))
+    return obs, StampBatch.from_observations(obs), psf, pars, guess
+
+
+PRIOR_CASES = {
+    # no bounds: plain MINPACK with five prior rows
+    "erf": dict(T_term=("erf", -0.05, 0.03, 5.0, 0.5), F_term=("erf", -1.0, 0.5, 1.0e4, 10.0),
+                bounds=None),
+    # T bounded on both sides, the flux below: leastsqbound's sin / sqrt maps
+    "bounded": dict(T_term=("flat", -0.1, 3.0), F_term=("erf", -1.0, 0.5, 1.0e4, 10.0),
+                    bounds=[(None, None)] * 4 + [(-0.1, 3.0), (0.0, None)]),
+}
+
+
+def _compare(res, fits, analytic, ptol):
+    for i, fit in enumerate(fits):
+        assert res["flags"][i] == fit["flags"] == 0, i
+        assert res["ier"][i] == fit["ier"], i
+        if analytic:
+            assert res["nfev"][i] == fit["nfev"], (i, res["nfev"][i], fit["nfev"])
+        else:
+            assert abs(res["nfev"][i] - fit["nfev"]) <= 8, i
+        np.testing.assert_allclose(res["pars"][i], fit["pars"], rtol=ptol, atol=ptol * 1e-2)
+        sig = np.sqrt(np.diag(fit["pars_cov"]))
+        np.testing.assert_allclose(res["pars_cov"][i], fit["pars_cov"], rtol=1e-3,
+                                   atol=1e-6 * np.outer(sig, sig).max())
+        np.testing.assert_allclose(res["lnprob"][i], fit["lnprob"], rtol=1e-8, atol=1e-6)
+        np.testing.assert_allclose(res["chi2per"][i], fit["chi2per"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("case", list(PRIOR_CASES))
+@pytest.mark.parametrize("analytic", [True, False], ids=["lmder", "lmdif"])
+def test_batch_prior_matches_per_object_fitter(case, analytic):
+    cfg = PRIOR_CASES[case]
+    obs, sb, psf, truth, guess = _sim("exp", 10, 40 + len(case))
+    sprior = ScalarSimpleSep(0.1, 0.3, cfg["T_term"], cfg["F_term"], cfg["bounds"])
+    bprior = _batch_prior(0.1, 0.3, cfg["T_term"], cfg["F_term"], cfg["bounds"])
+    assert (bprior.bounds is None) == (cfg["bounds"] is None)
+    fits = [ngmix.fitting.Fitter(model="exp", prior=sprior,
+                                 analytic_jacobian=analytic).go(obs=o, guess=g)
+            for o, g in zip(obs, guess)]
+    res = LMBatchFitter("exp", prior=bprior, analytic_jacobian=analytic).go(
+        sb, guess, psf=psf)
+    _compare(res, fits, analytic, 1e-6 if analytic else 2e-5)
+    if cfg["bounds"] is not None:
+        assert np.all(res["pars"][:, 4] >= -0.1) and np.all(res["pars"][:, 4] <= 3.0)
+
+
+def test_prior_pulls_the_fit_and_adapter_agrees():
+    """a tight centre prior moves the solution; the per-object adapter around
+    a reference-style prior gives the vectorised prior's answer"""
+    cfg = PRIOR_CASES["erf"]
+    obs, sb, psf, truth, guess = _sim("gauss", 6, 7, noise=0.05)
+    bprior = _batch_prior(0.002, 0.3, cfg["T_term"], cfg["F_term"])
+    sprior = ScalarSimpleSep(0.002, 0.3, cfg["T_term"], cfg["F_term"])
+    free = LMBatchFitter("gauss").go(sb, guess, psf=psf)
+    tight = LMBatchFitter("gauss", prior=bprior).go(sb, guess, psf=psf)
+    adapt = LMBatchFitter("gauss", prior=pb.PriorBatchAdapter(sprior, 5)).go(
+        sb, guess, psf=psf)
+    assert np.all(tight["flags"] == 0) and np.all(adapt["flags"] == 0)
+    assert np.all(np.abs(tight["pars"][:, 0:2]) < 0.6 * np.abs(free["pars"][:, 0:2]) + 1e-4)
+    np.testing.assert_allclose(adapt["pars"], tight["pars"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_array_equal(adapt["nfev"], tight["nfev"])
+    np.testing.assert_allclose(adapt["lnprob"], tight["lnprob"], rtol=1e-12)
+
+
+def test_out_of_range_prior_is_a_rejected_step():
+    """a flat prior the fit tries to leave: the trial is refused (the
+    reference's all -inf residuals) and the solution stays inside"""
+    obs, sb, psf, truth, guess = _sim("gauss", 8, 11)
+    Tmax = float(truth[:, 4].min()) * 0.9   # every true T is outside
+    T_term, F_term = ("flat", 0.0, Tmax), PRIOR_CASES["erf"]["F_term"]
+    g0 = guess.copy()
+    g0[:, 4] = 0.5 * Tmax
+    bprior = _batch_prior(0.1, 0.3, T_term, F_term)
+    sprior = ScalarSimpleSep(0.1, 0.3, T_term, F_term)
+    res = LMBatchFitter("gauss", prior=bprior).go(sb, g0, psf=psf)
+    ok = res["flags"] == 0
+    assert np.all(res["pars"][ok, 4] <= Tmax)
+    for i in range(len(obs)):
+        fit = ngmix.fitting.Fitter(model="gauss", prior=sprior).go(obs=obs[i], guess=g0[i])
+        assert res["flags"][i] == fit["flags"], i
+        if fit["flags"] == 0:
+            assert res["nfev"][i] == fit["nfev"]
+            np.testing.assert_allclose(res["pars"][i], fit["pars"], rtol=1e-6, atol=1e-8)

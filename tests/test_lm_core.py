@@ -30,15 +30,21 @@ def fd_jacobian(func, x, f0):
 
 
 def run_lm(func, jac, x0, ftol=1e-5, xtol=1e-5, gtol=0.0, maxfev=4000,
-           factor=100.0, maxrounds=10000, mode=0):
+           factor=100.0, maxrounds=10000, mode=0, bounds=None):
     """drive one fit through ngmix_lm_init / ngmix_lm_advance_host;
     mode 1: forward differences (jac is ignored)"""
     L = _lib.lib()
     x0 = np.ascontiguousarray(x0, dtype="f8").reshape(1, -1)
     n = x0.shape[1]
     st = np.zeros(1, dtype=_lib.LM_STATE_DTYPE)
+    lo = hi = None
+    if bounds is not None:
+        lo = np.array([-np.inf if b[0] is None else b[0] for b in bounds])
+        hi = np.array([np.inf if b[1] is None else b[1] for b in bounds])
     assert L.ngmix_lm_init(_lib.ptr(st), 1, n, _lib.ptr(x0), ftol, xtol, gtol,
-                           maxfev, factor, mode) == 0
+                           maxfev, factor, mode,
+                           None if lo is None else _lib.ptr(lo),
+                           None if hi is None else _lib.ptr(hi)) == 0
     rounds = 0
     while st["phase"][0] != _lib.LM_PHASE_DONE:
         xt = st["xt"][0, :n].copy()
@@ -47,7 +53,15 @@ def run_lm(func, jac, x0, ftol=1e-5, xtol=1e-5, gtol=0.0, maxfev=4000,
         g = np.zeros((1, NP))
         A = np.zeros((1, NP, NP))
         if mode == 0 or st["phase"][0] != 1:   # not a plain trial of FD mode
-            J = jac(xt) if mode == 0 else fd_jacobian(func, xt, f)
+            if mode == 0:
+                J = jac(xt)
+            else:
+                # the state's own fdjac2 points (internal steps under bounds)
+                J = np.zeros((f.size, n))
+                for j in range(n):
+                    xp = xt.copy()
+                    xp[j] = st["xstep"][0, j]
+                    J[:, j] = (func(xp) - f) / st["hstep"][0, j]
             g[0, :n] = J.T @ f
             A[0, :n, :n] = J.T @ J
         L.ngmix_lm_advance_host(_lib.ptr(st), 1, _lib.ptr(ff), _lib.ptr(g),
@@ -178,7 +192,8 @@ def test_lm_core_maxfev_and_batch():
     _, f1, j1, _ = cases[0]
     starts = np.array([[1.0, 0.5, 0.0], [2.0, 1.0, 0.3], [5.0, 2.0, 1.0]])
     st = np.zeros(3, dtype=_lib.LM_STATE_DTYPE)
-    L.ngmix_lm_init(_lib.ptr(st), 3, 3, _lib.ptr(starts), 1e-5, 1e-5, 0.0, 4000, 100.0, 0)
+    L.ngmix_lm_init(_lib.ptr(st), 3, 3, _lib.ptr(starts), 1e-5, 1e-5, 0.0, 4000, 100.0, 0,
+                    None, None)
     running = 3
     while running:
         ff = np.zeros(3)
@@ -213,7 +228,8 @@ def test_lm_core_out_of_range_trial():
     L = _lib.lib()
     x0 = x0.reshape(1, -1)
     st = np.zeros(1, dtype=_lib.LM_STATE_DTYPE)
-    L.ngmix_lm_init(_lib.ptr(st), 1, 3, _lib.ptr(x0), 1e-5, 1e-5, 0.0, 200, 100.0, 0)
+    L.ngmix_lm_init(_lib.ptr(st), 1, 3, _lib.ptr(x0), 1e-5, 1e-5, 0.0, 200, 100.0, 0,
+                    None, None)
     while st["phase"][0] != _lib.LM_PHASE_DONE:
         xt = st["xt"][0, :3].copy()
         f, J = fwall(xt), jac(xt)
@@ -227,3 +243,87 @@ def test_lm_core_out_of_range_trial():
     assert st["x"][0, 1] <= 1.2
     assert np.isfinite(st["fnorm"][0])
     assert int(st["info"][0]) in (1, 2, 3, 5)
+
+
+# ---- bounds: leastsqbound's transform (ngmix/fitting/leastsqbound.py:183-262,
+# 440-552) = MINPACK on the unconstrained internal parameters
+def _i2e(v, b):
+    lo, hi = b
+    if lo is None and hi is None:
+        return v
+    if hi is None:
+        return lo - 1.0 + np.sqrt(v * v + 1.0)
+    if lo is None:
+        return hi + 1.0 - np.sqrt(v * v + 1.0)
+    return lo + ((hi - lo) / 2.0) * (np.sin(v) + 1.0)
+
+
+def _e2i(x, b):
+    lo, hi = b
+    if lo is None and hi is None:
+        return x
+    if hi is None:
+        return np.sqrt((x - lo + 1.0) ** 2 - 1.0)
+    if lo is None:
+        return np.sqrt((hi - x + 1.0) ** 2 - 1.0)
+    return np.arcsin((2.0 * (x - lo) / (hi - lo)) - 1.0)
+
+
+def _grad(v, b):
+    lo, hi = b
+    if lo is None and hi is None:
+        return 1.0
+    if hi is None:
+        return v / np.sqrt(v * v + 1.0)
+    if lo is None:
+        return -v / np.sqrt(v * v + 1.0)
+    return (hi - lo) * np.cos(v) / 2.0
+
+
+def leastsqbound_oracle(func, x0, bounds, jac=None, **kw):
+    """the reference's leastsqbound restated on scipy.optimize.leastsq"""
+    i2e = lambda xi: np.array([_i2e(v, b) for v, b in zip(xi, bounds)])
+    i0 = np.array([_e2i(v, b) for v, b in zip(x0, bounds)])
+    wfunc = lambda xi: func(i2e(xi))
+    wjac = None
+    if jac is not None:
+        wjac = lambda xi: jac(i2e(xi)) * np.array(
+            [_grad(v, b) for v, b in zip(xi, bounds)])
+    xi, cov, info, mesg, ier = leastsq(wfunc, i0, Dfun=wjac, full_output=1, **kw)
+    g = np.array([_grad(v, b) for v, b in zip(xi, bounds)])
+    if cov is not None:
+        cov = cov * g[:, None] * g[None, :]
+    return i2e(xi), cov, info, ier
+
+
+BOUND_CASES = [
+    # expdecay with the rate boxed (the truth 1.3 inside; then outside: the fit
+    # ends against the wall), the amplitude bounded below, the offset above
+    ("inside", 0, [(0.0, None), (0.2, 3.0), (None, 2.0)]),
+    ("wall", 0, [(None, None), (0.1, 1.0), (None, None)]),
+    ("gauss_box", 2, [(10.0, 1000.0), (-2.0, 2.0), (0.2, None)]),
+]
+
+
+@pytest.mark.parametrize("case", BOUND_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", [0, 1], ids=["lmder", "lmdif"])
+def test_lm_core_bounds_follow_leastsqbound(case, mode):
+    name, iprob, bounds = case
+    _, func, jac, x0 = list(problems())[iprob]
+    xs, cov, info, ier = leastsqbound_oracle(
+        func, x0, bounds, jac=jac if mode == 0 else None, ftol=1e-8, xtol=1e-8,
+        maxfev=4000)
+    st = run_lm(func, jac, x0, ftol=1e-8, xtol=1e-8, mode=mode, bounds=bounds)
+    n = x0.size
+    assert int(st["bounded"]) == 1
+    assert int(st["info"]) == ier, (name, st["info"], ier)
+    assert int(st["nfev"]) == info["nfev"], name
+    tol = 1e-7 if mode == 0 else 1e-5
+    scale = np.maximum(np.abs(xs), 1e-3)
+    assert np.all(np.abs(st["x"][:n] - xs) <= tol * scale), (name, st["x"][:n], xs)
+    for (lo, hi), v in zip(bounds, st["x"][:n]):
+        assert (lo is None or v >= lo) and (hi is None or v <= hi)
+    if cov is not None and name != "wall":
+        g = np.array([_grad(v, b) for v, b in zip(st["xi"][:n], bounds)])
+        got = cov_from_state(st) * g[:, None] * g[None, :]
+        np.testing.assert_allclose(got, cov, rtol=1e-4 if mode == 0 else 1e-3)
