@@ -425,6 +425,12 @@ int ngmix_lm_init(ngmix_lm_state *states, int64_t nobj, int npars,
                   const double *x0, double ftol, double xtol, double gtol,
                   int maxfev, double factor, int mode, const double *lo,
                   const double *hi);
+/* DEVICE: the same initialisation for states resident on the device; x0
+   (nobj, npars) device array; lo / hi host arrays or NULL */
+int ngmix_lm_init_batch(ngmix_lm_state *states, int64_t nobj, int npars,
+                        const double *x0, double ftol, double xtol, double gtol,
+                        int maxfev, double factor, int mode, const double *lo,
+                        const double *hi, void *stream);
 /* HOST: consume one evaluation per object -- ff (nobj,), g (nobj, NPMAX),
    A (nobj, NPMAX*NPMAX) at states[i].xt -- and advance; returns the number
    of fits still running.  The same code the device kernel runs; exists for

@@ -194,6 +194,8 @@ SIGNATURES = {
     "ngmix_abi_sizeof": (_i64, [ctypes.c_char_p]),
     "ngmix_lm_init": (_i32, [_vp, _i64, _i32, _vp, _f64, _f64, _f64, _i32, _f64, _i32,
                               _vp, _vp]),
+    "ngmix_lm_init_batch": (_i32, [_vp, _i64, _i32, _vp, _f64, _f64, _f64, _i32, _f64,
+                                    _i32, _vp, _vp, _vp]),
     "ngmix_lm_advance_host": (_i64, [_vp, _i64, _vp, _vp, _vp]),
     "ngmix_lm_eval_batch": (_i32, [_pb, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp,
                                    _vp, _vp]),

@@ -573,6 +573,18 @@ int ngmix_lm_init(ngmix_lm_state *states, int64_t nobj, int npars, const double 
     return NGMIX_OK;
 }
 
+int ngmix_lm_init_batch(ngmix_lm_state *states, int64_t nobj, int npars, const double *x0,
+                        double ftol, double xtol, double gtol, int maxfev, double factor,
+                        int mode, const double *lo, const double *hi, void *stream)
+{
+    if (npars < 1 || npars > NGMIX_LM_NPMAX || nobj < 0) {
+        set_last_error_msg("ngmix_lm_init_batch: npars must be 1..NGMIX_LM_NPMAX");
+        return NGMIX_ERR_BAD_ARG;
+    }
+    return launch_lm_init(states, nobj, npars, x0, ftol, xtol, gtol, maxfev, factor, mode,
+                          lo, hi, (hipStream_t)stream);
+}
+
 int64_t ngmix_lm_advance_host(ngmix_lm_state *states, int64_t nobj, const double *ff,
                               const double *g, const double *A)
 {

@@ -677,6 +677,49 @@ __global__ __launch_bounds__(BLOCK) void lm_finalize_kernel(
     r[3] = (double)dof;
 }
 
+struct LmInitPars {
+    double ftol, xtol, gtol, factor;
+    double lo[LM_NPMAX], hi[LM_NPMAX];
+    int n, maxfev, mode, has_bounds;
+};
+
+__global__ __launch_bounds__(BLOCK) void lm_init_kernel(lm_state *states, int64_t nobj,
+                                                        const double *__restrict__ x0,
+                                                        LmInitPars P)
+{
+    const int64_t o = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+    if (o >= nobj) return;
+    lm_state s;
+    lmcore::lm_init(s, P.n, x0 + o * P.n, P.ftol, P.xtol, P.gtol, P.maxfev, P.factor,
+                    P.mode, P.has_bounds ? P.lo : nullptr, P.has_bounds ? P.hi : nullptr);
+    states[o] = s;
+}
+
+int launch_lm_init(lm_state *states, int64_t nobj, int npars, const double *x0,
+                   double ftol, double xtol, double gtol, int maxfev, double factor,
+                   int mode, const double *lo, const double *hi, hipStream_t s)
+{
+    if (nobj <= 0) return NGMIX_OK;
+    if (npars < 1 || npars > LM_NPMAX) return NGMIX_ERR_BAD_ARG;
+    LmInitPars P;
+    P.ftol = ftol;
+    P.xtol = xtol;
+    P.gtol = gtol;
+    P.factor = factor;
+    P.n = npars;
+    P.maxfev = maxfev;
+    P.mode = mode;
+    P.has_bounds = (lo != nullptr || hi != nullptr) ? 1 : 0;
+    for (int j = 0; j < LM_NPMAX; j++) {
+        P.lo[j] = (lo && j < npars) ? lo[j] : -INFINITY;
+        P.hi[j] = (hi && j < npars) ? hi[j] : INFINITY;
+    }
+    hipLaunchKernelGGL(lm_init_kernel, dim3((unsigned)((nobj + BLOCK - 1) / BLOCK)),
+                       dim3(BLOCK), 0, s, states, nobj, x0, P);
+    NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
+}
+
 int launch_lm_finalize(const lm_state *states, int64_t nobj, const int64_t *npix_obj,
                        const double *ff_extra, double pdef, double cdef, double *rec,
                        hipStream_t s)

@@ -129,18 +129,19 @@ class LMBatchFitter(object):
         lo = hi = None
         if self.prior is not None and getattr(self.prior, "bounds", None) is not None:
             lo, hi = bounds_arrays(self.prior.bounds, npars)
-        states = np.zeros(nobj, dtype=_lib.LM_STATE_DTYPE)
-        _lib.check(L.ngmix_lm_init(
-            _lib.ptr(states), nobj, npars, _lib.ptr(guess),
-            float(fp.get("ftol", 1.49012e-8)), float(fp.get("xtol", 1.49012e-8)),
-            float(fp.get("gtol", 0.0)), int(fp.get("maxfev", 100 * (npars + 1))),
-            float(fp.get("factor", 100.0)),
-            _lib.LM_MODE_FD if self.fd else _lib.LM_MODE_ANALYTIC,
-            _lib.ptr(lo) if lo is not None else None,
-            _lib.ptr(hi) if hi is not None else None), "ngmix_lm_init")
-        maxfev = int(states["maxfev"][0])
-
-        d_states = torch.from_numpy(states.view(np.uint8).reshape(nobj, -1)).to(dev)
+        maxfev = int(fp.get("maxfev", 100 * (npars + 1)))
+        d_states = torch.empty((nobj, _lib.LM_STATE_DTYPE.itemsize), dtype=torch.uint8,
+                               device=dev)
+        d_guess = torch.from_numpy(guess).to(dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.ngmix_lm_init_batch(
+                _dptr(d_states), nobj, npars, _dptr(d_guess),
+                float(fp.get("ftol", 1.49012e-8)), float(fp.get("xtol", 1.49012e-8)),
+                float(fp.get("gtol", 0.0)), maxfev, float(fp.get("factor", 100.0)),
+                _lib.LM_MODE_FD if self.fd else _lib.LM_MODE_ANALYTIC,
+                _lib.ptr(lo) if lo is not None else None,
+                _lib.ptr(hi) if hi is not None else None, _stream()),
+                "ngmix_lm_init_batch")
         d_sobj = torch.from_numpy(sobj).to(dev)
         d_sband = torch.from_numpy(sband).to(dev)
         d_start = torch.from_numpy(obj_start).to(dev)
@@ -229,10 +230,15 @@ class LMBatchFitter(object):
             "nfev": rec[:, 1].astype(np.int64),
             "njev": njev.astype(np.int64),
             "ier": rec[:, 2].astype(np.int64),
-            "pars": rec[:, 4:4 + n].copy(),
-            "pars_err": rec[:, 4 + n:4 + 2 * n].copy(),
-            "pars_cov0": rec[:, 4 + 2 * n:4 + 2 * n + n * n].reshape(nobj, n, n).copy(),
-            "pars_cov": rec[:, 4 + 2 * n + n * n:].reshape(nobj, n, n).copy(),
+            # views of the record array (no copies)
+            "pars": rec[:, 4:4 + n],
+            "pars_err": rec[:, 4 + n:4 + 2 * n],
+            "pars_cov0": np.lib.stride_tricks.as_strided(
+                rec[:, 4 + 2 * n:], shape=(nobj, n, n),
+                strides=(rec.strides[0], n * 8, 8), writeable=False),
+            "pars_cov": np.lib.stride_tricks.as_strided(
+                rec[:, 4 + 2 * n + n * n:], shape=(nobj, n, n),
+                strides=(rec.strides[0], n * 8, 8), writeable=False),
             "npix": npix_obj,
             "dof": rec[:, 3].astype(np.int64),
         }
