@@ -44,7 +44,7 @@ from . import bootstrap  # noqa: F401
 from . import gaussmom  # noqa: F401
 from .gaussmom import GaussMom, GaussMomBatch  # noqa: F401
 from . import psfflux  # noqa: F401
-from .psfflux import PSFFluxFitter  # noqa: F401
+from .psfflux import PSFFluxFitter, PSFFluxBatch  # noqa: F401
 from . import batch  # noqa: F401
 from . import prior_batch  # noqa: F401
 from . import lm_batch  # noqa: F401

@@ -9,7 +9,7 @@ from .defaults import PDEF, CDEF
 from .flags import ZERO_DOF, DIV_ZERO, BAD_VAR
 from .observation import Observation, ObsList
 
-__all__ = ["PSFFluxFitter", "PSFFluxFitModel"]
+__all__ = ["PSFFluxFitter", "PSFFluxFitModel", "PSFFluxBatch"]
 
 
 class PSFFluxFitModel(dict):
@@ -153,3 +153,87 @@ class PSFFluxFitter(object):
                                     normalize_psf=self.normalize_psf)
         fit_model.go()
         return fit_model
+
+
+class PSFFluxBatch(object):
+    """
+    PSFFluxFitter over a device-resident batch: one exact render of every
+    stamp's (flux-normalised) psf mixture, then the zero-lag cross-correlation
+    sums of PSFFluxFitModel.go (results.py:700-770) as segmented reductions on
+    the device.  Objects may own several stamps (epochs), as an ObsList does.
+
+        res = PSFFluxBatch().go(stamps, psf_gmixes, stamp_obj=None)
+
+    res: dict of (nobj,) arrays flags, flux, flux_err, chi2per, dof
+    """
+
+    def __init__(self, normalize_psf=True):
+        self.normalize_psf = normalize_psf
+
+    def go(self, stamps, gm, stamp_obj=None):
+        import torch
+        dev = stamps.device
+        ns = stamps.n
+        assert gm.n == ns, "one mixture per stamp"
+        if stamp_obj is None:
+            sobj = np.arange(ns, dtype=np.int64)
+        else:
+            sobj = np.ascontiguousarray(stamp_obj, dtype=np.int64)
+            if sobj.shape != (ns,) or np.any(np.diff(sobj) < 0):
+                raise ValueError("stamp_obj must be (nstamps,) and non-decreasing")
+        nobj = int(sobj.max()) + 1 if ns else 0
+        d_sobj = torch.from_numpy(sobj).to(dev)
+
+        # the unit-flux template and the norm the fitted flux multiplies
+        g = gm.clone()
+        data = g.data.reshape(ns, g.ngauss, 13)
+        psum = data[:, :, 0].sum(dim=1)
+        safe = torch.where(psum != 0, psum, torch.ones_like(psum))
+        data[:, :, 0] /= safe[:, None]
+        data[:, :, 7] = 0.0  # norms are stale (gmix.py set_flux)
+        model, status = stamps.render(g, fast_exp=False)
+        lengths = torch.from_numpy(stamps.npix).to(dev)
+        if not self.normalize_psf:
+            # the mixture keeps its own flux: norm_list = gmix.get_flux()
+            model = model * torch.repeat_interleave(psum, lengths)
+        wt = stamps.ierr * stamps.ierr
+
+        def per_object(x):
+            s = torch.segment_reduce(x, "sum", lengths=lengths)
+            out = torch.zeros(nobj, dtype=torch.float64, device=dev)
+            return out.index_add_(0, d_sobj, s)
+
+        xcorr = per_object(model * stamps.val * wt)
+        msq = per_object(model * model * wt)
+        zero = msq == 0
+        flux = torch.where(zero, torch.full_like(msq, PDEF),
+                           xcorr / torch.where(zero, torch.ones_like(msq), msq))
+        # second pass: chi2 of the scaled template (linear in the flux)
+        fl = torch.repeat_interleave(flux[d_sobj], lengths)
+        chi2 = per_object((fl * model - stamps.val) ** 2 * wt)
+        chi2 = torch.where(zero, torch.zeros_like(chi2), chi2)
+
+        xcorr, msq, flux, chi2 = (t.cpu().numpy() for t in (xcorr, msq, flux, chi2))
+        kept = np.zeros(nobj, dtype=np.int64)
+        np.add.at(kept, sobj, stamps.npix_kept.astype(np.int64))
+        eff = np.zeros(nobj, dtype=np.int64)
+        positive = torch.segment_reduce((stamps.ierr > 0).to(torch.float64), "sum",
+                                        lengths=lengths).cpu().numpy()
+        np.add.at(eff, sobj, positive.astype(np.int64))
+        dof = (eff - 1).astype("f8")
+        flags = np.zeros(nobj, dtype=np.int64)
+        # get_dof floors a non-positive dof at 1e-6, so ZERO_DOF is never
+        # raised and chi2per is always set (results.py:752-757,822-830)
+        dof_used = np.where(dof <= 0, 1.0e-6, dof)
+        chi2per = chi2 / dof_used
+        flux_err = np.full(nobj, CDEF)
+        bad = (msq == 0) | (kept == 1)
+        flags[bad] |= DIV_ZERO
+        with np.errstate(all="ignore"):
+            arg = chi2 / np.where(msq == 0, 1.0, msq) / np.where(kept == 1, 1, kept - 1)
+        neg = ~bad & ~(arg >= 0.0)
+        flags[neg] |= BAD_VAR
+        okv = ~bad & (arg >= 0.0)
+        flux_err[okv] = np.sqrt(arg[okv])
+        return {"flags": flags, "flux": flux, "flux_err": flux_err, "chi2per": chi2per,
+                "dof": dof_used, "status": status.cpu().numpy()}

@@ -125,3 +125,45 @@ def test_noise_cov_central_difference_images(golden):
     ana = noise_cov._dmodel_images_all(fm, g["nc_sandwich_pars"])[0]
     for a in range(6):
         assert np.abs(ana[a] - ref[a]).max() <= 2e-4 * np.abs(ref[a]).max()
+
+
+def test_psf_flux_batch_matches_per_object():
+    """PSFFluxBatch against PSFFluxFitter object by object: single- and
+    multi-epoch objects, masked pixels, normalised and raw psf mixtures"""
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    rng = np.random.RandomState(3)
+    scale = 0.263
+    objs, stamps_obs, sobj, psf_recs = [], [], [], []
+    for o in range(7):
+        nep = 1 + o % 3
+        ol = ngmix.ObsList()
+        for e in range(nep):
+            dim = 17 + 2 * ((o + e) % 3)
+            cen = (dim - 1) / 2.0 + rng.uniform(-0.3, 0.3, size=2)
+            jac = ngmix.DiagonalJacobian(row=cen[0], col=cen[1], scale=scale)
+            pgm = ngmix.GMix(pars=[0.7, 0.0, 0.0, 0.06, 0.002, 0.07,
+                                   0.5, 0.01, -0.01, 0.15, 0.0, 0.16])
+            flux = rng.uniform(5.0, 50.0)
+            im = pgm.make_image((dim, dim), jacobian=jac) * (flux / pgm.get_flux())
+            im += 0.01 * rng.normal(size=im.shape)
+            wt = np.full(im.shape, 1.0e4)
+            if o == 4:
+                wt[3:5, 2:9] = 0.0
+            pobs = ngmix.Observation(np.zeros((5, 5)), jacobian=jac, gmix=pgm)
+            ob = ngmix.Observation(im, weight=wt, jacobian=jac, psf=pobs)
+            ol.append(ob)
+            stamps_obs.append(ob)
+            sobj.append(o)
+            psf_recs.append(pgm.get_data().copy())
+        objs.append(ol)
+    sb = StampBatch.from_observations(stamps_obs)
+    psf = GMixBatch.from_numpy(np.stack(psf_recs))
+    for normalize in (True, False):
+        res = ngmix.PSFFluxBatch(normalize_psf=normalize).go(sb, psf, stamp_obj=sobj)
+        for o, ol in enumerate(objs):
+            one = ngmix.PSFFluxFitter(normalize_psf=normalize).go(ol)
+            assert res["flags"][o] == one["flags"] == 0
+            np.testing.assert_allclose(res["flux"][o], one["flux"], rtol=1e-11)
+            np.testing.assert_allclose(res["flux_err"][o], one["flux_err"], rtol=1e-9)
+            np.testing.assert_allclose(res["chi2per"][o], one["chi2per"], rtol=1e-9)
+            np.testing.assert_allclose(res["dof"][o], one["dof"])
