@@ -19,7 +19,8 @@ import numpy as np
 from . import gmix as gmix_mod
 from .gexceptions import GMixRangeError
 
-__all__ = ["calc_noise_cov", "apply_noise_cov"]
+__all__ = ["calc_noise_cov", "apply_noise_cov", "calc_noise_cov_batch",
+           "apply_noise_cov_batch"]
 
 # absolute floors of the central-difference steps (results.py:929-936)
 STEP_CEN = 1.0e-3
@@ -155,3 +156,157 @@ def _dmodel(fit_model, pars, ipar, band, obs):
             gm = gm.convolve(obs.psf.gmix)
         ims.append(gm.make_image(obs.image.shape, jacobian=obs.jacobian, fast_exp=True))
     return (ims[0] - ims[1]) / (2 * step)
+
+
+# ---------------------------------------------------------------------------
+# the same for a device-resident batch of fits (LMBatchFitter results)
+# ---------------------------------------------------------------------------
+
+def calc_noise_cov_batch(stamps, noise, model, pars, pars_cov0, psf=None,
+                         stamp_obj=None, stamp_band=None, chunk_stamps=4096):
+    """
+    calc_noise_cov for N fits at once.
+
+    stamps: StampBatch of every epoch of every object (its weights are the
+        `obs.weight` of the reference's kernels)
+    noise: flat float64 device tensor laid out like stamps.val: each stamp's
+        noise image (Observation.noise)
+    model: 'gauss' | 'exp' | 'dev' (the models with analytic derivative images)
+    pars (nobj, 5 + nband), pars_cov0 (nobj, npars, npars): the solutions and
+        their unscaled covariances (LMBatchFitter's 'pars' / 'pars_cov0')
+    psf: GMixBatch, one mixture per stamp, or None
+
+    One deriv_images launch per chunk of equally shaped stamps, then rocFFT
+    (torch.fft) of weight x derivative images and of the noise images, the
+    per-mode sums as one contraction, and A^-1 B A^-1 per object.
+    Returns the (nobj, npars, npars) sandwich covariances as a numpy array
+    (NaN where the model is out of range or a flux is zero).
+    """
+    import torch
+    from .batch import GMixBatch, StampBatch, _as_device_f64
+    from .fitting import SIMPLE_ANALYTIC_MODELS
+    if model not in SIMPLE_ANALYTIC_MODELS:
+        raise NotImplementedError(
+            "calc_noise_cov_batch needs analytic derivative images (%s); use "
+            "Fitter(use_noise_image=True) per object for '%s'"
+            % (", ".join(SIMPLE_ANALYTIC_MODELS), model))
+    dev = stamps.device
+    ns = stamps.n
+    pars = np.ascontiguousarray(pars, dtype="f8")
+    nobj, npars = pars.shape
+    nshape = 5
+    nband = npars - nshape
+    sobj = (np.arange(ns, dtype=np.int64) if stamp_obj is None
+            else np.ascontiguousarray(stamp_obj, dtype=np.int64))
+    sband = (np.zeros(ns, dtype=np.int64) if stamp_band is None
+             else np.ascontiguousarray(stamp_band, dtype=np.int64))
+
+    # every stamp's mixtures at its object's solution
+    bp = np.empty((ns, 6))
+    bp[:, :5] = pars[sobj, :5]
+    bp[:, 5] = pars[sobj, 5 + sband]
+    gm0, st0 = GMixBatch.from_pars(bp, model, device=dev)
+    gmc = gm0
+    if psf is not None:
+        gmc, _ = gm0.convolve(psf)
+    ng0, G = gm0.ngauss, gmc.ngauss
+    npsf = G // ng0
+    G0 = gm0.data.reshape(ns, ng0, 13)
+    GC = gmc.data.reshape(ns, G, 13)
+    gpars = GC[:, :, 0:6].contiguous()
+    modcov = G0[:, :, 3:6].repeat_interleave(npsf, dim=1)          # (ns, G, 3)
+    # d(irr, irc, icc) / d(g1, g2, T) of each component (results.py:955-1010)
+    d_bp = _as_device_f64(bp, dev)
+    g1, g2, T, flux = d_bp[:, 2], d_bp[:, 3], d_bp[:, 4], d_bp[:, 5]
+    gsq = g1 * g1 + g2 * g2
+    f = 2.0 / (1.0 + gsq)
+    dfac = -f / (1.0 + gsq)
+    de1 = torch.stack([f + 2.0 * g1 * g1 * dfac, 2.0 * g1 * g2 * dfac], dim=1)  # d e1 / d g1,g2
+    de2 = torch.stack([2.0 * g1 * g2 * dfac, f + 2.0 * g2 * g2 * dfac], dim=1)  # d e2 / d g1,g2
+    Tk = modcov[:, :, 0] + modcov[:, :, 2]
+    dcov = torch.zeros((ns, G, 3, 3), dtype=torch.float64, device=dev)
+    for i in range(2):
+        dcov[:, :, i, 0] = -0.5 * Tk * de1[:, i, None]
+        dcov[:, :, i, 1] = 0.5 * Tk * de2[:, i, None]
+        dcov[:, :, i, 2] = 0.5 * Tk * de1[:, i, None]
+    dcov[:, :, 2, :] = modcov / T[:, None, None]
+
+    wt = stamps.ierr * stamps.ierr
+    d_sobj = torch.from_numpy(sobj).to(dev)
+    # local parameter k of a stamp -> column of its object's matrix
+    cols = np.concatenate([np.tile(np.arange(5), (ns, 1)), (5 + sband)[:, None]], axis=1)
+    d_cols = torch.from_numpy(cols).to(dev)
+    B = torch.zeros((nobj, npars, npars), dtype=torch.float64, device=dev)
+    bad = (st0 != 0) | (flux == 0.0)
+
+    shapes = np.stack([stamps.nrow, stamps.ncol], axis=1)
+    for shp in np.unique(shapes, axis=0):
+        members = np.nonzero((shapes == shp).all(axis=1))[0]
+        nrow, ncol = int(shp[0]), int(shp[1])
+        npix = nrow * ncol
+        for a in range(0, members.size, chunk_stamps):
+            idx = members[a:a + chunk_stamps]
+            m = idx.size
+            d_idx = torch.from_numpy(idx).to(dev)
+            geom = StampBatch(None, None, stamps.jac[d_idx], np.full(m, nrow),
+                              np.full(m, ncol), np.arange(m, dtype=np.int64) * npix, True)
+            out = geom.deriv_images(gpars[d_idx].reshape(-1, 6),
+                                    dcov[d_idx].reshape(-1, 3, 3), G)
+            out = out.reshape(m, 6, nrow, ncol)
+            # [cen1, cen2, g1, g2, T, flux]: the flux derivative is value / flux
+            D = torch.cat([out[:, 1:6], (out[:, 0] / flux[d_idx, None, None])[:, None]],
+                          dim=1)
+            pix = (torch.from_numpy(stamps.pix_off[idx]).to(dev)[:, None] +
+                   torch.arange(npix, device=dev)[None, :])
+            W = wt[pix].reshape(m, 1, nrow, ncol)
+            K = torch.fft.fft2(W * D)
+            P = torch.fft.fft2(noise[pix].reshape(m, nrow, ncol)).abs() ** 2
+            Bs = torch.einsum("naxy,nbxy,nxy->nab", K.conj(), K,
+                              P.to(K.dtype)).real / float(npix) ** 2
+            # scatter the 6x6 blocks into the objects' matrices
+            oi = d_sobj[d_idx][:, None, None].expand(m, 6, 6)
+            ci = d_cols[d_idx]
+            B.index_put_((oi, ci[:, :, None].expand(m, 6, 6), ci[:, None, :].expand(m, 6, 6)),
+                         Bs, accumulate=True)
+    cov0 = _as_device_f64(np.ascontiguousarray(pars_cov0, dtype="f8"), dev)
+    cov = cov0 @ B @ cov0
+    obad = torch.zeros(nobj, dtype=torch.bool, device=dev)
+    obad.index_put_((d_sobj,), bad, accumulate=True)
+    cov[obad] = float("nan")
+    return cov.cpu().numpy()
+
+
+def apply_noise_cov_batch(res, stamps, noise, model, psf=None, stamp_obj=None,
+                          stamp_band=None):
+    """apply_noise_cov for an LMBatchFitter result dict (modified in place):
+    the fits with flags == 0 get the sandwich covariance, or the covariance
+    sanity flags and default errors when it is not positive"""
+    from .defaults import CDEF
+    from .flags import LM_NEG_COV_EIG, LM_NEG_COV_DIAG
+    ok = res["flags"] == 0
+    if not np.any(ok):
+        return res
+    cov0 = np.where(ok[:, None, None], res["pars_cov0"], 0.0)
+    pars = res["pars"].copy()
+    pars[~ok] = 1.0  # any in-range point: their rows are not used
+    pars[~ok, 2:4] = 0.0
+    cov = calc_noise_cov_batch(stamps, noise, model, pars, cov0, psf=psf,
+                               stamp_obj=stamp_obj, stamp_band=stamp_band)
+    finite = np.all(np.isfinite(cov), axis=(1, 2))
+    sym = 0.5 * (cov + np.transpose(cov, (0, 2, 1)))
+    eig = np.linalg.eigvalsh(np.where(finite[:, None, None], sym, np.eye(cov.shape[1])))
+    diag = np.diagonal(cov, axis1=1, axis2=2)
+    cflags = np.where(~finite | (eig.min(axis=1) < 0), LM_NEG_COV_EIG, 0)
+    cflags |= np.where(~finite | np.any(diag < 0, axis=1), LM_NEG_COV_DIAG, 0)
+    good = ok & (cflags == 0)
+    failed = ok & (cflags != 0)
+    pc = np.array(res["pars_cov"])
+    pe = np.array(res["pars_err"])
+    pc[good] = cov[good]
+    with np.errstate(invalid="ignore"):
+        pe[good] = np.sqrt(diag[good])
+    pc[failed] = CDEF
+    pe[failed] = CDEF
+    res["flags"] = res["flags"] | np.where(failed, cflags, 0)
+    res["pars_cov"], res["pars_err"] = pc, pe
+    return res

@@ -167,3 +167,69 @@ def test_psf_flux_batch_matches_per_object():
             np.testing.assert_allclose(res["flux_err"][o], one["flux_err"], rtol=1e-9)
             np.testing.assert_allclose(res["chi2per"][o], one["chi2per"], rtol=1e-9)
             np.testing.assert_allclose(res["dof"][o], one["dof"])
+
+
+def test_noise_cov_batch_matches_per_object(golden):
+    """calc_noise_cov_batch / apply_noise_cov_batch on LMBatchFitter results
+    against Fitter(use_noise_image=True) object by object (which the golden
+    pins to the reference): the golden two-epoch object, plus single-epoch
+    objects of another shape with correlated noise"""
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    from ngmix_amd.lm_batch import LMBatchFitter
+    from ngmix_amd.noise_cov import apply_noise_cov_batch
+    g = golden("extra")
+    objs = [(_nc_obslist(g), g["nc_guess"])]
+    rng = np.random.RandomState(12)
+    scale = 0.263
+    for o in range(3):
+        dim = 32
+        jac = ngmix.DiagonalJacobian(row=15.5 + 0.2 * o, col=15.5 - 0.1 * o, scale=scale)
+        pgm = ngmix.GMixModel([0.0, 0.0, 0.01, 0.02, 0.25, 1.0], "gauss")
+        truth = np.array([0.02, -0.03, 0.1, -0.05, 0.5 + 0.1 * o, 80.0])
+        im = ngmix.GMixModel(truth, "exp").convolve(pgm).make_image(
+            (dim, dim), jacobian=jac, fast_exp=True)
+        white = rng.normal(size=(2, dim, dim))
+        # correlate along rows: stationary, non-white
+        noise = [0.02 * (w + np.roll(w, 1, axis=0) + np.roll(w, 1, axis=1)) for w in white]
+        pobs = ngmix.Observation(np.zeros((5, 5)), jacobian=jac, gmix=pgm)
+        ob = ngmix.Observation(im + noise[0], weight=np.full(im.shape, 1.0 / (3 * 0.02 ** 2)),
+                               jacobian=jac, psf=pobs, noise=noise[1])
+        ol = ngmix.ObsList()
+        ol.append(ob)
+        objs.append((ol, truth * (1.0 + 0.03 * rng.uniform(-1, 1, size=6))))
+    flat, sobj, psfs, guesses = [], [], [], []
+    for i, (ol, guess) in enumerate(objs):
+        for ob in ol:
+            flat.append(ob)
+            sobj.append(i)
+            psfs.append(ob.psf.gmix.get_data().copy())
+        guesses.append(guess)
+    sb = StampBatch.from_observations(flat)
+    noise = np.concatenate([np.asarray(ob.noise, dtype="f8").ravel() for ob in flat])
+    import torch
+    d_noise = torch.from_numpy(noise).to(sb.device)
+    # one gaussian count per batch: pad the smaller psf mixtures with
+    # zero-flux components (they add nothing to any convolved model)
+    ngmax = max(p.size for p in psfs)
+    padded = []
+    for p in psfs:
+        q = np.concatenate([p] + [p[:1]] * (ngmax - p.size))
+        q["p"][p.size:] = 0.0
+        padded.append(q)
+    psf = GMixBatch.from_numpy(np.stack(padded))
+    psf.set_norms()
+    sobj = np.array(sobj, dtype=np.int32)
+    res = LMBatchFitter("exp").go(sb, np.array(guesses), psf=psf, stamp_obj=sobj)
+    plain_err = res["pars_err"].copy()
+    apply_noise_cov_batch(res, sb, d_noise, "exp", psf=psf, stamp_obj=sobj)
+    assert np.all(res["flags"] == 0)
+    for i, (ol, guess) in enumerate(objs):
+        one = ngmix.fitting.Fitter(model="exp", use_noise_image=True).go(obs=ol, guess=guess)
+        assert one["flags"] == 0
+        np.testing.assert_allclose(res["pars"][i], one["pars"], rtol=1e-6, atol=1e-8)
+        sig = np.sqrt(np.diag(one["pars_cov"]))
+        assert np.all(np.abs(res["pars_cov"][i] - one["pars_cov"]) <=
+                      1e-4 * np.abs(one["pars_cov"]) + 1e-6 * np.outer(sig, sig)), i
+        np.testing.assert_allclose(res["pars_err"][i], one["pars_err"], rtol=1e-4)
+    # correlated noise: well above the chi2-scaled errors
+    assert np.all(res["pars_err"][0] > 2 * plain_err[0])
