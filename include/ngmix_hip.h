@@ -142,7 +142,8 @@ const char *ngmix_version(void);
 const char *ngmix_last_error(void);
 /* sizeof() of an ABI record by its type name ("ngmix_gauss2d", "ngmix_pixel",
    "ngmix_coord", "ngmix_jacobian", "ngmix_admom_conf", "ngmix_admom_result",
-   "ngmix_em_conf", "ngmix_stamp", "ngmix_batch", "ngmix_lm_state"), -1 for an
+   "ngmix_em_conf", "ngmix_stamp", "ngmix_batch", "ngmix_lm_state",
+   "ngmix_simple_sep_prior"), -1 for an
    unknown name: lets a binding check its own record layouts at load time */
 int64_t ngmix_abi_sizeof(const char *type_name);
 int ngmix_device_count(void);
@@ -463,6 +464,41 @@ int ngmix_lm_advance_batch(ngmix_lm_state *states, int64_t nobj,
                            const int64_t *obj_start, const int32_t *stamp_band,
                            const double *sums, int nloc, const double *obj_sums,
                            int32_t *nactive, void *stream);
+
+/* The separable joint prior of the reference's PriorSimpleSep
+   (joint_prior.py:10-120) in a form a kernel can evaluate: gaussian centre
+   terms (priors/multivariate.py CenPrior), the Bernstein-Armstrong shape
+   prior (priors/shape.py GPriorBA), and per T / band flux either FlatPrior
+   (par = minval, maxval) or TwoSidedErf (par = minval, width_at_min, maxval,
+   width_at_max) from priors/priors.py */
+#define NGMIX_PRIOR_FLAT 0
+#define NGMIX_PRIOR_TWO_SIDED_ERF 1
+#define NGMIX_PRIOR_MAXBAND 3
+typedef struct {
+    double cen1, cen2, cen_s2inv1, cen_s2inv2;
+    double g_sig2inv;
+    double T_par[4];
+    double F_par[NGMIX_PRIOR_MAXBAND][4];
+    int32_t T_kind, nband;
+    int32_t F_kind[NGMIX_PRIOR_MAXBAND];
+    int32_t pad_;
+} ngmix_simple_sep_prior; /* 176 B */
+/* DEVICE: the prior rows [cen1, cen2, g, T, F_band...] = sqrt(max(-2 ln p, 0))
+   of every object at its trial point states[i].xt, their jacobian by
+   differences (analytic mode: the reference's one-sided steps
+   step_rel * max(1, |x_j|), backward where the forward point is out of range,
+   results.py:572-625; forward-difference mode: the state's xstep / hstep),
+   reduced to obj_sums (nobj, NGMIX_LM_NSUMS(5 + nband)) for
+   ngmix_lm_advance_batch.  An out-of-range point (g >= 1, outside a flat
+   prior) gives r.r = +inf: the reference's GMixRangeError -> -inf residuals */
+int ngmix_lm_prior_sums_batch(const ngmix_lm_state *states, int64_t nobj,
+                              const ngmix_simple_sep_prior *prior, double step_rel,
+                              double *obj_sums, void *stream);
+/* HOST: rows (max 4 + nband) and ln p of one parameter vector: returns the
+   number of rows, or -1 when the point is out of range (testing aid; the same
+   code the kernel runs) */
+int ngmix_simple_sep_prior_eval(const ngmix_simple_sep_prior *prior,
+                                const double *pars, double *rows, double *lnprob);
 
 /* DEVICE: package every fit as run_leastsq does (leastsqbound.py:33-155):
    rec is (nobj, 4 + 2n + 2n^2) doubles per object, n = states[i].n:

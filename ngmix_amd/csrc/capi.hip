@@ -101,6 +101,7 @@ int64_t ngmix_abi_sizeof(const char *type_name)
     NGMIX_SIZEOF_CASE(ngmix_stamp);
     NGMIX_SIZEOF_CASE(ngmix_batch);
     NGMIX_SIZEOF_CASE(ngmix_lm_state);
+    NGMIX_SIZEOF_CASE(ngmix_simple_sep_prior);
 #undef NGMIX_SIZEOF_CASE
     return -1;
 }
@@ -583,6 +584,26 @@ int ngmix_lm_init_batch(ngmix_lm_state *states, int64_t nobj, int npars, const d
     }
     return launch_lm_init(states, nobj, npars, x0, ftol, xtol, gtol, maxfev, factor, mode,
                           lo, hi, (hipStream_t)stream);
+}
+
+int ngmix_lm_prior_sums_batch(const ngmix_lm_state *states, int64_t nobj,
+                              const ngmix_simple_sep_prior *prior, double step_rel,
+                              double *obj_sums, void *stream)
+{
+    return launch_lm_prior_sums(states, nobj, prior, step_rel, obj_sums,
+                                (hipStream_t)stream);
+}
+
+int ngmix_simple_sep_prior_eval(const ngmix_simple_sep_prior *prior, const double *pars,
+                                double *rows, double *lnprob)
+{
+    if (!prior || prior->nband < 1 || prior->nband > NGMIX_PRIOR_MAXBAND) return -2;
+    double r[4 + NGMIX_PRIOR_MAXBAND], lnp = 0.0;
+    if (!lmcore::simple_sep_rows(*prior, pars, r, &lnp)) return -1;
+    const int k = 4 + prior->nband;
+    for (int i = 0; i < k; i++) rows[i] = r[i];
+    if (lnprob) *lnprob = lnp;
+    return k;
 }
 
 int64_t ngmix_lm_advance_host(ngmix_lm_state *states, int64_t nobj, const double *ff,

@@ -49,6 +49,9 @@ int launch_lm_advance(ngmix_lm_state *states, int64_t nobj, const int64_t *obj_s
                       const int32_t *stamp_band, const double *sums, int nloc,
                       const double *obj_sums, int32_t *nactive, hipStream_t s);
 
+int launch_lm_prior_sums(const ngmix_lm_state *states, int64_t nobj,
+                         const ngmix_simple_sep_prior *prior, double step_rel,
+                         double *obj_sums, hipStream_t s);
 int launch_lm_init(ngmix_lm_state *states, int64_t nobj, int npars, const double *x0,
                    double ftol, double xtol, double gtol, int maxfev, double factor,
                    int mode, const double *lo, const double *hi, hipStream_t s);

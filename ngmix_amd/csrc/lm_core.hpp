@@ -556,4 +556,103 @@ NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g_in, const doubl
     }
 }
 
+// ---- the separable joint prior (ngmix_simple_sep_prior) --------------------
+// ln p of one T / flux term; returns false where the reference raises
+// GMixRangeError (FlatPrior outside its range, priors/priors.py:85-100)
+NGMIX_HD bool prior_term_lnp(int kind, const double *par, double x, double &lnp)
+{
+    if (kind == NGMIX_PRIOR_TWO_SIDED_ERF) {
+        // priors/priors.py:219-251
+        const double p = 0.5 * erf((par[2] - x) / par[3]) + 0.5 * erf((x - par[0]) / par[1]);
+        lnp = p > 0.0 ? log(p) : -INFINITY;
+        return true;
+    }
+    lnp = 0.0;
+    return !(x < par[0] || x > par[1]);
+}
+
+// rows[k] = sqrt(max(-2 ln p_k, 0)) for k = cen1, cen2, g, T, F_0.. ; false
+// when out of range (joint_prior.py:86-120)
+NGMIX_HD bool simple_sep_rows(const ngmix_simple_sep_prior &P, const double *x,
+                              double *rows, double *lnp_total)
+{
+    double lnp[4 + NGMIX_PRIOR_MAXBAND];
+    const double d1 = P.cen1 - x[0], d2 = P.cen2 - x[1];
+    lnp[0] = -0.5 * d1 * d1 * P.cen_s2inv1;
+    lnp[1] = -0.5 * d2 * d2 * P.cen_s2inv2;
+    const double gsq = x[2] * x[2] + x[3] * x[3];
+    const double omgsq = 1.0 - gsq;
+    if (omgsq <= 0.0) return false;
+    lnp[2] = 2.0 * log(omgsq) - 0.5 * gsq * P.g_sig2inv;
+    if (!prior_term_lnp(P.T_kind, P.T_par, x[4], lnp[3])) return false;
+    for (int b = 0; b < P.nband; b++)
+        if (!prior_term_lnp(P.F_kind[b], P.F_par[b], x[5 + b], lnp[4 + b])) return false;
+    double tot = 0.0;
+    for (int k = 0; k < 4 + P.nband; k++) {
+        double chi2 = -2.0 * lnp[k];
+        if (chi2 < 0.0) chi2 = 0.0;
+        rows[k] = sqrt(chi2);
+        tot += lnp[k];
+    }
+    if (lnp_total) *lnp_total = tot;
+    return true;
+}
+
+// the prior rows of one fit at its trial point as normal-equation sums
+// [J^T J upper triangle | J^T r | r.r] over the fit's n = 5 + nband parameters
+NGMIX_HD void simple_sep_normal_sums(const ngmix_simple_sep_prior &P, const lm_state &s,
+                                     double step_rel, double *out)
+{
+    constexpr int KMAX = 4 + NGMIX_PRIOR_MAXBAND;
+    const int n = s.n, k = 4 + P.nband, nt = n * (n + 1) / 2;
+    double r0[KMAX], rj[KMAX], J[KMAX][LM_NPMAX];
+    for (int i = 0; i < nt + n + 1; i++) out[i] = 0.0;
+    double x[LM_NPMAX];
+    for (int j = 0; j < LM_NPMAX; j++) x[j] = s.xt[j];
+    if (!simple_sep_rows(P, x, r0, nullptr)) {
+        out[nt + n] = INFINITY;
+        return;
+    }
+    const bool fd = s.mode == NGMIX_LM_MODE_FD;
+    for (int j = 0; j < n; j++) {
+        double step;
+        bool ok;
+        const double xj = x[j];
+        if (fd) {
+            step = s.hstep[j];
+            x[j] = s.xstep[j];
+            ok = simple_sep_rows(P, x, rj, nullptr);
+        } else {
+            step = step_rel * fmax(1.0, fabs(xj));
+            x[j] = xj + step;
+            ok = simple_sep_rows(P, x, rj, nullptr);
+            if (!ok) {
+                step = -step;
+                x[j] = xj + step;
+                ok = simple_sep_rows(P, x, rj, nullptr);
+            }
+        }
+        x[j] = xj;
+        for (int i = 0; i < k; i++) {
+            const bool good = ok && fabs(r0[i]) < INFINITY && fabs(rj[i]) < INFINITY;
+            J[i][j] = good ? (rj[i] - r0[i]) / step : 0.0;
+        }
+    }
+    int t = 0;
+    for (int a = 0; a < n; a++) {
+        for (int b = a; b < n; b++) {
+            double acc = 0.0;
+            for (int i = 0; i < k; i++) acc += J[i][a] * J[i][b];
+            out[t++] = acc;
+        }
+        double acc = 0.0;
+        for (int i = 0; i < k; i++)
+            if (fabs(r0[i]) < INFINITY) acc += J[i][a] * r0[i];
+        out[nt + a] = acc;
+    }
+    double ff = 0.0;
+    for (int i = 0; i < k; i++) ff += r0[i] * r0[i];
+    out[nt + n] = ff;
+}
+
 }  // namespace lmcore

@@ -677,6 +677,34 @@ __global__ __launch_bounds__(BLOCK) void lm_finalize_kernel(
     r[3] = (double)dof;
 }
 
+__global__ __launch_bounds__(BLOCK) void lm_prior_sums_kernel(
+    const lm_state *__restrict__ states, int64_t nobj, ngmix_simple_sep_prior P,
+    double step_rel, double *__restrict__ obj_sums)
+{
+    const int64_t o = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+    if (o >= nobj) return;
+    const lm_state &s = states[o];
+    const int n = s.n;
+    double out[NGMIX_LM_NSUMS(LM_NPMAX)];
+    if (s.phase == LM_PHASE_DONE) return;
+    lmcore::simple_sep_normal_sums(P, s, step_rel, out);
+    double *dst = obj_sums + o * (int64_t)(n * (n + 1) / 2 + n + 1);
+    for (int i = 0; i < n * (n + 1) / 2 + n + 1; i++) dst[i] = out[i];
+}
+
+int launch_lm_prior_sums(const lm_state *states, int64_t nobj,
+                         const ngmix_simple_sep_prior *prior, double step_rel,
+                         double *obj_sums, hipStream_t s)
+{
+    if (nobj <= 0) return NGMIX_OK;
+    if (!prior || prior->nband < 1 || prior->nband > NGMIX_PRIOR_MAXBAND)
+        return NGMIX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(lm_prior_sums_kernel, dim3((unsigned)((nobj + BLOCK - 1) / BLOCK)),
+                       dim3(BLOCK), 0, s, states, nobj, *prior, step_rel, obj_sums);
+    NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
+}
+
 struct LmInitPars {
     double ftol, xtol, gtol, factor;
     double lo[LM_NPMAX], hi[LM_NPMAX];
