@@ -482,7 +482,7 @@ typedef struct {
     int32_t T_kind, nband;
     int32_t F_kind[NGMIX_PRIOR_MAXBAND];
     int32_t pad_;
-} ngmix_simple_sep_prior; /* 176 B */
+} ngmix_simple_sep_prior; /* 192 B */
 /* DEVICE: the prior rows [cen1, cen2, g, T, F_band...] = sqrt(max(-2 ln p, 0))
    of every object at its trial point states[i].xt, their jacobian by
    differences (analytic mode: the reference's one-sided steps

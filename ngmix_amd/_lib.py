@@ -115,6 +115,18 @@ LM_STATE_DTYPE = np.dtype([
 ], align=True)
 
 
+PRIOR_FLAT = 0
+PRIOR_TWO_SIDED_ERF = 1
+PRIOR_MAXBAND = 3
+# ngmix_simple_sep_prior (include/ngmix_hip.h)
+SIMPLE_SEP_PRIOR_DTYPE = np.dtype([
+    ("cen1", "f8"), ("cen2", "f8"), ("cen_s2inv1", "f8"), ("cen_s2inv2", "f8"),
+    ("g_sig2inv", "f8"), ("T_par", "f8", 4), ("F_par", "f8", (PRIOR_MAXBAND, 4)),
+    ("T_kind", "i4"), ("nband", "i4"), ("F_kind", "i4", PRIOR_MAXBAND), ("pad_", "i4"),
+], align=True)
+assert SIMPLE_SEP_PRIOR_DTYPE.itemsize == 192
+
+
 class Batch(ctypes.Structure):
     """ngmix_batch: host struct of device pointers"""
     _fields_ = [
@@ -196,6 +208,8 @@ SIGNATURES = {
                               _vp, _vp]),
     "ngmix_lm_init_batch": (_i32, [_vp, _i64, _i32, _vp, _f64, _f64, _f64, _i32, _f64,
                                     _i32, _vp, _vp, _vp]),
+    "ngmix_lm_prior_sums_batch": (_i32, [_vp, _i64, _vp, _f64, _vp, _vp]),
+    "ngmix_simple_sep_prior_eval": (_i32, [_vp, _vp, _vp, _vp]),
     "ngmix_lm_advance_host": (_i64, [_vp, _i64, _vp, _vp, _vp]),
     "ngmix_lm_eval_batch": (_i32, [_pb, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp,
                                    _vp, _vp]),

@@ -38,7 +38,7 @@ from . import _lib
 from .batch import GMixBatch, _dptr, _stream, _torch
 from .defaults import PDEF, CDEF, DEFAULT_LM_PARS
 from .gmix import get_model_num
-from .fitting import get_lm_n_prior_pars
+from .fitting import get_lm_n_prior_pars, STEP_PRIOR
 from .prior_batch import bounds_arrays, prior_normal_sums
 
 __all__ = ["LMBatchFitter"]
@@ -66,8 +66,11 @@ class LMBatchFitter(object):
         around a reference-style prior, or anything with their three members)
     """
 
-    def __init__(self, model, fit_pars=None, analytic_jacobian=True, prior=None):
+    def __init__(self, model, fit_pars=None, analytic_jacobian=True, prior=None,
+                 device_prior=True):
         self.prior = prior
+        # evaluate a PriorSimpleSepBatch inside one kernel (False: torch ops)
+        self.device_prior = device_prior
         if model not in MODEL_NLOC:
             raise ValueError("LMBatchFitter supports %s" % (tuple(MODEL_NLOC),))
         self.model = model
@@ -159,6 +162,18 @@ class LMBatchFitter(object):
             a = fields[name][1] // 8
             return sview[:, a:a + npars]
         d_osums = None
+        prior_desc = None
+        if self.prior is not None and self.device_prior and \
+                hasattr(self.prior, "descriptor") and nshape == 5:
+            prior_desc = self.prior.descriptor()
+            if prior_desc is not None and int(prior_desc["nband"][0]) != nband:
+                raise ValueError("the prior has %d flux terms, the guess %d bands"
+                                 % (int(prior_desc["nband"][0]), nband))
+        if prior_desc is not None:
+            d_osums = torch.zeros((nobj, npars * (npars + 1) // 2 + npars + 1),
+                                  dtype=torch.float64, device=dev)
+        self.prior_path = ("kernel" if prior_desc is not None else
+                           "torch" if self.prior is not None else None)
         rounds = 0
         import time
         torch.cuda.synchronize(dev)
@@ -170,8 +185,12 @@ class LMBatchFitter(object):
                     _dptr(d_sband), _dptr(psf.data) if psf is not None else None,
                     npsf, _dptr(d_sums), _dptr(d_status), _stream()),
                     "ngmix_lm_eval_batch")
-                if self.prior is not None:
+                if prior_desc is not None:
                     # the prior rows at the same trial points (results.py:454)
+                    _lib.check(L.ngmix_lm_prior_sums_batch(
+                        _dptr(d_states), nobj, _lib.ptr(prior_desc), STEP_PRIOR,
+                        _dptr(d_osums), _stream()), "ngmix_lm_prior_sums_batch")
+                elif self.prior is not None:
                     if self.fd:
                         d_osums, _ = prior_normal_sums(
                             self.prior, col("xt"), col("xstep"), col("hstep"))

@@ -122,6 +122,40 @@ class PriorSimpleSepBatch(object):
                 bounds.append((None, None))
         self.bounds = bounds if some else None
 
+    def descriptor(self):
+        """the ngmix_simple_sep_prior record of this prior, for the kernel
+        that evaluates the prior rows of all fits in one launch
+        (ngmix_lm_prior_sums_batch); None when a term is not one of the
+        kinds the kernel knows, the torch path then serves"""
+        from . import _lib
+        if not isinstance(self.cen_prior, GaussianCen) or \
+                not isinstance(self.g_prior, GPriorBA) or self.nband > _lib.PRIOR_MAXBAND:
+            return None
+        d = np.zeros(1, dtype=_lib.SIMPLE_SEP_PRIOR_DTYPE)
+        d["cen1"], d["cen2"] = self.cen_prior.cen1, self.cen_prior.cen2
+        d["cen_s2inv1"], d["cen_s2inv2"] = self.cen_prior.s2inv1, self.cen_prior.s2inv2
+        d["g_sig2inv"] = self.g_prior.sig2inv
+        d["nband"] = self.nband
+
+        def term(p):
+            if isinstance(p, TwoSidedErf):
+                return _lib.PRIOR_TWO_SIDED_ERF, [p.minval, p.width_at_min, p.maxval,
+                                                  p.width_at_max]
+            if isinstance(p, Flat):
+                return _lib.PRIOR_FLAT, [p.minval, p.maxval, 0.0, 0.0]
+            return None, None
+        kind, par = term(self.T_prior)
+        if kind is None:
+            return None
+        d["T_kind"], d["T_par"] = kind, par
+        for i, Fp in enumerate(self.F_priors):
+            kind, par = term(Fp)
+            if kind is None:
+                return None
+            d["F_kind"][0, i] = kind
+            d["F_par"][0, i] = par
+        return d
+
     def _lnprobs(self, pars):
         torch = _torch()
         l1, l2 = self.cen_prior.lnprob_sep(pars[:, 0], pars[:, 1])

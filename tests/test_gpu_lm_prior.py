@@ -124,7 +124,8 @@ def _compare(res, fits, analytic, ptol):
 
 @pytest.mark.parametrize("case", list(PRIOR_CASES))
 @pytest.mark.parametrize("analytic", [True, False], ids=["lmder", "lmdif"])
-def test_batch_prior_matches_per_object_fitter(case, analytic):
+@pytest.mark.parametrize("device_prior", [True, False], ids=["kernel", "torch"])
+def test_batch_prior_matches_per_object_fitter(case, analytic, device_prior):
     cfg = PRIOR_CASES[case]
     obs, sb, psf, truth, guess = _sim("exp", 10, 40 + len(case))
     sprior = ScalarSimpleSep(0.1, 0.3, cfg["T_term"], cfg["F_term"], cfg["bounds"])
@@ -133,8 +134,10 @@ def test_batch_prior_matches_per_object_fitter(case, analytic):
     fits = [ngmix.fitting.Fitter(model="exp", prior=sprior,
                                  analytic_jacobian=analytic).go(obs=o, guess=g)
             for o, g in zip(obs, guess)]
-    res = LMBatchFitter("exp", prior=bprior, analytic_jacobian=analytic).go(
-        sb, guess, psf=psf)
+    fitter = LMBatchFitter("exp", prior=bprior, analytic_jacobian=analytic,
+                           device_prior=device_prior)
+    res = fitter.go(sb, guess, psf=psf)
+    assert fitter.prior_path == ("kernel" if device_prior else "torch")
     _compare(res, fits, analytic, 1e-6 if analytic else 2e-5)
     if cfg["bounds"] is not None:
         assert np.all(res["pars"][:, 4] >= -0.1) and np.all(res["pars"][:, 4] <= 3.0)
@@ -168,7 +171,9 @@ def test_out_of_range_prior_is_a_rejected_step():
     g0[:, 4] = 0.5 * Tmax
     bprior = _batch_prior(0.1, 0.3, T_term, F_term)
     sprior = ScalarSimpleSep(0.1, 0.3, T_term, F_term)
-    res = LMBatchFitter("gauss", prior=bprior).go(sb, g0, psf=psf)
+    fitter = LMBatchFitter("gauss", prior=bprior)
+    res = fitter.go(sb, g0, psf=psf)
+    assert fitter.prior_path == "kernel"
     ok = res["flags"] == 0
     assert np.all(res["pars"][ok, 4] <= Tmax)
     for i in range(len(obs)):
@@ -177,3 +182,45 @@ def test_out_of_range_prior_is_a_rejected_step():
         if fit["flags"] == 0:
             assert res["nfev"][i] == fit["nfev"]
             np.testing.assert_allclose(res["pars"][i], fit["pars"], rtol=1e-6, atol=1e-8)
+
+
+def test_prior_kernel_sums_match_the_torch_path():
+    """ngmix_lm_prior_sums_batch against prior_normal_sums on the same
+    states, both jacobian modes, with out-of-range and zero-probability rows"""
+    import torch
+    from ngmix_amd import _lib
+    from ngmix_amd.batch import _dptr, _stream
+    prior = _batch_prior(0.1, 0.3, ("flat", -0.1, 3.0), ("erf", -1.0, 0.5, 100.0, 10.0))
+    desc = prior.descriptor()
+    rng = np.random.RandomState(9)
+    n = 500
+    x0 = np.zeros((n, 6))
+    x0[:, 0:2] = rng.normal(scale=0.1, size=(n, 2))
+    x0[:, 2:4] = rng.uniform(-0.75, 0.75, size=(n, 2))
+    x0[:, 4] = rng.uniform(-0.2, 3.2, size=n)
+    x0[:, 4][::7] = 3.0 - 1e-9      # a forward step leaves the flat prior
+    x0[:, 5] = rng.uniform(-4.0, 120.0, size=n)
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    for mode in (_lib.LM_MODE_ANALYTIC, _lib.LM_MODE_FD):
+        st = np.zeros(n, dtype=_lib.LM_STATE_DTYPE)
+        L.ngmix_lm_init(_lib.ptr(st), n, 6, _lib.ptr(x0), 1e-8, 1e-8, 0.0, 100, 100.0,
+                        mode, None, None)
+        d_st = torch.from_numpy(st.view(np.uint8).reshape(n, -1)).to(dev)
+        d_out = torch.zeros((n, 28), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.ngmix_lm_prior_sums_batch(_dptr(d_st), n, _lib.ptr(desc), 1.0e-8,
+                                                   _dptr(d_out), _stream()), "prior sums")
+        xt = torch.from_numpy(st["xt"][:, :6].copy()).to(dev)
+        if mode == _lib.LM_MODE_FD:
+            ref, _ = pb.prior_normal_sums(
+                prior, xt, torch.from_numpy(st["xstep"][:, :6].copy()).to(dev),
+                torch.from_numpy(st["hstep"][:, :6].copy()).to(dev))
+        else:
+            ref, _ = pb.prior_normal_sums(prior, xt)
+        got, ref = d_out.cpu().numpy(), ref.cpu().numpy()
+        inf = ~np.isfinite(ref[:, -1])
+        assert inf.any() and not inf.all()
+        np.testing.assert_array_equal(np.isfinite(got[:, -1]), ~inf)
+        scale = np.abs(ref[~inf]).max(axis=1, keepdims=True)
+        assert np.all(np.abs(got[~inf] - ref[~inf]) <= 1e-6 * scale + 1e-12)

@@ -327,3 +327,42 @@ def test_lm_core_bounds_follow_leastsqbound(case, mode):
         g = np.array([_grad(v, b) for v, b in zip(st["xi"][:n], bounds)])
         got = cov_from_state(st) * g[:, None] * g[None, :]
         np.testing.assert_allclose(got, cov, rtol=1e-4 if mode == 0 else 1e-3)
+
+
+def test_simple_sep_prior_host_eval_matches_the_batch_prior():
+    """ngmix_simple_sep_prior_eval (the code the prior kernel runs) against
+    PriorSimpleSepBatch's torch arithmetic, in and out of range"""
+    import torch
+    from ngmix_amd import prior_batch as pb
+    prior = pb.PriorSimpleSepBatch(
+        pb.GaussianCen(0.01, -0.02, 0.1, 0.2), pb.GPriorBA(0.3),
+        pb.Flat(-0.1, 3.0), [pb.TwoSidedErf(-1.0, 0.5, 100.0, 10.0),
+                             pb.TwoSidedErf(0.0, 0.1, 50.0, 1.0)])
+    desc = prior.descriptor()
+    assert desc is not None and int(desc["nband"][0]) == 2
+    rng = np.random.RandomState(2)
+    pars = np.zeros((40, 7))
+    pars[:, 0:2] = rng.normal(scale=0.1, size=(40, 2))
+    pars[:, 2:4] = rng.uniform(-0.75, 0.75, size=(40, 2))   # some with g >= 1
+    pars[:, 4] = rng.uniform(-0.3, 3.3, size=40)             # some outside the flat T
+    pars[:, 5] = rng.uniform(-3.0, 120.0, size=40)
+    pars[:, 6] = rng.uniform(-0.3, 52.0, size=40)            # some with p == 0
+    rows, bad = prior.fill_fdiff_batch(torch.from_numpy(pars))
+    lnp = prior.get_lnprob_batch(torch.from_numpy(pars)).numpy()
+    rows, bad = rows.numpy(), bad.numpy()
+    assert bad.any() and not bad.all()
+    L = _lib.lib()
+    for i in range(40):
+        r = np.zeros(7)
+        l = np.zeros(1)
+        k = L.ngmix_simple_sep_prior_eval(_lib.ptr(desc), _lib.ptr(pars[i].copy()),
+                                          _lib.ptr(r), _lib.ptr(l))
+        if bad[i]:
+            assert k == -1
+            continue
+        assert k == 6
+        np.testing.assert_allclose(r[:6], rows[i], rtol=1e-12, atol=1e-14)
+        if np.isfinite(lnp[i]):
+            np.testing.assert_allclose(l[0], lnp[i], rtol=1e-12)
+        else:
+            assert l[0] == -np.inf
