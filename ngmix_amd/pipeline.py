@@ -99,7 +99,7 @@ def _em_psf(psf_stamps, ngauss, T0, cen, rng, em_pars):
 
 
 def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None,
-                    fit_pars=None, rng=None, psf_ngauss=1, em_pars=None):
+                    fit_pars=None, rng=None, psf_ngauss=1, em_pars=None, prior=None):
     """
     stamps, psf_stamps: StampBatch of the object images and of their psf images
         (stamp i of one belongs to stamp i of the other)
@@ -109,6 +109,7 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
     psf_ngauss: 1: the psf is its adaptive-moments gaussian; 2 or 3: an EM fit
         of that many free gaussians started from the adaptive-moments size
         (em_pars: miniter / maxiter / tol of that fit)
+    prior: a batch prior for the object fits (prior_batch.PriorSimpleSepBatch ...)
 
     Returns a dict: the LMBatchFitter result arrays, plus 'psf_T', 'psf_flags',
     'psf_g', 'guess' (the LM starting points) and 'guess_flags'.
@@ -158,7 +159,7 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
     guess[:, 5] = np.where(flux > 0, flux, 1.0)
 
     # 3. the fits
-    fitter = LMBatchFitter(model, fit_pars=fit_pars)
+    fitter = LMBatchFitter(model, fit_pars=fit_pars, prior=prior)
     res = fitter.go(stamps, guess, psf=psf_gm)
     res["flags"] = res["flags"] | np.where(psf_bad, BOOT_PSF_FAILURE, 0)
     res["psf_T"] = psf_T
