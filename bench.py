@@ -118,6 +118,16 @@ def cpu_baseline(sb, gm, target_seconds=12.0):
         ora.render_loglike_batch(gm_all, pixels, coords, images, nthreads)
     dt = time.perf_counter() - t0
     pairs = 2.0 * S * PAIRS_PER_STAMP * reps
+    # and one core on a slice of the sample (SURVEY 8d asks for both)
+    S1 = min(S, 32)
+    t0 = time.perf_counter()
+    ora.render_loglike_batch(gm_all[:S1], pixels[:S1], coords[:S1], images[:S1], 1)
+    t1 = time.perf_counter() - t0
+    reps1 = int(max(1, min(50, 2.0 / max(t1, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps1):
+        ora.render_loglike_batch(gm_all[:S1], pixels[:S1], coords[:S1], images[:S1], 1)
+    single = 2.0 * S1 * PAIRS_PER_STAMP * reps1 / (time.perf_counter() - t0)
     return {
         "value": pairs / dt,
         "unit": "pixel-gaussian evals/s",
@@ -126,6 +136,7 @@ def cpu_baseline(sb, gm, target_seconds=12.0):
         "sample": "%d stamps x %d passes of render+loglike (48x48x6), OpenMP "
                   "over stamps, C port of the numba loops, -O2 no-FMA" % (S, reps),
         "seconds": dt,
+        "single_core_value": single,
     }
 
 

@@ -1184,3 +1184,38 @@ void ora_render_loglike_batch(const ora_gauss2d *gm_all, int64_t ng,
     }
     (void)nthreads;
 }
+
+/* config-4 cpu_baseline legs: one admom / one 1-gaussian em_run per stamp over
+   the reference's AoS pixel arrays, stamps in parallel (tools/cpu_baseline.py) */
+void ora_admom_batch(const ora_admom_conf *conf, ora_gauss2d *wt_all,
+                     const ora_pixel *pixels_all, int64_t npix, int64_t nstamps,
+                     ora_admom_result *res_all, int nthreads)
+{
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+    for (int64_t s = 0; s < nstamps; s++)
+        ora_admom(conf, wt_all + s, pixels_all + s * npix, npix, res_all + s);
+    (void)nthreads;
+}
+
+void ora_em_batch(const ora_em_conf *conf, ora_pixel *pixels_all, int64_t npix,
+                  int64_t nstamps, ora_gauss2d *gmix_all, int64_t ngauss,
+                  ora_gauss2d *psf_all, int64_t npsf, ora_gauss2d *conv_all,
+                  int32_t *numiter_out, int32_t *status_out, int nthreads)
+{
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+    for (int64_t s = 0; s < nstamps; s++) {
+        double sums[14 * 8];
+        double frac, sky;
+        memset(sums, 0, sizeof(sums));
+        status_out[s] = ora_em_run(0, conf, pixels_all + s * npix, npix, sums,
+                                   gmix_all + s * ngauss, ngauss < 8 ? ngauss : 8,
+                                   psf_all + s * npsf, npsf,
+                                   conv_all + s * ngauss * npsf, 0,
+                                   numiter_out + s, &frac, &sky);
+    }
+    (void)nthreads;
+}

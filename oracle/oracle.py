@@ -335,3 +335,33 @@ def render_loglike_batch(gm_all, pixels_all, coords_all, images_all, nthreads):
                                    _i64(nstamps), _p(out),
                                    ctypes.c_int(int(nthreads)))
     return out
+
+
+def admom_batch(conf, wt_all, pixels_all, res_all, nthreads):
+    """cpu_baseline leg: one admom per stamp; wt_all (n,) gauss2d guesses
+    (updated), pixels_all (n, npix), res_all (n,) result records"""
+    _check_c(conf, ADMOM_CONF_DTYPE)
+    _check_c(wt_all, GAUSS2D_DTYPE)
+    _check_c(pixels_all, PIXEL_DTYPE)
+    _check_c(res_all, ADMOM_RESULT_DTYPE)
+    n, npix = pixels_all.shape
+    lib().ora_admom_batch(_p(conf), _p(wt_all), _p(pixels_all), _i64(npix), _i64(n),
+                          _p(res_all), ctypes.c_int(int(nthreads)))
+
+
+def em_batch(conf, pixels_all, gmix_all, psf_all, conv_all, nthreads):
+    """cpu_baseline leg: one em_run (kind 0) per stamp; gmix_all (n, ng),
+    psf_all (n, npsf), conv_all (n, ng*npsf); returns (numiter, status)"""
+    _check_c(conf, EM_CONF_DTYPE)
+    _check_c(pixels_all, PIXEL_DTYPE)
+    _check_c(gmix_all, GAUSS2D_DTYPE)
+    _check_c(psf_all, GAUSS2D_DTYPE)
+    _check_c(conv_all, GAUSS2D_DTYPE)
+    n, npix = pixels_all.shape
+    numiter = np.zeros(n, dtype=np.int32)
+    status = np.zeros(n, dtype=np.int32)
+    lib().ora_em_batch(_p(conf), _p(pixels_all), _i64(npix), _i64(n), _p(gmix_all),
+                       _i64(gmix_all.shape[1]), _p(psf_all), _i64(psf_all.shape[1]),
+                       _p(conv_all), _p(numiter), _p(status),
+                       ctypes.c_int(int(nthreads)))
+    return numiter, status
