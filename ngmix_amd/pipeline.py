@@ -18,7 +18,7 @@ remove_failed_psf_obs / BootPSFFailure drop them in the reference.
 import numpy as np
 
 from . import _lib
-from .batch import GMixBatch, records_to_numpy
+from .batch import GMixBatch
 from .lm_batch import LMBatchFitter
 
 __all__ = ["bootstrap_batch", "BOOT_PSF_FAILURE"]
@@ -36,7 +36,9 @@ def _e1e2_to_g1g2(e1, e2):
 
 def _admom_gaussians(stamps, Tguess, rng):
     """admom on every stamp from a round guess of size Tguess; returns the
-    converged weight gaussians (records) and the result records"""
+    converged weight gaussians (a dict of host arrays row, col, irr, irc,
+    icc), the result flags and the kernel status.  Only those columns leave
+    the device, not the 584-byte result records."""
     n = stamps.n
     guess = np.zeros((n, 6))
     guess[:, 0:2] = rng.uniform(-0.1, 0.1, size=(n, 2)) * np.sqrt(Tguess / 2.0)
@@ -44,8 +46,12 @@ def _admom_gaussians(stamps, Tguess, rng):
     guess[:, 5] = 1.0
     wt, _ = GMixBatch.from_pars(guess, "gauss", device=stamps.device)
     res, status = stamps.admom(wt)
-    rec = records_to_numpy(res, _lib.ADMOM_RESULT_DTYPE)
-    return wt.to_numpy()[:, 0], rec, status.cpu().numpy()
+    cols = wt.data[:, 1:6].cpu().numpy()  # row, col, irr, irc, icc of the record
+    w = {"row": cols[:, 0], "col": cols[:, 1], "irr": cols[:, 2], "irc": cols[:, 3],
+         "icc": cols[:, 4]}
+    import torch
+    flags = res[:, 0].contiguous().view(torch.int32)[::2].cpu().numpy()
+    return w, {"flags": flags}, status.cpu().numpy()
 
 
 # starting mixtures of the EM psf fit: flux fractions and size factors relative

@@ -43,3 +43,13 @@ print("bootstrap_batch: %d objects in %.3f s -> %.3g objects/s; LM rounds %d; fl
           n, dt, n / dt, res["rounds"], int(ok.sum()), int((res["psf_flags"] != 0).sum()),
           int((res["guess_flags"] != 0).sum()),
           np.round(np.sqrt((pull ** 2).mean(axis=0)), 2)))
+
+if len(sys.argv) > 2:
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    bootstrap_batch(sb, psb, model="exp")
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
