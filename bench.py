@@ -155,8 +155,12 @@ def load_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--settle-steps", type=int, default=100,
+                    help="untimed steps run before the warm-up steps: the GPU's "
+                         "clock governor needs ~50-100 ms of load to reach its "
+                         "steady state (DESIGN.md section 5); 0 disables")
     ap.add_argument("--nstamps", type=int, default=100000,
                     help="stamps per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -217,6 +221,11 @@ def main():
                 pending = torch.cuda.Event()
                 pending.record()
 
+    # steady-state clocks first (untimed, like the warm-up steps that follow)
+    # (a fixed count, so that every rank issues the same collectives)
+    for _ in range(max(args.settle_steps, 0)):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -289,6 +298,7 @@ def main():
             "loglike_stamp_evals_per_s_per_gpu": n / (loglike_ms * 1e-3),
             "render_stamp_evals_per_s_per_gpu": n / (render_ms * 1e-3),
             "bad_status": bad,
+            "settle_steps": max(args.settle_steps, 0),
             "kernel_mode": "exact" if args.exact else "fused",
         }
         if world == 1 and not args.no_cpu_baseline:
