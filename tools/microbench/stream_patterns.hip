@@ -59,14 +59,16 @@ __global__ __launch_bounds__(64) void k(const double *__restrict__ a, double *b,
     if (!RMW && acc == 12345.678) sink[0] = acc;
 }
 
+static int g_reps = 10;
+
 template <int MODE, bool RMW, int PF>
 void run(const char *name, const double *a, double *b, double *sink, int n)
 {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k<MODE, RMW, PF>), dim3(n), dim3(64), 0, 0, a, b, sink);
+    for (int i = 0; i < (g_reps > 50 ? 100 : 3); i++) hipLaunchKernelGGL((k<MODE, RMW, PF>), dim3(n), dim3(64), 0, 0, a, b, sink);
     CHECK(hipEventRecord(e0));
-    const int reps = 10;
+    const int reps = g_reps;
     for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k<MODE, RMW, PF>), dim3(n), dim3(64), 0, 0, a, b, sink);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
@@ -75,8 +77,10 @@ void run(const char *name, const double *a, double *b, double *sink, int n)
     printf("%-28s PF=%d  %.4f ms  %.2f TB/s\n", name, PF, ms, bytes / ms / 1e9);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    // reps per pattern: 10 measures a cold GPU, 300 the settled clocks
+    if (argc > 1) g_reps = atoi(argv[1]);
     const int n = 100000;
     double *a, *b, *sink;
     CHECK(hipMalloc(&a, (size_t)n * NSTAMP_PIX * 8));
