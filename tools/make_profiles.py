@@ -60,7 +60,7 @@ for sub, name in (("bench_stats", "bench"), ("iter_stats", "iter"), ("lm_stats",
     with open(os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, name)), "w") as fo:
         csv.writer(fo, quoting=csv.QUOTE_ALL).writerows(keep)
     lines.append("# rocprofv3 --kernel-trace --stats -- %s (ngmix kernels): calls, average ns"
-                 % {"bench": "python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline",
+                 % {"bench": "python3 bench.py --no-cpu-baseline",
                     "iter": "python3 tools/bench_iter.py 200000 3",
                     "lm": "python3 tools/bench_lm.py 100000 0"}[name])
     for r in keep[1:]:

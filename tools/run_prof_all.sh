@@ -9,7 +9,7 @@ mkdir -p $OUT
 bash $ROOT/tools/run_prof.sh $TAG 100000 > $OUT/run_prof.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 # 2. the bench command itself (kernel stats must agree with bench.py's HIP-event timing)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -o run -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -o run -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_stats.log
 # 3. iterative kernels and batched LM
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/iter_stats -o run -- python3 $ROOT/tools/bench_iter.py 200000 3 > $OUT/iter.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lm_stats -o run -- python3 $ROOT/tools/bench_lm.py 100000 0 > $OUT/lm.log 2>&1
