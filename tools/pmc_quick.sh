@@ -6,7 +6,7 @@ OUT=$ROOT/gpurun_out/pmcq_$2
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export NGMIX_HIP_LIB=$1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY --output-format csv -d $OUT -o run -- python3 $ROOT/tools/prof_pixpass.py 100000 3 > $OUT/log.txt 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY --output-format csv -d $OUT -o run -- python3 $ROOT/tools/prof_pixpass.py 100000 3 > $OUT/log.txt 2>&1
 python3 - <<PY
 import csv, collections
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
