@@ -530,3 +530,63 @@ def test_multi_epoch_bdf_loglike_vs_oracle():
         np.testing.assert_allclose(per_obj2.cpu().numpy()[i],
                                    ps[rag_start[i]:rag_start[i + 1]].sum(axis=0),
                                    rtol=1e-14)
+
+
+def test_batch_edge_shapes_and_empty_inputs():
+    """1x1 and 1xN stamps, a stamp with more tiles than the fused kernel's
+    LDS table holds (falls back to the exact kernel), a stamp whose pixels are
+    all masked, an empty batch, NaN parameters -- against the oracle"""
+    import ngmix_amd as ngmix
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    rng = np.random.RandomState(99)
+    scale = 0.263
+    shapes = [(1, 1), (1, 37), (53, 1), (3, 5), (400, 400), (16, 16)]
+    obs, gms = [], []
+    for k, (nrow, ncol) in enumerate(shapes):
+        im = rng.normal(size=(nrow, ncol))
+        wt = rng.uniform(0.5, 2.0, size=(nrow, ncol))
+        if k == 5:
+            wt[:] = 0.0
+            wt[7, 9] = 1.3   # Observation refuses all-zero weights: keep one, mask below
+        jac = ngmix.Jacobian(row=(nrow - 1) / 2.0 + 0.2, col=(ncol - 1) / 2.0 - 0.1,
+                             dvdrow=scale, dvdcol=0.01, dudrow=-0.02, dudcol=scale * 1.03)
+        obs.append(ngmix.Observation(im, weight=wt, jacobian=jac))
+    gmh = _random_mixtures(rng, len(shapes), 4, scale)
+    sb = StampBatch.from_observations(obs)
+    gm = GMixBatch.from_numpy(gmh)
+    out, status = sb.loglike(gm)
+    fd, _ = sb.fill_fdiff(gm)
+    im, _ = sb.render(gm)
+    assert np.all(status.cpu().numpy() == 0)
+    out, fd, im = out.cpu().numpy(), fd.cpu().numpy(), im.cpu().numpy()
+    offs = sb.kept_offsets()
+    for i, o in enumerate(obs):
+        jrec = o.jacobian.get_data().view(np.float64).reshape(8)
+        res, rfd, rim = _oracle_eval(gmh[i], o.image, o.weight, jrec, True)
+        assert out[i, 3] == res[3]
+        np.testing.assert_allclose(out[i, 0], res[0], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(fd[offs[i]:offs[i] + res[3]], rfd, rtol=1e-9,
+                                   atol=1e-10 * max(np.abs(rfd).max(), 1.0))
+        a = int(sb.pix_off[i])
+        np.testing.assert_allclose(im[a:a + rim.size].reshape(rim.shape), rim, rtol=1e-9,
+                                   atol=1e-12 * np.abs(rim).max())
+    # an empty batch is a no-op, not an error
+    empty = StampBatch.from_images(np.zeros((0, 8, 8)), None, None)
+    egm = GMixBatch.empty(0, 4)
+    eo, es = empty.loglike(egm)
+    assert eo.shape[0] == 0 and es.shape[0] == 0
+    # NaN parameters: chi2 is NaN for every pixel, which fails the reference's
+    # `chi2 < 25 and chi2 >= 0` gate, so the model is 0 there
+    # (gmix_nb.py:52-63) and loglike = -sum(val^2 ivar)/2; the other stamps
+    # are untouched
+    pars = np.tile([0.0, 0.0, 0.1, 0.0, 0.5, 10.0], (3, 1))
+    pars[1, 4] = np.nan
+    g3, st3 = GMixBatch.from_pars(pars, "exp")
+    ims = rng.normal(size=(3, 16, 16))
+    ims[2] = ims[0]
+    sb3 = StampBatch.from_images(ims, None, None)
+    o3, s3 = sb3.loglike(g3)
+    o3 = o3.cpu().numpy()
+    assert np.all(s3.cpu().numpy() == 0)
+    np.testing.assert_allclose(o3[1, 0], -0.5 * (ims[1] ** 2).sum(), rtol=1e-13)
+    assert o3[0, 0] == o3[2, 0] and o3[1, 2] == 0.0
