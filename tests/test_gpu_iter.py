@@ -427,3 +427,84 @@ def test_em_multi_wave_vs_reference_order_kernel(dim, kind):
     for f in ("p", "row", "col", "irr", "irc", "icc"):
         np.testing.assert_allclose(g1[f], g2[f], rtol=1e-9, atol=1e-11, err_msg=f)
         np.testing.assert_allclose(c1[f], c2[f], rtol=1e-9, atol=1e-11, err_msg=f)
+
+
+def test_admom_and_em_ragged_shapes_vs_oracle():
+    """one batch holding tiny, odd-shaped and > 4096-pixel stamps (every
+    kernel variant: one / two / four waves per stamp and the generic
+    256-thread kernels): admom records and EM mixtures against the oracle"""
+    import ngmix_amd as ngmix
+    from ngmix_amd.batch import StampBatch, GMixBatch, records_to_numpy
+    from oracle import oracle as ora
+    rng = np.random.RandomState(77)
+    scale = 0.263
+    shapes = [(9, 9), (17, 23), (32, 32), (40, 44), (48, 48), (64, 64), (70, 66), (101, 97)]
+    obs, gms, jrecs = [], [], []
+    for nrow, ncol in shapes:
+        jac = ngmix.DiagonalJacobian(row=(nrow - 1) / 2.0 + 0.3, col=(ncol - 1) / 2.0 - 0.2,
+                                     scale=scale)
+        T = 0.25 + 0.01 * min(nrow, ncol)
+        gm = ngmix.GMixModel([0.02, -0.03, 0.08, -0.05, T, 30.0], "gauss")
+        im = gm.make_image((nrow, ncol), jacobian=jac)
+        im += 0.002 * rng.normal(size=im.shape)
+        wt = np.full(im.shape, 1.0 / 0.002 ** 2)
+        wt[nrow // 3, ncol // 2] = 0.0
+        obs.append(ngmix.Observation(im, weight=wt, jacobian=jac))
+        gms.append(T)
+        jrecs.append(jac.get_data().view(np.float64).reshape(8))
+    n = len(obs)
+    sb = StampBatch.from_observations(obs)
+    guess = np.zeros((n, 6))
+    guess[:, 4] = np.array(gms) * 1.1
+    guess[:, 5] = 1.0
+    wt, _ = GMixBatch.from_pars(guess, "gauss")
+    wt_in = wt.to_numpy()
+    res, status = sb.admom(wt)
+    assert int(status.abs().sum()) == 0
+    res = records_to_numpy(res, _lib.ADMOM_RESULT_DTYPE)
+    wt_out = wt.to_numpy()
+    conf = np.zeros(1, dtype=ora.ADMOM_CONF_DTYPE)
+    conf["maxiter"], conf["shiftmax"], conf["etol"], conf["Ttol"] = 200, 5.0, 1e-5, 1e-3
+    pixlist = []
+    for i, o in enumerate(obs):
+        j = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+        j[0] = tuple(jrecs[i])
+        pix = ora.make_pixels(o.image, o.weight, j, True)
+        pixlist.append(pix)
+        w = conv_rec(wt_in[i], ora.GAUSS2D_DTYPE)
+        r = np.zeros(1, dtype=ora.ADMOM_RESULT_DTYPE)
+        assert ora.admom(conf, w, pix, r) == 0
+        _check_admom("shape %s" % (shapes[i],), res[i:i + 1], wt_out[i], r, w)
+    # EM: one gaussian, unit psf, image + sky
+    sky = 0.01
+    skyobs = [ngmix.Observation(o.image + sky, weight=o.weight, jacobian=o.jacobian)
+              for o in obs]
+    sbe = StampBatch.from_observations(skyobs)
+    eg = np.zeros((n, 6))
+    eg[:, 4] = np.array(gms) * 0.9
+    eg[:, 5] = 30.0 * scale ** 2
+    gm0, _ = GMixBatch.from_pars(eg, "gauss")
+    delta = np.zeros((n, 6))
+    delta[:, 5] = 1.0
+    psf, _ = GMixBatch.from_pars(delta, "gauss")
+    gm_in, psf_in = gm0.to_numpy(), psf.to_numpy()
+    out, status, conv = sbe.em(gm0, psf, sky=sky, miniter=20, maxiter=300, tol=1e-6)
+    assert int(status.abs().sum()) == 0
+    out = out.cpu().numpy()
+    gm_out = gm0.to_numpy()
+    econf = np.zeros(1, dtype=ora.EM_CONF_DTYPE)
+    econf["tol"], econf["maxiter"], econf["miniter"], econf["sky"] = 1e-6, 300, 20, sky
+    for i in range(n):
+        pix = pixlist[i].copy()
+        pix["val"] += sky
+        g = conv_rec(gm_in[i], ora.GAUSS2D_DTYPE)
+        p = conv_rec(psf_in[i], ora.GAUSS2D_DTYPE)
+        c = np.zeros(1, dtype=ora.GAUSS2D_DTYPE)
+        ora.gmix_convolve_fill(c, g, p)
+        sums = np.zeros((1, ora.EM_SUMS_NDOUBLE[0]))
+        st, numiter, frac, _ = ora.em_run(0, econf, pix, sums, g, p, c)
+        assert st == 0
+        assert int(out[i, 0]) == numiter, shapes[i]
+        for f in ("p", "row", "col", "irr", "irc", "icc"):
+            np.testing.assert_allclose(gm_out[i][f], g[f], rtol=1e-9, atol=1e-12,
+                                       err_msg="%s %s" % (shapes[i], f))
