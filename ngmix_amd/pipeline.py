@@ -105,7 +105,8 @@ def _em_psf(psf_stamps, ngauss, T0, cen, rng, em_pars):
 
 
 def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None,
-                    fit_pars=None, rng=None, psf_ngauss=1, em_pars=None, prior=None):
+                    fit_pars=None, rng=None, psf_ngauss=1, em_pars=None, prior=None,
+                    stamp_obj=None, stamp_band=None):
     """
     stamps, psf_stamps: StampBatch of the object images and of their psf images
         (stamp i of one belongs to stamp i of the other)
@@ -116,6 +117,12 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
         of that many free gaussians started from the adaptive-moments size
         (em_pars: miniter / maxiter / tol of that fit)
     prior: a batch prior for the object fits (prior_batch.PriorSimpleSepBatch ...)
+    stamp_obj / stamp_band: as for LMBatchFitter.go -- objects with several
+        epochs and bands (a MultiBandObsList each).  Every stamp gets its own
+        psf fit; the guess is the mean of the object's stamps' adaptive
+        moments and, per band, of their pixel sums.  An object one of whose
+        psf fits failed is flagged BOOT_PSF_FAILURE (the reference drops such
+        epochs and fails only when none is left, bootstrap.py:118-154).
 
     Returns a dict: the LMBatchFitter result arrays, plus 'psf_T', 'psf_flags',
     'psf_g', 'guess' (the LM starting points) and 'guess_flags'.
@@ -157,17 +164,42 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
         cs = np.concatenate([[0], np.cumsum(npix)])
         v = stamps.val.cpu().numpy()
         flux = np.array([v[cs[i]:cs[i + 1]].sum() for i in range(n)])
-    guess = np.zeros((n, 6))
-    guess[:, 0] = np.where(gbad, 0.0, ow["row"])
-    guess[:, 1] = np.where(gbad, 0.0, ow["col"])
-    guess[:, 2], guess[:, 3] = g1, g2
-    guess[:, 4] = np.maximum(T_obs - psf_T, 0.1 * psf_T)
-    guess[:, 5] = np.where(flux > 0, flux, 1.0)
+    if stamp_obj is None:
+        sobj = np.arange(n, dtype=np.int64)
+        sband = np.zeros(n, dtype=np.int64)
+    else:
+        sobj = np.ascontiguousarray(stamp_obj, dtype=np.int64)
+        sband = (np.zeros(n, dtype=np.int64) if stamp_band is None
+                 else np.ascontiguousarray(stamp_band, dtype=np.int64))
+    nobj = int(sobj.max()) + 1
+    nband = int(sband.max()) + 1
+    good = (~gbad).astype("f8")
+    ngood = np.bincount(sobj, weights=good, minlength=nobj)
+
+    def obj_mean(x, default):
+        tot = np.bincount(sobj, weights=np.where(gbad, 0.0, x), minlength=nobj)
+        return np.where(ngood > 0, tot / np.maximum(ngood, 1.0), default)
+    Tdiff = np.maximum(T_obs - psf_T, 0.1 * psf_T)
+    guess = np.zeros((nobj, 5 + nband))
+    guess[:, 0] = obj_mean(ow["row"], 0.0)
+    guess[:, 1] = obj_mean(ow["col"], 0.0)
+    guess[:, 2], guess[:, 3] = obj_mean(g1, 0.0), obj_mean(g2, 0.0)
+    # (stamps whose moments failed carry the neutral size 2 T_psf - T_psf)
+    guess[:, 4] = np.bincount(sobj, weights=Tdiff, minlength=nobj) / \
+        np.maximum(np.bincount(sobj, minlength=nobj), 1)
+    key = sobj * nband + sband
+    fsum = np.bincount(key, weights=flux, minlength=nobj * nband)
+    fcnt = np.bincount(key, minlength=nobj * nband)
+    fmean = (fsum / np.maximum(fcnt, 1)).reshape(nobj, nband)
+    guess[:, 5:] = np.where(fmean > 0, fmean, 1.0)
 
     # 3. the fits
     fitter = LMBatchFitter(model, fit_pars=fit_pars, prior=prior)
-    res = fitter.go(stamps, guess, psf=psf_gm)
-    res["flags"] = res["flags"] | np.where(psf_bad, BOOT_PSF_FAILURE, 0)
+    res = fitter.go(stamps, guess, psf=psf_gm,
+                    stamp_obj=None if stamp_obj is None else sobj.astype(np.int32),
+                    stamp_band=None if stamp_obj is None else sband.astype(np.int32))
+    obj_psf_bad = np.bincount(sobj, weights=psf_bad.astype("f8"), minlength=nobj) > 0
+    res["flags"] = res["flags"] | np.where(obj_psf_bad, BOOT_PSF_FAILURE, 0)
     res["psf_T"] = psf_T
     res["psf_g"] = np.stack([pg1, pg2], axis=1)
     res["psf_flags"] = np.where(pst != 0, -1, prec["flags"])

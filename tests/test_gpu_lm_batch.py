@@ -320,3 +320,54 @@ def test_batch_forward_difference_mode(model):
     pull = (res["pars"][ok] - pars[ok]) / res["pars_err"][ok]
     if model != "bdf":   # fracdev is nearly unconstrained at this S/N
         assert np.all(np.abs(pull) < 6.0)
+
+
+def test_bootstrap_batch_multiband_multiepoch():
+    """objects with 2 bands x 2 epochs, different psf per epoch, sub-pixel
+    offsets per epoch: one bootstrap_batch call recovers shape, size and both
+    fluxes"""
+    from ngmix_amd.pipeline import bootstrap_batch
+    rng = np.random.RandomState(101)
+    nobj, nband, nepoch, dim, pdim, scale, noise = 60, 2, 2, 36, 25, 0.263, 0.01
+    truth = np.zeros((nobj, 7))
+    truth[:, 0:2] = rng.uniform(-0.3, 0.3, size=(nobj, 2)) * scale
+    truth[:, 2:4] = rng.normal(scale=0.1, size=(nobj, 2))
+    truth[:, 4] = rng.uniform(0.3, 0.8, size=nobj)
+    truth[:, 5] = rng.uniform(60.0, 120.0, size=nobj)
+    truth[:, 6] = rng.uniform(100.0, 200.0, size=nobj)
+    ns = nobj * nband * nepoch
+    sobj = np.repeat(np.arange(nobj), nband * nepoch)
+    sband = np.tile(np.repeat(np.arange(nband), nepoch), nobj)
+    bp = np.zeros((ns, 6))
+    bp[:, :5] = truth[sobj, :5]
+    bp[:, 5] = truth[sobj, 5 + sband]
+    psf_pars = np.zeros((ns, 6))
+    psf_pars[:, 2:4] = rng.normal(scale=0.02, size=(ns, 2))
+    psf_pars[:, 4] = rng.uniform(0.22, 0.32, size=ns)
+    psf_pars[:, 5] = 1.0
+    jac = np.zeros((ns, 8))
+    jac[:, 0] = (dim - 1) / 2.0 + rng.uniform(-0.5, 0.5, size=ns)
+    jac[:, 1] = (dim - 1) / 2.0 + rng.uniform(-0.5, 0.5, size=ns)
+    jac[:, 2] = jac[:, 5] = jac[:, 7] = scale
+    jac[:, 6] = scale ** 2
+    gm0, _ = GMixBatch.from_pars(bp, "exp")
+    psf, _ = GMixBatch.from_pars(psf_pars, "gauss")
+    gm, _ = gm0.convolve(psf)
+    geom = StampBatch.from_images(np.zeros((ns, dim, dim)), None, jac)
+    images = geom.render(gm)[0].cpu().numpy().reshape(ns, dim, dim)
+    images = images + noise * rng.normal(size=images.shape)
+    sb = StampBatch.from_images(images, np.full(images.shape, 1.0 / noise ** 2), jac)
+    pjac = np.array([12.0, 12.0, scale, 0.0, 0.0, scale, scale ** 2, scale])
+    pgeom = StampBatch.from_images(np.zeros((ns, pdim, pdim)), None, pjac)
+    pim = pgeom.render(psf)[0].cpu().numpy().reshape(ns, pdim, pdim)
+    pim = pim + 1e-5 * rng.normal(size=pim.shape)
+    psb = StampBatch.from_images(pim, np.full(pim.shape, 1e10), pjac)
+    res = bootstrap_batch(sb, psb, model="exp", psf_Tguess=0.3, stamp_obj=sobj,
+                          stamp_band=sband)
+    assert res["pars"].shape == (nobj, 7)
+    assert np.all(res["flags"] == 0)
+    assert np.all(res["npix"] == nband * nepoch * dim * dim)
+    pull = (res["pars"] - truth) / res["pars_err"]
+    assert np.all(np.abs(pull) < 6.0)
+    assert 0.7 < np.sqrt((pull ** 2).mean()) < 1.3
+    assert res["flux"].shape == (nobj, 2) and res["flux_cov"].shape == (nobj, 2, 2)
