@@ -561,6 +561,29 @@ class StampBatch(object):
         _lib.check(st, "ngmix_em_batch")
         return out, status, conv
 
+    def select(self, index):
+        """
+        a new batch holding stamps `index` (any order, repeats allowed): their
+        pixels are gathered into a fresh contiguous buffer on the device --
+        for refitting a subset (Runner's retries) or processing in chunks
+        """
+        torch = _torch()
+        index = np.ascontiguousarray(index, dtype=np.int64)
+        npix = self.npix[index]
+        off = np.concatenate([[0], np.cumsum(npix)[:-1]]).astype(np.int64)
+        d_idx = torch.from_numpy(index).to(self.device)
+        if index.size and np.all(npix == npix[0]) and np.all(self.npix == npix[0]) and \
+                np.all(self.pix_off == np.arange(self.n, dtype=np.int64) * npix[0]):
+            take = lambda t: t.reshape(self.n, -1)[d_idx].reshape(-1)  # noqa: E731
+        else:
+            src = torch.from_numpy(np.repeat(self.pix_off[index] - off, npix) +
+                                   np.arange(int(npix.sum()), dtype=np.int64)).to(self.device)
+            take = lambda t: t[src]  # noqa: E731
+        izw = (self.flags[index] & _lib.STAMP_IGNORE_ZERO_WEIGHT) != 0
+        return StampBatch(take(self.val) if self.val is not None else None,
+                          take(self.ierr) if self.ierr is not None else None,
+                          self.jac[d_idx], self.nrow[index], self.ncol[index], off, izw)
+
     def prep_em(self):
         """
         the batched prep_obs of the EM fitters (em.py prep_image): every stamp

@@ -26,6 +26,11 @@ __all__ = ["bootstrap_batch", "BOOT_PSF_FAILURE"]
 BOOT_PSF_FAILURE = 1 << 30
 
 
+def _to_device(index, device):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(index, dtype=np.int64)).to(device)
+
+
 def _e1e2_to_g1g2(e1, e2):
     e = np.sqrt(e1 ** 2 + e2 ** 2)
     e = np.minimum(e, 0.999999)
@@ -106,7 +111,7 @@ def _em_psf(psf_stamps, ngauss, T0, cen, rng, em_pars):
 
 def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None,
                     fit_pars=None, rng=None, psf_ngauss=1, em_pars=None, prior=None,
-                    stamp_obj=None, stamp_band=None):
+                    stamp_obj=None, stamp_band=None, ntry=1):
     """
     stamps, psf_stamps: StampBatch of the object images and of their psf images
         (stamp i of one belongs to stamp i of the other)
@@ -117,6 +122,9 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
         of that many free gaussians started from the adaptive-moments size
         (em_pars: miniter / maxiter / tol of that fit)
     prior: a batch prior for the object fits (prior_batch.PriorSimpleSepBatch ...)
+    ntry: fits that end with flags != 0 are repeated from a perturbed guess up
+        to ntry times in all, as Runner does object by object
+        (runners.py:95-150); 'ntry' of the result counts the attempts
     stamp_obj / stamp_band: as for LMBatchFitter.go -- objects with several
         epochs and bands (a MultiBandObsList each).  Every stamp gets its own
         psf fit; the guess is the mean of the object's stamps' adaptive
@@ -198,6 +206,31 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
     res = fitter.go(stamps, guess, psf=psf_gm,
                     stamp_obj=None if stamp_obj is None else sobj.astype(np.int32),
                     stamp_band=None if stamp_obj is None else sband.astype(np.int32))
+    tries = np.ones(nobj, dtype=np.int64)
+    for _ in range(1, int(ntry)):
+        redo = np.nonzero(res["flags"] != 0)[0]
+        if redo.size == 0:
+            break
+        # the failed objects' stamps as a batch of their own
+        member = np.isin(sobj, redo)
+        sidx = np.nonzero(member)[0]
+        sub_obj = np.searchsorted(redo, sobj[sidx]).astype(np.int32)
+        g2_ = guess[redo] * (1.0 + 0.1 * rng.uniform(-1, 1, size=guess[redo].shape))
+        g2_[:, 0:2] = guess[redo, 0:2] + 0.05 * rng.uniform(-1, 1, size=(redo.size, 2)) * \
+            np.sqrt(guess[redo, 4:5])
+        sub_psf = GMixBatch(psf_gm.data.reshape(n, psf_gm.ngauss, 13)[
+            _to_device(sidx, stamps.device)].reshape(-1, 13).contiguous(), sidx.size,
+            psf_gm.ngauss)
+        sub = fitter.go(stamps.select(sidx), g2_, psf=sub_psf, stamp_obj=sub_obj,
+                        stamp_band=sband[sidx].astype(np.int32))
+        tries[redo] += 1
+        for k, v in sub.items():
+            if isinstance(v, np.ndarray) and v.shape[:1] == (redo.size,) and k in res:
+                if not res[k].flags.writeable:
+                    res[k] = np.array(res[k])
+                res[k][redo] = v
+        guess[redo] = g2_
+    res["ntry"] = tries
     obj_psf_bad = np.bincount(sobj, weights=psf_bad.astype("f8"), minlength=nobj) > 0
     res["flags"] = res["flags"] | np.where(obj_psf_bad, BOOT_PSF_FAILURE, 0)
     res["psf_T"] = psf_T

@@ -371,3 +371,53 @@ def test_bootstrap_batch_multiband_multiepoch():
     assert np.all(np.abs(pull) < 6.0)
     assert 0.7 < np.sqrt((pull ** 2).mean()) < 1.3
     assert res["flux"].shape == (nobj, 2) and res["flux_cov"].shape == (nobj, 2, 2)
+
+
+def test_select_and_bootstrap_retries():
+    """StampBatch.select gathers stamps (uniform and ragged batches);
+    bootstrap_batch(ntry=...) refits only the failed objects"""
+    from ngmix_amd.pipeline import bootstrap_batch
+    rng = np.random.RandomState(55)
+    n, dim, scale = 40, 32, 0.263
+    pars, guess, images, weights, jac, _, psf = _make_objects(n, "exp", rng)
+    sb = StampBatch.from_images(images, weights, jac)
+    gm0, _ = GMixBatch.from_pars(pars, "exp")
+    gm, _ = gm0.convolve(psf)
+    full = sb.loglike(gm)[0].cpu().numpy()
+    idx = np.array([5, 0, 17, 17, 39, 2])
+    sub = sb.select(idx)
+    gsub = GMixBatch(gm.data.reshape(n, gm.ngauss, 13)[idx].reshape(-1, 13).contiguous(),
+                     idx.size, gm.ngauss)
+    np.testing.assert_array_equal(sub.loglike(gsub)[0].cpu().numpy(), full[idx])
+    obs = [ngmix.Observation(rng.normal(size=(6 + i, 9 - i)),
+                             weight=rng.uniform(0.5, 2, size=(6 + i, 9 - i)))
+           for i in range(5)]
+    rb = StampBatch.from_observations(obs)
+    pick = np.array([3, 1, 4])
+    rs = rb.select(pick)
+    assert list(rs.nrow) == [9, 7, 10] and rs.total_pix == sum(obs[i].image.size for i in pick)
+    v = rs.val.cpu().numpy()
+    a = 0
+    for i in pick:
+        np.testing.assert_array_equal(v[a:a + obs[i].image.size], obs[i].image.ravel())
+        a += obs[i].image.size
+    # retries: with a tiny maxfev some fits end with flags != 0; those, and
+    # only those, are tried again
+    pdim = 25
+    pjac = np.array([12.0, 12.0, scale, 0.0, 0.0, scale, scale ** 2, scale])
+    pgeom = StampBatch.from_images(np.zeros((n, pdim, pdim)), None, pjac)
+    pim = pgeom.render(psf)[0].cpu().numpy().reshape(n, pdim, pdim)
+    psb = StampBatch.from_images(pim + 1e-6 * rng.normal(size=pim.shape),
+                                 np.full(pim.shape, 1e10), pjac)
+    ref = bootstrap_batch(sb, psb, model="exp", fit_pars={"ftol": 1e-10, "xtol": 1e-10},
+                          rng=np.random.RandomState(1))
+    assert ref["nfev"].min() < ref["nfev"].max()
+    fp = {"maxfev": int(np.sort(ref["nfev"])[n // 2]), "ftol": 1e-10, "xtol": 1e-10}
+    one = bootstrap_batch(sb, psb, model="exp", fit_pars=fp, rng=np.random.RandomState(1))
+    three = bootstrap_batch(sb, psb, model="exp", fit_pars=fp, rng=np.random.RandomState(1),
+                            ntry=3)
+    failed = one["flags"] != 0
+    assert failed.any() and not failed.all()
+    assert np.all(three["ntry"][~failed] == 1) and np.all(three["ntry"][failed] >= 2)
+    np.testing.assert_array_equal(three["pars"][~failed], one["pars"][~failed])
+    assert (three["flags"] != 0).sum() <= failed.sum()
