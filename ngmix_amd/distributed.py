@@ -80,6 +80,11 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # testing hook: NGMIX_DIST_BACKEND=gloo runs several ranks on one GPU
+        # (RCCL refuses two ranks per device), local_rank wraps around then
+        backend = os.environ.get("NGMIX_DIST_BACKEND", backend)
+        if torch.cuda.is_available():
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
