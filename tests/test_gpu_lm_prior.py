@@ -224,3 +224,113 @@ def test_prior_kernel_sums_match_the_torch_path():
         np.testing.assert_array_equal(np.isfinite(got[:, -1]), ~inf)
         scale = np.abs(ref[~inf]).max(axis=1, keepdims=True)
         assert np.all(np.abs(got[~inf] - ref[~inf]) <= 1e-6 * scale + 1e-12)
+
+
+def _golden_prior_setup(g, tag):
+    nband = 2 if tag == "b2" else 1
+    obs, band = [], []
+    psf_pars = g[tag + "_psf_pars"]
+    for b in range(nband):
+        j = g["%s_jac%d" % (tag, b)]
+        j = j[0] if j.ndim else j
+        jac = ngmix.Jacobian(row=float(j["row0"]), col=float(j["col0"]),
+                             dvdrow=float(j["dvdrow"]), dvdcol=float(j["dvdcol"]),
+                             dudrow=float(j["dudrow"]), dudcol=float(j["dudcol"]))
+        pobs = ngmix.Observation(np.zeros((5, 5)), jacobian=jac,
+                                 gmix=ngmix.GMix(pars=psf_pars))
+        obs.append(ngmix.Observation(g["%s_image%d" % (tag, b)],
+                                     weight=g["%s_weight%d" % (tag, b)], jacobian=jac,
+                                     psf=pobs))
+        band.append(b)
+    te, fe = tuple(g["T_erf"]), tuple(g["F_erf"])
+    cs, gs = float(g["cen_sigma"]), float(g["g_sigma"])
+    prior = pb.PriorSimpleSepBatch(pb.GaussianCen(0.0, 0.0, cs, cs), pb.GPriorBA(gs),
+                                   pb.TwoSidedErf(*te),
+                                   [pb.TwoSidedErf(*fe) for _ in range(nband)])
+    return obs, np.array(band, dtype=np.int32), prior
+
+
+@pytest.mark.parametrize("tag", ["b1", "b2"])
+def test_reference_prior_fits(golden, tag):
+    """tests/golden/prior.npz: the REFERENCE's Fitter with its own
+    PriorSimpleSep (CenPrior, GPriorBA, TwoSidedErf), one and two bands,
+    lmder and lmdif -- the batch prior's rows and ln p equal the reference
+    prior's, and the batched fits reproduce the reference's results through
+    the prior kernel and through the torch path"""
+    import torch
+    g = golden("prior")
+    obs, band, prior = _golden_prior_setup(g, tag)
+    pts = torch.from_numpy(g[tag + "_prior_pts"]).cuda()
+    rows, bad = prior.fill_fdiff_batch(pts)
+    assert not bool(bad.any())
+    np.testing.assert_allclose(rows.cpu().numpy(), g[tag + "_prior_rows"], rtol=1e-12,
+                               atol=1e-14)
+    np.testing.assert_allclose(prior.get_lnprob_batch(pts).cpu().numpy(),
+                               g[tag + "_prior_lnp"], rtol=1e-12)
+    sb = StampBatch.from_observations(obs)
+    psf = GMixBatch.from_numpy(np.stack([o.psf.gmix.get_data().copy() for o in obs]))
+    sobj = np.zeros(len(obs), dtype=np.int32)
+    for mode, analytic in (("lmder", True), ("lmdif", False)):
+        pre = "%s_%s_" % (tag, mode)
+        assert int(g[pre + "flags"]) == 0
+        for device_prior in (True, False):
+            res = LMBatchFitter("exp", prior=prior, analytic_jacobian=analytic,
+                                device_prior=device_prior).go(
+                sb, g[tag + "_guess"][None, :], psf=psf, stamp_obj=sobj, stamp_band=band)
+            assert res["flags"][0] == 0
+            assert res["ier"][0] == int(g[pre + "ier"])
+            if analytic:
+                assert res["nfev"][0] == int(g[pre + "nfev"])
+            else:
+                assert abs(res["nfev"][0] - int(g[pre + "nfev"])) <= 8
+            ptol = 1e-6 if analytic else 2e-5
+            np.testing.assert_allclose(res["pars"][0], g[pre + "pars"], rtol=ptol,
+                                       atol=ptol * 1e-2)
+            refcov = g[pre + "pars_cov"]
+            sig = np.sqrt(np.diag(refcov))
+            assert np.all(np.abs(res["pars_cov"][0] - refcov) <=
+                          1e-3 * np.abs(refcov) + 1e-6 * np.outer(sig, sig)), pre
+            np.testing.assert_allclose(res["lnprob"][0], float(g[pre + "lnprob"]),
+                                       rtol=1e-7, atol=1e-6)
+            np.testing.assert_allclose(res["chi2per"][0], float(g[pre + "chi2per"]),
+                                       rtol=1e-6)
+        # and the per-object Fitter given a reference-style prior object
+        one = ngmix.fitting.Fitter(
+            model="exp", prior=_ScalarFromBatch(prior), analytic_jacobian=analytic).go(
+            obs=_as_mb(obs, band), guess=g[tag + "_guess"])
+        assert one["flags"] == 0 and one["ier"] == int(g[pre + "ier"])
+        if analytic:
+            assert one["nfev"] == int(g[pre + "nfev"])
+        np.testing.assert_allclose(one["pars"], g[pre + "pars"], rtol=ptol, atol=ptol * 1e-2)
+
+
+class _ScalarFromBatch(object):
+    """a batch prior behind the reference's per-object prior interface"""
+
+    def __init__(self, prior):
+        self.prior = prior
+        self.bounds = prior.bounds
+
+    def fill_fdiff(self, pars, fdiff):
+        import torch
+        rows, bad = self.prior.fill_fdiff_batch(torch.from_numpy(np.array([pars])))
+        if bool(bad[0]):
+            raise GMixRangeError("prior out of range")
+        r = rows[0].numpy()
+        fdiff[:r.size] = r
+        return r.size
+
+    def get_lnprob_scalar(self, pars):
+        import torch
+        return float(self.prior.get_lnprob_batch(torch.from_numpy(np.array([pars])))[0])
+
+
+def _as_mb(obs, band):
+    mb = ngmix.MultiBandObsList()
+    for b in sorted(set(band.tolist())):
+        ol = ngmix.ObsList()
+        for o, bb in zip(obs, band):
+            if bb == b:
+                ol.append(o)
+        mb.append(ol)
+    return mb

@@ -366,3 +366,34 @@ def test_simple_sep_prior_host_eval_matches_the_batch_prior():
             np.testing.assert_allclose(l[0], lnp[i], rtol=1e-12)
         else:
             assert l[0] == -np.inf
+
+
+@pytest.mark.parametrize("tag", ["b1", "b2"])
+def test_batch_prior_equals_the_reference_prior(golden, tag):
+    """rows and ln p of the reference's own PriorSimpleSep (tests/golden/
+    prior.npz, generated by oracle/gen_golden_prior.py) from the torch prior on
+    the CPU and from the C code the prior kernel runs"""
+    import torch
+    from ngmix_amd import prior_batch as pb
+    g = golden("prior")
+    nband = 2 if tag == "b2" else 1
+    cs, gs = float(g["cen_sigma"]), float(g["g_sigma"])
+    prior = pb.PriorSimpleSepBatch(
+        pb.GaussianCen(0.0, 0.0, cs, cs), pb.GPriorBA(gs), pb.TwoSidedErf(*g["T_erf"]),
+        [pb.TwoSidedErf(*g["F_erf"]) for _ in range(nband)])
+    pts = g[tag + "_prior_pts"]
+    rows, bad = prior.fill_fdiff_batch(torch.from_numpy(pts))
+    assert not bool(bad.any())
+    np.testing.assert_allclose(rows.numpy(), g[tag + "_prior_rows"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(prior.get_lnprob_batch(torch.from_numpy(pts)).numpy(),
+                               g[tag + "_prior_lnp"], rtol=1e-12)
+    desc = prior.descriptor()
+    L = _lib.lib()
+    for i in range(pts.shape[0]):
+        r = np.zeros(7)
+        l = np.zeros(1)
+        k = L.ngmix_simple_sep_prior_eval(_lib.ptr(desc), _lib.ptr(pts[i].copy()),
+                                          _lib.ptr(r), _lib.ptr(l))
+        assert k == 4 + nband
+        np.testing.assert_allclose(r[:k], g[tag + "_prior_rows"][i], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(l[0], g[tag + "_prior_lnp"][i], rtol=1e-12)
