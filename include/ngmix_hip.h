@@ -469,10 +469,11 @@ int ngmix_lm_advance_batch(ngmix_lm_state *states, int64_t nobj,
    (joint_prior.py:10-120) in a form a kernel can evaluate: gaussian centre
    terms (priors/multivariate.py CenPrior), the Bernstein-Armstrong shape
    prior (priors/shape.py GPriorBA), and per T / band flux either FlatPrior
-   (par = minval, maxval) or TwoSidedErf (par = minval, width_at_min, maxval,
-   width_at_max) from priors/priors.py */
+   (par = minval, maxval), TwoSidedErf (par = minval, width_at_min, maxval,
+   width_at_max) or Normal (par = mean, sigma) from priors/priors.py */
 #define NGMIX_PRIOR_FLAT 0
 #define NGMIX_PRIOR_TWO_SIDED_ERF 1
+#define NGMIX_PRIOR_NORMAL 2
 #define NGMIX_PRIOR_MAXBAND 3
 typedef struct {
     double cen1, cen2, cen_s2inv1, cen_s2inv2;

@@ -117,6 +117,7 @@ LM_STATE_DTYPE = np.dtype([
 
 PRIOR_FLAT = 0
 PRIOR_TWO_SIDED_ERF = 1
+PRIOR_NORMAL = 2
 PRIOR_MAXBAND = 3
 # ngmix_simple_sep_prior (include/ngmix_hip.h)
 SIMPLE_SEP_PRIOR_DTYPE = np.dtype([

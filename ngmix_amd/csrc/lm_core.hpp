@@ -567,6 +567,12 @@ NGMIX_HD bool prior_term_lnp(int kind, const double *par, double x, double &lnp)
         lnp = p > 0.0 ? log(p) : -INFINITY;
         return true;
     }
+    if (kind == NGMIX_PRIOR_NORMAL) {
+        // priors/priors.py:424-434
+        const double diff = x - par[0];
+        lnp = -0.5 * diff * diff * (1.0 / (par[1] * par[1]));
+        return true;
+    }
     lnp = 0.0;
     return !(x < par[0] || x > par[1]);
 }

@@ -27,7 +27,7 @@ import numpy as np
 
 from .gexceptions import GMixRangeError
 
-__all__ = ["GaussianCen", "GPriorBA", "Flat", "TwoSidedErf", "PriorSimpleSepBatch",
+__all__ = ["GaussianCen", "GPriorBA", "Flat", "TwoSidedErf", "Normal", "PriorSimpleSepBatch",
            "PriorBatchAdapter", "prior_normal_sums"]
 
 
@@ -98,6 +98,21 @@ class TwoSidedErf(object):
         return lnp, torch.zeros_like(pos)
 
 
+class Normal(object):
+    """Normal (priors/priors.py:395-434): ln p = -(x - mean)^2 / (2 sigma^2);
+    bounds, if given, go to leastsqbound"""
+
+    def __init__(self, mean, sigma, bounds=None):
+        self.mean, self.sigma = float(mean), float(sigma)
+        self.s2inv = 1.0 / self.sigma ** 2
+        self.bounds = bounds
+
+    def lnprob(self, x):
+        torch = _torch()
+        diff = x - self.mean
+        return -0.5 * diff * diff * self.s2inv, torch.zeros_like(x, dtype=torch.bool)
+
+
 class PriorSimpleSepBatch(object):
     """
     PriorSimpleSep (joint_prior.py:10-120) over a batch: rows
@@ -143,6 +158,8 @@ class PriorSimpleSepBatch(object):
                                                   p.width_at_max]
             if isinstance(p, Flat):
                 return _lib.PRIOR_FLAT, [p.minval, p.maxval, 0.0, 0.0]
+            if isinstance(p, Normal):
+                return _lib.PRIOR_NORMAL, [p.mean, p.sigma, 0.0, 0.0]
             return None, None
         kind, par = term(self.T_prior)
         if kind is None:

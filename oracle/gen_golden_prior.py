@@ -29,21 +29,34 @@ T_ERF = (-0.05, 0.03, 3.0, 0.3)
 F_ERF = (-1.0, 0.5, 500.0, 20.0)
 
 
-def make_prior(nband, rng):
-    Fp = [priors.TwoSidedErf(*F_ERF, rng=rng) for _ in range(nband)]
+# the bounded case ("bb"): Normal T and flux priors carrying leastsqbound
+# bounds, two-sided and one-sided
+T_NORMAL = (0.5, 0.3, (0.05, 2.0))
+F_NORMAL = (70.0, 40.0, (1.0, None))
+
+
+def make_prior(nband, rng, bounded=False):
+    if bounded:
+        Tp = priors.Normal(T_NORMAL[0], T_NORMAL[1], rng=rng, bounds=T_NORMAL[2])
+        Fp = [priors.Normal(F_NORMAL[0], F_NORMAL[1], rng=rng, bounds=F_NORMAL[2])
+              for _ in range(nband)]
+    else:
+        Tp = priors.TwoSidedErf(*T_ERF, rng=rng)
+        Fp = [priors.TwoSidedErf(*F_ERF, rng=rng) for _ in range(nband)]
     return joint_prior.PriorSimpleSep(
         priors.CenPrior(0.0, 0.0, CEN_SIGMA, CEN_SIGMA, rng=rng),
-        priors.GPriorBA(G_SIGMA, rng=rng),
-        priors.TwoSidedErf(*T_ERF, rng=rng), Fp if nband > 1 else Fp[0])
+        priors.GPriorBA(G_SIGMA, rng=rng), Tp, Fp if nband > 1 else Fp[0])
 
 
 def main():
     rng = np.random.RandomState(2718)
     out = dict(cen_sigma=CEN_SIGMA, g_sigma=G_SIGMA, T_erf=np.array(T_ERF),
-               F_erf=np.array(F_ERF))
+               F_erf=np.array(F_ERF), T_normal=np.array(T_NORMAL[:2]),
+               T_bounds=np.array(T_NORMAL[2]), F_normal=np.array(F_NORMAL[:2]),
+               F_lower_bound=F_NORMAL[2][0])
     psf_gm = ngmix.GMixModel([0.0, 0.0, 0.01, -0.02, 0.27, 1.0], "gauss")
     dim = 28
-    for tag, nband in (("b1", 1), ("b2", 2)):
+    for tag, nband in (("b1", 1), ("b2", 2), ("bb", 1)):
         truth = np.array([0.04, -0.03, 0.25, -0.15, 0.45] + [60.0, 95.0][:nband])
         mb = ngmix.MultiBandObsList()
         for b in range(nband):
@@ -65,7 +78,13 @@ def main():
         guess = truth * (1.0 + 0.05 * rng.uniform(-1, 1, size=truth.size))
         guess[0:2] = truth[0:2] + 0.02 * rng.uniform(-1, 1, size=2)
         out[tag + "_guess"] = guess
-        prior = make_prior(nband, rng)
+        prior = make_prior(nband, rng, bounded=(tag == "bb"))
+        if tag == "bb":
+            assert prior.bounds is not None
+            # (scipy >= 1.15 returns a 0-based ipvt; the reference's `ipvt - 1`
+            # then scrambles pars_cov of bounded fits -- pars / nfev / ier and
+            # lnprob are unaffected and are what the tests use)
+            out["bb_scipy_version"] = np.array(__import__("scipy").__version__)
         # the prior itself at a few points (rows and ln p)
         pts = np.array([guess, truth, truth * 1.1])
         rows = np.zeros((pts.shape[0], 4 + nband))

@@ -368,7 +368,7 @@ def test_simple_sep_prior_host_eval_matches_the_batch_prior():
             assert l[0] == -np.inf
 
 
-@pytest.mark.parametrize("tag", ["b1", "b2"])
+@pytest.mark.parametrize("tag", ["b1", "b2", "bb"])
 def test_batch_prior_equals_the_reference_prior(golden, tag):
     """rows and ln p of the reference's own PriorSimpleSep (tests/golden/
     prior.npz, generated by oracle/gen_golden_prior.py) from the torch prior on
@@ -378,9 +378,13 @@ def test_batch_prior_equals_the_reference_prior(golden, tag):
     g = golden("prior")
     nband = 2 if tag == "b2" else 1
     cs, gs = float(g["cen_sigma"]), float(g["g_sigma"])
-    prior = pb.PriorSimpleSepBatch(
-        pb.GaussianCen(0.0, 0.0, cs, cs), pb.GPriorBA(gs), pb.TwoSidedErf(*g["T_erf"]),
-        [pb.TwoSidedErf(*g["F_erf"]) for _ in range(nband)])
+    if tag == "bb":
+        Tp = pb.Normal(*g["T_normal"], bounds=tuple(g["T_bounds"]))
+        Fp = [pb.Normal(*g["F_normal"], bounds=(float(g["F_lower_bound"]), None))]
+    else:
+        Tp = pb.TwoSidedErf(*g["T_erf"])
+        Fp = [pb.TwoSidedErf(*g["F_erf"]) for _ in range(nband)]
+    prior = pb.PriorSimpleSepBatch(pb.GaussianCen(0.0, 0.0, cs, cs), pb.GPriorBA(gs), Tp, Fp)
     pts = g[tag + "_prior_pts"]
     rows, bad = prior.fill_fdiff_batch(torch.from_numpy(pts))
     assert not bool(bad.any())
