@@ -421,3 +421,53 @@ def test_select_and_bootstrap_retries():
     assert np.all(three["ntry"][~failed] == 1) and np.all(three["ntry"][failed] >= 2)
     np.testing.assert_array_equal(three["pars"][~failed], one["pars"][~failed])
     assert (three["flags"] != 0).sum() <= failed.sum()
+
+
+@pytest.mark.parametrize("model", ["turb", "bdf", "dev", "bd"])
+def test_reference_lmdif_fits(golden, model):
+    """tests/golden/lmfd.npz: the REFERENCE's Fitter on two-band objects for
+    the models it fits with MINPACK lmdif (no analytic derivatives).  The
+    per-object Fitter reproduces nfev / ier / pars; the batched forward-
+    difference mode (fdjac2 inside the pixel pass) reaches the same solution
+    ('bd' with two bands has 9 parameters, one more than the batch state
+    holds: per-object only)"""
+    g = golden("lmfd")
+    nband = 2
+    obs, band = [], []
+    mb = ngmix.MultiBandObsList()
+    for b in range(nband):
+        jac = _jac(g["%s_jac%d" % (model, b)])
+        pobs = ngmix.Observation(np.zeros((5, 5)), jacobian=jac,
+                                 gmix=ngmix.GMix(pars=g["psf_pars"]))
+        o = ngmix.Observation(g["%s_image%d" % (model, b)],
+                              weight=g["%s_weight%d" % (model, b)], jacobian=jac, psf=pobs)
+        ol = ngmix.ObsList()
+        ol.append(o)
+        mb.append(ol)
+        obs.append(o)
+        band.append(b)
+    guess = g[model + "_guess"]
+    ref = {k: g["%s_%s" % (model, k)] for k in ("flags", "nfev", "ier", "pars", "pars_err",
+                                                 "pars_cov", "lnprob", "chi2per")}
+    assert int(ref["flags"]) == 0
+    one = ngmix.fitting.Fitter(model=model, analytic_jacobian=False).go(obs=mb, guess=guess)
+    assert one["flags"] == 0 and one["ier"] == int(ref["ier"])
+    assert abs(one["nfev"] - int(ref["nfev"])) <= 2 * guess.size + 2
+    # forward differences of a fast-exp model: the two implementations' 1e-13
+    # pixel differences are amplified by 1/h ~ 1e8 in the jacobian
+    assert np.all(np.abs(one["pars"] - ref["pars"]) <= 2e-3 * ref["pars_err"])
+    np.testing.assert_allclose(one["pars_err"], ref["pars_err"], rtol=2e-3)
+    np.testing.assert_allclose(one["lnprob"], float(ref["lnprob"]), rtol=1e-8)
+    if model == "bd":
+        return
+    sb = StampBatch.from_observations(obs)
+    psf = GMixBatch.from_numpy(np.stack([o.psf.gmix.get_data().copy() for o in obs]))
+    res = LMBatchFitter(model, analytic_jacobian=False).go(
+        sb, guess[None, :], psf=psf, stamp_obj=np.zeros(nband, dtype=np.int32),
+        stamp_band=np.array(band, dtype=np.int32))
+    assert res["flags"][0] == 0
+    assert abs(res["nfev"][0] - int(ref["nfev"])) <= 2 * guess.size + 2
+    assert np.all(np.abs(res["pars"][0] - ref["pars"]) <= 2e-3 * ref["pars_err"])
+    np.testing.assert_allclose(res["pars_err"][0], ref["pars_err"], rtol=2e-3)
+    np.testing.assert_allclose(res["lnprob"][0], float(ref["lnprob"]), rtol=1e-8)
+    np.testing.assert_allclose(res["chi2per"][0], float(ref["chi2per"]), rtol=1e-7)
