@@ -64,6 +64,27 @@ def main():
         for k in ("pars", "pars_err", "pars_cov"):
             out["%s_%s" % (model, k)] = np.array(res[k])
         print(model, res["flags"], res["nfev"], res["ier"], res["pars"])
+    # ---- CoellipFitter (the psf fitter of the LM psf runners): co-elliptical
+    # gaussians fitted to a psf image, lmdif
+    cjac = ngmix.DiagonalJacobian(row=12.2, col=11.7, scale=SCALE)
+    truth_psf = ngmix.GMixCoellip([0.01, -0.02, 0.03, 0.02, 0.12, 0.32, 0.9, 0.6, 0.3, 0.1])
+    cim = truth_psf.make_image((25, 25), jacobian=cjac)
+    cim += 2.0e-4 * rng.normal(size=cim.shape)
+    cobs = ngmix.Observation(cim, weight=np.full(cim.shape, 1.0 / 2.0e-4 ** 2), jacobian=cjac)
+    out["coellip_image"] = cim
+    out["coellip_jac"] = cjac.get_data().copy()
+    for ng, guess in ((2, [0.0, 0.0, 0.0, 0.0, 0.15, 0.6, 0.7, 0.3]),
+                      (3, [0.0, 0.0, 0.01, 0.01, 0.1, 0.3, 0.8, 0.55, 0.35, 0.1])):
+        guess = np.array(guess)
+        res = ngmix.fitting.CoellipFitter(ngauss=ng).go(obs=cobs, guess=guess)
+        pre = "coellip%d_" % ng
+        out[pre + "guess"] = guess
+        for k in ("flags", "nfev", "ier", "lnprob", "chi2per"):
+            out[pre + k] = res[k]
+        for k in ("pars", "pars_err", "pars_cov"):
+            out[pre + k] = np.array(res[k])
+        out[pre + "gmix_pars"] = res.get_gmix().get_full_pars()
+        print(pre, res["flags"], res["nfev"], res["ier"], res["pars"])
     np.savez_compressed(OUT, **out)
     print("wrote %s (%.1f kB)" % (OUT, os.path.getsize(OUT) / 1e3))
 
