@@ -17,7 +17,6 @@ remove_failed_psf_obs / BootPSFFailure drop them in the reference.
 """
 import numpy as np
 
-from . import _lib
 from .batch import GMixBatch
 from .lm_batch import LMBatchFitter
 

@@ -43,11 +43,6 @@ print("batched LM: %d fits in %.3f s -> %.3g fits/s (lock-step loop alone %.4f s
           fitter.rounds, int(ok.sum()), np.median(res["nfev"][ok]),
           res["nfev"][ok].max(), np.round(np.sqrt((pull ** 2).mean(axis=0)), 2)))
 
-# the kernels alone: one evaluation + one advance over the whole batch
-import ctypes  # noqa: E402
-from ngmix_amd import _lib  # noqa: E402
-from ngmix_amd.batch import _dptr, _stream  # noqa: E402
-
 if nsample > 0:
     val = sb.val.cpu().numpy().reshape(n, 48, 48)
     ierr = sb.ierr.cpu().numpy().reshape(n, 48, 48)
