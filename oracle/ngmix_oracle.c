@@ -1186,7 +1186,7 @@ void ora_render_loglike_batch(const ora_gauss2d *gm_all, int64_t ng,
 }
 
 /* config-4 cpu_baseline legs: one admom / one 1-gaussian em_run per stamp over
-   the reference's AoS pixel arrays, stamps in parallel (tools/cpu_baseline.py) */
+   the reference's AoS pixel arrays, stamps in parallel (bench.py --cpu-baselines) */
 void ora_admom_batch(const ora_admom_conf *conf, ora_gauss2d *wt_all,
                      const ora_pixel *pixels_all, int64_t npix, int64_t nstamps,
                      ora_admom_result *res_all, int nthreads)
