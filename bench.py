@@ -282,6 +282,16 @@ def cpu_baseline_configs(budget=4.0):
 
 
 
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim"""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except (OSError, KeyError, ValueError):
+        return ("pixel-Gaussian evals/sec (render+loglike), 48\u00d748\u00d76-gauss stamps, "
+                "1/2/4/8 GPU")
+
+
 def load_traffic():
     """HBM bytes per loglike launch from the committed rocprofv3 PMC pass
     (profiles/), if one exists for this workload size"""
@@ -411,7 +421,7 @@ def main():
         if traffic and traffic.get("nstamps") == n:
             traffic_bytes = traffic.get(dominant + "_hbm_bytes_per_launch")
         line = {
-            "metric": "pixel-Gaussian evals/sec (render+loglike), 48x48x6-gauss stamps",
+            "metric": baseline_metric(),
             "value": value,
             "unit": "pixel-gaussian evals/s",
             "n_gpus": world,
