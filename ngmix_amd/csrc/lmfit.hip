@@ -557,9 +557,10 @@ __global__ __launch_bounds__(WAVE) void lm_eval_fd_kernel(
         if ((lane & 15) == 15) red[k * 4 + (lane >> 4)] = r;
     }
     __syncthreads();
-    if (lane < NSUM) {
-        const double *r = red + lane * 4;
-        out[lane] = ((r[0] + r[1]) + r[2]) + r[3];
+    // (NLOC = 10 has 66 sums, two more than the wave has lanes)
+    for (int k = lane; k < NSUM; k += WAVE) {
+        const double *r = red + k * 4;
+        out[k] = ((r[0] + r[1]) + r[2]) + r[3];
     }
     if (lane == 0 && status) status[s] = NGMIX_OK;
 }
@@ -768,8 +769,19 @@ static int model_ngauss_npars(int model, int &ng0, int &nloc)
     case NGMIX_MODEL_DEV: ng0 = 10; nloc = 6; return 0;
     case NGMIX_MODEL_BDF: ng0 = 16; nloc = 7; return 0;
     case NGMIX_MODEL_BD: ng0 = 16; nloc = 8; return 0;
-    default: return -1;
+    default: break;
     }
+    // co-elliptical gaussians: the count rides in the model argument,
+    // NGMIX_MODEL_COELLIP + 256 * ngauss (parameters: cen1, cen2, g1, g2,
+    // T_1..T_n, F_1..F_n; one band)
+    if ((model & 0xff) == NGMIX_MODEL_COELLIP) {
+        const int n = model >> 8;
+        if (n < 1 || 4 + 2 * n > LM_NPMAX) return -1;
+        ng0 = n;
+        nloc = 4 + 2 * n;
+        return 0;
+    }
+    return -1;
 }
 
 int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *states,
@@ -780,9 +792,11 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *stat
     if (b->nstamps <= 0) return NGMIX_OK;
     int ng0, nloc;
     if (model_ngauss_npars(model, ng0, nloc) != 0 || npsf < 0) {
-        set_last_error_msg("lm_eval: model must be gauss, turb, exp, dev, bdf or bd");
+        set_last_error_msg("lm_eval: model must be gauss, turb, exp, dev, bdf, bd or "
+                           "coellip + 256 * ngauss (ngauss <= 3)");
         return NGMIX_ERR_BAD_ARG;
     }
+    model &= 0xff;
     const int no_skip = (b->flags & NGMIX_BATCH_NO_SKIP) ? 1 : 0;
     const int G = ng0 * (npsf > 0 ? npsf : 1);
     dim3 grid((unsigned)b->nstamps), block(WAVE);
@@ -824,7 +838,8 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *stat
     } while (0)
     if (nloc == 6) NGMIX_FD_LAUNCH(6);
     else if (nloc == 7) NGMIX_FD_LAUNCH(7);
-    else NGMIX_FD_LAUNCH(8);
+    else if (nloc == 8) NGMIX_FD_LAUNCH(8);
+    else NGMIX_FD_LAUNCH(10);
 #undef NGMIX_FD_LAUNCH
     NGMIX_HIP_CHECK(hipGetLastError());
     return NGMIX_OK;

@@ -57,7 +57,7 @@ class LMBatchFitter(object):
     model: 'gauss' | 'exp' | 'dev' (analytic jacobian, MINPACK lmder, as the
         reference's Fitter) or 'turb' | 'bdf' | 'bd' (forward differences,
         MINPACK lmdif, as the reference runs the models without analytic
-        derivatives)
+        derivatives), or 'coellip' with ngauss = 1..3 (CoellipFitter, lmdif)
     fit_pars: dict with maxfev / ftol / xtol as for Fitter (defaults
         DEFAULT_LM_PARS, ngmix/defaults.py:17)
     analytic_jacobian: False forces forward differences for gauss/exp/dev
@@ -67,14 +67,24 @@ class LMBatchFitter(object):
     """
 
     def __init__(self, model, fit_pars=None, analytic_jacobian=True, prior=None,
-                 device_prior=True):
+                 device_prior=True, ngauss=None):
         self.prior = prior
         # evaluate a PriorSimpleSepBatch inside one kernel (False: torch ops)
         self.device_prior = device_prior
-        if model not in MODEL_NLOC:
-            raise ValueError("LMBatchFitter supports %s" % (tuple(MODEL_NLOC),))
-        self.model = model
-        self.nloc = MODEL_NLOC[model]
+        self.ngauss = None
+        if model == "coellip":
+            # CoellipFitter (fitters.py:120-141): ngauss co-elliptical gaussians,
+            # parameters cen1, cen2, g1, g2, T_1.., F_1.., one band, lmdif
+            if ngauss is None or not 1 <= int(ngauss) <= (_lib.LM_NPMAX - 4) // 2:
+                raise ValueError("coellip needs ngauss = 1..%d" % ((_lib.LM_NPMAX - 4) // 2))
+            self.ngauss = int(ngauss)
+            self.model = model
+            self.nloc = 4 + 2 * self.ngauss
+        elif model not in MODEL_NLOC:
+            raise ValueError("LMBatchFitter supports %s and 'coellip'" % (tuple(MODEL_NLOC),))
+        else:
+            self.model = model
+            self.nloc = MODEL_NLOC[model]
         self.fd = not (analytic_jacobian and model in SIMPLE_ANALYTIC_MODELS)
         self.fit_pars = dict(DEFAULT_LM_PARS if fit_pars is None else fit_pars)
 
@@ -154,6 +164,10 @@ class LMBatchFitter(object):
         d_nact = torch.zeros(1, dtype=torch.int32, device=dev)
         b = stamps._batch(1)
         modnum = get_model_num(self.model)
+        if self.ngauss is not None:
+            modnum += 256 * self.ngauss   # the count rides with the model id
+            if nband != 1:
+                raise ValueError("coellip fits one band: guess needs %d columns" % self.nloc)
         # float64 view of the state records: the columns a prior needs
         fields = _lib.LM_STATE_DTYPE.fields
         sview = d_states.view(torch.float64)
@@ -277,7 +291,7 @@ class LMBatchFitter(object):
         band_pars[:, :nshape] = x[:, :nshape]
         idx = torch.from_numpy(nshape + sband[s0].astype(np.int64)).to(dev)
         band_pars[:, nshape] = x.gather(1, idx[:, None])[:, 0]
-        gm, _ = GMixBatch.from_pars(band_pars, self.model, device=dev)
+        gm, _ = GMixBatch.from_pars(band_pars, self.model, device=dev, ngauss=self.ngauss)
         d_s0 = torch.from_numpy(s0).to(dev)
         if psf is not None:
             pdata = psf.data.reshape(stamps.n, psf.ngauss, 13)[d_s0]
@@ -341,13 +355,17 @@ class LMBatchFitter(object):
         if self.model == "bd":
             usable[~ok, 6] = 0.5
         usable[~ok, nshape:] = 1.0
+        if self.model == "coellip":
+            usable[~ok, 4:] = 1.0
         band_pars = np.empty((stamps.n, self.nloc))
         band_pars[:, :nshape] = usable[sobj, :nshape]
         band_pars[:, nshape] = usable[sobj, nshape + sband]
-        gm0, st0 = GMixBatch.from_pars(band_pars, self.model, device=stamps.device)
+        gm0, st0 = GMixBatch.from_pars(band_pars, self.model, device=stamps.device,
+                                       ngauss=self.ngauss)
         gm = gm0
         if psf is not None:
             gm, _ = gm0.convolve(psf)
+        self.gmix = gm0  # the fitted (pre-psf) mixtures, one per stamp
         out, st1 = stamps.loglike(gm)
         out = out.cpu().numpy()
         lnprob = np.add.reduceat(out[:, 0], obj_start[:-1])
@@ -372,6 +390,12 @@ class LMBatchFitter(object):
             res["s2n_w"] = np.where(ok, s2n, nan)
             res["s2n"] = res["s2n_w"]
             pc = res["pars_cov"]
+            if self.model == "coellip":
+                # CoellipFitModel._set_flux is a no-op (results.py:648-652)
+                res["g"] = pars[:, 2:4].copy()
+                res["g_cov"] = pc[:, 2:4, 2:4].copy()
+                res["g_err"] = res["pars_err"][:, 2:4].copy()
+                return
             res["g"] = pars[:, 2:4].copy()
             res["g_cov"] = pc[:, 2:4, 2:4].copy()
             res["g_err"] = res["pars_err"][:, 2:4].copy()

@@ -108,9 +108,44 @@ def _em_psf(psf_stamps, ngauss, T0, cen, rng, em_pars):
     return gm, flags
 
 
+def _coellip_psf(psf_stamps, ngauss, T0, cen, g, rng):
+    """lock-step LM fit of ngauss co-elliptical gaussians to every psf stamp
+    (PSFRunner + CoellipFitter, runners.py:152-223, fitters.py:120-141) from
+    the adaptive-moments centre, shape and size; returns the flux-normalised
+    mixtures and the fit flags"""
+    n = psf_stamps.n
+    frac, fac = _EM_PSF_GUESS[ngauss]
+    npix = psf_stamps.npix.astype(np.int64)
+    if np.all(npix == npix[0]):
+        flux = psf_stamps.val.reshape(n, -1).sum(dim=1).cpu().numpy()
+    else:
+        import torch
+        flux = torch.segment_reduce(
+            psf_stamps.val, "sum",
+            lengths=torch.from_numpy(npix).to(psf_stamps.device)).cpu().numpy()
+    area = (psf_stamps.jac[:, 7] ** 2).cpu().numpy()
+    flux = np.where(flux > 0, flux * area, 1.0)
+    guess = np.zeros((n, 4 + 2 * ngauss))
+    guess[:, 0:2] = cen
+    guess[:, 2:4] = g
+    for i in range(ngauss):
+        guess[:, 4 + i] = T0 * fac[i] * (1.0 + rng.uniform(-0.05, 0.05, size=n))
+        guess[:, 4 + ngauss + i] = flux * frac[i]
+    fitter = LMBatchFitter("coellip", ngauss=ngauss)
+    res = fitter.go(psf_stamps, guess)
+    gm = fitter.gmix
+    data = gm.data.reshape(n, ngauss, 13)  # a view: edited in place
+    import torch
+    psum = data[:, :, 0].sum(dim=1, keepdim=True)
+    psum = torch.where(psum > 0, psum, torch.ones_like(psum))
+    data[:, :, 0] /= psum
+    gm.set_norms()
+    return gm, res["flags"].copy()
+
+
 def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None,
                     fit_pars=None, rng=None, psf_ngauss=1, em_pars=None, prior=None,
-                    stamp_obj=None, stamp_band=None, ntry=1):
+                    stamp_obj=None, stamp_band=None, ntry=1, psf_fitter="em"):
     """
     stamps, psf_stamps: StampBatch of the object images and of their psf images
         (stamp i of one belongs to stamp i of the other)
@@ -119,7 +154,9 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
         Tguess defaults to 2 * psf_Tguess
     psf_ngauss: 1: the psf is its adaptive-moments gaussian; 2 or 3: an EM fit
         of that many free gaussians started from the adaptive-moments size
-        (em_pars: miniter / maxiter / tol of that fit)
+        (em_pars: miniter / maxiter / tol of that fit), or with
+        psf_fitter='coellip' a lock-step LM fit of that many co-elliptical
+        gaussians (the reference's CoellipFitter psf runners)
     prior: a batch prior for the object fits (prior_batch.PriorSimpleSepBatch ...)
     ntry: fits that end with flags != 0 are repeated from a perturbed guess up
         to ntry times in all, as Runner does object by object
@@ -154,7 +191,11 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
     em_flags = np.zeros(n, dtype=np.int64)
     if psf_ngauss > 1:
         cen = np.where(psf_bad[:, None], 0.0, np.stack([pw["row"], pw["col"]], axis=1))
-        psf_gm, em_flags = _em_psf(psf_stamps, psf_ngauss, psf_T, cen, rng, em_pars)
+        if psf_fitter == "coellip":
+            psf_gm, em_flags = _coellip_psf(psf_stamps, psf_ngauss, psf_T, cen,
+                                            np.stack([pg1, pg2], axis=1), rng)
+        else:
+            psf_gm, em_flags = _em_psf(psf_stamps, psf_ngauss, psf_T, cen, rng, em_pars)
         psf_bad = psf_bad | (em_flags != 0)
 
     # 2. guess: adaptive moments of the object, psf size taken out

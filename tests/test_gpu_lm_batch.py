@@ -248,6 +248,12 @@ def test_bootstrap_batch_with_em_psf():
     pimages = pim.cpu().numpy().reshape(n, pdim, pdim) + 1e-6 * rng.normal(size=(n, pdim, pdim))
     psb = StampBatch.from_images(pimages, np.full((n, pdim, pdim), 1e12), pjac)
 
+    # the same psf fit with co-elliptical gaussians in the lock-step LM
+    resc = bootstrap_batch(sb, psb, model="exp", psf_Tguess=0.3, psf_ngauss=2,
+                           psf_fitter="coellip")
+    assert np.all(resc["psf_em_flags"] == 0) and np.all(resc["flags"] == 0)
+    pullc = (resc["pars"] - pars) / resc["pars_err"]
+    assert np.all(np.abs(pullc) < 6.0) and np.sqrt((pullc ** 2).mean()) < 1.4
     res2 = bootstrap_batch(sb, psb, model="exp", psf_Tguess=0.3, psf_ngauss=2)
     assert np.all(res2["psf_em_flags"] == 0)
     assert np.all(res2["flags"] == 0)
@@ -429,8 +435,7 @@ def test_reference_lmdif_fits(golden, model):
     the models it fits with MINPACK lmdif (no analytic derivatives).  The
     per-object Fitter reproduces nfev / ier / pars; the batched forward-
     difference mode (fdjac2 inside the pixel pass) reaches the same solution
-    ('bd' with two bands has 9 parameters, one more than the batch state
-    holds: per-object only)"""
+    ('bd' with two bands has 9 of the batch state's 10 parameters)"""
     g = golden("lmfd")
     nband = 2
     obs, band = [], []
@@ -458,8 +463,6 @@ def test_reference_lmdif_fits(golden, model):
     assert np.all(np.abs(one["pars"] - ref["pars"]) <= 2e-3 * ref["pars_err"])
     np.testing.assert_allclose(one["pars_err"], ref["pars_err"], rtol=2e-3)
     np.testing.assert_allclose(one["lnprob"], float(ref["lnprob"]), rtol=1e-8)
-    if model == "bd":
-        return
     sb = StampBatch.from_observations(obs)
     psf = GMixBatch.from_numpy(np.stack([o.psf.gmix.get_data().copy() for o in obs]))
     res = LMBatchFitter(model, analytic_jacobian=False).go(
@@ -471,3 +474,36 @@ def test_reference_lmdif_fits(golden, model):
     np.testing.assert_allclose(res["pars_err"][0], ref["pars_err"], rtol=2e-3)
     np.testing.assert_allclose(res["lnprob"][0], float(ref["lnprob"]), rtol=1e-8)
     np.testing.assert_allclose(res["chi2per"][0], float(ref["chi2per"]), rtol=1e-7)
+
+
+@pytest.mark.parametrize("ngauss", [2, 3])
+def test_reference_coellip_fits_batched(golden, ngauss):
+    """LMBatchFitter('coellip', ngauss=...) -- the batched CoellipFitter, the
+    psf fitter of the LM psf runners -- against the reference's own fits of a
+    psf image (tests/golden/lmfd.npz), several copies of it in one batch"""
+    g = golden("lmfd")
+    jac = _jac(g["coellip_jac"])
+    im = g["coellip_image"]
+    wt = np.full(im.shape, 1.0 / 2.0e-4 ** 2)
+    pre = "coellip%d_" % ngauss
+    guess = g[pre + "guess"]
+    nrep = 3
+    obs = [ngmix.Observation(im, weight=wt, jacobian=jac) for _ in range(nrep)]
+    sb = StampBatch.from_observations(obs)
+    fitter = LMBatchFitter("coellip", ngauss=ngauss)
+    res = fitter.go(sb, np.tile(guess, (nrep, 1)))
+    assert res["pars"].shape == (nrep, 4 + 2 * ngauss)
+    err = g[pre + "pars_err"]
+    for i in range(nrep):
+        assert res["flags"][i] == int(g[pre + "flags"]) == 0
+        assert res["ier"][i] in (1, 2, 3)
+        assert abs(res["nfev"][i] - int(g[pre + "nfev"])) <= 4 * (4 + 2 * ngauss)
+        assert np.all(np.abs(res["pars"][i] - g[pre + "pars"]) <= 1e-2 * err), i
+        np.testing.assert_allclose(res["pars_err"][i], err, rtol=1e-2)
+        np.testing.assert_allclose(res["lnprob"][i], float(g[pre + "lnprob"]), rtol=1e-6)
+    np.testing.assert_array_equal(res["pars"][0], res["pars"][1])
+    fitted = fitter.gmix.to_numpy()[0]
+    ref = g[pre + "gmix_pars"].reshape(ngauss, 6)
+    np.testing.assert_allclose(np.sort(fitted["p"]), np.sort(ref[:, 0]), rtol=2e-3)
+    with pytest.raises(ValueError):
+        LMBatchFitter("coellip", ngauss=4)
