@@ -590,3 +590,33 @@ def test_batch_edge_shapes_and_empty_inputs():
     assert np.all(s3.cpu().numpy() == 0)
     np.testing.assert_allclose(o3[1, 0], -0.5 * (ims[1] ** 2).sum(), rtol=1e-13)
     assert o3[0, 0] == o3[2, 0] and o3[1, 2] == 0.0
+
+
+def test_batch_beyond_4_gib():
+    """64-bit addressing: pixel arrays larger than 4 GiB (the C2 workload
+    tiled 15 times, 300k stamps); every block of stamps must equal the small
+    batch bit for bit in loglike, and the last one in fill_fdiff and render"""
+    import os
+    import sys
+    import torch
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dev = torch.device("cuda", 0)
+    base, reps, npix = 20000, 15, 48 * 48
+    n = base * reps
+    sb0, gm0, _ = bench.make_workload(base, seed=7, device=dev)
+    sb = StampBatch(sb0.val.repeat(reps), sb0.ierr.repeat(reps), sb0.jac.repeat(reps, 1),
+                    np.full(n, 48), np.full(n, 48), np.arange(n, dtype=np.int64) * npix, True)
+    assert sb.val.numel() * 8 > 2 ** 32
+    gm = GMixBatch(gm0.data.repeat(reps, 1), n, gm0.ngauss)
+    ref = sb0.loglike(gm0)[0].cpu().numpy()
+    out, st = sb.loglike(gm)
+    assert int(st.abs().sum()) == 0
+    out = out.cpu().numpy().reshape(reps, base, 4)
+    for r in range(reps):
+        assert np.array_equal(out[r], ref), r
+    fd0 = sb0.fill_fdiff(gm0)[0].cpu().numpy()
+    assert np.array_equal(sb.fill_fdiff(gm)[0][-base * npix:].cpu().numpy(), fd0)
+    im0 = sb0.render(gm0)[0].cpu().numpy()
+    assert np.array_equal(sb.render(gm)[0][-base * npix:].cpu().numpy(), im0)
