@@ -275,7 +275,7 @@ class LMBatchFitter(object):
             "npix": npix_obj,
             "dof": rec[:, 3].astype(np.int64),
         }
-        self._add_stats(res, stamps, psf, sobj, sband, obj_start, nband)
+        self._add_stats(res, stamps, psf, sobj, sband, obj_start, nband, d_rec)
         return res
 
     def _first_pixels_fdiff2(self, stamps, psf, x, obj_start, sband, nskip):
@@ -339,44 +339,57 @@ class LMBatchFitter(object):
         """the raw ngmix_lm_state records of the last go() (debugging)"""
         return self._d_states.cpu().numpy().reshape(-1).view(_lib.LM_STATE_DTYPE)
 
-    def _add_stats(self, res, stamps, psf, sobj, sband, obj_start, nband):
+    def _add_stats(self, res, stamps, psf, sobj, sband, obj_start, nband, d_rec):
         """FitModel.set_fit_result (results.py:45-72, 398-408, 1079-1109) for
-        the fits with flags == 0: one batched get_loglike at the solutions"""
+        the fits with flags == 0: one batched get_loglike at the solutions,
+        folded per object on the device; one (nobj, 4) download"""
         torch = _torch()
+        dev = stamps.device
         nobj = res["flags"].size
         ok = res["flags"] == 0
         pars = res["pars"]
+        n = pars.shape[1]
         nshape = self.nloc - 1
-        usable = np.where(ok[:, None], pars, 0.0)
         # a harmless model for failed fits (their statistics are not reported)
-        usable[~ok, 4] = 1.0
+        default = np.zeros(n)
+        default[4] = 1.0
         if self.model == "bdf":
-            usable[~ok, 5] = 0.5
+            default[5] = 0.5
         if self.model == "bd":
-            usable[~ok, 6] = 0.5
-        usable[~ok, nshape:] = 1.0
+            default[6] = 0.5
+        default[nshape:] = 1.0
         if self.model == "coellip":
-            usable[~ok, 4:] = 1.0
-        band_pars = np.empty((stamps.n, self.nloc))
-        band_pars[:, :nshape] = usable[sobj, :nshape]
-        band_pars[:, nshape] = usable[sobj, nshape + sband]
-        gm0, st0 = GMixBatch.from_pars(band_pars, self.model, device=stamps.device,
+            default[4:] = 1.0
+        d_ok = d_rec[:, 0] == 0.0
+        usable = torch.where(d_ok[:, None], d_rec[:, 4:4 + n],
+                             torch.from_numpy(default).to(dev)[None, :])
+        d_sobj = torch.from_numpy(sobj.astype(np.int64)).to(dev)
+        d_sband = torch.from_numpy(sband.astype(np.int64)).to(dev)
+        band_pars = torch.empty((stamps.n, self.nloc), dtype=torch.float64, device=dev)
+        per_stamp = usable[d_sobj]
+        band_pars[:, :nshape] = per_stamp[:, :nshape]
+        band_pars[:, nshape] = per_stamp.gather(1, (nshape + d_sband)[:, None])[:, 0]
+        gm0, st0 = GMixBatch.from_pars(band_pars, self.model, device=dev,
                                        ngauss=self.ngauss)
         gm = gm0
         if psf is not None:
             gm, _ = gm0.convolve(psf)
         self.gmix = gm0  # the fitted (pre-psf) mixtures, one per stamp
         out, st1 = stamps.loglike(gm)
-        out = out.cpu().numpy()
-        lnprob = np.add.reduceat(out[:, 0], obj_start[:-1])
+        if stamps.n == nobj:
+            tot = out
+        else:
+            # (stamps of an object are contiguous: a fixed-order segmented sum)
+            lengths = torch.from_numpy(np.diff(obj_start)).to(dev)
+            tot = torch.segment_reduce(out, "sum", lengths=lengths, axis=0)
         if self.prior is not None:
             # calc_lnprob adds the joint prior (results.py:410-437)
-            lnp = self.prior.get_lnprob_batch(
-                torch.from_numpy(np.ascontiguousarray(usable)).to(stamps.device))
-            lnprob = lnprob + lnp.cpu().numpy()
-        s2n_numer = np.add.reduceat(out[:, 1], obj_start[:-1])
-        s2n_denom = np.add.reduceat(out[:, 2], obj_start[:-1])
-        npix = np.add.reduceat(out[:, 3], obj_start[:-1]).astype(np.int64)
+            tot = tot.clone()
+            tot[:, 0] += self.prior.get_lnprob_batch(usable.contiguous())
+        out = tot.cpu().numpy()
+        lnprob = out[:, 0]
+        s2n_numer, s2n_denom = out[:, 1], out[:, 2]
+        npix = np.rint(out[:, 3]).astype(np.int64)
         nan = np.full(nobj, np.nan)
         with np.errstate(all="ignore"):
             s2n = np.where(s2n_denom > 0, s2n_numer / np.sqrt(s2n_denom), 0.0)
