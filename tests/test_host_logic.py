@@ -219,3 +219,58 @@ def test_fitting_host_pieces():
     assert ier in (1, 2, 3, 4) and xfit[0] <= 1.5 + 1e-12
     xfree, _ = leastsqbound(func, np.array([1.0, 0.0]))
     np.testing.assert_allclose(xfree, [2.0, 0.1], atol=1e-8)
+
+
+def test_run_leastsq_error_mapping():
+    """run_leastsq's exception handling (leastsqbound.py:33-155, pinned by the
+    reference's test_leastsqbound.py:187-208): a ValueError mentioning NaNs or
+    infs -> LM_FUNC_NOTFINITE, ZeroDivisionError -> DIV_ZERO, any other
+    ValueError propagates; maxfev exhaustion -> flags 2**(ier-5) with default
+    pars; zero degrees of freedom -> ZERO_DOF"""
+    from ngmix_amd.fitting import run_leastsq
+    from ngmix_amd import flags as fl
+    from ngmix_amd.defaults import PDEF, CDEF
+    t = np.linspace(0, 1, 12)
+    y = 3.0 * t + 0.5
+
+    def good(p):
+        return p[0] * t + p[1] - y
+
+    res = run_leastsq(good, np.array([1.0, 0.0]), 0)
+    assert res["flags"] == 0 and res["nfev"] > 0
+    np.testing.assert_allclose(res["pars"], [3.0, 0.5], atol=1e-8)
+    assert res["pars_cov"].shape == (2, 2) and np.all(np.isfinite(res["pars_err"]))
+
+    def nan_error(p):
+        raise ValueError("array must not contain infs or NaNs")
+
+    res = run_leastsq(nan_error, np.array([1.0, 0.0]), 0)
+    assert res["flags"] == fl.LM_FUNC_NOTFINITE and res["nfev"] == -1
+    assert np.all(res["pars"] == PDEF) and np.all(res["pars_cov"] == CDEF)
+
+    def zero_div(p):
+        raise ZeroDivisionError("division by zero")
+
+    res = run_leastsq(zero_div, np.array([1.0, 0.0]), 0)
+    assert res["flags"] == fl.DIV_ZERO and res["nfev"] == -1
+
+    def other(p):
+        raise ValueError("something else")
+
+    with pytest.raises(ValueError):
+        run_leastsq(other, np.array([1.0, 0.0]), 0)
+
+    # maxfev exhausted: ier 5 -> flags 2**0, default pars
+    def rosen(p):
+        return np.array([10.0 * (p[1] - p[0] ** 2), 1.0 - p[0], 0.0])
+
+    res = run_leastsq(rosen, np.array([-1.2, 1.0]), 0, maxfev=4)
+    assert res["ier"] == 5 and res["flags"] == 2 ** 0
+    assert np.all(res["pars"] == PDEF)
+
+    # as many residuals as parameters: zero degrees of freedom
+    def square(p):
+        return np.array([p[0] - 1.0, p[1] + 2.0])
+
+    res = run_leastsq(square, np.array([0.0, 0.0]), 0)
+    assert res["flags"] & fl.ZERO_DOF
