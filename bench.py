@@ -12,14 +12,26 @@ independent, so there is no data-path collective -- only the all-gather of the
 32-byte per-stamp result records named by north_star, overlapped on a side
 stream.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--nstamps S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C4|C5]
 
-N > 1 is launched by torch.distributed.run (one process per GPU, RCCL).
+--gpus N > 1 without a torch.distributed.run environment: this process starts
+the N ranks itself (one child process per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set) before anything touches the GPU, relays rank 0's JSON line and
+exits with the worst child status.  Under torch.distributed.run (WORLD_SIZE
+already set) it is one of the ranks.  Either way the job refuses to run unless
+world size == --gpus and (on GPUs) the backend is nccl (= RCCL).
 Rank 0 prints ONE JSON line.
+
+Other configs of BASELINE.json, same contract, own rooflines:
+  --config C4   admom + em_run over 32x32 stamps (fp64-VALU bound)
+  --config C5   10 epochs x 64x64, 16-gaussian 'bdf' loglike (HBM bound)
+A default (C2, N = 1) run appends a short C4 and C5 measurement under
+"other_configs" so that the driver's record carries them too.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,16 +40,168 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SCALE = 0.263
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec
+FP64_VALU_PEAK_TF = 78.6  # MI355X_MICROARCH.md: fp64 vector peak (FMA = 2 flop)
+
+# ---- C2: 48x48 stamps, 6 gaussians
 NROW = NCOL = 48
 NGAUSS = 6
 NPIX = NROW * NCOL
 PAIRS_PER_STAMP = NPIX * NGAUSS  # 13,824 pixel-gaussian evaluations
-SCALE = 0.263
 # algorithmic bytes per stamp evaluation (SURVEY.md 8d / BASELINE.md section 3)
 LOGLIKE_BYTES = 16 * NPIX + 64 + 48 + 32   # 37,008
 RENDER_BYTES = 16 * NPIX                   # 36,864 (8 read + 8 written)
-HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec
 
+# ---- C4: flop model of the iterative kernels,
+# counted from the kernel source, FMA = 2 flop, per pixel:
+#   admom centroid pass   31  (chi2 8, gate+fexp+apod-free weight 15, 3 sums 5, ...)
+#   admom moments pass    45  (7 moment sums + wsum; no covariance in the loop)
+#   admom covariance pass 96  (once per object: 28 unique w^2 var F_i F_j sums)
+#   em_run pixel pass     73  (1 object gaussian (x) 1 psf gaussian: chi2, hard-cut
+#                              fexp, 6 scratch sums, logL, two reciprocals by
+#                              v_rcp + 2 Newton steps, 8 accumulators)
+ADMOM_FLOP_ITER_PX = 31 + 45
+ADMOM_FLOP_ONCE_PX = 96
+EM_FLOP_ITER_PX = 73
+
+
+# --------------------------------------------------------------------------
+# launching
+# --------------------------------------------------------------------------
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 and no WORLD_SIZE in the environment: start the N ranks as
+    child processes (ngmix_amd.distributed.launch_local_ranks).  Nothing in
+    this (parent) process initialises the GPU."""
+    from ngmix_amd import distributed as nd
+    return nd.launch_local_ranks(os.path.abspath(__file__), argv, args.gpus, cwd=ROOT)
+
+
+def init_rank(args):
+    """one process per GPU; "nccl" is RCCL on ROCm (xGMI inside the node).
+    Returns (rank, world, device, backend); refuses a world size other than
+    --gpus."""
+    import torch
+    import torch.distributed as dist
+    from ngmix_amd import distributed as nd
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP kernels are the product)")
+    rank, world, local_rank = nd.init_from_env(backend="nccl")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s); "
+                         "refusing to report a mislabelled number" % (args.gpus, world))
+    backend = None
+    if world > 1:
+        backend = dist.get_backend()
+        allowed = ("nccl", os.environ.get("NGMIX_DIST_BACKEND", "nccl"))
+        if backend not in allowed or dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: backend %r / world %d is not the RCCL job "
+                             "that was asked for" % (backend, dist.get_world_size()))
+    torch.cuda.set_device(local_rank)
+    return rank, world, torch.device("cuda", local_rank), backend
+
+
+def timed_steps(step, args, distributed, device):
+    """settle + W warm-up steps untimed, then exactly K steps between barrier +
+    synchronize on both sides; returns the max over ranks of the elapsed time"""
+    import torch
+    import torch.distributed as dist
+    for _ in range(max(args.settle_steps, 0)):
+        step(None)
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step(None)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+class Gather:
+    """north_star's all-gather of per-object result records, on a side stream
+    so that it overlaps the next step's first kernel"""
+
+    def __init__(self, world, device):
+        import torch
+        self.world = world
+        self.on = world > 1
+        self.side = torch.cuda.Stream(device=device) if self.on else None
+        self.pending = None
+        self.bufs = {}
+
+    def wait_consumed(self):
+        """the previous gather must have read its source before the kernel
+        that rewrites it is launched"""
+        import torch
+        if self.pending is not None:
+            torch.cuda.current_stream().wait_event(self.pending)
+            self.pending = None
+
+    def gather(self, key, records):
+        import torch
+        from ngmix_amd import distributed as nd
+        if not self.on:
+            return records
+        n = records.shape[0]
+        if key not in self.bufs:
+            self.bufs[key] = torch.empty((self.world * n,) + tuple(records.shape[1:]),
+                                         dtype=records.dtype, device=records.device)
+        done = torch.cuda.Event()
+        done.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(done)
+            nd.allgather_records(records, n_objects=self.world * n, out=self.bufs[key])
+            self.pending = torch.cuda.Event()
+            self.pending.record()
+        return self.bufs[key]
+
+
+def _events(k):
+    import torch
+    return [torch.cuda.Event(enable_timing=True) for _ in range(k)]
+
+
+def _mean_ms(a, b):
+    return float(np.mean([x.elapsed_time(y) for x, y in zip(a, b)]))
+
+
+def kernel_symbols(fragments):
+    """the device symbols of libngmix_hip.so that contain every fragment of one
+    of the given tuples (so that the JSON line names the kernel as rocprofv3
+    will, not a made-up label)"""
+    from ngmix_amd import _lib
+    try:
+        out = subprocess.run(["nm", "-D", "--defined-only", "-C", _lib.LIB_PATH],
+                             capture_output=True, text=True, timeout=30).stdout
+    except Exception:
+        return {}
+    found = {}
+    for key, frags in fragments.items():
+        for ln in out.splitlines():
+            name = ln.split(" ", 2)[-1]
+            if all(f in name for f in frags) and "__device_stub__" in name:
+                found[key] = name.split("__device_stub__")[-1].strip()
+                break
+    return found
+
+
+# --------------------------------------------------------------------------
+# C2 (the metric's config)
+# --------------------------------------------------------------------------
 
 def make_workload(nstamps, seed, device):
     """per-stamp 'exp' model x gaussian psf T=0.27, noise
@@ -86,6 +250,359 @@ def make_workload(nstamps, seed, device):
     gmp.set_norms()
     return sb, gmp, pars
 
+
+def run_c2(args, rank, world, device, backend):
+    import torch
+    n = args.nstamps or 100000
+    distributed = world > 1
+    sb, gm, _ = make_workload(n, seed=1000 + rank, device=device)
+    image = torch.zeros(sb.total_pix, dtype=torch.float64, device=device)
+    out = torch.empty((n, 4), dtype=torch.float64, device=device)
+    status = torch.empty(n, dtype=torch.int32, device=device)
+    gat = Gather(world, device)
+    ev_r0, ev_r1 = _events(args.steps), _events(args.steps)
+    ev_l0, ev_l1 = _events(args.steps), _events(args.steps)
+
+    def step(i):
+        if i is not None:
+            ev_r0[i].record()
+        sb.render(gm, image=image, fast_exp=True, status=status, exact=args.exact)
+        if i is not None:
+            ev_r1[i].record()
+        gat.wait_consumed()      # before the events: only the kernel is timed
+        if i is not None:
+            ev_l0[i].record()
+        sb.loglike(gm, out=out, status=status, exact=args.exact)
+        if i is not None:
+            ev_l1[i].record()
+        gat.gather("loglike", out)
+
+    elapsed = timed_steps(step, args, distributed, device)
+    bad = int((status != 0).sum().item())
+    render_ms = _mean_ms(ev_r0, ev_r1)
+    loglike_ms = _mean_ms(ev_l0, ev_l1)
+    if rank != 0:
+        return None
+
+    pairs_per_step = 2.0 * world * n * PAIRS_PER_STAMP
+    value = pairs_per_step * args.steps / elapsed
+    dominant = "loglike" if loglike_ms >= render_ms else "render"
+    dom_ms = max(loglike_ms, render_ms)
+    dom_bytes = (LOGLIKE_BYTES if dominant == "loglike" else RENDER_BYTES) * n
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    if args.exact:
+        syms = kernel_symbols({"loglike": ("pixpass_grid_kernel<0,",),
+                               "render": ("pixpass_grid_kernel<2,",)})
+    else:
+        syms = kernel_symbols({"loglike": ("pixpass_wave_kernel<0,", "false"),
+                               "render": ("pixpass_wave_kernel<2,", "false")})
+    traffic_bytes, traffic_source = load_traffic(dominant, n)
+    line = {
+        "metric": baseline_metric(),
+        "value": value,
+        "unit": "pixel-gaussian evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "C2: %d stamps/GPU, 48x48 px, 6-gaussian 'exp' (x) "
+                        "gaussian psf; one step = render + get_loglike of "
+                        "every stamp" % n,
+            "stamps_per_gpu": n,
+            "parallelism": "stamps sharded across %d rank(s); all-gather of "
+                           "32-B result records" % world,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": syms.get(dominant, "pixpass_%s_kernel (%s)" % (
+                "grid" if args.exact else "wave", dominant)),
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic_bytes,
+            "traffic_source": traffic_source,
+            "algorithmic_bytes_per_launch": dom_bytes,
+            "avg_launch_ms": dom_ms,
+        },
+        "kernels_ms": {"render": render_ms, "loglike": loglike_ms},
+        "loglike_stamp_evals_per_s_per_gpu": n / (loglike_ms * 1e-3),
+        "render_stamp_evals_per_s_per_gpu": n / (render_ms * 1e-3),
+        "loglike_hbm_frac": LOGLIKE_BYTES * n / (loglike_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "render_hbm_frac": RENDER_BYTES * n / (render_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "bad_status": bad,
+        "settle_steps": max(args.settle_steps, 0),
+        "kernel_mode": "exact" if args.exact else "fused",
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(sb, gm)
+    return line
+
+
+# --------------------------------------------------------------------------
+# C4: admom + em_run over 32x32 stamps
+# --------------------------------------------------------------------------
+
+def make_c4(n, seed, device, dim=32):
+    """round-ish gaussian (x) gaussian-psf objects on 32x32
+    stamps; admom guess T = T_true U(0.9,1.1); 1-gaussian EM guess"""
+    import torch
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    rng = np.random.RandomState(seed)
+    pars = np.zeros((n, 6))
+    pars[:, 0:2] = rng.uniform(-0.5, 0.5, size=(n, 2)) * SCALE
+    pars[:, 2:4] = rng.normal(scale=0.05, size=(n, 2))
+    pars[:, 4] = rng.uniform(0.3, 0.9, size=n) + 0.27
+    pars[:, 5] = rng.uniform(50, 200, size=n)
+    gm_true, _ = GMixBatch.from_pars(pars, "gauss", device=device)
+    c = (dim - 1) / 2
+    jac = np.array([c, c, SCALE, 0, 0, SCALE, SCALE ** 2, SCALE])
+    d_jac = torch.from_numpy(np.tile(jac, (n, 1))).to(device)
+    shape = np.full(n, dim)
+    off = np.arange(n, dtype=np.int64) * dim * dim
+    geom = StampBatch(None, None, d_jac, shape, shape, off, True)
+    truth, _ = geom.render(gm_true)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    sky = 0.05
+    val = truth + 0.01 * torch.randn(truth.shape, generator=gen, device=device,
+                                     dtype=torch.float64)
+    ierr = torch.full_like(val, 100.0)
+    sb = StampBatch(val, ierr, d_jac, shape, shape, off, True)
+    sb_em = StampBatch(val + sky, ierr, d_jac, shape, shape, off, True)
+    guess = np.zeros((n, 6))
+    guess[:, 4] = pars[:, 4] * rng.uniform(0.9, 1.1, size=n)
+    guess[:, 5] = 1.0
+    wt0, _ = GMixBatch.from_pars(guess, "gauss", device=device)
+    emguess = pars.copy()
+    emguess[:, 4] = (pars[:, 4] - 0.27) * rng.uniform(0.9, 1.1, size=n)
+    emguess[:, 5] = pars[:, 5] * SCALE ** 2 * rng.uniform(0.9, 1.1, size=n)
+    gm0, _ = GMixBatch.from_pars(emguess, "gauss", device=device)
+    psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (n, 1)),
+                                 "gauss", device=device)
+    return dict(sb=sb, sb_em=sb_em, wt0=wt0, gm0=gm0, psf=psf, sky=sky, dim=dim, n=n)
+
+
+def run_c4(args, rank, world, device, backend, nstamps=None, steps=None, quiet=False):
+    """one step = adaptive moments of every stamp, then em_run of every stamp
+    (one launch each); the 584-byte admom records and the 72-byte EM records
+    are all-gathered on the side stream"""
+    import torch
+    n = nstamps or args.nstamps or 125000
+    w = make_c4(n, 5 + rank, device)
+    sb, sb_em, dim = w["sb"], w["sb_em"], w["dim"]
+    npx = dim * dim
+    distributed = world > 1
+    gat = Gather(world, device)
+    wt = w["wt0"].clone()
+    gm = w["gm0"].clone()
+    conv, _ = gm.convolve(w["psf"])
+    res = torch.zeros((n, 73), dtype=torch.float64, device=device)
+    st_a = torch.empty(n, dtype=torch.int32, device=device)
+    out_e = torch.empty((n, 3), dtype=torch.float64, device=device)
+    st_e = torch.empty(n, dtype=torch.int32, device=device)
+    rec_e = torch.empty((n, 9), dtype=torch.float64, device=device)
+    K = steps or args.steps
+    ev = [_events(K) for _ in range(4)]
+
+    def step(i):
+        # the guesses are copied back in (device-to-device, untimed by the
+        # kernel events but inside the step: it is part of the job)
+        wt.data.copy_(w["wt0"].data)
+        gm.data.copy_(w["gm0"].data)
+        gat.wait_consumed()
+        res.zero_()
+        if i is not None:
+            ev[0][i].record()
+        sb.admom(wt, res=res, status=st_a)
+        if i is not None:
+            ev[1][i].record()
+        gat.gather("admom", res)
+        conv_i, _ = gm.convolve(w["psf"])
+        if i is not None:
+            ev[2][i].record()
+        sb_em.em(gm, w["psf"], conv=conv_i, sky=w["sky"], out=out_e, status=st_e)
+        if i is not None:
+            ev[3][i].record()
+        rec_e[:, :6] = gm.data.reshape(n, -1)[:, :6]
+        rec_e[:, 6:] = out_e
+        gat.gather("em", rec_e)
+
+    import copy
+    a2 = copy.copy(args)
+    a2.steps = K
+    if steps is not None:       # the short leg of a C2 run
+        a2.warmup, a2.settle_steps = 2, 0
+    elapsed = timed_steps(step, a2, distributed, device)
+    admom_ms = _mean_ms(ev[0], ev[1])
+    em_ms = _mean_ms(ev[2], ev[3])
+    # iteration counts of the last pass: the flop model's multiplier
+    numiter = res.view(torch.int32).reshape(n, -1)[:, 1].double()
+    flags_bad = int((res.view(torch.int32).reshape(n, -1)[:, 0] != 0).sum().item())
+    it_admom = float(numiter.mean().item())
+    it_em = float(out_e[:, 0].mean().item())
+    bad = int((st_a != 0).sum().item()) + int((st_e != 0).sum().item())
+    if rank != 0:
+        return None
+    fl_admom = n * npx * (it_admom * ADMOM_FLOP_ITER_PX + ADMOM_FLOP_ONCE_PX)
+    fl_em = n * npx * it_em * EM_FLOP_ITER_PX
+    syms = kernel_symbols({"admom": ("admom_grid_kernel<64, 16>",),
+                           "em": ("em_wave_kernel<64, 16, 0, 1, true>",)})
+
+    def roof(ms, flop, key, nbytes):
+        tf = flop / (ms * 1e-3) / 1e12
+        return {"bound": "fp64_valu", "kernel": syms.get(key, key),
+                "achieved": tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                "frac": tf / FP64_VALU_PEAK_TF, "traffic": None,
+                "flop_per_launch": flop, "avg_launch_ms": ms,
+                "objects_per_s": n / (ms * 1e-3),
+                "hbm_algorithmic_GBs": nbytes * n / (ms * 1e-3) / 1e9}
+
+    r_admom = roof(admom_ms, fl_admom, "admom", 16 * npx + 64 + 48 + 584)
+    r_em = roof(em_ms, fl_em, "em", 16 * npx + 64 + 6 * 8 * 2 + 24)
+    dom = r_em if em_ms >= admom_ms else r_admom
+    line = {
+        "metric": "objects/sec (admom + em_run), 32x32 stamps, 1/2/4/8 GPU",
+        "value": world * n * K / elapsed,
+        "unit": "objects/s",
+        "n_gpus": world, "steps": K, "warmup": a2.warmup,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": "C4: %d stamps/GPU, 32x32 px, gaussian (x) gaussian psf; one "
+                        "step = run_admom + 1-gaussian em_run of every stamp" % n,
+            "stamps_per_gpu": n,
+            "parallelism": "stamps sharded across %d rank(s); all-gather of 584-B "
+                           "admom and 72-B EM records" % world,
+        },
+        "roofline": dom,
+        "rooflines": {"admom": r_admom, "em_run": r_em},
+        "mean_numiter": {"admom": it_admom, "em_run": it_em},
+        "kernels_ms": {"admom": admom_ms, "em_run": em_ms},
+        "bad_status": bad, "admom_flags_nonzero": flags_bad,
+        "settle_steps": max(a2.settle_steps, 0),
+    }
+    return line
+
+
+# --------------------------------------------------------------------------
+# C5: multi-epoch 'bdf' loglike
+# --------------------------------------------------------------------------
+
+def run_c5(args, rank, world, device, backend, nobj=None, steps=None):
+    """one step = the joint loglike of every object: 10 epochs x 64x64 pixels,
+    16-gaussian 'bdf' (x) gaussian psf, per-epoch sub-pixel jacobian offsets
+    (ngmix/tests/_sims.py:150-159), float64, summed over the object's epochs on
+    the device; 32-byte per-object records all-gathered"""
+    import torch
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    nobj = nobj or args.nstamps or 20000
+    nepoch, dim = 10, 64
+    ns = nobj * nepoch
+    rng = np.random.RandomState(3 + rank)
+    pars = np.zeros((nobj, 7))
+    pars[:, 0:2] = rng.uniform(-0.3, 0.3, size=(nobj, 2)) * SCALE
+    pars[:, 2:4] = rng.normal(scale=0.08, size=(nobj, 2))
+    pars[:, 4] = rng.uniform(0.5, 2.0, size=nobj)
+    pars[:, 5] = rng.uniform(0.2, 0.8, size=nobj)
+    pars[:, 6] = rng.uniform(100, 400, size=nobj)
+    spars = np.repeat(pars, nepoch, axis=0)
+    jac = np.zeros((ns, 8))
+    jac[:, 0] = (dim - 1) / 2 + rng.uniform(-0.5, 0.5, size=ns)
+    jac[:, 1] = (dim - 1) / 2 + rng.uniform(-0.5, 0.5, size=ns)
+    jac[:, 2] = jac[:, 5] = jac[:, 7] = SCALE
+    jac[:, 6] = SCALE ** 2
+    gm0, _ = GMixBatch.from_pars(spars, "bdf", device=device)
+    psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (ns, 1)),
+                                 "gauss", device=device)
+    gm, _ = gm0.convolve(psf)
+    gm.set_norms()
+    jt = torch.from_numpy(jac).to(device)
+    shape = np.full(ns, dim)
+    off = np.arange(ns, dtype=np.int64) * dim * dim
+    geom = StampBatch(None, None, jt, shape, shape, off, True)
+    truth, _ = geom.render(gm)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1 + rank)
+    val = truth
+    val += 0.05 * torch.randn(truth.shape, generator=gen, device=device,
+                              dtype=torch.float64)
+    ierr = torch.full_like(val, 20.0)
+    sb = StampBatch(val, ierr, jt, shape, shape, off, True)
+    obj_start = np.arange(nobj + 1) * nepoch
+    out = torch.empty((ns, 4), dtype=torch.float64, device=device)
+    status = torch.empty(ns, dtype=torch.int32, device=device)
+    distributed = world > 1
+    gat = Gather(world, device)
+    K = steps or args.steps
+    ev0, ev1, ev2 = _events(K), _events(K), _events(K)
+    holder = {}
+
+    def step(i):
+        gat.wait_consumed()
+        if i is not None:
+            ev0[i].record()
+        sb.loglike(gm, out=out, status=status)
+        if i is not None:
+            ev1[i].record()
+        per_obj = sb.sum_over_epochs(out, obj_start)
+        if i is not None:
+            ev2[i].record()
+        holder["per_obj"] = per_obj
+        gat.gather("c5", per_obj)
+
+    import copy
+    a2 = copy.copy(args)
+    a2.steps = K
+    if steps is not None:
+        a2.warmup, a2.settle_steps = 2, 0
+    elapsed = timed_steps(step, a2, distributed, device)
+    ll_ms = _mean_ms(ev0, ev1)
+    red_ms = _mean_ms(ev1, ev2)
+    bad = int((status != 0).sum().item())
+    if rank != 0:
+        return None
+    epoch_bytes = 16 * dim * dim + 64 + 48 + 32      # 65,680 B (SURVEY 8d)
+    achieved = epoch_bytes * ns / (ll_ms * 1e-3) / 1e9
+    syms = kernel_symbols({"loglike": ("pixpass_wave_kernel<0,", "false")})
+    return {
+        "metric": "object loglikes/sec, 10 epochs x 64x64, 16-gaussian 'bdf', 1/2/4/8 GPU",
+        "value": world * nobj * K / elapsed,
+        "unit": "object loglikes/s",
+        "n_gpus": world, "steps": K, "warmup": a2.warmup,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": "C5: %d objects/GPU x %d epochs of 64x64 px, 16-gaussian 'bdf' "
+                        "(x) gaussian psf; one step = joint loglike of every object"
+                        % (nobj, nepoch),
+            "objects_per_gpu": nobj,
+            "parallelism": "objects (all their epochs) sharded across %d rank(s); "
+                           "all-gather of 32-B per-object records" % world,
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": syms.get("loglike", "pixpass_wave_kernel (loglike)"),
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": epoch_bytes * ns, "avg_launch_ms": ll_ms,
+        },
+        "kernels_ms": {"loglike": ll_ms, "epoch_reduce": red_ms},
+        "pixel_gaussian_evals_per_s": world * ns * dim * dim * 16 * K / elapsed,
+        "bad_status": bad, "settle_steps": max(a2.settle_steps, 0),
+    }
+
+
+# --------------------------------------------------------------------------
+# CPU baseline (the checker, timed beside the product; never the product)
+# --------------------------------------------------------------------------
 
 def cpu_baseline(sb, gm, target_seconds=12.0):
     """the CPU oracle (a port of the numba loops: oracle/ngmix_oracle.c) timed
@@ -137,6 +654,9 @@ def cpu_baseline(sb, gm, target_seconds=12.0):
                   "over stamps, C port of the numba loops, -O2 no-FMA" % (S, reps),
         "seconds": dt,
         "single_core_value": single,
+        # the GPU box's host is shared with the node's other pods: the
+        # all-thread figure is a lower bound, the single-core one is stable
+        "shared_host": True,
     }
 
 
@@ -151,13 +671,11 @@ def cpu_baseline_configs(budget=4.0):
     nth = ora.num_threads()
     scale = SCALE
 
-
     def jac(dim):
         j = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
         c = (dim - 1) / 2.0
         j[0] = (c, c, scale, 0.0, 0.0, scale, scale * scale, scale)
         return j
-
 
     def mixture(pars, model, psf_T=0.27):
         ng = {"gauss": 1, "exp": 6}[model]
@@ -169,7 +687,6 @@ def cpu_baseline_configs(budget=4.0):
         ora.gmix_convolve_fill(out, gm, psf)
         ora.gmix_set_norms(out)
         return gm, psf, out
-
 
     def stamps(n, dim, model, rng):
         j = jac(dim)
@@ -189,7 +706,6 @@ def cpu_baseline_configs(budget=4.0):
             pars_all.append(pars)
         return np.array(gms), pix, np.tile(coords, (n, 1)), np.array(pars_all)
 
-
     def timed(fn, nunits):
         fn()
         t0 = time.perf_counter()
@@ -201,7 +717,6 @@ def cpu_baseline_configs(budget=4.0):
             fn()
         dt = time.perf_counter() - t0
         return nunits * reps / dt
-
 
     rng = np.random.RandomState(1)
     print("host threads available: %d" % nth)
@@ -281,27 +796,32 @@ def cpu_baseline_configs(budget=4.0):
             threads, run_em.n / run_em.dt, run_em.iters))
 
 
-
 def baseline_metric():
     """BASELINE.json's metric string, verbatim"""
     try:
         with open(os.path.join(ROOT, "BASELINE.json")) as f:
             return json.load(f)["metric"]
     except (OSError, KeyError, ValueError):
-        return ("pixel-Gaussian evals/sec (render+loglike), 48\u00d748\u00d76-gauss stamps, "
+        return ("pixel-Gaussian evals/sec (render+loglike), 48×48×6-gauss stamps, "
                 "1/2/4/8 GPU")
 
 
-def load_traffic():
-    """HBM bytes per loglike launch from the committed rocprofv3 PMC pass
-    (profiles/), if one exists for this workload size"""
+def load_traffic(kernel, nstamps):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC pass
+    (counters cannot be read from inside the timed run: rocprofv3 --pmc is a
+    separate, serialising pass).  Returns (bytes or None, source or None)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(path):
-        try:
-            return json.load(open(path))
-        except Exception:
-            return None
-    return None
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    if t.get("nstamps") != nstamps:
+        return None, None
+    v = t.get(kernel + "_hbm_bytes_per_launch")
+    if v is None:
+        return None, None
+    return v, "profiles/pmc_traffic.json (%s)" % t.get("source", "rocprofv3 --pmc pass")
 
 
 def main():
@@ -309,13 +829,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--settle-steps", type=int, default=100,
+    ap.add_argument("--config", default="C2", choices=["C2", "C4", "C5"])
+    ap.add_argument("--settle-steps", type=int, default=None,
                     help="untimed steps run before the warm-up steps: the GPU's "
                          "clock governor needs ~50-100 ms of load to reach its "
-                         "steady state (DESIGN.md section 5); 0 disables")
-    ap.add_argument("--nstamps", type=int, default=100000,
-                    help="stamps per GPU (weak scaling)")
+                         "steady state (DESIGN.md section 5); 0 disables "
+                         "(default: 100 for C2, 10 for C4 / C5)")
+    ap.add_argument("--nstamps", type=int, default=None,
+                    help="stamps (C5: objects) per GPU (weak scaling); default "
+                         "100000 (C2), 125000 (C4), 20000 (C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="C2 at N = 1 only: skip the short C4 / C5 legs")
     ap.add_argument("--cpu-baselines", type=float, nargs="?", const=4.0, default=None,
                     metavar="SECONDS",
                     help="only time the CPU port on configs C1 / C2 / C4 (single core "
@@ -326,148 +851,46 @@ def main():
     args = ap.parse_args()
     if args.cpu_baselines is not None:
         cpu_baseline_configs(args.cpu_baselines)
-        return
+        return 0
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.settle_steps is None:
+        args.settle_steps = 100 if args.config == "C2" else 10
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, sys.argv[1:])
 
-    import torch
     import torch.distributed as dist
-    from ngmix_amd import distributed as nd
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP kernels are the product)")
-    # one process per GPU; "nccl" is RCCL on ROCm (xGMI inside the node)
-    rank, world, local_rank = nd.init_from_env(backend="nccl")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    distributed = world > 1
-
-    n = args.nstamps
-    sb, gm, _ = make_workload(n, seed=1000 + rank, device=device)
-    image = torch.zeros(sb.total_pix, dtype=torch.float64, device=device)
-    out = torch.empty((n, 4), dtype=torch.float64, device=device)
-    status = torch.empty(n, dtype=torch.int32, device=device)
-    gathered = None
-    side = None
-    if distributed:
-        gathered = torch.empty((world * n, 4), dtype=torch.float64, device=device)
-        side = torch.cuda.Stream(device=device)
-
-    ev_r0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev_r1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev_l1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    pending = None
-
-    def step(i=None):
-        nonlocal pending
-        if i is not None:
-            ev_r0[i].record()
-        sb.render(gm, image=image, fast_exp=True, status=status, exact=args.exact)
-        if i is not None:
-            ev_r1[i].record()
-        if pending is not None:
-            # the previous step's gather must have consumed `out`
-            torch.cuda.current_stream().wait_event(pending)
-        sb.loglike(gm, out=out, status=status, exact=args.exact)
-        if i is not None:
-            ev_l1[i].record()
-        if distributed:
-            # north_star's all-gather of per-object result records, on a side
-            # stream so it overlaps the next step's render
-            done = torch.cuda.Event()
-            done.record()
-            with torch.cuda.stream(side):
-                side.wait_event(done)
-                nd.allgather_records(out, n_objects=world * n, out=gathered)
-                pending = torch.cuda.Event()
-                pending.record()
-
-    # steady-state clocks first (untimed, like the warm-up steps that follow)
-    # (a fixed count, so that every rank issues the same collectives)
-    for _ in range(max(args.settle_steps, 0)):
-        step()
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    bad = int((status != 0).sum().item())
-    render_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_r0, ev_r1)]))
-    loglike_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_r1, ev_l1)]))
-
+    rank, world, device, backend = init_rank(args)
+    run = {"C2": run_c2, "C4": run_c4, "C5": run_c5}[args.config]
+    line = run(args, rank, world, device, backend)
     if rank == 0:
-        pairs_per_step = 2.0 * world * n * PAIRS_PER_STAMP
-        value = pairs_per_step * args.steps / elapsed
-        dominant = "loglike" if loglike_ms >= render_ms else "render"
-        dom_ms = max(loglike_ms, render_ms)
-        dom_bytes = (LOGLIKE_BYTES if dominant == "loglike" else RENDER_BYTES) * n
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = load_traffic()
-        traffic_bytes = None
-        if traffic and traffic.get("nstamps") == n:
-            traffic_bytes = traffic.get(dominant + "_hbm_bytes_per_launch")
-        line = {
-            "metric": baseline_metric(),
-            "value": value,
-            "unit": "pixel-gaussian evals/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": "C2: %d stamps/GPU, 48x48 px, 6-gaussian 'exp' (x) "
-                            "gaussian psf; one step = render + get_loglike of "
-                            "every stamp" % n,
-                "stamps_per_gpu": n,
-                "parallelism": "stamps sharded across %d rank(s); all-gather of "
-                               "32-B result records" % world,
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "pixpass_%s_kernel<%s>" % (
-                    "grid" if args.exact else "wave", dominant),
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic_bytes,
-                "algorithmic_bytes_per_launch": dom_bytes,
-                "avg_launch_ms": dom_ms,
-            },
-            "kernels_ms": {"render": render_ms, "loglike": loglike_ms},
-            "loglike_stamp_evals_per_s_per_gpu": n / (loglike_ms * 1e-3),
-            "render_stamp_evals_per_s_per_gpu": n / (render_ms * 1e-3),
-            "bad_status": bad,
-            "settle_steps": max(args.settle_steps, 0),
-            "kernel_mode": "exact" if args.exact else "fused",
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sb, gm)
+        line["rccl_ranks"] = dist.get_world_size() if world > 1 else 1
+        line["backend"] = backend or "none (single process)"
+        if args.config == "C2" and world == 1 and not args.no_other_configs:
+            import torch
+            torch.cuda.empty_cache()
+            other = {}
+            for name, fn, kw in (("C4", run_c4, dict(nstamps=125000, steps=5)),
+                                 ("C5", run_c5, dict(nobj=20000, steps=10))):
+                try:
+                    o = fn(args, rank, world, device, backend, **kw)
+                    other[name] = {k: o[k] for k in (
+                        "metric", "value", "unit", "config", "roofline", "kernels_ms",
+                        "bad_status") if k in o}
+                    for k in ("rooflines", "mean_numiter"):
+                        if k in o:
+                            other[name][k] = o[k]
+                except Exception as e:   # never lose the headline line
+                    other[name] = {"error": repr(e)}
+                torch.cuda.empty_cache()
+            line["other_configs"] = other
         print(json.dumps(line))
         sys.stdout.flush()
-    if distributed:
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

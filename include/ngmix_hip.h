@@ -20,9 +20,21 @@
  *       asynchronous on the given hipStream_t.  This is the form the
  *       throughput numbers are quoted on.
  *
- * All arithmetic is IEEE float64 with no FMA contraction, in the reference's
- * operation order: per-pixel values (render, fdiff) are bit-identical to the
- * reference; sums over pixels differ only by summation order.
+ * Numerics (all IEEE float64; no reduced precision anywhere):
+ *   - SEAM forms, and BATCH forms called with NGMIX_BATCH_EXACT: no FMA
+ *     contraction, the reference's operation order.  Per-pixel values (render,
+ *     fill_fdiff, deriv_images, fill_pixels / fill_coords) are BIT-IDENTICAL
+ *     to the reference's; sums over pixels (loglike, s2n, moments) differ only
+ *     by summation order (<= 1e-12 relative in the tests).
+ *   - BATCH forms by DEFAULT run the fused kernels: explicit fma(), a shared-
+ *     centre form of chi^2 and the fexp cell index taken as round(chi^2/2)
+ *     (differs from the reference's int(x - 0.5) only on exact ties, where its
+ *     C2 polynomial changes by 1 ulp).  Same gates, same order of the sum over
+ *     gaussians, results equal TO ROUNDING, not bit for bit: per-pixel values
+ *     within 2e-13 of the stamp's peak and 1e-10 relative (BASELINE
+ *     north_star's tolerance) wherever the value is not a cancellation
+ *     residue; loglike / s2n sums within 1e-11 relative.  A binding that
+ *     asserts equality must pass NGMIX_BATCH_EXACT.
  *
  * Return value: 0 = NGMIX_OK, >0 = the reference would have raised (code
  * below), <0 = runtime failure (ngmix_last_error() has the message).  Batch
@@ -276,6 +288,10 @@ typedef struct {
    reference) instead of the default FUSED kernels (FMA + shared-centre
    algebra: the same values to <= ~1e-13 relative, about twice as fast) */
 #define NGMIX_BATCH_EXACT 2
+/* fused pixel-pass kernels: route complete-tile stamps through the compiler-
+ * tracked load path instead of the hand-counted look-ahead loads (same
+ * arithmetic, bit-identical results; a diagnostic for toolchain changes) */
+#define NGMIX_BATCH_TRACKED_LOADS 4
 
 /* A batch of stamps: HOST struct holding DEVICE pointers plus the few host
    facts a launch needs (LDS sizing, tile schedule). */
@@ -293,6 +309,24 @@ typedef struct {
     int32_t max_ncol;           /* max stamps[i].ncol, 0 = unknown (LDS is
                                    then sized from max_npix alone) */
 } ngmix_batch;
+
+/* Library-owned stamp store: builds the ngmix_batch above in HBM from HOST
+   arrays -- for N objects at once what Observation.update_pixels -> make_pixels
+   does per object (ngmix/observation.py:814-830, ngmix/pixels/pixels.py:6-52).
+   create: stamp i is nrow[i] x ncol[i]; every stamp's mixture has `ngauss`
+   gaussians (stamps[i].gm_off = i*ngauss).  upload: `images` (and `weights`,
+   or NULL for unit weights) hold the stamps back to back, row-major; `jac` one
+   record per stamp; ierr = sqrt(max(weight,0)) and the kept-pixel counts are
+   computed on the device; a stamp without any positive weight is
+   NGMIX_ERR_BAD_ARG (the reference's GMixFatalError).  The returned pointer
+   is what the *_batch entry points take; release it with ngmix_batch_free. */
+int ngmix_batch_create(ngmix_batch **out, int64_t nstamps, const int32_t *nrow,
+                       const int32_t *ncol, int32_t ngauss, int ignore_zero_weight);
+int ngmix_batch_upload(ngmix_batch *b, const double *images, const double *weights,
+                       const ngmix_jacobian *jac, void *stream);
+/* npix_kept[i] = size of the reference's pixel list of stamp i (after upload) */
+int ngmix_batch_npix_kept(const ngmix_batch *b, int32_t *npix_kept);
+int ngmix_batch_free(ngmix_batch *b);
 
 /* ierr = sqrt(max(weight,0)) elementwise (pixels_nb.py:49-52) */
 int ngmix_weight_to_ierr_batch(const double *weight, double *ierr, int64_t n,
@@ -513,6 +547,26 @@ int ngmix_simple_sep_prior_eval(const ngmix_simple_sep_prior *prior,
 int ngmix_lm_finalize_batch(const ngmix_lm_state *states, int64_t nobj,
                             const int64_t *npix_obj, const double *ff_extra,
                             double pdef, double cdef, double *rec, void *stream);
+
+/* ======================================================================
+ * (4) MULTI-GPU: one process per GPU; objects are sharded by contiguous
+ * blocks and nothing crosses ranks except the per-object RESULT RECORDS
+ * (32 B loglike, 584 B admom, ...), all-gathered over RCCL / xGMI.  The
+ * reference loops objects serially (ngmix/runners.py:116-149,
+ * ngmix/bootstrap.py:67-154); this is the exchange that replaces its loop's
+ * result list.  RCCL is bound at first use (dlopen): without it these entry
+ * points return NGMIX_ERR_HIP with a message, they never fall back.
+ *   rank 0: ngmix_comm_unique_id(id) -> ship the 128 bytes to the other ranks
+ *   every rank (after ngmix_set_device): ngmix_comm_init_rank(&comm, n, id, r)
+ *   ngmix_allgather_results(comm, send, recv, nrecords, record_bytes, stream):
+ *       recv[r*nrecords .. ] = rank r's `nrecords` records, device pointers,
+ *       asynchronous on `stream` (every rank passes the same nrecords)
+ * ====================================================================== */
+int ngmix_comm_unique_id(void *id128);
+int ngmix_comm_init_rank(void **comm, int nranks, const void *id128, int rank);
+int ngmix_comm_destroy(void *comm);
+int ngmix_allgather_results(void *comm, const void *send, void *recv,
+                            int64_t nrecords, int64_t record_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -41,6 +41,7 @@ _RANGE_MESSAGES = {
 STAMP_IGNORE_ZERO_WEIGHT = 1
 BATCH_NO_SKIP = 1
 BATCH_EXACT = 2
+BATCH_TRACKED_LOADS = 4
 
 # ---- record layouts = the reference's numpy dtypes ----
 GAUSS2D_DTYPE = np.dtype([
@@ -203,6 +204,15 @@ SIGNATURES = {
     "ngmix_em_batch": (_i32, [_i32, _vp, _pb, _vp, _i32, _vp, _i32, _vp, _vp,
                               _i32, _vp, _vp, _vp]),
     "ngmix_deriv_images_batch": (_i32, [_pb, _vp, _vp, _vp, _vp, _vp]),
+    # library-owned stamp store and the RCCL gather of result records
+    "ngmix_batch_create": (_i32, [ctypes.POINTER(_pb), _i64, _vp, _vp, _i32, _i32]),
+    "ngmix_batch_upload": (_i32, [_pb, _vp, _vp, _vp, _vp]),
+    "ngmix_batch_npix_kept": (_i32, [_pb, _vp]),
+    "ngmix_batch_free": (_i32, [_pb]),
+    "ngmix_comm_unique_id": (_i32, [_vp]),
+    "ngmix_comm_init_rank": (_i32, [ctypes.POINTER(_vp), _i32, _vp, _i32]),
+    "ngmix_comm_destroy": (_i32, [_vp]),
+    "ngmix_allgather_results": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp]),
     # batched Levenberg-Marquardt
     "ngmix_abi_sizeof": (_i64, [ctypes.c_char_p]),
     "ngmix_lm_init": (_i32, [_vp, _i64, _i32, _vp, _f64, _f64, _f64, _i32, _f64, _i32,

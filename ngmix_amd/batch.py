@@ -181,6 +181,8 @@ class StampBatch(object):
         izw = np.broadcast_to(np.asarray(ignore_zero_weight, dtype=bool), (self.n,))
         self.flags = np.where(izw, _lib.STAMP_IGNORE_ZERO_WEIGHT, 0).astype(np.int32)
         self.npix = self.nrow.astype(np.int64) * self.ncol
+        # diagnostic: fused kernels through the compiler-tracked load path
+        self.tracked_loads = False
         self.max_npix = int(self.npix.max()) if self.n else 0
         self.total_pix = int(self.npix.sum())
         self._stamp_tables = {}
@@ -345,7 +347,8 @@ class StampBatch(object):
         b.max_nrow = int(self.nrow.max()) if self.n else 0
         b.max_ncol = int(self.ncol.max()) if self.n else 0
         b.flags = (_lib.BATCH_NO_SKIP if no_skip else 0) | \
-            (_lib.BATCH_EXACT if exact else 0)
+            (_lib.BATCH_EXACT if exact else 0) | \
+            (_lib.BATCH_TRACKED_LOADS if self.tracked_loads else 0)
         return b
 
     def kept_offsets(self):
@@ -388,18 +391,22 @@ class StampBatch(object):
         (object, epoch) stamps plus a fixed-order segmented sum on the device.
         Returns (per_object (nobj, 4), per_stamp (N, 4), status).
         """
-        torch = _torch()
         per_stamp, status = self.loglike(gm, out=out, status=status, exact=exact)
+        per_obj = self.sum_over_epochs(per_stamp, obj_start)
+        return per_obj, per_stamp, status
+
+    def sum_over_epochs(self, per_stamp, obj_start):
+        """fixed-order sum of per-stamp records over each object's stamps
+        obj_start[i] .. obj_start[i+1] (on the device)"""
+        torch = _torch()
         obj_start = np.asarray(obj_start, dtype=np.int64)
         lengths = np.diff(obj_start)
         assert obj_start[0] == 0 and obj_start[-1] == self.n and np.all(lengths > 0)
+        width = per_stamp.shape[1]
         if np.all(lengths == lengths[0]):
-            per_obj = per_stamp.reshape(-1, int(lengths[0]), 4).sum(dim=1)
-        else:
-            per_obj = torch.segment_reduce(
-                per_stamp, "sum", lengths=torch.from_numpy(lengths).to(self.device),
-                axis=0)
-        return per_obj, per_stamp, status
+            return per_stamp.reshape(-1, int(lengths[0]), width).sum(dim=1)
+        return torch.segment_reduce(
+            per_stamp, "sum", lengths=torch.from_numpy(lengths).to(self.device), axis=0)
 
     def fill_fdiff(self, gm, fdiff=None, fdiff_start=None, status=None,
                    no_skip=False, exact=False):

@@ -25,25 +25,32 @@ void set_last_error(const char *what, hipError_t err)
 
 void set_last_error_msg(const char *msg) { g_last_error = msg; }
 
-// grow-only device scratch, one set per host thread
+// grow-only device scratch, one set per host thread AND per device: after
+// ngmix_set_device(other) on the same thread the seam forms must not reuse
+// pointers that belong to the previous device
 class Workspace {
 public:
     static constexpr int NSLOT = 8;
+    static constexpr int NDEV = 16;
     void *get(int slot, size_t nbytes)
     {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NDEV) return nullptr;
+        void *&ptr = ptr_[dev][slot];
+        size_t &cap = cap_[dev][slot];
         if (nbytes == 0) nbytes = 8;
-        if (cap_[slot] < nbytes) {
-            if (ptr_[slot]) (void)hipFree(ptr_[slot]);
-            ptr_[slot] = nullptr;
-            cap_[slot] = 0;
+        if (cap < nbytes) {
+            if (ptr) (void)hipFree(ptr);
+            ptr = nullptr;
+            cap = 0;
             size_t want = nbytes + nbytes / 4 + 256;
-            if (hipMalloc(&ptr_[slot], want) != hipSuccess) {
-                ptr_[slot] = nullptr;
+            if (hipMalloc(&ptr, want) != hipSuccess) {
+                ptr = nullptr;
                 return nullptr;
             }
-            cap_[slot] = want;
+            cap = want;
         }
-        return ptr_[slot];
+        return ptr;
     }
     ~Workspace()
     {
@@ -51,8 +58,8 @@ public:
     }
 
 private:
-    void *ptr_[NSLOT] = {nullptr};
-    size_t cap_[NSLOT] = {0};
+    void *ptr_[NDEV][NSLOT] = {{nullptr}};
+    size_t cap_[NDEV][NSLOT] = {{0}};
 };
 
 static thread_local Workspace g_ws;

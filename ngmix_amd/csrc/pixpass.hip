@@ -664,7 +664,8 @@ __global__ __launch_bounds__(WAVE) void pixpass_wave_kernel(
     __syncthreads();  // one wave: orders the LDS writes above, no s_barrier
 
     // ---- request the first tiles now: they fly while the gaussians are staged
-    const bool full = (nrow % TH) == 0 && (ncol % TW) == 0;
+    // (no_skip bit 1 = NGMIX_BATCH_TRACKED_LOADS: the compiler-tracked path)
+    const bool full = (nrow % TH) == 0 && (ncol % TW) == 0 && !(no_skip & 2);
     double pv[FUSED_PF], pe[FUSED_PF];
 #pragma unroll
     for (int t = 0; t < FUSED_PF; t++) {
@@ -702,7 +703,7 @@ __global__ __launch_bounds__(WAVE) void pixpass_wave_kernel(
         r.pa = t.pnorm * area;
         r.row = t.row;
         r.col = t.col;
-        r.box = no_skip ? full_box() : gauss_pixel_box(t, jac);
+        r.box = (no_skip & 1) ? full_box() : gauss_pixel_box(t, jac);
         gf[g] = r;
         if (!(t.row == row0 && t.col == col0)) L.ctl[2] = 0;
         const double detq = t.dcc * t.drr - t.drc * t.drc;
@@ -805,7 +806,8 @@ static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
                            "(too many gaussians or masked stamp too large)");
         return NGMIX_ERR_BAD_ARG;
     }
-    const int no_skip = (b->flags & NGMIX_BATCH_NO_SKIP) ? 1 : 0;
+    const int no_skip = ((b->flags & NGMIX_BATCH_NO_SKIP) ? 1 : 0) |
+                        ((b->flags & NGMIX_BATCH_TRACKED_LOADS) ? 2 : 0);
     // per-tile records of the fused kernels: exact when the batch carries its
     // largest stamp shape, else ntiles <= npix/8 + 1 holds for any shape
     int a_tc = b->max_npix / 8 + 1;
@@ -823,6 +825,7 @@ static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
     const ngmix_jacobian *a_jac = b->jac;
     int a_ng = max_ng, a_nc = nchunks_cap, a_ns = no_skip;
     if (exact) {
+        a_ns = no_skip & 1;
         dim3 grid((unsigned)b->nstamps), block(BLOCK);
         const bool k4 = pick_k(b->max_npix) == 4;
         const void *kern = k4 ? (const void *)pixpass_grid_kernel<OP, 4>

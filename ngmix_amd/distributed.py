@@ -57,13 +57,38 @@ def allgather_records(local, n_objects=None, group=None, out=None, async_op=Fals
     padded = torch.zeros((per,) + tail, dtype=local.dtype, device=local.device)
     padded[:local.shape[0]] = local
     buf = torch.empty((world * per,) + tail, dtype=local.dtype, device=local.device)
-    work = dist.all_gather_into_tensor(buf, padded, group=group, async_op=False)
-    pieces = [buf[r * per:r * per + sizes[r]] for r in range(world)]
-    full = torch.cat(pieces, dim=0)
-    if out is not None:
-        out.copy_(full)
-        full = out
-    return (full, work) if async_op else full
+    work = dist.all_gather_into_tensor(buf, padded, group=group, async_op=async_op)
+    if out is None:
+        out = torch.empty((n_objects,) + tail, dtype=local.dtype, device=local.device)
+
+    def trim():
+        lo = 0
+        for r in range(world):
+            out[lo:lo + sizes[r]] = buf[r * per:r * per + sizes[r]]
+            lo += sizes[r]
+
+    if async_op:
+        return out, _TrimAfterWait(work, trim)
+    trim()
+    return out
+
+
+class _TrimAfterWait:
+    """work handle of an uneven async all-gather: wait() completes the
+    collective and then copies the shards out of the padded buffer"""
+
+    def __init__(self, work, trim):
+        self._work, self._trim = work, trim
+
+    def wait(self, *a, **kw):
+        r = self._work.wait(*a, **kw)
+        if self._trim is not None:
+            self._trim()
+            self._trim = None
+        return r
+
+    def is_completed(self):
+        return self._work.is_completed()
 
 
 def init_from_env(backend=None):
@@ -93,6 +118,87 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
+def visible_gpu_count():
+    """number of GPUs this process could use, WITHOUT initialising the HIP
+    runtime (torch.cuda.device_count() only counts)"""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def launch_local_ranks(script, argv, nproc, cwd=None, timeout=None, need_gpus=True):
+    """
+    Start `nproc` ranks of `script` on this node, one child process per GPU,
+    with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as
+    torch.distributed.run would, and wait for them.  The caller must not have
+    initialised the GPU (children are fork+exec'ed).  Rank 0's stdout is this
+    process's stdout.  Returns 0 when every rank exited 0; otherwise the first
+    non-zero status, after terminating the ranks that were still running (they
+    would wait in a collective forever).
+
+    Refuses (returns 2, message on stderr) when the node has fewer GPUs than
+    ranks and the backend is RCCL: RCCL needs one device per rank, and a job
+    silently run on fewer GPUs than asked for would be mislabelled.
+    NGMIX_DIST_BACKEND=gloo (testing hook) lifts that restriction.
+    """
+    import os
+    import socket
+    import subprocess
+    import sys
+    import time
+    backend = os.environ.get("NGMIX_DIST_BACKEND", "nccl")
+    if need_gpus:
+        ndev = visible_gpu_count()
+        if ndev < 1:
+            sys.stderr.write("%s: %d ranks asked for but no GPU is visible (the HIP "
+                             "kernels are the product; there is no CPU path)\n"
+                             % (os.path.basename(script), nproc))
+            return 2
+        if backend == "nccl" and ndev < nproc:
+            sys.stderr.write(
+                "%s: %d ranks asked for but only %d GPU(s) are visible; RCCL needs one "
+                "device per rank.  Refusing to measure fewer GPUs than asked for.\n"
+                % (os.path.basename(script), nproc, ndev))
+            return 2
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+        s.close()
+    procs = []
+    for r in range(nproc):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc),
+                   LOCAL_WORLD_SIZE=str(nproc), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                      cwd=cwd))
+    if timeout is None:
+        timeout = float(os.environ.get("NGMIX_LAUNCH_TIMEOUT", "3000"))
+    deadline = time.time() + timeout
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:
+                    q.terminate()
+        if pending and time.time() > deadline:
+            for q in pending:
+                q.kill()
+            sys.stderr.write("%s: ranks timed out after %.0f s\n"
+                             % (os.path.basename(script), timeout))
+            return 3
+        time.sleep(0.02)
+    if rc:
+        sys.stderr.write("%s: a rank exited with status %d\n"
+                         % (os.path.basename(script), rc))
+    return rc
+
+
 def gather_object_results(compute_shard, n_objects, record_shape, dtype=None,
                           device=None, group=None):
     """
@@ -109,6 +215,10 @@ def gather_object_results(compute_shard, n_objects, record_shape, dtype=None,
     lo, hi = shard_bounds(n_objects, rank, world)
     local = compute_shard(lo, hi)
     if local is None or local.shape[0] == 0:
+        # an empty shard (n_objects < world, or a short tail): the placeholder
+        # must live where the backend communicates -- the current GPU for RCCL
+        if device is None and dist.get_backend(group) == "nccl":
+            device = torch.device("cuda", torch.cuda.current_device())
         local = torch.empty((0,) + tuple(record_shape),
                             dtype=dtype or torch.float64, device=device)
     return allgather_records(local, n_objects=n_objects, group=group)

@@ -20,7 +20,6 @@ import copy
 import logging
 
 import numpy as np
-from numpy import diag, sqrt
 
 from . import _lib
 from . import gmix as gmix_mod
@@ -47,21 +46,33 @@ STEP_PRIOR = 1.0e-8  # results.py:935
 # bounded least squares (reference: ngmix/fitting/leastsqbound.py)
 # ---------------------------------------------------------------------------
 
+class _Sentinels(object):
+    """the 'no value' arrays of a failed fit (defaults.py: PDEF for parameters,
+    CDEF for covariances and errors)"""
+
+    def __init__(self, npars):
+        self.pars = np.full(npars, PDEF)
+        self.cov = np.full((npars, npars), CDEF)
+        self.err = np.full(npars, CDEF)
+
+
 def _get_def_stuff(npars):
-    return (np.zeros(npars) + PDEF, np.zeros((npars, npars)) + CDEF,
-            np.zeros(npars) + CDEF)
+    d = _Sentinels(npars)
+    return d.pars, d.cov, d.err
 
 
 def _test_cov(pcov):
-    flags = 0
+    """flag bits for a covariance with negative eigenvalues / diagonal, or
+    one whose eigenvalues cannot be computed"""
     try:
-        e, _ = np.linalg.eig(pcov)
-        if np.any(e < 0):
-            flags |= LM_NEG_COV_EIG
-        if np.any(np.diag(pcov) < 0):
-            flags |= LM_NEG_COV_DIAG
+        eigvals = np.linalg.eigvals(pcov)
     except np.linalg.LinAlgError:
-        flags |= EIG_NOTFINITE
+        return EIG_NOTFINITE
+    flags = 0
+    if (eigvals < 0).any():
+        flags |= LM_NEG_COV_EIG
+    if (pcov.diagonal() < 0).any():
+        flags |= LM_NEG_COV_DIAG
     return flags
 
 
@@ -175,69 +186,77 @@ def leastsqbound(func, x0, args=(), bounds=None, Dfun=None, full_output=0,
     return x, cov_x, infodict, mesg, ier
 
 
+def _aborted(npars, flags, errmsg):
+    """result of a fit whose objective could not be evaluated: no pars_err,
+    no ier, nfev = -1 (leastsqbound.py:127-153)"""
+    LOGGER.debug(errmsg)
+    d = _Sentinels(npars)
+    return {"flags": flags, "nfev": -1, "errmsg": errmsg, "pars": d.pars,
+            "pars_cov0": d.cov, "pars_cov": d.cov}
+
+
+def _scaled_covariance(func, pars, cov0, n_prior_pars, k_space):
+    """(flags, pars_cov, pars_err, errmsg or None) of a converged fit: cov0
+    scaled by chi^2 / dof of the pixel rows (leastsqbound.py:92-116)"""
+    npars = pars.size
+    none = _Sentinels(npars)
+    resid = func(pars)
+    ndata = resid.size - n_prior_pars
+    if k_space:
+        ndata //= 2       # real and imaginary parts are one datum
+    dof = ndata - npars
+    if dof == 0:
+        return ZERO_DOF, none.cov, none.err, None
+    pix = resid[n_prior_pars:]
+    cov = cov0 * ((pix ** 2).sum() / dof)
+    bad = _test_cov(cov)
+    if bad:
+        return bad, cov, none.err, "bad covariance matrix"
+    return 0, cov, np.sqrt(cov.diagonal()), None
+
+
 def run_leastsq(func, guess, n_prior_pars, **keys):
     """
-    Run the (bounded) LM fit and package flags / covariance the way the
-    reference does (leastsqbound.py:33-155): ier > 4 -> flags 2**(ier-5) with
-    default pars, singular -> LM_SINGULAR_MATRIX, pars_cov = cov0 * chi2/dof,
-    covariance sanity flags, ZERO_DOF, DIV_ZERO, LM_FUNC_NOTFINITE.
+    One (bounded) MINPACK fit, packaged as the reference's run_leastsq does
+    (leastsqbound.py:33-155).  Outcomes, by what leastsq reports:
+
+      ier 1-4, cov_x given   flags from the chi^2-scaled covariance's sanity
+                             checks (0 when fine), ZERO_DOF when no freedom
+      ier 1-4, cov_x None    LM_SINGULAR_MATRIX, parameters kept
+      ier > 4                2**(ier-5), sentinel parameters
+      ier 0                  ValueError(errmsg)
+      NaN / inf residuals    LM_FUNC_NOTFINITE (scipy's ValueError)
+      ZeroDivisionError      DIV_ZERO
     """
-    npars = guess.size
+    npars = np.size(guess)
     k_space = keys.pop("k_space", False)
-    res = {}
     try:
-        pars, pcov0, infodict, errmsg, ier = leastsqbound(
-            func, guess, full_output=1, **keys)
+        pars, cov0, info, errmsg, ier = leastsqbound(func, guess, full_output=1, **keys)
         if ier == 0:
             raise ValueError(errmsg)
-        flags = 0
+        none = _Sentinels(npars)
         if ier > 4:
-            flags |= 2 ** (ier - 5)
-            pars, pcov, perr = _get_def_stuff(npars)
             LOGGER.debug(errmsg)
-        elif pcov0 is None:
-            flags |= LM_SINGULAR_MATRIX
+            flags, pars, cov, err = 2 ** (ier - 5), none.pars, none.cov, none.err
+        elif cov0 is None:
             errmsg = "singular covariance"
             LOGGER.debug(errmsg)
             print_pars(pars, front="    pars at singular:", logger=LOGGER)
-            _, pcov, perr = _get_def_stuff(npars)
+            flags, cov, err = LM_SINGULAR_MATRIX, none.cov, none.err
         else:
-            fdiff = func(pars)
-            if k_space:
-                dof = (fdiff.size - n_prior_pars) // 2 - npars
-            else:
-                dof = fdiff.size - n_prior_pars - npars
-            if dof == 0:
-                _, pcov, perr = _get_def_stuff(npars)
-                flags |= ZERO_DOF
-            else:
-                s_sq = (fdiff[n_prior_pars:] ** 2).sum() / dof
-                pcov = pcov0 * s_sq
-                cflags = _test_cov(pcov)
-                if cflags != 0:
-                    flags |= cflags
-                    errmsg = "bad covariance matrix"
-                    LOGGER.debug(errmsg)
-                    _, _, perr = _get_def_stuff(npars)
-                else:
-                    perr = sqrt(diag(pcov))
-        res.update(flags=flags, nfev=infodict["nfev"], ier=ier, errmsg=errmsg,
-                   pars=pars, pars_err=perr, pars_cov0=pcov0, pars_cov=pcov)
-    except ValueError as e:
-        serr = str(e)
-        if "NaNs" in serr or "infs" in serr:
-            pars, pcov, perr = _get_def_stuff(npars)
-            res.update(pars=pars, pars_cov0=pcov, pars_cov=pcov, nfev=-1,
-                       flags=LM_FUNC_NOTFINITE, errmsg="not finite")
-            LOGGER.debug("not finite")
-        else:
-            raise e
+            flags, cov, err, msg = _scaled_covariance(func, pars, cov0, n_prior_pars,
+                                                      k_space)
+            if msg is not None:
+                errmsg = msg
+                LOGGER.debug(errmsg)
+        return {"flags": flags, "nfev": info["nfev"], "ier": ier, "errmsg": errmsg,
+                "pars": pars, "pars_err": err, "pars_cov0": cov0, "pars_cov": cov}
     except ZeroDivisionError:
-        pars, pcov, perr = _get_def_stuff(npars)
-        res.update(pars=pars, pars_cov0=pcov, pars_cov=pcov, nfev=-1,
-                   flags=DIV_ZERO, errmsg="zero division")
-        LOGGER.debug("zero division")
-    return res
+        return _aborted(npars, DIV_ZERO, "zero division")
+    except ValueError as err:
+        if not any(word in str(err) for word in ("NaNs", "infs")):
+            raise
+        return _aborted(npars, LM_FUNC_NOTFINITE, "not finite")
 
 
 # ---------------------------------------------------------------------------
@@ -266,34 +285,37 @@ def get_lm_n_prior_pars(model, nband):
     raise ValueError("bad model: %s" % model)
 
 
+# d(irr, irc, icc) per unit of (e1, e2) at T_k / 2 = 1:
+# Sigma_k = (T_k/2) [[1 - e1, e2], [e2, 1 + e1]]
+_DCOV_DE = np.array([[-1.0, 0.0, 1.0],
+                     [0.0, 1.0, 0.0]])
+
+
 def get_model_deriv_data(gm0, gmc, g1, g2, T):
     """
-    composed gaussians [p, v, u, irr, irc, icc] and d(irr, irc, icc)/d(g1, g2,
-    T) of each, for models whose components share one shape
-    (results.py:955-1010): Sigma_k = (T_k/2) [[1-e1, e2],[e2, 1+e1]] with
-    e = 2g/(1+g^2).
+    For a model whose components share one shape (gauss / exp / dev), the
+    composed gaussians as rows [p, v, u, irr, irc, icc] and, per composed
+    gaussian, d(irr, irc, icc)/d(g1, g2, T) (results.py:955-1010).  The psf
+    part of a composed covariance does not depend on the model, so only the
+    model component's Sigma_k = (T_k/2) [[1-e1, e2], [e2, 1+e1]],
+    e = 2 g / (1 + |g|^2), is differentiated: chain rule through
+    J = d(e1, e2)/d(g1, g2), and d Sigma_k / dT = Sigma_k / T.
     """
-    gpars = gmc.get_full_pars().reshape(-1, 6)
-    modpars = gm0.get_full_pars().reshape(-1, 6)
-    npsf = gpars.shape[0] // modpars.shape[0]
-    modcov = np.repeat(modpars[:, 3:6], npsf, axis=0)
+    composed = gmc.get_full_pars().reshape(-1, 6)
+    model_cov = gm0.get_full_pars().reshape(-1, 6)[:, 3:6]
+    # convolve() orders the composed gaussians model-major
+    model_cov = np.repeat(model_cov, composed.shape[0] // model_cov.shape[0], axis=0)
+    half_Tk = 0.5 * (model_cov[:, 0] + model_cov[:, 2])
 
+    g = np.array([g1, g2])
     gsq = g1 * g1 + g2 * g2
     f = 2.0 / (1.0 + gsq)
-    dfac = -f / (1.0 + gsq)
-    de1dg1 = f + 2.0 * g1 * g1 * dfac
-    de1dg2 = 2.0 * g1 * g2 * dfac
-    de2dg1 = de1dg2
-    de2dg2 = f + 2.0 * g2 * g2 * dfac
+    jac_e = f * np.eye(2) + (2.0 * g[:, None] * g[None, :]) * (-f / (1.0 + gsq))
 
-    Tk = modcov[:, 0] + modcov[:, 2]
-    dcov = np.zeros((gpars.shape[0], 3, 3))
-    for i, (de1, de2) in enumerate(((de1dg1, de2dg1), (de1dg2, de2dg2))):
-        dcov[:, i, 0] = -0.5 * Tk * de1
-        dcov[:, i, 1] = 0.5 * Tk * de2
-        dcov[:, i, 2] = 0.5 * Tk * de1
-    dcov[:, 2, :] = modcov / T
-    return gpars, dcov
+    dcov = np.empty((composed.shape[0], 3, 3))
+    dcov[:, 0:2, :] = half_Tk[:, None, None] * (jac_e @ _DCOV_DE)[None, :, :]
+    dcov[:, 2, :] = model_cov / T
+    return composed, dcov
 
 
 class _RaggedGMix(object):
@@ -525,72 +547,83 @@ class FitModel(dict):
             jac[:] = 0.0
         return jac
 
+    def _prior_rows(self, pars):
+        """the prior's residual rows at pars, or None where it is undefined"""
+        rows = np.zeros(self.n_prior_pars)
+        try:
+            n = self.prior.fill_fdiff(pars, rows)
+        except GMixRangeError:
+            return None
+        return rows[:n]
+
     def _fill_prior_jacobian(self, pars, jac):
-        """forward (else backward) differences of prior.fill_fdiff
-        (results.py:572-625); returns the number of prior rows"""
+        """
+        The prior rows of the jacobian by one-sided differences of
+        prior.fill_fdiff with relative step STEP_PRIOR, forward unless the
+        forward point is outside the prior's domain (results.py:572-625).  A
+        row that is not finite at either point gets zeros.  Returns the number
+        of prior rows.
+        """
         if self.prior is None:
             return 0
-        f0 = np.zeros(self.n_prior_pars)
-        fs = np.zeros(self.n_prior_pars)
-        n = self.prior.fill_fdiff(pars, f0)
-        good0 = np.isfinite(f0[:n])
-        p = pars.copy()
-        for ipar in range(self.npars):
-            step = STEP_PRIOR * max(1.0, abs(pars[ipar]))
-            p[:] = pars
-            p[ipar] = pars[ipar] + step
-            try:
-                self.prior.fill_fdiff(p, fs)
-            except GMixRangeError:
-                try:
-                    step = -step
-                    p[ipar] = pars[ipar] + step
-                    self.prior.fill_fdiff(p, fs)
-                except GMixRangeError:
-                    raise GMixRangeError(
-                        "prior not evaluable within a step of parameter %d" % ipar)
-            good = good0 & np.isfinite(fs[:n])
-            d = np.zeros(n)
-            d[good] = (fs[:n][good] - f0[:n][good]) / step
-            jac[:n, ipar] = d
+        base = np.zeros(self.n_prior_pars)
+        n = self.prior.fill_fdiff(pars, base)   # a range error here propagates
+        base = base[:n]
+        steps = STEP_PRIOR * np.maximum(1.0, np.abs(pars))
+        shifted = np.empty((n, self.npars))
+        for j in range(self.npars):
+            for h in (steps[j], -steps[j]):
+                trial = np.array(pars, dtype="f8")
+                trial[j] = pars[j] + h
+                rows = self._prior_rows(trial)
+                if rows is not None:
+                    break
+            else:
+                raise GMixRangeError(
+                    "prior not evaluable within a step of parameter %d" % j)
+            steps[j] = h
+            shifted[:, j] = rows
+        usable = np.isfinite(base)[:, None] & np.isfinite(shifted)
+        with np.errstate(invalid="ignore"):
+            slope = (shifted - base[:, None]) / steps[None, :]
+        jac[:n, :] = np.where(usable, slope, 0.0)
         return n
 
     # ---- results
+    def _flux_start(self):
+        """index of the first flux parameter"""
+        return {"bd": 7, "bdf": 6}.get(self["model"], 5)
+
+    def _fit_statistics(self):
+        """lnprob / s2n / chi2 of the solution, and the shape, size and flux
+        blocks of pars / pars_cov / pars_err under their own keys
+        (results.py:45-72, 398-408, 1079-1109)"""
+        pars, cov, err = self["pars"], self["pars_cov"], self["pars_err"]
+        st = self.calc_lnprob(pars, more=True)
+        s2n = st["s2n_numer"] / np.sqrt(st["s2n_denom"]) if st["s2n_denom"] > 0 else 0.0
+        dof = st["npix"] - self.npars
+        st.update(chi2per=st["lnprob"] / (-0.5) / dof, dof=dof, s2n_w=s2n, s2n=s2n)
+        shape = slice(2, 4)
+        st.update(g=pars[shape].copy(), g_cov=cov[shape, shape].copy(),
+                  g_err=err[shape].copy(), T=pars[4], T_err=np.sqrt(cov[4, 4]))
+        return st
+
     def set_fit_result(self, result):
         self.update(result)
-        if self["flags"] == 0:
-            self.update(self.calc_lnprob(self["pars"], more=True))
-            if self["s2n_denom"] > 0:
-                s2n = self["s2n_numer"] / np.sqrt(self["s2n_denom"])
-            else:
-                s2n = 0.0
-            dof = self["npix"] - self.npars
-            self["chi2per"] = self["lnprob"] / (-0.5) / dof
-            self["dof"] = dof
-            self["s2n_w"] = s2n
-            self["s2n"] = s2n
-            self._set_g()
-            self._set_T()
-            self._set_flux()
-
-    def _set_g(self):
-        self["g"] = self["pars"][2:4].copy()
-        self["g_cov"] = self["pars_cov"][2:4, 2:4].copy()
-        self["g_err"] = self["pars_err"][2:4].copy()
-
-    def _set_T(self):
-        self["T"] = self["pars"][4]
-        self["T_err"] = np.sqrt(self["pars_cov"][4, 4])
+        if self["flags"] != 0:
+            return
+        self.update(self._fit_statistics())
+        self._set_flux()
 
     def _set_flux(self):
-        start = {"bd": 7, "bdf": 6}.get(self["model"], 5)
-        if self.nband == 1:
-            self["flux"] = self["pars"][start]
-            self["flux_err"] = np.sqrt(self["pars_cov"][start, start])
+        first = self._flux_start()
+        if self.nband > 1:
+            block = self["pars_cov"][first:, first:]
+            self.update(flux=self["pars"][first:], flux_cov=block,
+                        flux_err=np.sqrt(block.diagonal()))
         else:
-            self["flux"] = self["pars"][start:]
-            self["flux_cov"] = self["pars_cov"][start:, start:]
-            self["flux_err"] = sqrt(diag(self["flux_cov"]))
+            self.update(flux=self["pars"][first],
+                        flux_err=np.sqrt(self["pars_cov"][first, first]))
 
     def get_gmix(self, band=0):
         pars = self.get_band_pars(pars=self["pars"], band=band)

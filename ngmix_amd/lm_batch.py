@@ -142,7 +142,9 @@ class LMBatchFitter(object):
         lo = hi = None
         if self.prior is not None and getattr(self.prior, "bounds", None) is not None:
             lo, hi = bounds_arrays(self.prior.bounds, npars)
-        maxfev = int(fp.get("maxfev", 100 * (npars + 1)))
+        # leastsq's convention: maxfev = 0 (or absent) means 100 (n + 1) function
+        # calls with an analytic jacobian, 200 (n + 1) in forward-difference mode
+        maxfev = int(fp.get("maxfev", 0)) or (200 if self.fd else 100) * (npars + 1)
         d_states = torch.empty((nobj, _lib.LM_STATE_DTYPE.itemsize), dtype=torch.uint8,
                                device=dev)
         d_guess = torch.from_numpy(guess).to(dev)

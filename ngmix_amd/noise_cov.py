@@ -31,17 +31,13 @@ STEP_FRAC = 1.0e-3
 
 
 def get_step(pars, ipar, nband):
-    """results.py:939-952"""
-    npars = pars.size
-    nshape = npars - nband
-    if ipar < 2:
-        return STEP_CEN
-    elif ipar < 4:
-        return STEP_SHAPE
-    elif ipar < nshape:
-        return max(STEP_STRUCT_MIN, STEP_FRAC * abs(pars[ipar]))
-    else:
-        return max(STEP_FLUX_MIN, STEP_FRAC * abs(pars[ipar]))
+    """central-difference step of parameter ipar (results.py:939-952):
+    fixed for the centre and the shape, 1e-3 of the value with a floor for
+    the structural parameters (T, fracdev ...) and for the nband fluxes"""
+    if ipar < 4:
+        return (STEP_CEN, STEP_CEN, STEP_SHAPE, STEP_SHAPE)[ipar]
+    floor = STEP_FLUX_MIN if ipar >= pars.size - nband else STEP_STRUCT_MIN
+    return max(floor, STEP_FRAC * abs(pars[ipar]))
 
 
 def apply_noise_cov(fit_model, result):

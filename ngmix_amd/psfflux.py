@@ -1,144 +1,103 @@
 """
-Linear template / psf flux by zero-lag cross-correlation (reference:
-ngmix/fitting/fitters.py:144-181, results.py:677-914).  The model images come
-from GMix.make_image (the render HIP kernel); the sums are O(npix) numpy.
+Linear template / psf flux by zero-lag cross-correlation (reference API:
+ngmix/fitting/fitters.py:144-181, results.py:677-914).
+
+The arithmetic lives in ONE place, PSFFluxBatch: an exact render of every
+stamp's unit-flux mixture (the render HIP kernel) or an uploaded template
+image, then the cross-correlation sums as segmented reductions on the device.
+The per-object PSFFluxFitter / PSFFluxFitModel of the reference API is a
+one-object view of that batch.
 """
 import numpy as np
 
 from .defaults import PDEF, CDEF
-from .flags import ZERO_DOF, DIV_ZERO, BAD_VAR
+from .flags import DIV_ZERO, BAD_VAR
 from .observation import Observation, ObsList
 
 __all__ = ["PSFFluxFitter", "PSFFluxFitModel", "PSFFluxBatch"]
 
+_RESULT_KEYS = ("flags", "chi2per", "dof", "flux", "flux_err")
+
 
 class PSFFluxFitModel(dict):
+    """
+    Result dict of the template-flux fit of ONE object (an Observation or an
+    ObsList of its epochs): keys model, flags, chi2per, dof, flux, flux_err.
+
+    What is correlated with the image, per epoch (results.py:832-897):
+      do_psf=True   the psf observation's mixture (unit flux when
+                    normalize_psf, its own flux otherwise), or its `template`
+                    image when it has no mixture (normalised likewise);
+      do_psf=False  the observation's own mixture / template, unit flux.
+    """
+
     def __init__(self, obs, do_psf=True, normalize_psf=True):
-        self.do_psf = do_psf
-        self.normalize_psf = normalize_psf
         self["model"] = "template"
         self.npars = 1
-        self._set_obs(obs)
+        self.do_psf = do_psf
+        self.normalize_psf = normalize_psf
+        if isinstance(obs, Observation):
+            epochs = ObsList()
+            epochs.append(obs)
+        elif isinstance(obs, ObsList):
+            epochs = obs
+        else:
+            raise ValueError("obs should be Observation or ObsList")
+        self.obs = epochs
+        holders = [o.psf if do_psf else o for o in epochs]
+        first = holders[0]
+        self.use_template = not first.has_gmix()
+        if self.use_template and not hasattr(first, "template"):
+            raise ValueError("neither gmix or template image are set")
+        self._holders = holders
+        self.totpix = sum(o.pixels.size for o in epochs)
+
+    # what the batch needs from the epochs ---------------------------------
+    def _mixtures(self):
+        """(nepoch, ngmax) gauss2d records; shorter mixtures are padded with
+        zero-flux round gaussians, which render exactly 0"""
+        from . import _lib
+        mixes = [h.get_gmix().get_data() for h in self._holders]
+        ngmax = max(m.size for m in mixes)
+        rec = np.zeros((len(mixes), ngmax), dtype=_lib.GAUSS2D_DTYPE)
+        rec["irr"] = rec["icc"] = rec["det"] = 1.0
+        for i, m in enumerate(mixes):
+            for name in ("p", "row", "col", "irr", "irc", "icc", "det"):
+                rec[name][i, :m.size] = m[name]
+        return rec
+
+    def _templates(self):
+        """flattened template images with unit sum, and the sums"""
+        flat = [np.asarray(h.template, dtype="f8").ravel() for h in self._holders]
+        sums = np.array([t.sum() for t in flat])
+        return np.concatenate([t * (1.0 / s) for t, s in zip(flat, sums)]), sums
 
     def go(self):
-        flags = 0
-        xcorr_sum = 0.0
-        msq_sum = 0.0
-        chi2 = 0.0
-        flux = PDEF
-        flux_err = CDEF
-        for ipass in (1, 2):
-            for iobs, obs in enumerate(self.obs):
-                im = obs.image
-                wt = obs.weight
-                if ipass == 1:
-                    model = self._get_model(iobs)
-                    xcorr_sum += (model * im * wt).sum()
-                    msq_sum += (model * model * wt).sum()
-                else:
-                    model = self._get_model(iobs, flux=flux)
-                    chi2 += ((model - im) ** 2 * wt).sum()
-            if ipass == 1:
-                if msq_sum == 0:
-                    break
-                flux = xcorr_sum / msq_sum
-        dof = self.get_dof()
-        chi2per = 9999.0
-        if dof > 0:
-            chi2per = chi2 / dof
-        else:
-            flags |= ZERO_DOF
-        if msq_sum == 0 or self.totpix == 1:
-            flags |= DIV_ZERO
-        else:
-            arg = chi2 / msq_sum / (self.totpix - 1)
-            if arg >= 0.0:
-                flux_err = np.sqrt(arg)
-            else:
-                flags |= BAD_VAR
-        self.update({"flags": flags, "chi2per": chi2per, "dof": dof, "flux": flux,
-                     "flux_err": flux_err})
-
-    def _get_model(self, iobs, flux=None):
+        from .batch import StampBatch, GMixBatch
+        stamps = StampBatch.from_observations(list(self.obs))
+        nep = len(self.obs)
+        same_object = np.zeros(nep, dtype=np.int64)
+        # only the psf keeps its own normalisation, and only when asked to
+        unit = not (self.do_psf and not self.normalize_psf)
+        batch = PSFFluxBatch(normalize_psf=unit)
         if self.use_template:
-            if flux is not None:
-                model = self.template_list[iobs].copy()
-                model *= (self.norm_list[iobs] * flux) / model.sum()
-            else:
-                model = self.template_list[iobs]
-            return model
-        if flux is None:
-            gm = self.gmix_list[iobs]
+            tmpl, sums = self._templates()
+            res = batch.go_templates(stamps, tmpl, None if unit else sums,
+                                     stamp_obj=same_object)
         else:
-            gm = self.gmix_list[iobs].copy()
-            gm.set_flux(flux * self.norm_list[iobs])
-        obs = self.obs[iobs]
-        return gm.make_image(obs.image.shape, jacobian=obs.jacobian)
+            gm = GMixBatch.from_numpy(self._mixtures(), device=stamps.device)
+            res = batch.go(stamps, gm, stamp_obj=same_object)
+        for k in _RESULT_KEYS:
+            v = res[k][0]
+            self[k] = int(v) if k == "flags" else float(v)
+
+    def get_effective_npix(self):
+        """pixels with positive weight, over all epochs"""
+        return sum(int((o.weight > 0).sum()) for o in self.obs)
 
     def get_dof(self):
         dof = self.get_effective_npix() - self.npars
-        if dof <= 0:
-            dof = 1.0e-6
-        return dof
-
-    def _set_obs(self, obs_in):
-        if isinstance(obs_in, Observation):
-            obs_list = ObsList()
-            obs_list.append(obs_in)
-        elif isinstance(obs_in, ObsList):
-            obs_list = obs_in
-        else:
-            raise ValueError("obs should be Observation or ObsList")
-        tobs = obs_list[0]
-        if self.do_psf:
-            tobs = tobs.psf
-        if not tobs.has_gmix():
-            if not hasattr(tobs, "template"):
-                raise ValueError("neither gmix or template image are set")
-        self.obs = obs_list
-        if tobs.has_gmix():
-            self._set_gmix_and_norms()
-        else:
-            self._set_templates_and_norms()
-        self.totpix = sum(obs.pixels.size for obs in self.obs)
-
-    def _set_gmix_and_norms(self):
-        self.use_template = False
-        self.gmix_list = []
-        self.norm_list = []
-        for obs in self.obs:
-            if self.do_psf:
-                gmix = obs.get_psf_gmix()
-                if self.normalize_psf:
-                    gmix.set_flux(1.0)
-            else:
-                gmix = obs.get_gmix()
-                gmix.set_flux(1.0)
-            self.gmix_list.append(gmix)
-            self.norm_list.append(gmix.get_flux())
-
-    def _set_templates_and_norms(self):
-        self.use_template = True
-        self.template_list = []
-        self.norm_list = []
-        for obs in self.obs:
-            if self.do_psf:
-                template = obs.psf.template.copy()
-                norm = template.sum()
-                if self.normalize_psf:
-                    template *= 1.0 / norm
-                    norm = 1.0
-            else:
-                template = obs.template.copy()
-                template *= 1.0 / template.sum()
-                norm = 1.0
-            self.template_list.append(template)
-            self.norm_list.append(norm)
-
-    def get_effective_npix(self):
-        if not hasattr(self, "eff_npix"):
-            self.eff_npix = sum(int((obs.weight > 0).sum()) for obs in self.obs)
-        return self.eff_npix
+        return dof if dof > 0 else 1.0e-6
 
 
 class PSFFluxFitter(object):
@@ -171,19 +130,10 @@ class PSFFluxBatch(object):
         self.normalize_psf = normalize_psf
 
     def go(self, stamps, gm, stamp_obj=None):
+        """gm: GMixBatch, one mixture per stamp (any flux)"""
         import torch
-        dev = stamps.device
         ns = stamps.n
         assert gm.n == ns, "one mixture per stamp"
-        if stamp_obj is None:
-            sobj = np.arange(ns, dtype=np.int64)
-        else:
-            sobj = np.ascontiguousarray(stamp_obj, dtype=np.int64)
-            if sobj.shape != (ns,) or np.any(np.diff(sobj) < 0):
-                raise ValueError("stamp_obj must be (nstamps,) and non-decreasing")
-        nobj = int(sobj.max()) + 1 if ns else 0
-        d_sobj = torch.from_numpy(sobj).to(dev)
-
         # the unit-flux template and the norm the fitted flux multiplies
         g = gm.clone()
         data = g.data.reshape(ns, g.ngauss, 13)
@@ -192,10 +142,45 @@ class PSFFluxBatch(object):
         data[:, :, 0] /= safe[:, None]
         data[:, :, 7] = 0.0  # norms are stale (gmix.py set_flux)
         model, status = stamps.render(g, fast_exp=False)
+        # without normalisation the mixture keeps its own flux
+        norm = None if self.normalize_psf else psum
+        res = self._solve(stamps, model, norm, stamp_obj)
+        res["status"] = status.cpu().numpy()
+        return res
+
+    def go_templates(self, stamps, templates, norms=None, stamp_obj=None):
+        """templates: the stamps' template images (unit sum), flattened back to
+        back in stamp order, host or device; norms: per-stamp factor the
+        template keeps (None: 1)"""
+        import torch
+        dev = stamps.device
+        model = torch.as_tensor(np.asarray(templates, dtype="f8")
+                                if not isinstance(templates, torch.Tensor) else templates,
+                                dtype=torch.float64).to(dev).reshape(-1)
+        assert model.numel() == stamps.total_pix
+        if norms is not None and not isinstance(norms, torch.Tensor):
+            norms = torch.from_numpy(np.asarray(norms, dtype="f8")).to(dev)
+        return self._solve(stamps, model, norms, stamp_obj)
+
+    @staticmethod
+    def _solve(stamps, model, norm, stamp_obj):
+        """flux = sum(m I w) / sum(m m w) per object, chi2 of the scaled
+        template, and the flags / errors of PSFFluxFitModel.go
+        (results.py:700-770) for every object at once"""
+        import torch
+        dev = stamps.device
+        ns = stamps.n
+        if stamp_obj is None:
+            sobj = np.arange(ns, dtype=np.int64)
+        else:
+            sobj = np.ascontiguousarray(stamp_obj, dtype=np.int64)
+            if sobj.shape != (ns,) or np.any(np.diff(sobj) < 0):
+                raise ValueError("stamp_obj must be (nstamps,) and non-decreasing")
+        nobj = int(sobj.max()) + 1 if ns else 0
+        d_sobj = torch.from_numpy(sobj).to(dev)
         lengths = torch.from_numpy(stamps.npix).to(dev)
-        if not self.normalize_psf:
-            # the mixture keeps its own flux: norm_list = gmix.get_flux()
-            model = model * torch.repeat_interleave(psum, lengths)
+        if norm is not None:
+            model = model * torch.repeat_interleave(norm, lengths)
         wt = stamps.ierr * stamps.ierr
 
         def per_object(x):
@@ -236,4 +221,4 @@ class PSFFluxBatch(object):
         okv = ~bad & (arg >= 0.0)
         flux_err[okv] = np.sqrt(arg[okv])
         return {"flags": flags, "flux": flux, "flux_err": flux_err, "chi2per": chi2per,
-                "dof": dof_used, "status": status.cpu().numpy()}
+                "dof": dof_used}

@@ -181,3 +181,33 @@ def test_compute_fails_loudly_without_gpu():
     from ngmix_amd.batch import StampBatch
     with pytest.raises(RuntimeError):
         StampBatch.from_images(np.zeros((1, 4, 4)))
+
+
+def test_kernel_resource_guard():
+    """the build-time guard of the hand-scheduled kernels (tools/
+    kernel_resources.py, run by `make` after linking): no scratch / VGPR
+    spills in the kernels whose s_waitcnt vmcnt(N) are counted by hand, and
+    their register count inside the validated occupancy band"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(
+        "kernel_resources", os.path.join(root, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    table, problems = kr.check(_lib.LIB_PATH)
+    assert problems == []
+    wave = {k: v for k, v in table.items() if "pixpass_wave_kernel" in k}
+    assert len(wave) >= 8     # loglike / fdiff / render / s2n, masked and not
+    for name, md in wave.items():
+        assert md.get("private_segment_fixed_size", 0) == 0, name
+        assert md.get("vgpr_spill_count", 0) == 0, name
+        assert md["vgpr_count"] <= kr.GUARDS["pixpass_wave_kernel"], name
+    # the guard does fire: a kernel over its band is reported
+    old = kr.GUARDS["pixpass_wave_kernel"]
+    kr.GUARDS["pixpass_wave_kernel"] = 8
+    try:
+        _, problems = kr.check(_lib.LIB_PATH)
+    finally:
+        kr.GUARDS["pixpass_wave_kernel"] = old
+    assert any("outside the validated occupancy band" in p for p in problems)

@@ -45,6 +45,13 @@ def _worker(rank, world, port, n_objects, outdir):
     out, work = nd.allgather_records(compute(lo2, hi2), n_objects=even_n,
                                      async_op=True)
     work.wait()
+    # async form on an uneven split: wait() also trims the padding
+    odd_n = world * 5 - 1
+    lo3, hi3 = nd.shard_bounds(odd_n, rank, world)
+    odd, work3 = nd.allgather_records(compute(lo3, hi3), n_objects=odd_n, async_op=True)
+    work3.wait()
+    assert odd.shape == (odd_n, 4)
+    assert torch.equal(odd[:, 0], torch.arange(odd_n, dtype=torch.float64))
     np.save(os.path.join(outdir, "full_%d.npy" % rank), full.numpy())
     np.save(os.path.join(outdir, "even_%d.npy" % rank), out.numpy())
     np.save(os.path.join(outdir, "bounds_%d.npy" % rank), np.array([lo, hi]))
@@ -91,3 +98,82 @@ def test_shard_bounds_properties():
                 assert lo == prev and hi >= lo
                 prev = hi
             assert prev == n
+
+
+_RANK_SCRIPT = """
+import json, os, sys, time
+sys.path.insert(0, %(root)r)
+mode = sys.argv[1]
+rank = int(os.environ["RANK"])
+if mode == "fail" and rank == 1:
+    sys.exit(7)
+if mode == "fail":
+    time.sleep(120)          # would hang in a collective; the launcher ends it
+import torch
+import torch.distributed as dist
+from ngmix_amd import distributed as nd
+r, w, lr = nd.init_from_env(backend="gloo")
+assert r == rank == lr and w == int(os.environ["WORLD_SIZE"])
+n = 2 * w + 1
+lo, hi = nd.shard_bounds(n, r, w)
+rec = torch.arange(lo, hi, dtype=torch.float64)[:, None] * torch.ones(1, 3, dtype=torch.float64)
+full = nd.gather_object_results(lambda a, b: rec, n, (3,))
+if r == 0:
+    print(json.dumps({"n_gpus": w, "sum": float(full.sum()), "backend": dist.get_backend()}))
+    sys.stdout.flush()
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_launch_local_ranks(tmp_path, capfd):
+    """the launcher bench.py --gpus N uses when it is not started by
+    torch.distributed.run: N child processes with the rendezvous environment,
+    rank 0's line on stdout, exit status 0"""
+    import json
+    from ngmix_amd import distributed as nd
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT % {"root": ROOT})
+    env_before = dict(os.environ)
+    os.environ.pop("MASTER_PORT", None)
+    os.environ["NGMIX_DIST_BACKEND"] = "gloo"
+    try:
+        rc = nd.launch_local_ranks(str(script), ["ok"], 3, need_gpus=False, timeout=120)
+    finally:
+        os.environ.clear()
+        os.environ.update(env_before)
+    assert rc == 0
+    lines = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["backend"] == "gloo"
+    assert d["sum"] == 3 * sum(range(7))
+
+
+def test_launch_local_ranks_failure_propagates(tmp_path, capfd):
+    """one rank dying ends the job with its status instead of leaving the
+    others in a collective"""
+    import time
+    from ngmix_amd import distributed as nd
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT % {"root": ROOT})
+    t0 = time.time()
+    rc = nd.launch_local_ranks(str(script), ["fail"], 2, need_gpus=False, timeout=100)
+    assert rc == 7
+    assert time.time() - t0 < 60
+    assert "exited with status 7" in capfd.readouterr().err
+
+
+def test_bench_gpus_flag_is_honoured_or_refused():
+    """python bench.py --gpus 2 must never measure one GPU and label it two:
+    here (no GPU) it has to stop with a clear message and a non-zero status"""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the launch would really run")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                        "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=280, cwd=ROOT)
+    assert p.returncode != 0
+    assert "GPU" in p.stderr and "2 ranks asked for" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

@@ -78,6 +78,37 @@ def test_psf_flux(golden):
         np.testing.assert_allclose(res[k], float(g["tf_" + k]), rtol=1e-9)
 
 
+def test_psf_flux_templates_and_obslist(golden):
+    """PSFFluxFitter on template images (psf obs without a mixture) and on a
+    two-epoch ObsList, against the reference's own fits
+    (results.py:677-914; tests/golden/api2.npz)"""
+    g, g2 = golden("extra"), golden("api2")
+    for tag, kw in (("pft", {}), ("pft_nonorm", {"normalize_psf": False})):
+        psf_obs = ngmix.Observation(g["psf_image"], jacobian=_jac(g["psf_jac"]))
+        psf_obs.template = g2["pft_template"]
+        obs = ngmix.Observation(g["image"], weight=g["weight"], jacobian=_jac(g["jac"]),
+                                psf=psf_obs)
+        res = ngmix.PSFFluxFitter(**kw).go(obs)
+        assert res["flags"] == int(g2[tag + "_flags"]) and res["model"] == "template"
+        for k in ("chi2per", "dof", "flux", "flux_err"):
+            np.testing.assert_allclose(res[k], float(g2[tag + "_" + k]), rtol=1e-10,
+                                       err_msg=tag + k)
+    ol = _nc_obslist(g)
+    for tag, kw in (("pfol", {}), ("pfol_nonorm", {"normalize_psf": False})):
+        res = ngmix.PSFFluxFitter(**kw).go(ol)
+        assert res["flags"] == int(g2[tag + "_flags"])
+        for k in ("chi2per", "dof", "flux", "flux_err"):
+            np.testing.assert_allclose(res[k], float(g2[tag + "_" + k]), rtol=1e-9,
+                                       err_msg=tag + k)
+    with pytest.raises(ValueError):
+        ngmix.PSFFluxFitter().go([obs])
+    bare = ngmix.Observation(g["image"], weight=g["weight"], jacobian=_jac(g["jac"]),
+                             psf=ngmix.Observation(g["psf_image"],
+                                                   jacobian=_jac(g["psf_jac"])))
+    with pytest.raises(ValueError):
+        ngmix.PSFFluxFitter().go(bare)
+
+
 def _nc_obslist(g):
     psf = ngmix.Observation(g["psf_image"], jacobian=_jac(g["psf_jac"]),
                             gmix=ngmix.GMix(pars=g["psf_pars"]))
