@@ -194,7 +194,7 @@ def kernel_symbols(fragments):
         for ln in out.splitlines():
             name = ln.split(" ", 2)[-1]
             if all(f in name for f in frags) and "__device_stub__" in name:
-                found[key] = name.split("__device_stub__")[-1].strip()
+                found[key] = name.split("__device_stub__")[-1].split("(")[0].strip()
                 break
     return found
 
@@ -572,6 +572,7 @@ def run_c5(args, rank, world, device, backend, nobj=None, steps=None):
     epoch_bytes = 16 * dim * dim + 64 + 48 + 32      # 65,680 B
     achieved = epoch_bytes * ns / (ll_ms * 1e-3) / 1e9
     syms = kernel_symbols({"loglike": ("pixpass_wave_kernel<0,", "false")})
+    c5_traffic = load_traffic("c5_loglike", ns, key="c5_nstamps")
     return {
         "metric": "object loglikes/sec, 10 epochs x 64x64, 16-gaussian 'bdf', 1/2/4/8 GPU",
         "value": world * nobj * K / elapsed,
@@ -591,7 +592,8 @@ def run_c5(args, rank, world, device, backend, nobj=None, steps=None):
         "roofline": {
             "bound": "hbm", "kernel": syms.get("loglike", "pixpass_wave_kernel (loglike)"),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": c5_traffic[0],
+            "traffic_source": c5_traffic[1],
             "algorithmic_bytes_per_launch": epoch_bytes * ns, "avg_launch_ms": ll_ms,
         },
         "kernels_ms": {"loglike": ll_ms, "epoch_reduce": red_ms},
@@ -806,7 +808,7 @@ def baseline_metric():
                 "1/2/4/8 GPU")
 
 
-def load_traffic(kernel, nstamps):
+def load_traffic(kernel, nstamps, key="nstamps"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC pass
     (counters cannot be read from inside the timed run: rocprofv3 --pmc is a
     separate, serialising pass).  Returns (bytes or None, source or None)."""
@@ -816,7 +818,7 @@ def load_traffic(kernel, nstamps):
             t = json.load(f)
     except (OSError, ValueError):
         return None, None
-    if t.get("nstamps") != nstamps:
+    if t.get(key) != nstamps:
         return None, None
     v = t.get(kernel + "_hbm_bytes_per_launch")
     if v is None:

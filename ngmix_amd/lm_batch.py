@@ -256,9 +256,24 @@ class LMBatchFitter(object):
                 _dptr(d_states), nobj, _dptr(d_npix),
                 _dptr(d_ffx) if d_ffx is not None else None, float(PDEF), float(CDEF),
                 _dptr(d_rec), _stream()), "ngmix_lm_finalize_batch")
-        rec = d_rec.cpu().numpy()
+        # the record array comes back through pinned memory on a side stream
+        # (PyTorch's caching host allocator: no hipHostMalloc after the first
+        # call) while the statistics pass below runs on the launch stream
+        h_rec = torch.empty((nobj, width), dtype=torch.float64, pin_memory=True)
+        ready = torch.cuda.Event()
+        ready.record()
+        side = self._side_stream(dev)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            h_rec.copy_(d_rec, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record()
+        d_rec.record_stream(side)
+        stats = self._device_stats(stamps, psf, sobj, sband, obj_start, d_rec, n)
         njev = d_states.view(torch.int32).reshape(nobj, -1)[
             :, _lib.LM_STATE_DTYPE.fields["njev"][1] // 4].cpu().numpy()
+        copied.synchronize()
+        rec = h_rec.numpy()
         res = {
             "model": self.model,
             "flags": rec[:, 0].astype(np.int64),
@@ -277,8 +292,16 @@ class LMBatchFitter(object):
             "npix": npix_obj,
             "dof": rec[:, 3].astype(np.int64),
         }
-        self._add_stats(res, stamps, psf, sobj, sband, obj_start, nband, d_rec)
+        self._add_stats(res, stats, nband)
         return res
+
+    def _side_stream(self, dev):
+        torch = _torch()
+        cache = self.__dict__.setdefault("_side_streams", {})
+        key = (dev.type, dev.index)
+        if key not in cache:
+            cache[key] = torch.cuda.Stream(device=dev)
+        return cache[key]
 
     def _first_pixels_fdiff2(self, stamps, psf, x, obj_start, sband, nskip):
         """sum of fdiff^2 over the first nskip listed pixels of each object's
@@ -341,16 +364,14 @@ class LMBatchFitter(object):
         """the raw ngmix_lm_state records of the last go() (debugging)"""
         return self._d_states.cpu().numpy().reshape(-1).view(_lib.LM_STATE_DTYPE)
 
-    def _add_stats(self, res, stamps, psf, sobj, sband, obj_start, nband, d_rec):
-        """FitModel.set_fit_result (results.py:45-72, 398-408, 1079-1109) for
-        the fits with flags == 0: one batched get_loglike at the solutions,
-        folded per object on the device; one (nobj, 4) download"""
+    def _device_stats(self, stamps, psf, sobj, sband, obj_start, d_rec, n):
+        """the device half of FitModel.set_fit_result (results.py:45-72,
+        398-408): one batched get_loglike at the solutions, folded per object
+        on the device; returns the (nobj, 4) array lnprob, s2n_numer,
+        s2n_denom, npix (one small download)"""
         torch = _torch()
         dev = stamps.device
-        nobj = res["flags"].size
-        ok = res["flags"] == 0
-        pars = res["pars"]
-        n = pars.shape[1]
+        nobj = d_rec.shape[0]
         nshape = self.nloc - 1
         # a harmless model for failed fits (their statistics are not reported)
         default = np.zeros(n)
@@ -365,12 +386,16 @@ class LMBatchFitter(object):
         d_ok = d_rec[:, 0] == 0.0
         usable = torch.where(d_ok[:, None], d_rec[:, 4:4 + n],
                              torch.from_numpy(default).to(dev)[None, :])
-        d_sobj = torch.from_numpy(sobj.astype(np.int64)).to(dev)
-        d_sband = torch.from_numpy(sband.astype(np.int64)).to(dev)
-        band_pars = torch.empty((stamps.n, self.nloc), dtype=torch.float64, device=dev)
-        per_stamp = usable[d_sobj]
-        band_pars[:, :nshape] = per_stamp[:, :nshape]
-        band_pars[:, nshape] = per_stamp.gather(1, (nshape + d_sband)[:, None])[:, 0]
+        if stamps.n == nobj and np.all(sband == 0):
+            band_pars = usable[:, :self.nloc].contiguous()
+        else:
+            d_sobj = torch.from_numpy(sobj.astype(np.int64)).to(dev)
+            d_sband = torch.from_numpy(sband.astype(np.int64)).to(dev)
+            band_pars = torch.empty((stamps.n, self.nloc), dtype=torch.float64,
+                                    device=dev)
+            per_stamp = usable[d_sobj]
+            band_pars[:, :nshape] = per_stamp[:, :nshape]
+            band_pars[:, nshape] = per_stamp.gather(1, (nshape + d_sband)[:, None])[:, 0]
         gm0, st0 = GMixBatch.from_pars(band_pars, self.model, device=dev,
                                        ngauss=self.ngauss)
         gm = gm0
@@ -388,40 +413,48 @@ class LMBatchFitter(object):
             # calc_lnprob adds the joint prior (results.py:410-437)
             tot = tot.clone()
             tot[:, 0] += self.prior.get_lnprob_batch(usable.contiguous())
-        out = tot.cpu().numpy()
-        lnprob = out[:, 0]
-        s2n_numer, s2n_denom = out[:, 1], out[:, 2]
-        npix = np.rint(out[:, 3]).astype(np.int64)
-        nan = np.full(nobj, np.nan)
+        # lnprob, s2n_numer, s2n_denom, npix, dof, chi2per, s2n -- NaN for the
+        # fits that failed, as set_fit_result leaves those keys out
+        nan = torch.full((nobj,), float("nan"), dtype=torch.float64, device=dev)
+        npix = torch.round(tot[:, 3])
+        dof = npix - float(n)
+        s2n = torch.where(tot[:, 2] > 0, tot[:, 1] / torch.sqrt(tot[:, 2]),
+                          torch.zeros_like(nan))
+        cols = [torch.where(d_ok, tot[:, 0], nan), torch.where(d_ok, tot[:, 1], nan),
+                torch.where(d_ok, tot[:, 2], nan), npix, dof,
+                torch.where(d_ok, tot[:, 0] / (-0.5) / dof, nan),
+                torch.where(d_ok, s2n, nan)]
+        return torch.stack(cols, dim=1).cpu().numpy()
+
+    def _add_stats(self, res, out, nband):
+        """the host half: the keys FitModel.set_fit_result adds for fits with
+        flags == 0 (NaN elsewhere); g / T / flux blocks are VIEWS of the
+        record array"""
+        pars = res["pars"]
+        nshape = self.nloc - 1
+        res["lnprob"] = out[:, 0]
+        res["s2n_numer"] = out[:, 1]
+        res["s2n_denom"] = out[:, 2]
+        res["npix"] = out[:, 3].astype(np.int64)
+        res["dof"] = out[:, 4].astype(np.int64)
+        res["chi2per"] = out[:, 5]
+        res["s2n_w"] = out[:, 6]
+        res["s2n"] = res["s2n_w"]
         with np.errstate(all="ignore"):
-            s2n = np.where(s2n_denom > 0, s2n_numer / np.sqrt(s2n_denom), 0.0)
-            dof = npix - pars.shape[1]
-            res["lnprob"] = np.where(ok, lnprob, nan)
-            res["s2n_numer"] = np.where(ok, s2n_numer, nan)
-            res["s2n_denom"] = np.where(ok, s2n_denom, nan)
-            res["npix"] = npix
-            res["dof"] = dof
-            res["chi2per"] = np.where(ok, lnprob / (-0.5) / dof, nan)
-            res["s2n_w"] = np.where(ok, s2n, nan)
-            res["s2n"] = res["s2n_w"]
             pc = res["pars_cov"]
+            res["g"] = pars[:, 2:4]
+            res["g_cov"] = pc[:, 2:4, 2:4]
+            res["g_err"] = res["pars_err"][:, 2:4]
             if self.model == "coellip":
                 # CoellipFitModel._set_flux is a no-op (results.py:648-652)
-                res["g"] = pars[:, 2:4].copy()
-                res["g_cov"] = pc[:, 2:4, 2:4].copy()
-                res["g_err"] = res["pars_err"][:, 2:4].copy()
                 return
-            res["g"] = pars[:, 2:4].copy()
-            res["g_cov"] = pc[:, 2:4, 2:4].copy()
-            res["g_err"] = res["pars_err"][:, 2:4].copy()
-            res["T"] = pars[:, 4].copy()
+            res["T"] = pars[:, 4]
             res["T_err"] = np.sqrt(pc[:, 4, 4])
             if nband == 1:
-                res["flux"] = pars[:, nshape].copy()
+                res["flux"] = pars[:, nshape]
                 res["flux_err"] = np.sqrt(pc[:, nshape, nshape])
             else:
-                res["flux"] = pars[:, nshape:].copy()
-                res["flux_cov"] = pc[:, nshape:, nshape:].copy()
+                res["flux"] = pars[:, nshape:]
+                res["flux_cov"] = pc[:, nshape:, nshape:]
                 res["flux_err"] = np.sqrt(np.diagonal(res["flux_cov"], axis1=1,
                                                       axis2=2))
-        del torch

@@ -19,9 +19,16 @@ shutil.copy(os.path.join(src, "stats", "run_kernel_stats.csv"),
             os.path.join(out, "%s_kernel_stats.csv" % tag))
 
 acc = defaultdict(lambda: defaultdict(list))
+c5acc = defaultdict(list)
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     f = os.path.join(d, "run_counter_collection.csv")
     if not os.path.exists(f):
+        continue
+    if os.path.basename(d).startswith("pmc_c5"):
+        # config 5's loglike is the same kernel symbol as config 2's: kept apart
+        for row in csv.DictReader(open(f)):
+            if "pixpass_wave_kernel<0" in row["Kernel_Name"]:
+                c5acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
         continue
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0].replace("void ngmix::", "")
@@ -51,7 +58,18 @@ for k, cs in sorted(acc.items()):
             traffic[name + "_write_size_kb"] = write
 # kernel-trace --stats of the bench command itself and of the other configs'
 # drivers, trimmed to this library's kernels
-for sub, name in (("bench_stats", "bench"), ("iter_stats", "iter"), ("lm_stats", "lm")):
+if "FETCH_SIZE" in c5acc and "WRITE_SIZE" in c5acc:
+    fetch = sum(c5acc["FETCH_SIZE"]) / len(c5acc["FETCH_SIZE"])
+    write = sum(c5acc["WRITE_SIZE"]) / len(c5acc["WRITE_SIZE"])
+    lines.append("# config 5 (bench.py --config C5: 20000 objects x 10 epochs of 64x64 per launch)")
+    lines.append("%-36s %-26s n=%d mean %.6g" % ("pixpass_wave_kernel<0, false, 8>",
+                                                 "FETCH_SIZE", len(c5acc["FETCH_SIZE"]), fetch))
+    lines.append("%-36s %-26s n=%d mean %.6g" % ("pixpass_wave_kernel<0, false, 8>",
+                                                 "WRITE_SIZE", len(c5acc["WRITE_SIZE"]), write))
+    traffic["c5_loglike_hbm_bytes_per_launch"] = 2 * fetch * 1024 + write * 1024
+    traffic["c5_nstamps"] = 200000
+for sub, name in (("bench_stats", "bench"), ("c4_stats", "c4"), ("c5_stats", "c5"),
+                  ("iter_stats", "iter"), ("lm_stats", "lm")):
     f = os.path.join(src, sub, "run_kernel_stats.csv")
     if not os.path.exists(f):
         continue
@@ -60,15 +78,18 @@ for sub, name in (("bench_stats", "bench"), ("iter_stats", "iter"), ("lm_stats",
     with open(os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, name)), "w") as fo:
         csv.writer(fo, quoting=csv.QUOTE_ALL).writerows(keep)
     lines.append("# rocprofv3 --kernel-trace --stats -- %s (ngmix kernels): calls, average ns"
-                 % {"bench": "python3 bench.py --no-cpu-baseline",
+                 % {"bench": "python3 bench.py --no-cpu-baseline --no-other-configs",
+                    "c4": "python3 bench.py --config C4 --steps 20 --warmup 5",
+                    "c5": "python3 bench.py --config C5 --steps 50 --warmup 10",
                     "iter": "python3 tools/bench_iter.py 200000 3",
                     "lm": "python3 tools/bench_lm.py 100000 0"}[name])
     for r in keep[1:]:
         lines.append("%-60s calls %5s avg %12.0f ns" % (
             r[0].split("(")[0].replace("void ngmix::", "")[:60], r[1], float(r[3])))
-bj = os.path.join(src, "bench.json")
-if os.path.exists(bj):
-    shutil.copy(bj, os.path.join(out, "%s_bench.json" % tag))
+for bname in ("bench", "bench_c4", "bench_c5"):
+    bj = os.path.join(src, bname + ".json")
+    if os.path.exists(bj):
+        shutil.copy(bj, os.path.join(out, "%s_%s.json" % (tag, bname)))
 for logname in ("iter.log", "lm.log"):
     f = os.path.join(src, logname)
     if os.path.exists(f):
