@@ -158,8 +158,50 @@ def _dmodel(fit_model, pars, ipar, band, obs):
 # the same for a device-resident batch of fits (LMBatchFitter results)
 # ---------------------------------------------------------------------------
 
+_MODEL_NSHAPE = {"gauss": 5, "turb": 5, "exp": 5, "dev": 5, "bdf": 6, "bd": 7}
+
+
+def _central_difference_images(geom, model, bp, psf_chunk, nshape):
+    """
+    The batched form of _dmodel (noise_cov.py:200-224): for every stamp of the
+    chunk and every local parameter [shape..., this band's flux] the central
+    difference of two fast renders, steps as get_step (results.py:929-952).
+    geom: full-frame StampBatch of the chunk; bp: (m, nloc) device tensor of
+    band parameters; psf_chunk: GMixBatch or None.
+    Returns (D (m, nloc, npix), bad (m,) bool: a shifted model out of range).
+    """
+    import torch
+    from .batch import GMixBatch
+    m, nloc = bp.shape
+    npix = geom.total_pix // max(m, 1)
+    D = torch.empty((m, nloc, npix), dtype=torch.float64, device=bp.device)
+    bad = torch.zeros(m, dtype=torch.bool, device=bp.device)
+    for k in range(nloc):
+        if k < 2:
+            step = torch.full((m,), STEP_CEN, dtype=torch.float64, device=bp.device)
+        elif k < 4:
+            step = torch.full((m,), STEP_SHAPE, dtype=torch.float64, device=bp.device)
+        else:
+            floor = STEP_STRUCT_MIN if k < nshape else STEP_FLUX_MIN
+            step = torch.clamp(STEP_FRAC * bp[:, k].abs(), min=floor)
+        ims = []
+        for sign in (1.0, -1.0):
+            p = bp.clone()
+            p[:, k] += sign * step
+            gm, st = GMixBatch.from_pars(p, model, device=bp.device)
+            bad |= st != 0
+            if psf_chunk is not None:
+                gm, _ = gm.convolve(psf_chunk)
+            im, st2 = geom.render(gm, fast_exp=True)
+            bad |= st2 != 0
+            ims.append(im.reshape(m, npix))
+        D[:, k] = (ims[0] - ims[1]) / (2.0 * step)[:, None]
+    return D, bad
+
+
 def calc_noise_cov_batch(stamps, noise, model, pars, pars_cov0, psf=None,
-                         stamp_obj=None, stamp_band=None, chunk_stamps=4096):
+                         stamp_obj=None, stamp_band=None, chunk_stamps=4096,
+                         force_fd=False):
     """
     calc_noise_cov for N fits at once.
 
@@ -167,73 +209,79 @@ def calc_noise_cov_batch(stamps, noise, model, pars, pars_cov0, psf=None,
         `obs.weight` of the reference's kernels)
     noise: flat float64 device tensor laid out like stamps.val: each stamp's
         noise image (Observation.noise)
-    model: 'gauss' | 'exp' | 'dev' (the models with analytic derivative images)
-    pars (nobj, 5 + nband), pars_cov0 (nobj, npars, npars): the solutions and
-        their unscaled covariances (LMBatchFitter's 'pars' / 'pars_cov0')
+    model: 'gauss' | 'exp' | 'dev' (analytic derivative images, one
+        deriv_images launch per chunk) or 'turb' | 'bdf' | 'bd' (central
+        differences of fast renders, two launches per parameter and chunk, as
+        the reference's _dmodel); force_fd=True takes the second path for
+        every model
+    pars (nobj, nshape + nband), pars_cov0 (nobj, npars, npars): the solutions
+        and their unscaled covariances (LMBatchFitter's 'pars' / 'pars_cov0')
     psf: GMixBatch, one mixture per stamp, or None
 
-    One deriv_images launch per chunk of equally shaped stamps, then rocFFT
-    (torch.fft) of weight x derivative images and of the noise images, the
-    per-mode sums as one contraction, and A^-1 B A^-1 per object.
+    Then rocFFT (torch.fft) of weight x derivative images and of the noise
+    images, the per-mode sums as one contraction, and A^-1 B A^-1 per object.
     Returns the (nobj, npars, npars) sandwich covariances as a numpy array
     (NaN where the model is out of range or a flux is zero).
     """
     import torch
     from .batch import GMixBatch, StampBatch, _as_device_f64
     from .fitting import SIMPLE_ANALYTIC_MODELS
-    if model not in SIMPLE_ANALYTIC_MODELS:
-        raise NotImplementedError(
-            "calc_noise_cov_batch needs analytic derivative images (%s); use "
-            "Fitter(use_noise_image=True) per object for '%s'"
-            % (", ".join(SIMPLE_ANALYTIC_MODELS), model))
+    if model not in _MODEL_NSHAPE:
+        raise ValueError("calc_noise_cov_batch: model must be one of %s"
+                         % (tuple(_MODEL_NSHAPE),))
+    analytic = model in SIMPLE_ANALYTIC_MODELS and not force_fd
     dev = stamps.device
     ns = stamps.n
     pars = np.ascontiguousarray(pars, dtype="f8")
     nobj, npars = pars.shape
-    nshape = 5
+    nshape = _MODEL_NSHAPE[model]
+    nloc = nshape + 1
     nband = npars - nshape
     sobj = (np.arange(ns, dtype=np.int64) if stamp_obj is None
             else np.ascontiguousarray(stamp_obj, dtype=np.int64))
     sband = (np.zeros(ns, dtype=np.int64) if stamp_band is None
              else np.ascontiguousarray(stamp_band, dtype=np.int64))
 
-    # every stamp's mixtures at its object's solution
-    bp = np.empty((ns, 6))
-    bp[:, :5] = pars[sobj, :5]
-    bp[:, 5] = pars[sobj, 5 + sband]
-    gm0, st0 = GMixBatch.from_pars(bp, model, device=dev)
-    gmc = gm0
-    if psf is not None:
-        gmc, _ = gm0.convolve(psf)
-    ng0, G = gm0.ngauss, gmc.ngauss
-    npsf = G // ng0
-    G0 = gm0.data.reshape(ns, ng0, 13)
-    GC = gmc.data.reshape(ns, G, 13)
-    gpars = GC[:, :, 0:6].contiguous()
-    modcov = G0[:, :, 3:6].repeat_interleave(npsf, dim=1)          # (ns, G, 3)
-    # d(irr, irc, icc) / d(g1, g2, T) of each component (results.py:955-1010)
+    # every stamp's band parameters at its object's solution
+    bp = np.empty((ns, nloc))
+    bp[:, :nshape] = pars[sobj, :nshape]
+    bp[:, nshape] = pars[sobj, nshape + sband]
     d_bp = _as_device_f64(bp, dev)
-    g1, g2, T, flux = d_bp[:, 2], d_bp[:, 3], d_bp[:, 4], d_bp[:, 5]
-    gsq = g1 * g1 + g2 * g2
-    f = 2.0 / (1.0 + gsq)
-    dfac = -f / (1.0 + gsq)
-    de1 = torch.stack([f + 2.0 * g1 * g1 * dfac, 2.0 * g1 * g2 * dfac], dim=1)  # d e1 / d g1,g2
-    de2 = torch.stack([2.0 * g1 * g2 * dfac, f + 2.0 * g2 * g2 * dfac], dim=1)  # d e2 / d g1,g2
-    Tk = modcov[:, :, 0] + modcov[:, :, 2]
-    dcov = torch.zeros((ns, G, 3, 3), dtype=torch.float64, device=dev)
-    for i in range(2):
-        dcov[:, :, i, 0] = -0.5 * Tk * de1[:, i, None]
-        dcov[:, :, i, 1] = 0.5 * Tk * de2[:, i, None]
-        dcov[:, :, i, 2] = 0.5 * Tk * de1[:, i, None]
-    dcov[:, :, 2, :] = modcov / T[:, None, None]
+    flux = d_bp[:, nshape]
+    gm0, st0 = GMixBatch.from_pars(bp, model, device=dev)
+    bad = (st0 != 0) | (flux == 0.0)
+    npsf = psf.ngauss if psf is not None else 0
+    if analytic:
+        gmc = gm0
+        if psf is not None:
+            gmc, _ = gm0.convolve(psf)
+        ng0, G = gm0.ngauss, gmc.ngauss
+        G0 = gm0.data.reshape(ns, ng0, 13)
+        GC = gmc.data.reshape(ns, G, 13)
+        gpars = GC[:, :, 0:6].contiguous()
+        modcov = G0[:, :, 3:6].repeat_interleave(G // ng0, dim=1)          # (ns, G, 3)
+        # d(irr, irc, icc) / d(g1, g2, T) of each component (results.py:955-1010)
+        g1, g2, T = d_bp[:, 2], d_bp[:, 3], d_bp[:, 4]
+        gsq = g1 * g1 + g2 * g2
+        f = 2.0 / (1.0 + gsq)
+        dfac = -f / (1.0 + gsq)
+        de1 = torch.stack([f + 2.0 * g1 * g1 * dfac, 2.0 * g1 * g2 * dfac], dim=1)
+        de2 = torch.stack([2.0 * g1 * g2 * dfac, f + 2.0 * g2 * g2 * dfac], dim=1)
+        Tk = modcov[:, :, 0] + modcov[:, :, 2]
+        dcov = torch.zeros((ns, G, 3, 3), dtype=torch.float64, device=dev)
+        for i in range(2):
+            dcov[:, :, i, 0] = -0.5 * Tk * de1[:, i, None]
+            dcov[:, :, i, 1] = 0.5 * Tk * de2[:, i, None]
+            dcov[:, :, i, 2] = 0.5 * Tk * de1[:, i, None]
+        dcov[:, :, 2, :] = modcov / T[:, None, None]
 
     wt = stamps.ierr * stamps.ierr
     d_sobj = torch.from_numpy(sobj).to(dev)
     # local parameter k of a stamp -> column of its object's matrix
-    cols = np.concatenate([np.tile(np.arange(5), (ns, 1)), (5 + sband)[:, None]], axis=1)
+    cols = np.concatenate([np.tile(np.arange(nshape), (ns, 1)),
+                           (nshape + sband)[:, None]], axis=1)
     d_cols = torch.from_numpy(cols).to(dev)
     B = torch.zeros((nobj, npars, npars), dtype=torch.float64, device=dev)
-    bad = (st0 != 0) | (flux == 0.0)
 
     shapes = np.stack([stamps.nrow, stamps.ncol], axis=1)
     for shp in np.unique(shapes, axis=0):
@@ -246,12 +294,22 @@ def calc_noise_cov_batch(stamps, noise, model, pars, pars_cov0, psf=None,
             d_idx = torch.from_numpy(idx).to(dev)
             geom = StampBatch(None, None, stamps.jac[d_idx], np.full(m, nrow),
                               np.full(m, ncol), np.arange(m, dtype=np.int64) * npix, True)
-            out = geom.deriv_images(gpars[d_idx].reshape(-1, 6),
-                                    dcov[d_idx].reshape(-1, 3, 3), G)
-            out = out.reshape(m, 6, nrow, ncol)
-            # [cen1, cen2, g1, g2, T, flux]: the flux derivative is value / flux
-            D = torch.cat([out[:, 1:6], (out[:, 0] / flux[d_idx, None, None])[:, None]],
-                          dim=1)
+            if analytic:
+                out = geom.deriv_images(gpars[d_idx].reshape(-1, 6),
+                                        dcov[d_idx].reshape(-1, 3, 3), G)
+                out = out.reshape(m, 6, nrow, ncol)
+                # [cen1, cen2, g1, g2, T, flux]: the flux derivative is value / flux
+                D = torch.cat([out[:, 1:6],
+                               (out[:, 0] / flux[d_idx, None, None])[:, None]], dim=1)
+            else:
+                psf_chunk = None
+                if psf is not None:
+                    pdata = psf.data.reshape(ns, npsf, 13)[d_idx]
+                    psf_chunk = GMixBatch(pdata.reshape(-1, 13).contiguous(), m, npsf)
+                D, cbad = _central_difference_images(geom, model, d_bp[d_idx], psf_chunk,
+                                                     nshape)
+                D = D.reshape(m, nloc, nrow, ncol)
+                bad[d_idx] |= cbad
             pix = (torch.from_numpy(stamps.pix_off[idx]).to(dev)[:, None] +
                    torch.arange(npix, device=dev)[None, :])
             W = wt[pix].reshape(m, 1, nrow, ncol)
@@ -259,11 +317,11 @@ def calc_noise_cov_batch(stamps, noise, model, pars, pars_cov0, psf=None,
             P = torch.fft.fft2(noise[pix].reshape(m, nrow, ncol)).abs() ** 2
             Bs = torch.einsum("naxy,nbxy,nxy->nab", K.conj(), K,
                               P.to(K.dtype)).real / float(npix) ** 2
-            # scatter the 6x6 blocks into the objects' matrices
-            oi = d_sobj[d_idx][:, None, None].expand(m, 6, 6)
+            # scatter the nloc x nloc blocks into the objects' matrices
+            oi = d_sobj[d_idx][:, None, None].expand(m, nloc, nloc)
             ci = d_cols[d_idx]
-            B.index_put_((oi, ci[:, :, None].expand(m, 6, 6), ci[:, None, :].expand(m, 6, 6)),
-                         Bs, accumulate=True)
+            B.index_put_((oi, ci[:, :, None].expand(m, nloc, nloc),
+                          ci[:, None, :].expand(m, nloc, nloc)), Bs, accumulate=True)
     cov0 = _as_device_f64(np.ascontiguousarray(pars_cov0, dtype="f8"), dev)
     cov = cov0 @ B @ cov0
     obad = torch.zeros(nobj, dtype=torch.bool, device=dev)
@@ -286,6 +344,11 @@ def apply_noise_cov_batch(res, stamps, noise, model, psf=None, stamp_obj=None,
     pars = res["pars"].copy()
     pars[~ok] = 1.0  # any in-range point: their rows are not used
     pars[~ok, 2:4] = 0.0
+    if model == "bdf":
+        pars[~ok, 5] = 0.5
+    if model == "bd":
+        pars[~ok, 5] = 0.0
+        pars[~ok, 6] = 0.5
     cov = calc_noise_cov_batch(stamps, noise, model, pars, cov0, psf=psf,
                                stamp_obj=stamp_obj, stamp_band=stamp_band)
     finite = np.all(np.isfinite(cov), axis=(1, 2))

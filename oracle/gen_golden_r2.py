@@ -143,6 +143,25 @@ def main():
         for k in ("flags", "chi2per", "dof", "flux", "flux_err"):
             out[tag + "_" + k] = np.array(res[k])
         print(tag, res["flags"], res["flux"], res["flux_err"])
+    # ---- noise-power sandwich covariance for the models WITHOUT analytic
+    # derivative images (central differences, ngmix/fitting/noise_cov.py:140-224)
+    eol = ngmix.ObsList()
+    for e in range(2):
+        pre = "nc_e%d_" % e
+        eol.append(ngmix.Observation(x[pre + "image"], weight=x[pre + "weight"],
+                                     jacobian=_jac(x[pre + "jac"]), psf=psf,
+                                     noise=x[pre + "noise"]))
+    g0 = x["nc_guess"]
+    for model, guess in (("turb", g0), ("bdf", np.array(list(g0[:5]) + [0.3, g0[5]]))):
+        res = ngmix.fitting.Fitter(model=model, use_noise_image=True).go(obs=eol,
+                                                                         guess=guess)
+        pre = "ncfd_%s_" % model
+        out[pre + "guess"] = guess
+        for k in ("flags", "nfev", "ier"):
+            out[pre + k] = np.array(res[k])
+        for k in ("pars", "pars_err", "pars_cov", "pars_cov0"):
+            out[pre + k] = np.array(res[k])
+        print(pre, res["flags"], res["nfev"], res["pars"])
     np.savez_compressed(OUT, **out)
     print("wrote %s (%.1f kB)" % (OUT, os.path.getsize(OUT) / 1e3))
 

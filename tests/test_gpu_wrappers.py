@@ -264,3 +264,78 @@ def test_noise_cov_batch_matches_per_object(golden):
         np.testing.assert_allclose(res["pars_err"][i], one["pars_err"], rtol=1e-4)
     # correlated noise: well above the chi2-scaled errors
     assert np.all(res["pars_err"][0] > 2 * plain_err[0])
+
+
+def _nc_batch(g):
+    """the golden two-epoch object as a device batch: stamps, noise, psf"""
+    import torch
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    ol = _nc_obslist(g)
+    sb = StampBatch.from_observations(list(ol))
+    noise = torch.from_numpy(np.concatenate(
+        [np.asarray(ob.noise, dtype="f8").ravel() for ob in ol])).to(sb.device)
+    psf = GMixBatch.from_numpy(np.stack([ob.psf.gmix.get_data().copy() for ob in ol]))
+    return ol, sb, noise, psf
+
+
+@pytest.mark.parametrize("model", ["turb", "bdf"])
+def test_noise_cov_batch_central_differences_vs_reference(golden, model):
+    """the sandwich covariance for the models without analytic derivative
+    images (noise_cov.py:140-224: central differences of two fast renders per
+    parameter), batched, against the REFERENCE's own Fitter(model,
+    use_noise_image=True) on the two-epoch object (tests/golden/api2.npz)"""
+    from ngmix_amd.noise_cov import calc_noise_cov_batch
+    g, g2 = golden("extra"), golden("api2")
+    ol, sb, noise, psf = _nc_batch(g)
+    pre = "ncfd_%s_" % model
+    assert int(g2[pre + "flags"]) == 0
+    pars, cov0, ref = g2[pre + "pars"], g2[pre + "pars_cov0"], g2[pre + "pars_cov"]
+    sobj = np.zeros(2, dtype=np.int64)
+    cov = calc_noise_cov_batch(sb, noise, model, pars[None], cov0[None], psf=psf,
+                               stamp_obj=sobj)[0]
+    sig = np.sqrt(np.diag(ref))
+    np.testing.assert_allclose(cov, ref, rtol=1e-6, atol=1e-8 * np.outer(sig, sig).max())
+    # the same object twice in one batch, one copy shifted to another chunk
+    sb2 = type(sb).from_observations(list(ol) + list(ol))
+    import torch
+    cov2 = calc_noise_cov_batch(sb2, torch.cat([noise, noise]), model,
+                                np.stack([pars, pars]), np.stack([cov0, cov0]),
+                                psf=type(psf)(torch.cat([psf.data, psf.data]), 4, psf.ngauss),
+                                stamp_obj=np.array([0, 0, 1, 1]), chunk_stamps=3)
+    np.testing.assert_allclose(cov2[0], cov, rtol=1e-12)
+    np.testing.assert_allclose(cov2[1], cov, rtol=1e-12)
+    # the per-object Fitter of the shell goes through _dmodel for these models
+    one = ngmix.fitting.Fitter(model=model, use_noise_image=True).go(
+        obs=ol, guess=g2[pre + "guess"])
+    assert one["flags"] == 0
+    np.testing.assert_allclose(one["pars"], pars, rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(one["pars_cov"], ref, rtol=5e-3,
+                               atol=1e-5 * np.outer(sig, sig).max())
+
+
+def test_noise_cov_batch_forced_central_differences(golden):
+    """force_fd on an analytic model: the central-difference derivative images
+    equal the reference's (extra.npz nc_fd_images_e0) and the covariance the
+    analytic one to the differencing error"""
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    from ngmix_amd.noise_cov import calc_noise_cov_batch, _central_difference_images
+    import torch
+    g = golden("extra")
+    ol, sb, noise, psf = _nc_batch(g)
+    pars, cov0 = g["nc_sandwich_pars"], g["nc_sandwich_pars_cov0"]
+    sobj = np.zeros(2, dtype=np.int64)
+    a = calc_noise_cov_batch(sb, noise, "exp", pars[None], cov0[None], psf=psf,
+                             stamp_obj=sobj)[0]
+    b = calc_noise_cov_batch(sb, noise, "exp", pars[None], cov0[None], psf=psf,
+                             stamp_obj=sobj, force_fd=True)[0]
+    sig = np.sqrt(np.diag(a))
+    np.testing.assert_allclose(b, a, rtol=1e-5, atol=1e-7 * np.outer(sig, sig).max())
+    geom = StampBatch(None, None, sb.jac[:1], np.array([32]), np.array([32]),
+                      np.zeros(1, dtype=np.int64), True)
+    bp = torch.from_numpy(pars[None].copy()).to(sb.device)
+    D, bad = _central_difference_images(
+        geom, "exp", bp, GMixBatch(psf.data[:psf.ngauss].contiguous(), 1, psf.ngauss), 5)
+    assert not bool(bad.any())
+    ref = g["nc_fd_images_e0"]
+    got = D.cpu().numpy().reshape(ref.shape)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-11 * np.abs(ref).max())
