@@ -409,7 +409,7 @@ int ngmix_deriv_images_batch(const ngmix_batch *batch, const double *gpars,
  * reduced on chip to the 28 normal-equation sums per stamp) and
  * ngmix_lm_advance_batch (one step of the lmder logic per object).
  * ====================================================================== */
-#define NGMIX_LM_NPMAX 10 /* parameters per object: bdf + 4 bands, bd + 3 bands, coellip with 3 gaussians */
+#define NGMIX_LM_NPMAX 14 /* parameters per object: bdf + 8 bands, bd + 7 bands, coellip with 5 gaussians */
 /* per stamp sums over its nloc local parameters (the shared shape parameters
    followed by the flux of the stamp's band): J^T J upper triangle | J^T f | f.f */
 #define NGMIX_LM_NSUMS(nloc) ((nloc) * ((nloc) + 1) / 2 + (nloc) + 1)
@@ -477,7 +477,7 @@ int64_t ngmix_lm_advance_host(ngmix_lm_state *states, int64_t nobj,
    NGMIX_LM_MODE_ANALYTIC); fd = 1: residuals, plus MINPACK's forward-difference
    jacobian when the object's phase asks for one (gauss, turb, exp, dev, bdf,
    bd, and co-elliptical gaussians as model = NGMIX_MODEL_COELLIP + 256 * ngauss
-   with ngauss <= 3 and parameters cen1, cen2, g1, g2, T_1.., F_1..; states in
+   with ngauss <= 5 and parameters cen1, cen2, g1, g2, T_1.., F_1..; states in
    NGMIX_LM_MODE_FD).  states: device array; stamp_obj (nstamps,)
    object of each stamp or NULL (stamp i = object i); stamp_band (nstamps,) or
    NULL (band 0); psf: nstamps*npsf gauss2d records or NULL with npsf = 0;

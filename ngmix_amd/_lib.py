@@ -92,7 +92,7 @@ def moments_result_dtype(nmom):
     ], align=True)
 
 
-LM_NPMAX = 10
+LM_NPMAX = 14
 LM_NSUM = 28
 LM_PHASE_DONE = 2
 LM_PHASE_JAC = 3

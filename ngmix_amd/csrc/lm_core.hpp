@@ -76,7 +76,9 @@ NGMIX_HD void factor_normal(int n, const double *A, double *R, int32_t *ipvt,
         const double d = A[j * LM_NPMAX + j];
         acnorm[j] = d > 0.0 ? sqrt(d) : 0.0;
     }
-    for (int i = 0; i < LM_NPMAX * LM_NPMAX; i++) R[i] = 0.0;
+    // (only the leading n x n block of the LM_NPMAX-strided arrays is ever read)
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) R[i * LM_NPMAX + j] = 0.0;
     // S is kept in the permuted order: row/col k of S <-> parameter ipvt[k]
     for (int k = 0; k < n; k++) {
         int kmax = k;
@@ -332,7 +334,8 @@ NGMIX_HD void propose(lm_state &s)
 {
     const int n = s.n;
     double r[LM_NPMAX * LM_NPMAX], sdiag[LM_NPMAX], p[LM_NPMAX], wa3[LM_NPMAX];
-    for (int i = 0; i < LM_NPMAX * LM_NPMAX; i++) r[i] = s.R[i];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) r[i * LM_NPMAX + j] = s.R[i * LM_NPMAX + j];
     lmpar(n, r, s.ipvt, s.diag, s.qtf, s.delta, s.par, p, sdiag);
     for (int j = 0; j < n; j++) {
         s.step[j] = -p[j];
@@ -440,11 +443,10 @@ NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g_in, const doubl
     const double *g = g_in, *A = A_in;
     if (s.bounded && s.mode == NGMIX_LM_MODE_ANALYTIC) {
         double sc[LM_NPMAX];
-        for (int j = 0; j < LM_NPMAX; j++)
-            sc[j] = j < n ? i2e_grad(s.xti[j], s.lo[j], s.hi[j]) : 0.0;
-        for (int j = 0; j < LM_NPMAX; j++) {
+        for (int j = 0; j < n; j++) sc[j] = i2e_grad(s.xti[j], s.lo[j], s.hi[j]);
+        for (int j = 0; j < n; j++) {
             gs[j] = g_in[j] * sc[j];
-            for (int k = 0; k < LM_NPMAX; k++)
+            for (int k = 0; k < n; k++)
                 As[j * LM_NPMAX + k] = A_in[j * LM_NPMAX + k] * sc[j] * sc[k];
         }
         g = gs;

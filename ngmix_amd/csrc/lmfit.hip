@@ -304,8 +304,10 @@ __global__ __launch_bounds__(BLOCK) void lm_advance_kernel(
     if (s.phase == LM_PHASE_DONE) return;
     const int ntri = nloc * (nloc + 1) / 2, nsum = ntri + nloc + 1;
     double A[LM_NPMAX * LM_NPMAX], g[LM_NPMAX];
-    for (int i = 0; i < LM_NPMAX * LM_NPMAX; i++) A[i] = 0.0;
-    for (int i = 0; i < LM_NPMAX; i++) g[i] = 0.0;
+    for (int i = 0; i < s.n; i++) {
+        for (int j = 0; j < s.n; j++) A[i * LM_NPMAX + j] = 0.0;
+        g[i] = 0.0;
+    }
     double ff = 0.0;
     const int64_t s0 = obj_start ? obj_start[o] : o;
     const int64_t s1 = obj_start ? obj_start[o + 1] : o + 1;
@@ -372,9 +374,12 @@ __global__ __launch_bounds__(WAVE) void lm_eval_fd_kernel(
     constexpr int NTRI = NLOC * (NLOC + 1) / 2;
     constexpr int NSUM = NTRI + NLOC + 1;
     constexpr int NSETS = NLOC + 1;
+    static_assert(NLOC + 1 <= 16, "the normal equations are one 16 x 16 MFMA tile");
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     __shared__ double tabr[16];
-    __shared__ double red[NSUM * 4];
+    // one tile's rows [J_0 .. J_{NLOC-1}, f, 0 ..] per pixel, 17 doubles apart
+    constexpr int JSTRIDE = 17;
+    __shared__ double jbuf[WAVE * JSTRIDE];
 
     const int s = blockIdx.x;
     const int lane = threadIdx.x;
@@ -464,9 +469,20 @@ __global__ __launch_bounds__(WAVE) void lm_eval_fd_kernel(
     const double *sval = val + st.pix_off;
     const double *sierr = ierr + st.pix_off;
 
-    double acc[NSUM];
+    // J^T J, J^T f and f.f are X^T X for X = [J | f] (pixels x 16): a sum of
+    // outer products over the pixels -- v_mfma_f64_16x16x4_f64, four pixels
+    // per instruction, the whole 16 x 16 result in four accumulator registers
+    // per lane (row (lane >> 4) + 4 r, column lane & 15).  With the sums in
+    // per-lane VALU accumulators (NSUM of them) the ten-parameter kernel held
+    // 236 VGPRs = one wave per SIMD, and twelve parameters did not fit at all.
+    typedef double double4_t __attribute__((ext_vector_type(4)));
+    double4_t M = {0.0, 0.0, 0.0, 0.0};
+    double ff = 0.0;   // trial evaluations want only |f|^2
+    {
+        double *jb = jbuf + lane * JSTRIDE;
 #pragma unroll
-    for (int k = 0; k < NSUM; k++) acc[k] = 0.0;
+        for (int j = 0; j < JSTRIDE; j++) jb[j] = 0.0;
+    }
 
     auto load_tile = [&](int ty, int tx, double &pv, double &pe) {
         const int row = ty * TILE_H + lrow, col = tx * TILE_W + lcol;
@@ -528,39 +544,52 @@ __global__ __launch_bounds__(WAVE) void lm_eval_fd_kernel(
             }
         }
 
-        if (!masked || pierr > 0.0) {
-            const double f = (m[0] - pval) * pierr;
-            acc[NSUM - 1] = fma(f, f, acc[NSUM - 1]);
-            if (want_jac) {
-                double J[NLOC];
+        // a pixel outside the stamp or of zero weight has ierr == 0: its row
+        // is zero, except that a masked pixel may hold a non-finite value
+        const bool live = !masked || pierr > 0.0;
+        const double f = live ? (m[0] - pval) * pierr : 0.0;
+        if (!want_jac) {
+            ff = fma(f, f, ff);
+        } else {
+            double *jb = jbuf + lane * JSTRIDE;
 #pragma unroll
-                for (int j = 0; j < NLOC; j++) J[j] = (m[j + 1] - m[0]) * (pierr * ih[j]);
-                int k = 0;
+            for (int j = 0; j < NLOC; j++)
+                jb[j] = live ? (m[j + 1] - m[0]) * (pierr * ih[j]) : 0.0;
+            jb[NLOC] = f;
+            __syncthreads();   // one wave: orders the LDS traffic, no s_barrier
+            // A[i][k] = B[k][i] = X[pixel 4 t + k][i]: lane (i, k) reads one double
+            const double *src = jbuf + (lane >> 4) * JSTRIDE + (lane & 15);
 #pragma unroll
-                for (int a = 0; a < NLOC; a++)
-#pragma unroll
-                    for (int b = a; b < NLOC; b++) {
-                        acc[k] = fma(J[a], J[b], acc[k]);
-                        k++;
-                    }
-#pragma unroll
-                for (int a = 0; a < NLOC; a++) acc[NTRI + a] = fma(J[a], f, acc[NTRI + a]);
+            for (int t = 0; t < 16; t++) {
+                const double x = src[4 * t * JSTRIDE];
+                M = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, M, 0, 0, 0);
             }
+            __syncthreads();
         }
         ty = ty2;
         tx = tx2;
     }
 
+    if (!want_jac) {
+        const double tot = wave_total(ff);
+        // (the jacobian slots are not read for a trial evaluation)
+        if (lane == 0) out[NSUM - 1] = tot;
+    } else {
+        const int col = lane & 15;
 #pragma unroll
-    for (int k = 0; k < NSUM; k++) {
-        const double r = row16_sum(acc[k]);
-        if ((lane & 15) == 15) red[k * 4 + (lane >> 4)] = r;
-    }
-    __syncthreads();
-    // (NLOC = 10 has 66 sums, two more than the wave has lanes)
-    for (int k = lane; k < NSUM; k += WAVE) {
-        const double *r = red + k * 4;
-        out[k] = ((r[0] + r[1]) + r[2]) + r[3];
+        for (int r = 0; r < 4; r++) {
+            const int row = (lane >> 4) + 4 * r;
+            if (row > col || col > NLOC) continue;
+            const double v = M[r];
+            if (col < NLOC) {
+                // upper triangle, row-major: (a, b) -> a NLOC - a (a - 1) / 2 + (b - a)
+                out[row * NLOC - row * (row - 1) / 2 + (col - row)] = v;
+            } else if (row < NLOC) {
+                out[NTRI + row] = v;       // J^T f
+            } else {
+                out[NSUM - 1] = v;         // f . f
+            }
+        }
     }
     if (lane == 0 && status) status[s] = NGMIX_OK;
 }
@@ -839,7 +868,9 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *stat
     if (nloc == 6) NGMIX_FD_LAUNCH(6);
     else if (nloc == 7) NGMIX_FD_LAUNCH(7);
     else if (nloc == 8) NGMIX_FD_LAUNCH(8);
-    else NGMIX_FD_LAUNCH(10);
+    else if (nloc <= 10) NGMIX_FD_LAUNCH(10);
+    else if (nloc <= 12) NGMIX_FD_LAUNCH(12);
+    else NGMIX_FD_LAUNCH(14);
 #undef NGMIX_FD_LAUNCH
     NGMIX_HIP_CHECK(hipGetLastError());
     return NGMIX_OK;

@@ -108,11 +108,29 @@ def _em_psf(psf_stamps, ngauss, T0, cen, rng, em_pars):
     return gm, flags
 
 
-def _coellip_psf(psf_stamps, ngauss, T0, cen, g, rng):
+def _coellip_psf(psf_stamps, ngauss, T0, cen, g, rng, ntry=1):
     """lock-step LM fit of ngauss co-elliptical gaussians to every psf stamp
     (PSFRunner + CoellipFitter, runners.py:152-223, fitters.py:120-141) from
-    the adaptive-moments centre, shape and size; returns the flux-normalised
-    mixtures and the fit flags"""
+    the adaptive-moments centre, shape and size; the fits that end with flags
+    != 0 are repeated from a freshly perturbed guess, up to ntry attempts in
+    all (PSFRunner's retry loop, runners.py:176-199).  Returns the
+    flux-normalised mixtures and the fit flags"""
+    gm, flags = _coellip_psf_once(psf_stamps, ngauss, T0, cen, g, rng)
+    for _ in range(1, int(ntry)):
+        again = np.nonzero(flags != 0)[0]
+        if again.size == 0:
+            break
+        import torch
+        sub, sflags = _coellip_psf_once(psf_stamps.select(again), ngauss, T0[again],
+                                        cen[again], g[again], rng)
+        d_idx = torch.from_numpy(again).to(gm.data.device)
+        gm.data.reshape(psf_stamps.n, ngauss, 13)[d_idx] = sub.data.reshape(
+            again.size, ngauss, 13)
+        flags[again] = sflags
+    return gm, flags
+
+
+def _coellip_psf_once(psf_stamps, ngauss, T0, cen, g, rng):
     n = psf_stamps.n
     frac, fac = _EM_PSF_GUESS[ngauss]
     npix = psf_stamps.npix.astype(np.int64)
@@ -145,7 +163,8 @@ def _coellip_psf(psf_stamps, ngauss, T0, cen, g, rng):
 
 def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None,
                     fit_pars=None, rng=None, psf_ngauss=1, em_pars=None, prior=None,
-                    stamp_obj=None, stamp_band=None, ntry=1, psf_fitter="em"):
+                    stamp_obj=None, stamp_band=None, ntry=1, psf_fitter="em",
+                    psf_ntry=1):
     """
     stamps, psf_stamps: StampBatch of the object images and of their psf images
         (stamp i of one belongs to stamp i of the other)
@@ -158,6 +177,7 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
         psf_fitter='coellip' a lock-step LM fit of that many co-elliptical
         gaussians (the reference's CoellipFitter psf runners)
     prior: a batch prior for the object fits (prior_batch.PriorSimpleSepBatch ...)
+    psf_ntry: attempts per psf fit (psf_fitter='coellip'; PSFRunner's ntry)
     ntry: fits that end with flags != 0 are repeated from a perturbed guess up
         to ntry times in all, as Runner does object by object
         (runners.py:95-150); 'ntry' of the result counts the attempts
@@ -193,7 +213,8 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
         cen = np.where(psf_bad[:, None], 0.0, np.stack([pw["row"], pw["col"]], axis=1))
         if psf_fitter == "coellip":
             psf_gm, em_flags = _coellip_psf(psf_stamps, psf_ngauss, psf_T, cen,
-                                            np.stack([pg1, pg2], axis=1), rng)
+                                            np.stack([pg1, pg2], axis=1), rng,
+                                            ntry=psf_ntry)
         else:
             psf_gm, em_flags = _em_psf(psf_stamps, psf_ngauss, psf_T, cen, rng, em_pars)
         psf_bad = psf_bad | (em_flags != 0)

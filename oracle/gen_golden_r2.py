@@ -162,6 +162,33 @@ def main():
         for k in ("pars", "pars_err", "pars_cov", "pars_cov0"):
             out[pre + k] = np.array(res[k])
         print(pre, res["flags"], res["nfev"], res["pars"])
+    # ---- CoellipFitter with four and five gaussians (fitters.py:120-141; the
+    # reference's psf guessers go up to five, guessers.py:795-797)
+    rng = np.random.RandomState(9142)
+    cjac = ngmix.DiagonalJacobian(row=16.3, col=15.8, scale=0.263)
+    Ts = [0.08, 0.2, 0.5, 1.2, 3.0]
+    Fs = [0.35, 0.3, 0.2, 0.1, 0.05]
+    for ng in (4, 5):
+        truth = np.array([0.01, -0.02, 0.04, 0.03] + Ts[:ng] + Fs[:ng])
+        cim = ngmix.GMixCoellip(truth).make_image((33, 33), jacobian=cjac)
+        cim += 2.0e-5 * rng.normal(size=cim.shape)
+        cobs = ngmix.Observation(cim, weight=np.full(cim.shape, 1.0 / 2.0e-5 ** 2),
+                                 jacobian=cjac)
+        guess = truth.copy()
+        guess[4:] *= 1.0 + 0.04 * rng.uniform(-1, 1, size=2 * ng)
+        guess[0:4] += 0.005 * rng.uniform(-1, 1, size=4)
+        res = ngmix.fitting.CoellipFitter(ngauss=ng).go(obs=cobs, guess=guess)
+        pre = "coellip%d_" % ng
+        out[pre + "image"] = cim
+        out[pre + "jac"] = cjac.get_data().copy()
+        out[pre + "truth"] = truth
+        out[pre + "guess"] = guess
+        for k in ("flags", "nfev", "ier", "lnprob", "chi2per"):
+            out[pre + k] = np.array(res[k])
+        for k in ("pars", "pars_err", "pars_cov"):
+            out[pre + k] = np.array(res[k])
+        out[pre + "gmix_pars"] = res.get_gmix().get_full_pars()
+        print(pre, res["flags"], res["nfev"], res["ier"], res["pars"], res["pars_err"])
     np.savez_compressed(OUT, **out)
     print("wrote %s (%.1f kB)" % (OUT, os.path.getsize(OUT) / 1e3))
 
