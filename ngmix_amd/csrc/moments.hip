@@ -367,6 +367,151 @@ __device__ __forceinline__ void wsums_store(const double *tot, char *resbase)
     }
 }
 
+// The 17-moment sums (get_higher_order_weighted_sums, gmix_nb.py:737-821) in
+// ONE pass over the pixels.  sums_cov[i][j] = sum w^2 var F_i F_j is X^T X for
+// X = (w / ierr) F, a sum of outer products over the pixels: its leading
+// 16 x 16 block runs on v_mfma_f64_16x16x4_f64 (four pixels per instruction,
+// the result in four accumulator registers per lane), row 16 and the 17 data
+// sums sum w I F_i stay per-lane VALU accumulators.  With all 172 sums in VALU
+// accumulators the kernel needed four passes over the pixels (and four true
+// exp per pixel): 11.8 ms per 100k 48x48 stamps.
+__device__ __forceinline__ void wsums17_single_pass(const GridSrc &src, const EvalGauss *ge,
+                                                    int ng, double vcen, double ucen,
+                                                    double maxrad2, WsumsWaveShared &sh,
+                                                    char *resbase, int &lastp_out)
+{
+    constexpr int NMOM = 17;
+    constexpr int XS = 17;   // doubles between the rows of the transposition tile
+    __shared__ double xbuf[WAVE * XS];
+    typedef double double4_t __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x;
+    const int lrow = lane / TILE_W, lcol = lane % TILE_W;
+    const int nrow = src.nrow, ncol = src.ncol;
+    // two accumulators: consecutive MFMAs are independent of each other
+    double4_t M = {0.0, 0.0, 0.0, 0.0}, M2 = {0.0, 0.0, 0.0, 0.0};
+    double c16[NMOM], sm[NMOM];   // sums_cov[16][:] and sums[:]
+#pragma unroll
+    for (int k = 0; k < NMOM; k++) c16[k] = sm[k] = 0.0;
+    double wsum = 0.0;
+    int npix = 0, lastp = -1;
+    bool zero_div = false;
+    double *xrow = xbuf + lane * XS;
+    const double *xsrc = xbuf + (lane >> 4) * XS + (lane & 15);
+
+    for (int r0 = 0; r0 < nrow; r0 += TILE_H) {
+        for (int c0 = 0; c0 < ncol; c0 += TILE_W) {
+            const int row = r0 + lrow, col = c0 + lcol;
+            bool take = row < nrow && col < ncol;
+            const int p = row * ncol + col;
+            double val = 0.0, ierr = 0.0;
+            if (take) {
+                val = src.val[p];
+                ierr = src.ierr[p];
+                if (src.izw && !(ierr > 0.0)) take = false;  // not in the pixel list
+            }
+            double v, u;
+            {
+                const double rd = (double)row - src.jac.row0, cd = (double)col - src.jac.col0;
+                v = fma(src.jac.dvdrow, rd, src.jac.dvdcol * cd);
+                u = fma(src.jac.dudrow, rd, src.jac.dudcol * cd);
+            }
+            const double vmod = v - vcen, umod = u - ucen;
+            const double rad2 = fma(umod, umod, vmod * vmod);
+            take = take && rad2 < maxrad2;
+            if (take && ierr * ierr == 0.0) {
+                zero_div = true;  // gmix_nb.py:775: 1/ierr^2
+                take = false;
+            }
+            double F[NMOM];
+            wsums_F<NMOM>(vmod, umod, v, u, rad2, F);
+            double scale = 0.0, dcol = 0.0, weight = 0.0;
+            if (take) {
+                for (int g = 0; g < ng; g++) {
+                    const EvalGauss e = ge[g];
+                    const double vd = v - e.row, ud = u - e.col;
+                    const double chi2 =
+                        fma(e.dcc * vd, vd, fma(e.drr * ud, ud, -(e.drc2 * vd) * ud));
+                    weight = fma(e.pnorm * exp(-0.5 * chi2), src.area, weight);
+                }
+                scale = weight / ierr;   // scale^2 = w^2 var
+                dcol = val * ierr;       // dcol * X_i = w I F_i
+                lastp = p > lastp ? p : lastp;
+            }
+            npix += __popcll(__ballot(take));
+            wsum += weight;
+            // a pixel that is not used contributes a zero row (its F may be
+            // anything finite: the coordinates are, the values are not read)
+            const double x16 = take ? scale * F[16] : 0.0;
+#pragma unroll
+            for (int i = 0; i < NMOM; i++) {
+                const double x = take ? scale * F[i] : 0.0;
+                if (i < 16) xrow[i] = x;
+                c16[i] = fma(x16, x, c16[i]);
+                sm[i] = fma(dcol, x, sm[i]);
+            }
+            __syncthreads();   // one wave: orders the LDS traffic, no s_barrier
+#pragma unroll
+            for (int t = 0; t < 16; t += 2) {
+                const double xa = xsrc[4 * t * XS], xb = xsrc[4 * (t + 1) * XS];
+                M = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, xa, M, 0, 0, 0);
+                M2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xb, xb, M2, 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+    if (__ballot(zero_div) != 0ull && lane == 0) sh.err = NGMIX_ERR_ZERO_DIV;
+    // wave totals of the 35 VALU sums: DPP inside rows of 16 lanes, the 4 row
+    // sums through LDS
+    double *red = sh.red;   // 64 * 4 doubles
+    auto fold = [&](double x, int k) {
+        x += dpp_move_or_zero<0x111, 0xf>(x);
+        x += dpp_move_or_zero<0x112, 0xf>(x);
+        x += dpp_move_or_zero<0x114, 0xf>(x);
+        x += dpp_move_or_zero<0x118, 0xf>(x);
+        if ((lane & 15) == 15) red[k * 4 + (lane >> 4)] = x;
+    };
+#pragma unroll
+    for (int k = 0; k < NMOM; k++) {
+        fold(c16[k], k);
+        fold(sm[k], NMOM + k);
+    }
+    fold(wsum, 2 * NMOM);
+    for (int off = WAVE / 2; off > 0; off >>= 1) {
+        const int y = __shfl_down(lastp, off, WAVE);
+        lastp = y > lastp ? y : lastp;
+    }
+    lastp_out = __builtin_amdgcn_readfirstlane(lastp);
+    __syncthreads();
+    if (sh.err != 0) return;   // the reference raises: the record keeps its content
+
+    // ---- add into the caller's record (it may come pre-filled, gmix.py:740-744)
+    int32_t *r_npix = (int32_t *)(resbase + 4);
+    double *r_wsum = (double *)(resbase + 8);
+    double *r_sums = (double *)(resbase + 16);
+    double *r_cov = r_sums + NMOM;
+    {
+        const int colm = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int rowm = (lane >> 4) + 4 * r;
+            r_cov[rowm * NMOM + colm] += M[r] + M2[r];
+        }
+    }
+    if (lane < 2 * NMOM + 1) {
+        const double *q = red + lane * 4;
+        const double t = ((q[0] + q[1]) + q[2]) + q[3];
+        if (lane < NMOM) {
+            r_cov[16 * NMOM + lane] += t;
+            if (lane != 16) r_cov[lane * NMOM + 16] += t;
+        } else if (lane < 2 * NMOM) {
+            r_sums[lane - NMOM] += t;
+        } else {
+            *r_wsum += t;
+            *r_npix += npix;
+        }
+    }
+}
+
 template <int NMOM>
 __global__ __launch_bounds__(WAVE) void wsums_wave_kernel(
     const ngmix_stamp *stamps, const double *val, const double *ierr,
@@ -405,17 +550,7 @@ __global__ __launch_bounds__(WAVE) void wsums_wave_kernel(
         wsums_pass<6, 0, 6, true>(src, ge, ng, vcen, ucen, maxrad2, sh, tot, lastp);
         if (sh.err == 0) wsums_store<6, 0, 6, true>(tot, resbase);
     } else {
-        __shared__ double totb[3][64];
-        wsums_pass<NMOM, 0, 3, false>(src, ge, ng, vcen, ucen, maxrad2, sh, totb[0], lastp);
-        wsums_pass<NMOM, 3, 7, false>(src, ge, ng, vcen, ucen, maxrad2, sh, totb[1], lastp);
-        wsums_pass<NMOM, 7, 12, false>(src, ge, ng, vcen, ucen, maxrad2, sh, totb[2], lastp);
-        wsums_pass<NMOM, 12, NMOM, true>(src, ge, ng, vcen, ucen, maxrad2, sh, tot, lastp);
-        if (sh.err == 0) {
-            wsums_store<NMOM, 0, 3, false>(totb[0], resbase);
-            wsums_store<NMOM, 3, 7, false>(totb[1], resbase);
-            wsums_store<NMOM, 7, 12, false>(totb[2], resbase);
-            wsums_store<NMOM, 12, NMOM, true>(tot, resbase);
-        }
+        wsums17_single_pass(src, ge, ng, vcen, ucen, maxrad2, sh, resbase, lastp);
     }
     if (sh.err == 0 && lastp >= 0 && lane == 0) {
         // F of the last pixel used is left in the record (scratch field)
