@@ -229,10 +229,42 @@ SIGNATURES = {
 }
 
 
-def build(verbose=False):
+def _makefile_list(name):
+    """the file list `name = ...` of csrc/Makefile (SRCS, HDRS)"""
+    for line in open(os.path.join(_CSRC, "Makefile")):
+        if line.startswith(name + " ="):
+            return line.split("=", 1)[1].split()
+    raise RuntimeError("csrc/Makefile has no %s" % name)
+
+
+def source_hash():
+    """sha256 of the kernel sources in the Makefile's order: `make` leaves the
+    same digest next to the library (libngmix_hip.so.srchash)"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in _makefile_list("SRCS") + _makefile_list("HDRS"):
+        with open(os.path.join(_CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def library_is_stale():
+    """True when the in-tree library was built from other sources than the
+    ones in csrc/ now (an edit without a rebuild); a library selected with
+    NGMIX_HIP_LIB is taken as it is"""
+    if "NGMIX_HIP_LIB" in os.environ:
+        return False
+    try:
+        with open(LIB_PATH + ".srchash") as f:
+            return f.read().strip() != source_hash()
+    except OSError:
+        return True
+
+
+def build(verbose=False, force=False):
     """compile libngmix_hip.so in-tree for gfx950 (hipcc)"""
-    res = subprocess.run(["make", "-C", _CSRC, "-j4"], capture_output=True,
-                         text=True)
+    res = subprocess.run(["make", "-C", _CSRC, "-j4"] + (["-B"] if force else []),
+                         capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout[-4000:])
         print(res.stderr[-4000:])
@@ -249,6 +281,12 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             build()
+        elif library_is_stale():
+            # never run kernels that do not correspond to the sources
+            build(force=True)
+            if library_is_stale():
+                raise RuntimeError("libngmix_hip.so does not match ngmix_amd/csrc "
+                                   "and could not be rebuilt")
         # One HIP runtime per process: PyTorch-ROCm ships its own
         # libamdhip64; importing torch first makes our library bind to that
         # copy (same SONAME) instead of initialising a second runtime that

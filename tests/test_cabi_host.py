@@ -211,3 +211,12 @@ def test_kernel_resource_guard():
     finally:
         kr.GUARDS["pixpass_wave_kernel"] = old
     assert any("outside the validated occupancy band" in p for p in problems)
+
+
+def test_library_matches_sources():
+    """the loaded library was built from the sources in csrc/ (the digest `make`
+    leaves next to it); _lib.lib() rebuilds or refuses otherwise"""
+    assert _lib.source_hash() == open(_lib.LIB_PATH + ".srchash").read().strip()
+    assert not _lib.library_is_stale()
+    assert "pixpass.hip" in _lib._makefile_list("SRCS")
+    assert "common.hpp" in _lib._makefile_list("HDRS")
