@@ -49,6 +49,39 @@ SIMPLE_ANALYTIC_MODELS = ("gauss", "exp", "dev")
 MODEL_NLOC = {"gauss": 6, "turb": 6, "exp": 6, "dev": 6, "bdf": 7, "bd": 8}
 
 
+class LMBatchResult(dict):
+    """the dict of per-object arrays LMBatchFitter.go returns (run_leastsq's
+    and set_fit_result's keys); entries registered with set_lazy stay on the
+    device and are downloaded when first read"""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self._lazy = {}
+
+    def set_lazy(self, key, fetch):
+        self._lazy[key] = fetch
+
+    def __missing__(self, key):
+        if key in self._lazy:
+            value = self._lazy.pop(key)()
+            self[key] = value
+            return value
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        return list(dict.keys(self)) + list(self._lazy)
+
+    def __setitem__(self, key, value):
+        self._lazy.pop(key, None)
+        dict.__setitem__(self, key, value)
+
+
 class LMBatchFitter(object):
     """
     fitter = LMBatchFitter(model='exp')
@@ -130,7 +163,11 @@ class LMBatchFitter(object):
             sband = np.ascontiguousarray(stamp_band, dtype=np.int32)
             if sband.shape != (ns,) or sband.min() < 0 or sband.max() >= nband:
                 raise ValueError("stamp_band out of range")
-        obj_start = np.searchsorted(sobj, np.arange(nobj + 1)).astype(np.int64)
+        trivial_map = stamp_obj is None and stamp_band is None   # stamp i = object i
+        if trivial_map:
+            obj_start = np.arange(nobj + 1, dtype=np.int64)
+        else:
+            obj_start = np.searchsorted(sobj, np.arange(nobj + 1)).astype(np.int64)
         if np.any(np.diff(obj_start) == 0):
             raise ValueError("every object needs at least one stamp")
         npsf = 0
@@ -157,9 +194,15 @@ class LMBatchFitter(object):
                 _lib.ptr(lo) if lo is not None else None,
                 _lib.ptr(hi) if hi is not None else None, _stream()),
                 "ngmix_lm_init_batch")
-        d_sobj = torch.from_numpy(sobj).to(dev)
-        d_sband = torch.from_numpy(sband).to(dev)
-        d_start = torch.from_numpy(obj_start).to(dev)
+        if trivial_map:
+            # made on the device: three uploads less on the common path
+            d_sobj = torch.arange(ns, dtype=torch.int32, device=dev)
+            d_sband = torch.zeros(ns, dtype=torch.int32, device=dev)
+            d_start = torch.arange(nobj + 1, dtype=torch.int64, device=dev)
+        else:
+            d_sobj = torch.from_numpy(sobj).to(dev)
+            d_sband = torch.from_numpy(sband).to(dev)
+            d_start = torch.from_numpy(obj_start).to(dev)
         nsum = self.nloc * (self.nloc + 1) // 2 + self.nloc + 1
         d_sums = torch.zeros((ns, nsum), dtype=torch.float64, device=dev)
         d_status = torch.zeros(ns, dtype=torch.int32, device=dev)
@@ -231,7 +274,10 @@ class LMBatchFitter(object):
         self.rounds = rounds
         # run_leastsq's packaging, one thread per fit (ngmix_lm_finalize_batch)
         n = npars
-        npix_obj = np.add.reduceat(stamps.npix_kept.astype(np.int64), obj_start[:-1])
+        if trivial_map:
+            npix_obj = stamps.npix_kept.astype(np.int64)
+        else:
+            npix_obj = np.add.reduceat(stamps.npix_kept.astype(np.int64), obj_start[:-1])
         d_npix = torch.from_numpy(npix_obj).to(dev)
         width = 4 + 2 * n + 2 * n * n
         d_rec = torch.empty((nobj, width), dtype=torch.float64, device=dev)
@@ -259,39 +305,43 @@ class LMBatchFitter(object):
         # the record array comes back through pinned memory on a side stream
         # (PyTorch's caching host allocator: no hipHostMalloc after the first
         # call) while the statistics pass below runs on the launch stream
-        h_rec = torch.empty((nobj, width), dtype=torch.float64, pin_memory=True)
+        # (pars_cov0, 40 % of the record, stays on the device until it is asked for)
+        c0, c1 = 4 + 2 * n, 4 + 2 * n + n * n
+        d_head = d_rec[:, :4].to(torch.int64)       # flags, nfev, ier, dof
+        d_eager = torch.cat([d_rec[:, 4:c0], d_rec[:, c1:]], dim=1)
+        d_cov0 = d_rec[:, c0:c1].contiguous()
+        h_rec = torch.empty((nobj, width - n * n - 4), dtype=torch.float64, pin_memory=True)
         ready = torch.cuda.Event()
         ready.record()
         side = self._side_stream(dev)
         with torch.cuda.stream(side):
             side.wait_event(ready)
-            h_rec.copy_(d_rec, non_blocking=True)
+            h_rec.copy_(d_eager, non_blocking=True)
             copied = torch.cuda.Event()
             copied.record()
-        d_rec.record_stream(side)
+        d_eager.record_stream(side)
         stats = self._device_stats(stamps, psf, sobj, sband, obj_start, d_rec, n)
         njev = d_states.view(torch.int32).reshape(nobj, -1)[
             :, _lib.LM_STATE_DTYPE.fields["njev"][1] // 4].cpu().numpy()
+        head = d_head.t().contiguous().cpu().numpy()   # (4, nobj): contiguous columns
         copied.synchronize()
         rec = h_rec.numpy()
-        res = {
+        res = LMBatchResult({
             "model": self.model,
-            "flags": rec[:, 0].astype(np.int64),
-            "nfev": rec[:, 1].astype(np.int64),
+            "flags": head[0],
+            "nfev": head[1],
             "njev": njev.astype(np.int64),
-            "ier": rec[:, 2].astype(np.int64),
+            "ier": head[2],
             # views of the record array (no copies)
-            "pars": rec[:, 4:4 + n],
-            "pars_err": rec[:, 4 + n:4 + 2 * n],
-            "pars_cov0": np.lib.stride_tricks.as_strided(
-                rec[:, 4 + 2 * n:], shape=(nobj, n, n),
-                strides=(rec.strides[0], n * 8, 8), writeable=False),
+            "pars": rec[:, 0:n],
+            "pars_err": rec[:, n:2 * n],
             "pars_cov": np.lib.stride_tricks.as_strided(
-                rec[:, 4 + 2 * n + n * n:], shape=(nobj, n, n),
+                rec[:, 2 * n:], shape=(nobj, n, n),
                 strides=(rec.strides[0], n * 8, 8), writeable=False),
             "npix": npix_obj,
-            "dof": rec[:, 3].astype(np.int64),
-        }
+            "dof": head[3],
+        })
+        res.set_lazy("pars_cov0", lambda: d_cov0.cpu().numpy().reshape(nobj, n, n))
         self._add_stats(res, stats, nband)
         return res
 
