@@ -37,11 +37,13 @@ struct EmConvF {
 };
 static_assert(sizeof(EmConvF) == 64, "EmConvF");
 
-// 1/x to <= 1 ulp for normal x (x == 0 -> inf, as the reference's division)
+// 1/x by v_rcp_f64 (4.6e-8 relative on gfx950, tools/microbench/rcp_accuracy.hip)
+// and ONE Newton step: 2.1e-15, ten roundings' worth on a per-pixel factor of
+// a self-correcting fixed-point iteration whose results are compared at 1e-10
+// (x == 0 -> inf, as the reference's division)
 __device__ __forceinline__ double fast_rcp(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
     r = fma(fma(-x, r, 1.0), r, r);
     return r;
 }

@@ -292,7 +292,9 @@ __device__ __forceinline__ void wsums_pass(const GridSrc &src, const EvalGauss *
                     fma(e.dcc * vd, vd, fma(e.drr * ud, ud, -(e.drc2 * vd) * ud));
                 weight = fma(e.pnorm * exp(-0.5 * chi2), src.area, weight);
             }
-            const double var = 1.0 / ierr2;
+            // (fused kernel: v_rcp_f64 + two Newton steps, ~1 ulp, instead of the
+            // ~25-instruction IEEE division)
+            const double var = rcp_newton(ierr2);
             const double w2var = weight * weight * var;
             double F[NMOM];
             wsums_F<NMOM>(vmod, umod, v, u, rad2, F);
@@ -433,7 +435,7 @@ __device__ __forceinline__ void wsums17_single_pass(const GridSrc &src, const Ev
                         fma(e.dcc * vd, vd, fma(e.drr * ud, ud, -(e.drc2 * vd) * ud));
                     weight = fma(e.pnorm * exp(-0.5 * chi2), src.area, weight);
                 }
-                scale = weight / ierr;   // scale^2 = w^2 var
+                scale = weight * rcp_newton(ierr);   // scale^2 = w^2 var
                 dcol = val * ierr;       // dcol * X_i = w I F_i
                 lastp = p > lastp ? p : lastp;
             }
