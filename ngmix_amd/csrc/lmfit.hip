@@ -293,6 +293,51 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
 // parameter normal equations and advance the LM state.  A stamp's sums are
 // [J^T J upper triangle | J^T f | f.f] over its nloc LOCAL parameters: the
 // shared shape parameters followed by the flux of the stamp's band.
+// Copy the live part of a state record: the scalars, the first n entries of
+// each per-parameter array and the leading n x n block of R.  The record is
+// sized for NGMIX_LM_NPMAX = 14 parameters (2.9 kB); a six-parameter fit uses a
+// fifth of it, and lm_advance_kernel moves every record in and out once per
+// round.  (Entries beyond n keep the zeros lm_init wrote.)
+__device__ __forceinline__ void lm_state_copy_live(lm_state &d, const lm_state &g)
+{
+    const int n = g.n;
+    d.n = n;
+    d.iter = g.iter;
+    d.nfev = g.nfev;
+    d.njev = g.njev;
+    d.info = g.info;
+    d.phase = g.phase;
+    d.maxfev = g.maxfev;
+    d.mode = g.mode;
+    d.bounded = g.bounded;
+    d.pad_ = g.pad_;
+    d.fnorm = g.fnorm;
+    d.xnorm = g.xnorm;
+    d.delta = g.delta;
+    d.par = g.par;
+    d.gnorm = g.gnorm;
+    d.pnorm = g.pnorm;
+    d.ftol = g.ftol;
+    d.xtol = g.xtol;
+    d.gtol = g.gtol;
+    d.factor = g.factor;
+    for (int j = 0; j < n; j++) {
+        d.x[j] = g.x[j];
+        d.xt[j] = g.xt[j];
+        d.diag[j] = g.diag[j];
+        d.qtf[j] = g.qtf[j];
+        d.step[j] = g.step[j];
+        d.xi[j] = g.xi[j];
+        d.xti[j] = g.xti[j];
+        d.lo[j] = g.lo[j];
+        d.hi[j] = g.hi[j];
+        d.xstep[j] = g.xstep[j];
+        d.hstep[j] = g.hstep[j];
+        d.ipvt[j] = g.ipvt[j];
+        for (int k = 0; k < n; k++) d.R[j * LM_NPMAX + k] = g.R[j * LM_NPMAX + k];
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void lm_advance_kernel(
     lm_state *states, int64_t nobj, const int64_t *__restrict__ obj_start,
     const int32_t *__restrict__ stamp_band, const double *__restrict__ sums, int nloc,
@@ -300,8 +345,9 @@ __global__ __launch_bounds__(BLOCK) void lm_advance_kernel(
 {
     const int64_t o = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
     if (o >= nobj) return;
-    lm_state s = states[o];
-    if (s.phase == LM_PHASE_DONE) return;
+    if (states[o].phase == LM_PHASE_DONE) return;
+    lm_state s;
+    lm_state_copy_live(s, states[o]);
     const int ntri = nloc * (nloc + 1) / 2, nsum = ntri + nloc + 1;
     double A[LM_NPMAX * LM_NPMAX], g[LM_NPMAX];
     for (int i = 0; i < s.n; i++) {
@@ -343,7 +389,7 @@ __global__ __launch_bounds__(BLOCK) void lm_advance_kernel(
         ff += v[nt + n];
     }
     lmcore::lm_advance(s, ff, g, A);
-    states[o] = s;
+    lm_state_copy_live(states[o], s);
     if (s.phase != LM_PHASE_DONE && nactive) atomicAdd(nactive, 1);
 }
 
