@@ -14,6 +14,8 @@
 //
 // LIST kernels (seam forms): the reference's AoS pixel / coord arrays,
 // arbitrary coordinates, one thread per pixel.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "device_utils.hpp"
@@ -432,14 +434,12 @@ __device__ __forceinline__ void wave_tiles(
     const int CH = chunked ? WAVE / ng : 0;
     const unsigned ngmask = chunked ? (unsigned)((1ull << ng) - 1ull) : 0u;
     int k_l = 0;
-    PixBox mybox = full_box();
     bool lane_valid = false;
+    const PixBox *mybox_p = &gf[0].box;   // re-read at every ballot: 4 registers less
     if (chunked) {
         k_l = lane / ng;
         lane_valid = k_l < CH;
-        mybox = gf[lane - k_l * ng].box;
-        mybox.rmin -= TH - 1;
-        mybox.cmin -= TW - 1;
+        mybox_p = &gf[lane - k_l * ng].box;
     }
     unsigned long long allmask = 0ull;
     int kc = 0;
@@ -493,9 +493,10 @@ __device__ __forceinline__ void wave_tiles(
                     asm volatile("v_add_u32 %0, %1, %2" : "=v"(Tk) : "s"(Tc), "v"(k_l));
                     if (Tk > ntiles) Tk = ntiles;  // a sentinel
                     const int r0k = te[Tk].r0, c0k = te[Tk].c0;
+                    const PixBox mybox = *mybox_p;
                     const bool hit = lane_valid & (r0k <= mybox.rmax) &
-                                     (r0k >= mybox.rmin) & (c0k <= mybox.cmax) &
-                                     (c0k >= mybox.cmin);
+                                     (r0k >= mybox.rmin - (TH - 1)) & (c0k <= mybox.cmax) &
+                                     (c0k >= mybox.cmin - (TW - 1));
                     allmask = __ballot(hit);
                 }
                 gmask = (unsigned)allmask & ngmask;
@@ -535,8 +536,13 @@ __device__ __forceinline__ void wave_tiles(
                         // apod_window with FMAs (fastexp_nb.py:97-117);
                         // W(chi2 == 20) == 1 exactly
                         const double au = (12.5 - y) * 0.4;
-                        const double aq =
-                            fma(au, fma(au, __hiloint2double(K.w6hi, K.w6lo), K.wm15), K.w10);
+                        // (6.0 materialised here, in the rare band path: two
+                        // registers less across the tile loop)
+                        int w6l, w6h;
+                        asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0x40180000"
+                                     : "=v"(w6l), "=v"(w6h));
+                        const double w6v = __hiloint2double(w6h, w6l);
+                        const double aq = fma(au, fma(au, w6v, K.wm15), K.w10);
                         e *= (au * au) * (au * aq);
                     }
                     model = fma(gpa, e, model);
@@ -616,7 +622,7 @@ __device__ __forceinline__ void wave_tiles(
 }
 
 template <int OP, bool MASKED, int TW>
-__global__ __launch_bounds__(WAVE) void pixpass_wave_kernel(
+__device__ __forceinline__ void pixpass_wave_body(
     const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
     const double *__restrict__ ierr, const ngmix_jacobian *__restrict__ jacs,
     ngmix_gauss2d *gmix, double *out, const int64_t *__restrict__ out_start,
@@ -783,6 +789,33 @@ __global__ __launch_bounds__(WAVE) void pixpass_wave_kernel(
     }
 }
 
+template <int OP, bool MASKED, int TW>
+__global__ __launch_bounds__(WAVE) void pixpass_wave_kernel(
+    const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
+    const double *__restrict__ ierr, const ngmix_jacobian *__restrict__ jacs,
+    ngmix_gauss2d *gmix, double *out, const int64_t *__restrict__ out_start,
+    int32_t *status, int max_ngauss, int nchunks_cap, int no_skip, int tile_cap)
+{
+    pixpass_wave_body<OP, MASKED, TW>(stamps, val, ierr, jacs, gmix, out, out_start, status,
+                                      max_ngauss, nchunks_cap, no_skip, tile_cap);
+}
+
+// get_loglike at seven waves per SIMD: its body fits 72 VGPRs without spilling
+// (the boxes re-read at each ballot, 6.0 materialised in the band path), and
+// with instruction issue and memory both ~80 % busy one more resident wave per
+// SIMD is what overlaps them better
+template <int OP, bool MASKED, int TW>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(7, 7)))
+void pixpass_wave_kernel7(
+    const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
+    const double *__restrict__ ierr, const ngmix_jacobian *__restrict__ jacs,
+    ngmix_gauss2d *gmix, double *out, const int64_t *__restrict__ out_start,
+    int32_t *status, int max_ngauss, int nchunks_cap, int no_skip, int tile_cap)
+{
+    pixpass_wave_body<OP, MASKED, TW>(stamps, val, ierr, jacs, gmix, out, out_start, status,
+                                      max_ngauss, nchunks_cap, no_skip, tile_cap);
+}
+
 // ---------------------------------------------------------------- launchers
 
 // fused kernels keep one 32-byte record per 8x8 tile in LDS; batches with a
@@ -847,6 +880,10 @@ static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
     const bool mk = b->any_masked && FOP != OP_RENDER_FAST;
     const void *kern = mk ? (const void *)pixpass_wave_kernel<FOP, true, TW>
                           : (const void *)pixpass_wave_kernel<FOP, false, TW>;
+    static const bool six_waves = getenv("NGMIX_LOGLIKE_6WAVES") != nullptr;   // A/B knob
+    if (FOP == OP_LOGLIKE && !six_waves)
+        kern = mk ? (const void *)pixpass_wave_kernel7<OP_LOGLIKE, true, 8>
+                  : (const void *)pixpass_wave_kernel7<OP_LOGLIKE, false, 8>;
     const size_t flds = lds_bytes(max_ng, nchunks_cap, a_tc);
     if (flds > 160 * 1024) {
         set_last_error_msg("stamp needs more than 160 KiB of LDS");
