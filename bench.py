@@ -61,6 +61,10 @@ RENDER_BYTES = 16 * NPIX                   # 36,864 (8 read + 8 written)
 #   em_run pixel pass     73  (1 object gaussian (x) 1 psf gaussian: chi2, hard-cut
 #                              fexp, 6 scratch sums, logL, two reciprocals by
 #                              v_rcp + 2 Newton steps, 8 accumulators)
+# the fused get_loglike kernel the library launches (seven waves per SIMD unless
+# NGMIX_LOGLIKE_6WAVES selects the six-wave build for A/B)
+LOGLIKE_KERNEL = ("pixpass_wave_kernel<0," if os.environ.get("NGMIX_LOGLIKE_6WAVES")
+                  else "pixpass_wave_kernel7<0,")
 ADMOM_FLOP_ITER_PX = 31 + 45
 ADMOM_FLOP_ONCE_PX = 96
 EM_FLOP_ITER_PX = 73
@@ -294,7 +298,7 @@ def run_c2(args, rank, world, device, backend):
         syms = kernel_symbols({"loglike": ("pixpass_grid_kernel<0,",),
                                "render": ("pixpass_grid_kernel<2,",)})
     else:
-        syms = kernel_symbols({"loglike": ("pixpass_wave_kernel<0,", "false"),
+        syms = kernel_symbols({"loglike": (LOGLIKE_KERNEL, "false"),
                                "render": ("pixpass_wave_kernel<2,", "false")})
     traffic_bytes, traffic_source = load_traffic(dominant, n)
     line = {
@@ -571,7 +575,7 @@ def run_c5(args, rank, world, device, backend, nobj=None, steps=None):
         return None
     epoch_bytes = 16 * dim * dim + 64 + 48 + 32      # 65,680 B
     achieved = epoch_bytes * ns / (ll_ms * 1e-3) / 1e9
-    syms = kernel_symbols({"loglike": ("pixpass_wave_kernel<0,", "false")})
+    syms = kernel_symbols({"loglike": (LOGLIKE_KERNEL, "false")})
     c5_traffic = load_traffic("c5_loglike", ns, key="c5_nstamps")
     return {
         "metric": "object loglikes/sec, 10 epochs x 64x64, 16-gaussian 'bdf', 1/2/4/8 GPU",

@@ -27,7 +27,8 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if os.path.basename(d).startswith("pmc_c5"):
         # config 5's loglike is the same kernel symbol as config 2's: kept apart
         for row in csv.DictReader(open(f)):
-            if "pixpass_wave_kernel<0" in row["Kernel_Name"]:
+            if "pixpass_wave_kernel7<0" in row["Kernel_Name"] or \
+                    "pixpass_wave_kernel<0" in row["Kernel_Name"]:
                 c5acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
         continue
     for row in csv.DictReader(open(f)):
@@ -51,6 +52,7 @@ for k, cs in sorted(acc.items()):
         fetch = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"])
         write = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
         name = {"pixpass_wave_kernel<0, false, 8>": "loglike",
+                "pixpass_wave_kernel7<0, false, 8>": "loglike",
                 "pixpass_wave_kernel<2, false, 16>": "render"}.get(k)
         if name:
             traffic[name + "_hbm_bytes_per_launch"] = 2 * fetch * 1024 + write * 1024
@@ -62,9 +64,9 @@ if "FETCH_SIZE" in c5acc and "WRITE_SIZE" in c5acc:
     fetch = sum(c5acc["FETCH_SIZE"]) / len(c5acc["FETCH_SIZE"])
     write = sum(c5acc["WRITE_SIZE"]) / len(c5acc["WRITE_SIZE"])
     lines.append("# config 5 (bench.py --config C5: 20000 objects x 10 epochs of 64x64 per launch)")
-    lines.append("%-36s %-26s n=%d mean %.6g" % ("pixpass_wave_kernel<0, false, 8>",
+    lines.append("%-36s %-26s n=%d mean %.6g" % ("pixpass_wave_kernel7<0, false, 8>",
                                                  "FETCH_SIZE", len(c5acc["FETCH_SIZE"]), fetch))
-    lines.append("%-36s %-26s n=%d mean %.6g" % ("pixpass_wave_kernel<0, false, 8>",
+    lines.append("%-36s %-26s n=%d mean %.6g" % ("pixpass_wave_kernel7<0, false, 8>",
                                                  "WRITE_SIZE", len(c5acc["WRITE_SIZE"]), write))
     traffic["c5_loglike_hbm_bytes_per_launch"] = 2 * fetch * 1024 + write * 1024
     traffic["c5_nstamps"] = 200000
