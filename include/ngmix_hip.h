@@ -292,6 +292,11 @@ typedef struct {
  * tracked load path instead of the hand-counted look-ahead loads (same
  * arithmetic, bit-identical results; a diagnostic for toolchain changes) */
 #define NGMIX_BATCH_TRACKED_LOADS 4
+/* ngmix_render_batch: image = model instead of image += model -- GMix.make_image's
+ * zero-fill (ngmix/gmix/gmix.py:619-643) fused into the render, so that a fresh
+ * image costs 8 written bytes per pixel instead of a memset plus a
+ * read-modify-write; stamps that fail (and empty mixtures) are zero-filled */
+#define NGMIX_BATCH_RENDER_OVERWRITE 8
 
 /* A batch of stamps: HOST struct holding DEVICE pointers plus the few host
    facts a launch needs (LDS sizing, tile schedule). */

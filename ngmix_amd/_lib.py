@@ -42,6 +42,7 @@ STAMP_IGNORE_ZERO_WEIGHT = 1
 BATCH_NO_SKIP = 1
 BATCH_EXACT = 2
 BATCH_TRACKED_LOADS = 4
+BATCH_RENDER_OVERWRITE = 8
 
 # ---- record layouts = the reference's numpy dtypes ----
 GAUSS2D_DTYPE = np.dtype([

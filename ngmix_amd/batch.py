@@ -351,6 +351,14 @@ class StampBatch(object):
             (_lib.BATCH_TRACKED_LOADS if self.tracked_loads else 0)
         return b
 
+    def _packed(self):
+        """the stamps tile [0, total_pix) without gaps or overlaps, in order"""
+        if not hasattr(self, "_packed_layout"):
+            start = np.concatenate([[0], np.cumsum(self.npix)[:-1]]) if self.n else \
+                np.zeros(0, dtype=np.int64)
+            self._packed_layout = bool(np.array_equal(self.pix_off, start))
+        return self._packed_layout
+
     def kept_offsets(self):
         """start of each stamp's segment in a packed per-kept-pixel array
         (the layout of the LM residual vector, results.py:410-421)"""
@@ -439,17 +447,28 @@ class StampBatch(object):
                exact=False):
         """
         render every stamp's mixture (render_nb.py:9-36), ADDING into `image`
-        (flat, same layout as val); a zeroed image is made when none is given
-        (GMix.make_image, gmix.py:561-562).  Returns (image, status).
+        (flat, same layout as val).  With image=None a fresh image is made as
+        GMix.make_image does (gmix.py:561-562: zeros, then the render) -- fused:
+        the kernel writes the model without reading the buffer
+        (NGMIX_BATCH_RENDER_OVERWRITE), 8 bytes per pixel instead of a memset
+        plus a read-modify-write.  Returns (image, status).
         """
         torch = _torch()
         assert gm.n == self.n
+        overwrite = False
         if image is None:
-            image = torch.zeros(self.total_pix, dtype=torch.float64,
-                                device=self.device)
+            if self._packed():
+                image = torch.empty(self.total_pix, dtype=torch.float64,
+                                    device=self.device)
+                overwrite = True
+            else:
+                image = torch.zeros(self.total_pix, dtype=torch.float64,
+                                    device=self.device)
         if status is None:
             status = torch.empty(self.n, dtype=torch.int32, device=self.device)
         b = self._batch(gm.ngauss, no_skip, exact)
+        if overwrite:
+            b.flags |= _lib.BATCH_RENDER_OVERWRITE
         with torch.cuda.device(self.device):
             st = _lib.lib().ngmix_render_batch(
                 ctypes.byref(b), _dptr(gm.data), _dptr(image), int(fast_exp),

@@ -153,8 +153,11 @@ __global__ __launch_bounds__(BLOCK) void pixpass_grid_kernel(
     constexpr bool kNeedsVal = (OP == OP_LOGLIKE || OP == OP_FDIFF);
     constexpr bool kNeedsIerr = (OP != OP_RENDER_FAST && OP != OP_RENDER_EXACT);
 
-    const int stcode = stage_gaussians(L, gm, ng, jac, kFast && !no_skip);
+    const int stcode = stage_gaussians(L, gm, ng, jac, kFast && !(no_skip & 1));
     if (stcode != NGMIX_OK) {
+        // (an overwriting render leaves a defined image for a stamp that raises)
+        if ((OP == OP_RENDER_FAST || OP == OP_RENDER_EXACT) && (no_skip & 4))
+            for (int p = threadIdx.x; p < npix; p += BLOCK) out[st.pix_off + p] = 0.0;
         if (threadIdx.x == 0) status[s] = stcode;
         return;
     }
@@ -198,7 +201,8 @@ __global__ __launch_bounds__(BLOCK) void pixpass_grid_kernel(
             if (inb[k]) {
                 if (kNeedsVal) pval[k] = sval[pidx[k]];
                 if (kNeedsIerr) pierr[k] = sierr[pidx[k]];
-                if (OP == OP_RENDER_FAST || OP == OP_RENDER_EXACT)
+                // (no_skip bit 2 = NGMIX_BATCH_RENDER_OVERWRITE: image = model)
+                if ((OP == OP_RENDER_FAST || OP == OP_RENDER_EXACT) && !(no_skip & 4))
                     pval[k] = out[st.pix_off + pidx[k]];
             }
             jacobian_vu(jac, (double)row, (double)col, pv[k], pu[k]);
@@ -397,11 +401,15 @@ __device__ __forceinline__ void wave_tiles(
     const ngmix_stamp &st, const double *__restrict__ sval,
     const double *__restrict__ sierr, bool masked, double *out, int64_t out_base,
     const ngmix_jacobian &jac, double (&pv)[FUSED_PF], double (&pe)[FUSED_PF],
-    double &acc_ll, double &acc_sn, double &acc_sd)
+    double &acc_ll, double &acc_sn, double &acc_sd, const int keep = -1)
 {
     constexpr bool kNeedsVal = (OP == OP_LOGLIKE || OP == OP_FDIFF);
     constexpr bool kNeedsIerr = (OP != OP_RENDER_FAST);
     constexpr int TH = WAVE / TW;  // tile = TH rows x TW columns = one wave
+    // keep == 0: render with NGMIX_BATCH_RENDER_OVERWRITE -- the image is not
+    // read (the look-ahead loads are issued with EXEC = 0, their registers stay
+    // 0.0); keep == -1 otherwise.  A scalar mask, never a select.
+    const bool overwrite = keep == 0;
     const int lane = threadIdx.x;
     const int lrow = lane / TW, lcol = lane % TW;
     const int nrow = st.nrow, ncol = st.ncol;
@@ -460,7 +468,7 @@ __device__ __forceinline__ void wave_tiles(
             } else {
                 if (kNeedsVal) gload_f64_if(nval, bval, off2, on);
                 if (kNeedsIerr) gload_f64_if(nierr, bierr, off2, on);
-                if (OP == OP_RENDER_FAST) gload_f64_if(nval, bimg, off2, on);
+                if (OP == OP_RENDER_FAST) gload_f64_if(nval, bimg, off2, on & keep);
             }
         } else {
             const int r0n = te[Tn].r0, c0n = te[Tn].c0;
@@ -471,7 +479,7 @@ __device__ __forceinline__ void wave_tiles(
                 const unsigned off2 = lane_off + (unsigned)te[Tn].off;
                 if (kNeedsVal) nval = *(const double *)(bval + off2);
                 if (kNeedsIerr) nierr = *(const double *)(bierr + off2);
-                if (OP == OP_RENDER_FAST) nval = *(const double *)(bimg + off2);
+                if (OP == OP_RENDER_FAST && !overwrite) nval = *(const double *)(bimg + off2);
             }
         }
     };
@@ -673,6 +681,9 @@ __device__ __forceinline__ void pixpass_wave_body(
     }
     __syncthreads();  // one wave: orders the LDS writes above, no s_barrier
 
+    // 0 when an overwriting render must not read the image, else -1 (integer
+    // arithmetic on the kernel argument: stays on the scalar unit)
+    const int keep = (OP == OP_RENDER_FAST) ? (((no_skip >> 2) & 1) - 1) : -1;
     // ---- request the first tiles now: they fly while the gaussians are staged
     // (no_skip bit 1 = NGMIX_BATCH_TRACKED_LOADS: the compiler-tracked path)
     const bool full = (nrow % TH) == 0 && (ncol % TW) == 0 && !(no_skip & 2);
@@ -691,13 +702,18 @@ __device__ __forceinline__ void pixpass_wave_body(
             if (kNeedsVal) gload_f64_if(pv[t], (const char *)sval, off, on);
             if (OP != OP_RENDER_FAST) gload_f64_if(pe[t], (const char *)sierr, off, on);
             if (OP == OP_RENDER_FAST)
-                gload_f64_if(pv[t], (const char *)(out + st.pix_off), off, on);
+                gload_f64_if(pv[t], (const char *)(out + st.pix_off), off, on & keep);
         }
     }
 
     // ---- stage 2: norms (lazily, as the reference) and gaussian records
+    const bool overwrite = OP == OP_RENDER_FAST && (no_skip & 4);
     const int stcode = lazy_norms<WAVE>(L, gm, ng);
-    if (stcode != NGMIX_OK) {
+    if (stcode != NGMIX_OK || (overwrite && ng == 0)) {
+        // (an overwriting render leaves a defined image: zeros for a stamp the
+        // reference would have raised on, and for an empty mixture)
+        if (overwrite)
+            for (int p = lane; p < npix; p += WAVE) out[st.pix_off + p] = 0.0;
         if (lane == 0) status[s] = stcode;
         return;
     }
@@ -730,19 +746,19 @@ __device__ __forceinline__ void pixpass_wave_body(
         if (fast && full)
             wave_tiles<OP, MASKED, true, true, TW>(L, gf, te, ng, st, sval, sierr, masked,
                                                out, out_base, jac, pv, pe, acc_ll,
-                                               acc_sn, acc_sd);
+                                               acc_sn, acc_sd, keep);
         else if (fast)
             wave_tiles<OP, MASKED, true, false, TW>(L, gf, te, ng, st, sval, sierr, masked,
                                                 out, out_base, jac, pv, pe, acc_ll,
-                                                acc_sn, acc_sd);
+                                                acc_sn, acc_sd, keep);
         else if (full)
             wave_tiles<OP, MASKED, false, true, TW>(L, gf, te, ng, st, sval, sierr, masked,
                                                 out, out_base, jac, pv, pe, acc_ll,
-                                                acc_sn, acc_sd);
+                                                acc_sn, acc_sd, keep);
         else
             wave_tiles<OP, MASKED, false, false, TW>(L, gf, te, ng, st, sval, sierr,
                                                  masked, out, out_base, jac, pv, pe,
-                                                 acc_ll, acc_sn, acc_sd);
+                                                 acc_ll, acc_sn, acc_sd, keep);
     } else if (OP != OP_RENDER_FAST) {
         // an empty mixture: model == 0 everywhere
         for (int p = lane; p < npix; p += WAVE) {
@@ -844,7 +860,8 @@ static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
         return NGMIX_ERR_BAD_ARG;
     }
     const int no_skip = ((b->flags & NGMIX_BATCH_NO_SKIP) ? 1 : 0) |
-                        ((b->flags & NGMIX_BATCH_TRACKED_LOADS) ? 2 : 0);
+                        ((b->flags & NGMIX_BATCH_TRACKED_LOADS) ? 2 : 0) |
+                        ((b->flags & NGMIX_BATCH_RENDER_OVERWRITE) ? 4 : 0);
     // per-tile records of the fused kernels: exact when the batch carries its
     // largest stamp shape, else ntiles <= npix/8 + 1 holds for any shape
     int a_tc = b->max_npix / 8 + 1;
@@ -862,7 +879,7 @@ static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
     const ngmix_jacobian *a_jac = b->jac;
     int a_ng = max_ng, a_nc = nchunks_cap, a_ns = no_skip;
     if (exact) {
-        a_ns = no_skip & 1;
+        a_ns = no_skip & 5;
         dim3 grid((unsigned)b->nstamps), block(BLOCK);
         const bool k4 = pick_k(b->max_npix) == 4;
         const void *kern = k4 ? (const void *)pixpass_grid_kernel<OP, 4>

@@ -626,6 +626,52 @@ def test_cabi_stamp_store_and_rccl_gather():
     L.ngmix_batch_free(pb2)
 
 
+@pytest.mark.parametrize("exact", [False, True], ids=["fused", "exact"])
+def test_render_overwrite_equals_render_into_zeros(exact):
+    """a fresh render (image=None: NGMIX_BATCH_RENDER_OVERWRITE, the buffer is
+    never read) is bit for bit the accumulate-into render of a zeroed image,
+    GMix.make_image's two steps (gmix.py:561-562, 619-643); stamps that raise
+    and empty mixtures come out zero-filled"""
+    import torch
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    rng = np.random.RandomState(31)
+    shapes = [(48, 48)] * 5 + [(17, 23), (32, 32), (8, 16), (33, 9)]
+    n, ng = len(shapes), 4
+    nrow = np.array([sh[0] for sh in shapes])
+    ncol = np.array([sh[1] for sh in shapes])
+    pix_off = np.concatenate([[0], np.cumsum(nrow * ncol)[:-1]]).astype(np.int64)
+    jac = np.zeros((n, 8))
+    for i, sh in enumerate(shapes):
+        jac[i] = [(sh[0] - 1) / 2, (sh[1] - 1) / 2, 0.263, 0.01, -0.01, 0.27,
+                  0.263 * 0.27 + 1e-4, np.sqrt(0.263 * 0.27 + 1e-4)]
+    gmh = _random_mixtures(rng, n, ng, 0.263)
+    gmh["det"][3, 2] = 1e-250          # this stamp raises
+    gmh["norm_set"][3] = 0
+    for fast in (True, False):
+        sb = StampBatch(None, None, torch.from_numpy(jac).cuda(), nrow, ncol, pix_off, True)
+        zeros = torch.zeros(sb.total_pix, dtype=torch.float64, device=sb.device)
+        a, sa = sb.render(GMixBatch.from_numpy(gmh), image=zeros, fast_exp=fast, exact=exact)
+        # poison the allocator's next block so that a read of the buffer shows
+        junk = torch.full((sb.total_pix,), float("nan"), dtype=torch.float64,
+                          device=sb.device)
+        del junk
+        b, sbt = sb.render(GMixBatch.from_numpy(gmh), fast_exp=fast, exact=exact)
+        torch.cuda.synchronize()
+        assert list(sa.cpu().numpy()) == list(sbt.cpu().numpy())
+        assert int(sa[3]) == _lib.ERR_DET_TOO_LOW and int(sa.abs().sum()) == _lib.ERR_DET_TOO_LOW
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        assert np.all(np.isfinite(b))
+        np.testing.assert_array_equal(a, b)
+        off = sb.pix_off
+        assert np.all(b[off[3]:off[3] + 48 * 48] == 0.0)
+        assert np.abs(b[off[0]:off[0] + 48 * 48]).max() > 0
+    # an empty mixture
+    sb1 = StampBatch.from_images(np.zeros((2, 16, 16)))
+    empty = GMixBatch.empty(2, 0)
+    im, st = sb1.render(empty)
+    assert float(im.abs().sum()) == 0.0 and int(st.abs().sum()) == 0
+
+
 # ------------------------------------ properties at BASELINE's full stamp size
 def _c2_batch(n, seed=5):
     """SURVEY.md 8(d) C2-style synthetic batch: 48x48, 'exp' x gaussian psf"""
