@@ -23,6 +23,7 @@ world size == --gpus and (on GPUs) the backend is nccl (= RCCL).
 Rank 0 prints ONE JSON line.
 
 Other configs of BASELINE.json, same contract, own rooflines:
+  --config C3   complete LM fits of the C2 stamps (lock-step batched driver)
   --config C4   admom + em_run over 32x32 stamps (fp64-VALU bound)
   --config C5   10 epochs x 64x64, 16-gaussian 'bdf' loglike (HBM bound)
 A default (C2, N = 1) run appends a short C4 and C5 measurement under
@@ -347,6 +348,98 @@ def run_c2(args, rank, world, device, backend):
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(sb, gm)
     return line
+
+
+# --------------------------------------------------------------------------
+# C3: batched Levenberg-Marquardt fits
+# --------------------------------------------------------------------------
+
+def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
+    """one step = a complete maximum-likelihood fit ('exp' (x) gaussian psf,
+    analytic jacobian, lmder semantics) of every stamp of the C2 batch from
+    guess = truth x U(0.9, 1.1): LMBatchFitter.go end to end (lock-step rounds on
+    the device, packaging, statistics, download); the per-object result
+    records (flags, nfev, pars, errors: 112 B) are all-gathered"""
+    import torch
+    from ngmix_amd.batch import GMixBatch
+    from ngmix_amd.lm_batch import LMBatchFitter
+    n = nstamps or args.nstamps or 100000
+    distributed = world > 1
+    sb, _, pars = make_workload(n, seed=1000 + rank, device=device)
+    rng = np.random.RandomState(7 + rank)
+    guess = pars * rng.uniform(0.9, 1.1, size=pars.shape)
+    guess[:, 0:2] = pars[:, 0:2] + rng.uniform(-0.05, 0.05, size=(n, 2))
+    guess[:, 2:4] = pars[:, 2:4] + rng.uniform(-0.03, 0.03, size=(n, 2))
+    psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (n, 1)), "gauss",
+                                 device=device)
+    fitter = LMBatchFitter("exp")
+    fitter.time_kernels = True     # HIP events around every lm_eval launch
+    gat = Gather(world, device)
+    K = steps or args.steps
+    state = {"loop": 0.0, "rounds": 0, "bad": 0, "nfev": 0.0, "eval_ms": 0.0}
+
+    def step(i):
+        res = fitter.go(sb, guess, psf=psf)
+        if i is not None:
+            state["loop"] += fitter.loop_seconds
+            state["eval_ms"] += fitter.eval_ms
+            state["rounds"] = fitter.rounds
+            state["bad"] = int((res["flags"] != 0).sum())
+            state["nfev"] = float(np.mean(res["nfev"]))
+        if gat.on:
+            rec = np.concatenate([res["flags"][:, None].astype("f8"),
+                                  res["nfev"][:, None].astype("f8"), res["pars"],
+                                  res["pars_err"]], axis=1)
+            gat.wait_consumed()
+            gat.gather("lm", torch.from_numpy(rec).to(device))
+
+    import copy
+    a2 = copy.copy(args)
+    a2.steps = K
+    if steps is not None:
+        a2.warmup, a2.settle_steps = 1, 0
+    else:
+        a2.warmup = min(args.warmup, 5)
+        a2.settle_steps = min(max(args.settle_steps, 0), 3)
+    elapsed = timed_steps(step, a2, distributed, device)
+    if rank != 0:
+        return None
+    loop_ms = state["loop"] / K * 1e3
+    rounds = max(state["rounds"], 1)
+    # the dominant kernel, lm_eval_kernel: one pixel pass per round producing
+    # value + 5 derivative images per pixel in registers and the 28 sums
+    eval_bytes = LOGLIKE_BYTES + 28 * 8
+    eval_ms = state["eval_ms"] / K
+    achieved = eval_bytes * n / (eval_ms * 1e-3) / 1e9
+    return {
+        "metric": "LM fits/sec ('exp' (x) gaussian psf, 48x48 stamps), 1/2/4/8 GPU",
+        "value": world * n * K / elapsed,
+        "unit": "fits/s",
+        "n_gpus": world, "steps": K, "warmup": a2.warmup,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": "C3: %d stamps/GPU, 48x48 px, 'exp' (x) gaussian psf, guess = truth x "
+                        "U(0.9,1.1); one step = a complete lock-step LM fit of every stamp" % n,
+            "stamps_per_gpu": n,
+            "parallelism": "stamps sharded across %d rank(s); all-gather of 112-B fit "
+                           "records" % world,
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "ngmix::lm_eval_kernel",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": eval_bytes * n, "avg_launch_ms": eval_ms,
+            "note": "the kernel evaluates value + 5 derivative images per pixel-gaussian "
+                    "pair and is VALU-issue bound (91 % busy, profiles/*_pmc_summary.txt), "
+                    "not HBM bound",
+        },
+        "device_loop_ms": loop_ms, "rounds": rounds,
+        "fits_per_s_device_loop": n / (loop_ms * 1e-3) if loop_ms > 0 else None,
+        "mean_nfev": state["nfev"], "bad_status": state["bad"],
+        "settle_steps": a2.settle_steps,
+    }
 
 
 # --------------------------------------------------------------------------
@@ -835,12 +928,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--config", default="C2", choices=["C2", "C4", "C5"])
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--settle-steps", type=int, default=None,
                     help="untimed steps run before the warm-up steps: the GPU's "
                          "clock governor needs ~50-100 ms of load to reach its "
                          "steady state (DESIGN.md section 5); 0 disables "
-                         "(default: 100 for C2, 10 for C4 / C5)")
+                         "(default: 100 for C2, 10 for C4 / C5, 3 for C3)")
     ap.add_argument("--nstamps", type=int, default=None,
                     help="stamps (C5: objects) per GPU (weak scaling); default "
                          "100000 (C2), 125000 (C4), 20000 (C5)")
@@ -867,7 +960,7 @@ def main():
 
     import torch.distributed as dist
     rank, world, device, backend = init_rank(args)
-    run = {"C2": run_c2, "C4": run_c4, "C5": run_c5}[args.config]
+    run = {"C2": run_c2, "C3": run_c3, "C4": run_c4, "C5": run_c5}[args.config]
     line = run(args, rank, world, device, backend)
     if rank == 0:
         line["rccl_ranks"] = dist.get_world_size() if world > 1 else 1
@@ -876,14 +969,16 @@ def main():
             import torch
             torch.cuda.empty_cache()
             other = {}
-            for name, fn, kw in (("C4", run_c4, dict(nstamps=125000, steps=5)),
+            for name, fn, kw in (("C3", run_c3, dict(nstamps=100000, steps=3)),
+                                 ("C4", run_c4, dict(nstamps=125000, steps=5)),
                                  ("C5", run_c5, dict(nobj=20000, steps=10))):
                 try:
                     o = fn(args, rank, world, device, backend, **kw)
                     other[name] = {k: o[k] for k in (
                         "metric", "value", "unit", "config", "roofline", "kernels_ms",
                         "bad_status") if k in o}
-                    for k in ("rooflines", "mean_numiter"):
+                    for k in ("rooflines", "mean_numiter", "device_loop_ms", "rounds",
+                              "fits_per_s_device_loop", "mean_nfev", "ms_per_step"):
                         if k in o:
                             other[name][k] = o[k]
                 except Exception as e:   # never lose the headline line

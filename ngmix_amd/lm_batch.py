@@ -237,13 +237,21 @@ class LMBatchFitter(object):
         import time
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
+        # time_kernels: HIP events around every pixel-pass launch (bench.py)
+        ev = [] if getattr(self, "time_kernels", False) else None
         with torch.cuda.device(dev):
             while True:
+                if ev is not None:
+                    ev.append((torch.cuda.Event(enable_timing=True),
+                               torch.cuda.Event(enable_timing=True)))
+                    ev[-1][0].record()
                 _lib.check(L.ngmix_lm_eval_batch(
                     ctypes.byref(b), modnum, int(self.fd), _dptr(d_states), _dptr(d_sobj),
                     _dptr(d_sband), _dptr(psf.data) if psf is not None else None,
                     npsf, _dptr(d_sums), _dptr(d_status), _stream()),
                     "ngmix_lm_eval_batch")
+                if ev is not None:
+                    ev[-1][1].record()
                 if prior_desc is not None:
                     # the prior rows at the same trial points (results.py:454)
                     _lib.check(L.ngmix_lm_prior_sums_batch(
@@ -270,6 +278,8 @@ class LMBatchFitter(object):
         torch.cuda.synchronize(dev)
         # seconds in the lock-step loop (kernels + one 4-byte readback per round)
         self.loop_seconds = time.perf_counter() - t0
+        if ev is not None:
+            self.eval_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         self._d_states = d_states
         self.rounds = rounds
         # run_leastsq's packaging, one thread per fit (ngmix_lm_finalize_batch)

@@ -70,7 +70,8 @@ if "FETCH_SIZE" in c5acc and "WRITE_SIZE" in c5acc:
                                                  "WRITE_SIZE", len(c5acc["WRITE_SIZE"]), write))
     traffic["c5_loglike_hbm_bytes_per_launch"] = 2 * fetch * 1024 + write * 1024
     traffic["c5_nstamps"] = 200000
-for sub, name in (("bench_stats", "bench"), ("c4_stats", "c4"), ("c5_stats", "c5"),
+for sub, name in (("bench_stats", "bench"), ("c3_stats", "c3"), ("c4_stats", "c4"),
+                  ("c5_stats", "c5"),
                   ("iter_stats", "iter"), ("lm_stats", "lm")):
     f = os.path.join(src, sub, "run_kernel_stats.csv")
     if not os.path.exists(f):
@@ -81,6 +82,7 @@ for sub, name in (("bench_stats", "bench"), ("c4_stats", "c4"), ("c5_stats", "c5
         csv.writer(fo, quoting=csv.QUOTE_ALL).writerows(keep)
     lines.append("# rocprofv3 --kernel-trace --stats -- %s (ngmix kernels): calls, average ns"
                  % {"bench": "python3 bench.py --no-cpu-baseline --no-other-configs",
+                    "c3": "python3 bench.py --config C3 --steps 10 --warmup 2",
                     "c4": "python3 bench.py --config C4 --steps 20 --warmup 5",
                     "c5": "python3 bench.py --config C5 --steps 50 --warmup 10",
                     "iter": "python3 tools/bench_iter.py 200000 3",
@@ -88,7 +90,7 @@ for sub, name in (("bench_stats", "bench"), ("c4_stats", "c4"), ("c5_stats", "c5
     for r in keep[1:]:
         lines.append("%-60s calls %5s avg %12.0f ns" % (
             r[0].split("(")[0].replace("void ngmix::", "")[:60], r[1], float(r[3])))
-for bname in ("bench", "bench_c4", "bench_c5"):
+for bname in ("bench", "bench_c3", "bench_c4", "bench_c5"):
     bj = os.path.join(src, bname + ".json")
     if os.path.exists(bj):
         shutil.copy(bj, os.path.join(out, "%s_%s.json" % (tag, bname)))
