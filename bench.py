@@ -593,17 +593,14 @@ def run_c4(args, rank, world, device, backend, nstamps=None, steps=None, quiet=F
 # C5: multi-epoch 'bdf' loglike
 # --------------------------------------------------------------------------
 
-def run_c5(args, rank, world, device, backend, nobj=None, steps=None):
-    """one step = the joint loglike of every object: 10 epochs x 64x64 pixels,
-    16-gaussian 'bdf' (x) gaussian psf, per-epoch sub-pixel jacobian offsets
-    (ngmix/tests/_sims.py:150-159), float64, summed over the object's epochs on
-    the device; 32-byte per-object records all-gathered"""
+def make_c5(nobj, seed, device, nepoch=10, dim=64):
+    """objects of `nepoch` 64x64 epochs, 16-gaussian 'bdf'
+    (x) gaussian psf, per-epoch sub-pixel jacobian offsets
+    (ngmix/tests/_sims.py:150-159); returns (StampBatch, GMixBatch, obj_start)"""
     import torch
     from ngmix_amd.batch import StampBatch, GMixBatch
-    nobj = nobj or args.nstamps or 20000
-    nepoch, dim = 10, 64
     ns = nobj * nepoch
-    rng = np.random.RandomState(3 + rank)
+    rng = np.random.RandomState(seed)
     pars = np.zeros((nobj, 7))
     pars[:, 0:2] = rng.uniform(-0.3, 0.3, size=(nobj, 2)) * SCALE
     pars[:, 2:4] = rng.normal(scale=0.08, size=(nobj, 2))
@@ -627,13 +624,24 @@ def run_c5(args, rank, world, device, backend, nobj=None, steps=None):
     geom = StampBatch(None, None, jt, shape, shape, off, True)
     truth, _ = geom.render(gm)
     gen = torch.Generator(device=device)
-    gen.manual_seed(1 + rank)
+    gen.manual_seed(seed - 2)
     val = truth
     val += 0.05 * torch.randn(truth.shape, generator=gen, device=device,
                               dtype=torch.float64)
     ierr = torch.full_like(val, 20.0)
     sb = StampBatch(val, ierr, jt, shape, shape, off, True)
-    obj_start = np.arange(nobj + 1) * nepoch
+    return sb, gm, np.arange(nobj + 1) * nepoch
+
+
+def run_c5(args, rank, world, device, backend, nobj=None, steps=None):
+    """one step = the joint loglike of every object: 10 epochs x 64x64 pixels,
+    16-gaussian 'bdf' (x) gaussian psf, float64, summed over the object's
+    epochs on the device; 32-byte per-object records all-gathered"""
+    import torch
+    nobj = nobj or args.nstamps or 20000
+    nepoch, dim = 10, 64
+    ns = nobj * nepoch
+    sb, gm, obj_start = make_c5(nobj, 3 + rank, device, nepoch, dim)
     out = torch.empty((ns, 4), dtype=torch.float64, device=device)
     status = torch.empty(ns, dtype=torch.int32, device=device)
     distributed = world > 1

@@ -155,6 +155,15 @@ class GMixBatch(object):
     def clone(self):
         return GMixBatch(self.data.clone(), self.n, self.ngauss)
 
+    def select(self, index):
+        """the mixtures `index` (any order, repeats allowed) as a new batch;
+        the companion of StampBatch.select"""
+        torch = _torch()
+        idx = torch.as_tensor(np.ascontiguousarray(index, dtype=np.int64),
+                              device=self.device)
+        rows = self.data.reshape(self.n, self.ngauss * 13)[idx]
+        return GMixBatch(rows.reshape(-1, 13).contiguous(), idx.numel(), self.ngauss)
+
 
 class StampBatch(object):
     """
