@@ -59,16 +59,19 @@ RENDER_BYTES = 16 * NPIX                   # 36,864 (8 read + 8 written)
 #   admom centroid pass   31  (chi2 8, gate+fexp+apod-free weight 15, 3 sums 5, ...)
 #   admom moments pass    45  (7 moment sums + wsum; no covariance in the loop)
 #   admom covariance pass 96  (once per object: 28 unique w^2 var F_i F_j sums)
-#   em_run pixel pass     73  (1 object gaussian (x) 1 psf gaussian: chi2, hard-cut
-#                              fexp, 6 scratch sums, logL, two reciprocals by
-#                              v_rcp + 2 Newton steps, 8 accumulators)
+#   em_run pixel pass     48  (1 object gaussian (x) 1 psf gaussian: offsets 2,
+#                              squares 3, chi2/2 5, hard-cut fexp + norm 15,
+#                              K - y 1, gtot 1, one reciprocal by v_rcp + a
+#                              Newton step 5, factor 1, w = gi factor 1, eight
+#                              accumulators 14.  The reference's own loop is
+#                              ~60; round 1's kernel executed 73.)
 # the fused get_loglike kernel the library launches (seven waves per SIMD unless
 # NGMIX_LOGLIKE_6WAVES selects the six-wave build for A/B)
 LOGLIKE_KERNEL = ("pixpass_wave_kernel<0," if os.environ.get("NGMIX_LOGLIKE_6WAVES")
                   else "pixpass_wave_kernel7<0,")
 ADMOM_FLOP_ITER_PX = 31 + 45
 ADMOM_FLOP_ONCE_PX = 96
-EM_FLOP_ITER_PX = 73
+EM_FLOP_ITER_PX = 48
 
 
 # --------------------------------------------------------------------------

@@ -101,6 +101,51 @@ __device__ __forceinline__ double rcp_newton(double x)
     return r;
 }
 
+// ln(x) in ~45 straight-line VALU instructions (the library's is ~80): x = m 2^e
+// with m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1), ln m = 2 s (1 + z/3 +
+// ... + z^10/21), z = s^2 <= 0.0295 (the first dropped term is 1e-18 relative),
+// ln x = e ln2_hi + (e ln2_lo + ln m).  Within 2 ulp of the correctly rounded
+// value over the whole positive range, subnormals included
+// (tools/microbench/log_accuracy.hip); log(0) = -inf, log(x < 0) = log(nan) =
+// nan, log(inf) = inf as the library's, by selects -- no branch, no call.  Used
+// where a logarithm feeds a convergence test, not a per-pixel result.
+__device__ __forceinline__ double log_fast(double x)
+{
+    const bool tiny = x < 2.2250738585072014e-308;           // subnormal (or <= 0)
+    const double xs = tiny ? x * 18014398509481984.0 : x;    // 2^54
+    double m = __builtin_amdgcn_frexp_mant(xs);              // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(xs) - (tiny ? 54 : 0);
+    const bool low = m < 0.70710678118654752;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double a = m - 1.0, b = m + 1.0;       // both exact
+    const double r = rcp_newton(b);
+    double sq = a * r;
+    sq = fma(fma(-b, sq, a), r, sq);             // a / b to rounding
+    const double z = sq * sq;
+    double p = 1.0 / 21.0;
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    // ln m = 2 s + 2 s z p
+    const double s2 = sq + sq;
+    const double lnm = fma(s2 * z, p, s2);
+    const double ed = (double)e;
+    // ln 2 split: the high part has 32 trailing zero bits, e * hi is exact
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    double res = fma(ed, LN2_HI, fma(ed, LN2_LO, lnm));
+    res = x == INFINITY ? INFINITY : res;
+    res = x == 0.0 ? -INFINITY : res;
+    res = (x < 0.0 || x != x) ? NAN : res;
+    return res;
+}
+
 // ---- DPP wave reductions ------------------------------------------------------
 // The sum of x over the 64 lanes of a wave, returned uniform (in every lane):
 // an inclusive scan inside each row of 16 lanes (row_shr 1,2,4,8), row

@@ -232,7 +232,7 @@ __device__ __forceinline__ void em_wave_body(
             c.b = 0.5 * g.drr;
             c.c = -g.drc;
             c.pa = g.pnorm * area;
-            c.K = use_logl ? log(g.p) - 0.5 * log(g.det) : 0.0;
+            c.K = use_logl ? log_fast(g.p) - 0.5 * log_fast(g.det) : 0.0;
             c.pad = 0.0;
             ce[i] = c;
         }
@@ -258,6 +258,64 @@ __device__ __forceinline__ void em_wave_body(
             if (!(kept & (1u << k))) continue;
             const double v = pv[k], u = pu[k];
             const double val_pix = pval[k];
+            if constexpr (NPSF1) {
+                // One psf gaussian: object gaussian ii has ONE convolved
+                // component, so its scratch sums (em_nb.py:229-237) are all
+                // products with the same value, tvsum = v gi, tv2sum = vdiff^2 gi
+                // ..., and the sums (em_nb.py:262-279) are X (gi factor) for
+                // X = 1, v, u, udiff^2, udiff vdiff, vdiff^2: one product
+                // w = gi factor and six fused accumulates per gaussian instead
+                // of five scratch products and six accumulates.  (The
+                // reference rounds (X gi) factor; this rounds X (gi factor).)
+                double gi[NG], v2s[NG], uvs[NG], u2s[NG];
+                double gsum = 0.0, logL = 0.0;
+#pragma unroll
+                for (int ii = 0; ii < NG; ii++) {
+                    const EmConvF c = ce[ii];
+                    const double vdiff = v - c.row;
+                    const double udiff = u - c.col;
+                    u2s[ii] = udiff * udiff;
+                    v2s[ii] = vdiff * vdiff;
+                    uvs[ii] = udiff * vdiff;
+                    const double y = fma(c.a, v2s[ii], fma(c.b, u2s[ii], c.c * uvs[ii]));
+                    double val = 0.0;
+                    // hard cut: chi2 < 25 and chi2 >= 0 (em_nb.py:222-227)
+                    if (y < 12.5 && y >= 0.0) {
+                        val = c.pa * fexp_neg_fused(y, sh.tabr, K);
+                        // (one component in all: val (K - y) / gsum with
+                        // gsum == val is K - y to three roundings -- no product,
+                        // no reciprocal)
+                        if (use_logl && NG == 1) logL = val != 0.0 ? c.K - y : 0.0;
+                        if (use_logl && NG > 1) logL = fma(val, c.K - y, logL);
+                    }
+                    gi[ii] = val;
+                    gsum = ii == 0 ? val : gsum + val;
+                }
+                const double gtot = gsum + sky;
+                if (gtot == 0.0) {
+                    bad = true;  // GMixRangeError('gtot == 0')
+                    continue;
+                }
+                if (use_logl && NG > 1) logL = (gsum == 0.0) ? 0.0 : logL * fast_rcp(gsum);
+                const double factor = val_pix * fast_rcp(gtot);
+                acc[6 * NG + 0] += logL;
+                acc[6 * NG + 1] = fma(sky, factor, acc[6 * NG + 1]);
+#pragma unroll
+                for (int ii = 0; ii < NG; ii++) {
+                    const double w = gi[ii] * factor;
+                    acc[6 * ii + 0] += w;
+                    if (use_cen) {
+                        acc[6 * ii + 2] = fma(u, w, acc[6 * ii + 2]);
+                        acc[6 * ii + 1] = fma(v, w, acc[6 * ii + 1]);
+                    }
+                    if (use_cov) {
+                        acc[6 * ii + 3] = fma(u2s[ii], w, acc[6 * ii + 3]);
+                        acc[6 * ii + 4] = fma(uvs[ii], w, acc[6 * ii + 4]);
+                        acc[6 * ii + 5] = fma(v2s[ii], w, acc[6 * ii + 5]);
+                    }
+                }
+                continue;
+            }
             double gi[NG], tv[NG], tu[NG], tv2[NG], tuv[NG], tu2[NG];
             double gsum = 0.0, logL = 0.0;
 #pragma unroll
