@@ -1049,7 +1049,13 @@ __device__ __forceinline__ double weight_fused(double chi2, double pa,
     return w;
 }
 
-template <int NT, int PPT>
+// ALLCHUNKS: all PPT register slots of every thread are evaluated (a 32x32
+// stamp on one wave fills them; an empty slot holds val == 0 with kept bit 0
+// and a finite weight, so it adds exactly nothing): the pixel loops then have
+// a compile-time trip count and unroll fully.  With a run-time count the compiler keeps them rolled and
+// reaches pv[k] / pu[k] / pval[k] through relative register addressing
+// (s_set_gpr_idx + six v_mov_b32 per pixel per pass).
+template <int NT, int PPT, bool ALLCHUNKS>
 __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
                                                  const ngmix_admom_conf conf,
                                                  ngmix_gauss2d *wt_io,
@@ -1120,7 +1126,7 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
             double a[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int k = 0; k < PPT; k++) {
-                if (k >= nchunk) break;
+                if (!ALLCHUNKS && k >= nchunk) break;
                 const double vd = pv[k] - row, ud = pu[k] - col;
                 const double chi2 =
                     fma(dcc * vd, vd, fma(drr * ud, ud, (mdrc2 * vd) * ud));
@@ -1128,6 +1134,11 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
                 a[0] = fma(wdata, pv[k], a[0]);
                 a[1] = fma(wdata, pu[k], a[1]);
                 a[2] += wdata;
+                // one pixel at a time: left alone, the compiler evaluates all
+                // sixteen weights first and sinks the accumulations below them
+                // (409 registers -> one wave per SIMD); an opaque use of the
+                // accumulators ends each pixel where it is written
+                if (ALLCHUNKS) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]));
             }
             group_total<NT, 3>(a, sh.slots, phase);
             last_kind = 1;
@@ -1160,7 +1171,7 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
             double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < PPT; k++) {
-                if (k >= nchunk) break;
+                if (!ALLCHUNKS && k >= nchunk) break;
                 const double vd = pv[k] - row, ud = pu[k] - col;
                 const double vv = vd * vd, uu = ud * ud, vu = vd * ud;
                 const double chi2 = fma(dcc, vv, fma(drr, uu, mdrc2 * vu));
@@ -1173,7 +1184,16 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
                 a[4] = fma(wdata, uu + vv, a[4]);
                 a[5] += wdata;
                 a[6] = fma(wdata, chi2 * chi2, a[6]);
-                a[7] = fma(weight, (double)((kept >> k) & 1u), a[7]);
+                // (the bit is extracted by a volatile asm: as plain C the
+                // sixteen (double) conversions are hoisted out of the iteration
+                // loop and pin 32 registers)
+                unsigned kbit = (kept >> k) & 1u;
+                if (ALLCHUNKS)
+                    asm volatile("v_bfe_u32 %0, %1, %2, 1" : "=v"(kbit) : "v"(kept), "v"(k));
+                a[7] = fma(weight, (double)kbit, a[7]);
+                if (ALLCHUNKS)
+                    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]),
+                                      "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
             }
             group_total<NT, 8>(a, sh.slots, phase);
             last_kind = 2;
@@ -1264,7 +1284,7 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
     if (mom_ran) {
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
-            if (k >= nchunk) break;
+            if (!ALLCHUNKS && k >= nchunk) break;
             const int p = tid + k * NT;
             const double vd = pv[k] - used_row, ud = pu[k] - used_col;
             const double vv = vd * vd, uu = ud * ud, vu = vd * ud;
@@ -1298,6 +1318,10 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
                         idx++;
                     }
                 }
+            }
+            if (ALLCHUNKS) {
+#pragma unroll
+                for (int i = 0; i < 28; i++) asm volatile("" : "+v"(c[i]));
             }
         }
         if (want_cov) group_total<NT, 28>(c, sh.slots, phase);
@@ -1355,8 +1379,15 @@ __global__ __launch_bounds__(NT) void admom_grid_kernel(
     src.izw = (st.flags & NGMIX_STAMP_IGNORE_ZERO_WEIGHT) != 0;
     if constexpr (PPT > 0) {
         __shared__ AdmomFusedShared sh;
-        admom_fused_body<NT, PPT>(src, conf, wt + st.gm_off, res + s,
-                                  status ? status + s : nullptr, sh);
+        // (nearly) every register slot holds a pixel: evaluate all PPT slots --
+        // an empty slot has val == 0 and kept bit 0 and adds exactly nothing
+        const int nchunk = (st.nrow * st.ncol + NT - 1) / NT;
+        if (NT == WAVE && nchunk * 8 >= PPT * 7)
+            admom_fused_body<NT, PPT, NT == WAVE>(src, conf, wt + st.gm_off, res + s,
+                                            status ? status + s : nullptr, sh);
+        else
+            admom_fused_body<NT, PPT, false>(src, conf, wt + st.gm_off, res + s,
+                                             status ? status + s : nullptr, sh);
     } else {
         // stamps too large for registers: streaming passes, reference order
         __shared__ AdmomShared sh;

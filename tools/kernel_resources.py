@@ -109,9 +109,11 @@ def check(lib, verbose=False):
                                 "band)" % (name, vgpr, GUARDS[guard]))
         elif nospill:
             seen.add(nospill)
-            if vspill or scratch:
-                problems.append("%s: %d spilled VGPRs, %d B scratch" % (
-                    name, vspill, scratch))
+            # (VGPRs parked in AGPRs count as spilled but cost one move each and
+            # no memory: scratch is what must not happen)
+            if scratch:
+                problems.append("%s: %d B scratch (%d spilled VGPRs)" % (
+                    name, scratch, vspill))
     for k in list(GUARDS) + list(NO_SPILL_ONLY):
         if k not in seen:
             problems.append("guarded kernel %s not found in %s" % (k, lib))
