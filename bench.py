@@ -379,13 +379,17 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
     fitter.time_kernels = True     # HIP events around every lm_eval launch
     gat = Gather(world, device)
     K = steps or args.steps
-    state = {"loop": 0.0, "rounds": 0, "bad": 0, "nfev": 0.0, "eval_ms": 0.0}
+    state = {"loop": 0.0, "rounds": 0, "bad": 0, "nfev": 0.0, "eval_ms": 0.0,
+             "eval_stamps": 0.0, "launches": 0}
 
     def step(i):
         res = fitter.go(sb, guess, psf=psf)
         if i is not None:
             state["loop"] += fitter.loop_seconds
-            state["eval_ms"] += fitter.eval_ms
+            state["eval_ms"] += fitter.eval_ms_total
+            state["eval_stamps"] += fitter.eval_stamps_total
+            state["launches"] += int(round(fitter.eval_ms_total / fitter.eval_ms))
+            state["nsplit"] = fitter.nsplit_used
             state["rounds"] = fitter.rounds
             state["bad"] = int((res["flags"] != 0).sum())
             state["nfev"] = float(np.mean(res["nfev"]))
@@ -412,8 +416,13 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
     # the dominant kernel, lm_eval_kernel: one pixel pass per round producing
     # value + 5 derivative images per pixel in registers and the 28 sums
     eval_bytes = LOGLIKE_BYTES + 28 * 8
-    eval_ms = state["eval_ms"] / K
-    achieved = eval_bytes * n / (eval_ms * 1e-3) / 1e9
+    # over the whole fit: the stamps every launch still had to evaluate (fits
+    # that have converged leave the lock-step rounds; the fitter counts the
+    # running ones before each launch) / the HIP-event time of all the launches
+    nl = max(state["launches"], 1)
+    eval_ms = state["eval_ms"] / nl
+    stamps_per_launch = state["eval_stamps"] / nl
+    achieved = eval_bytes * state["eval_stamps"] / (state["eval_ms"] * 1e-3) / 1e9
     return {
         "metric": "LM fits/sec ('exp' (x) gaussian psf, 48x48 stamps), 1/2/4/8 GPU",
         "value": world * n * K / elapsed,
@@ -433,10 +442,13 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
             "bound": "hbm", "kernel": "ngmix::lm_eval_kernel",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "algorithmic_bytes_per_launch": eval_bytes * n, "avg_launch_ms": eval_ms,
+            "algorithmic_bytes_per_launch": eval_bytes * stamps_per_launch,
+            "avg_launch_ms": eval_ms, "stamps_per_launch": stamps_per_launch,
+            "launches_per_fit": nl / K, "pieces": state.get("nsplit", 1),
             "note": "the kernel evaluates value + 5 derivative images per pixel-gaussian "
-                    "pair and is VALU-issue bound (91 % busy, profiles/*_pmc_summary.txt), "
-                    "not HBM bound",
+                    "pair and is VALU-issue bound (profiles/*_pmc_summary.txt), not HBM "
+                    "bound; bytes and time are summed over the launches of whole fits, "
+                    "each launch counted with the stamps still being fitted",
         },
         "device_loop_ms": loop_ms, "rounds": rounds,
         "fits_per_s_device_loop": n / (loop_ms * 1e-3) if loop_ms > 0 else None,

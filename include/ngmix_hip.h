@@ -500,7 +500,10 @@ int ngmix_lm_eval_batch(const ngmix_batch *batch, int model, int fd,
    NULL): (nobj, NGMIX_LM_NSUMS(n)) further rows of each object's residual
    vector already reduced over the object's n parameters -- the prior rows at
    the head of the reference's fdiff (results.py:454, joint_prior.py:86-120);
-   in forward-difference mode their jacobian is by the state's xstep / hstep */
+   in forward-difference mode their jacobian is by the state's xstep / hstep.
+   nloc may carry the fits' parameter count as nloc + 256 * npars (npars =
+   nloc - 1 + the number of bands; 0 = not said): the step then runs with a
+   private state sized for npars instead of NGMIX_LM_NPMAX */
 int ngmix_lm_advance_batch(ngmix_lm_state *states, int64_t nobj,
                            const int64_t *obj_start, const int32_t *stamp_band,
                            const double *sums, int nloc, const double *obj_sums,

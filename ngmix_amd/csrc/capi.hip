@@ -12,6 +12,7 @@
 #include "common.hpp"
 #include "launch.hpp"
 #include "lm_core.hpp"
+#include "lm_core_reg.hpp"
 #include "launch_iter.hpp"
 
 namespace ngmix {
@@ -83,6 +84,22 @@ static int host_norms_if_needed(ngmix_gauss2d *gm, int64_t ng)
 }  // namespace ngmix
 
 using namespace ngmix;
+
+// one host step through the register form of the iteration (lm_core_reg.hpp)
+template <int N>
+static void lm_advance_host_reg(ngmix_lm_state &st, double ff, const double *g,
+                                const double *A)
+{
+    lmcore::lm_state_n<N> s;
+    lmreg::load_state<N>(s, st);
+    double gc[N], Ac[N * N];
+    for (int i = 0; i < N; i++) {
+        gc[i] = g[i];
+        for (int j = 0; j < N; j++) Ac[i * N + j] = A[i * NGMIX_LM_NPMAX + j];
+    }
+    lmreg::lm_advance<N>(s, ff, gc, Ac);
+    lmreg::store_state<N>(st, s);
+}
 
 extern "C" {
 
@@ -616,10 +633,18 @@ int ngmix_simple_sep_prior_eval(const ngmix_simple_sep_prior *prior, const doubl
 int64_t ngmix_lm_advance_host(ngmix_lm_state *states, int64_t nobj, const double *ff,
                               const double *g, const double *A)
 {
+    // fits of 6, 7 or 8 parameters run the code the device runs for them
+    // (NGMIX_LM_GENERIC: the generic code, for comparing the two)
+    const bool generic = getenv("NGMIX_LM_GENERIC") != nullptr;
     int64_t running = 0;
     for (int64_t i = 0; i < nobj; i++) {
-        lmcore::lm_advance(states[i], ff[i], g + i * NGMIX_LM_NPMAX,
-                           A + i * NGMIX_LM_NPMAX * NGMIX_LM_NPMAX);
+        const double *gi = g + i * NGMIX_LM_NPMAX;
+        const double *Ai = A + i * NGMIX_LM_NPMAX * NGMIX_LM_NPMAX;
+        const int n = states[i].n;
+        if (generic || n < 6 || n > 8) lmcore::lm_advance(states[i], ff[i], gi, Ai);
+        else if (n == 6) lm_advance_host_reg<6>(states[i], ff[i], gi, Ai);
+        else if (n == 7) lm_advance_host_reg<7>(states[i], ff[i], gi, Ai);
+        else lm_advance_host_reg<8>(states[i], ff[i], gi, Ai);
         if (states[i].phase != NGMIX_LM_PHASE_DONE) running++;
     }
     return running;

@@ -61,79 +61,97 @@ NGMIX_HD double enorm(int n, const double *x)
     return sqrt(s);
 }
 
+// The work arrays and the factor R are NP-strided, NP a template parameter:
+// NP = LM_NPMAX on the ngmix_lm_state record itself (host entry points, tests),
+// a smaller NP on a compact copy of the live part of the record (lm_state_n
+// below) in the device kernel -- one thread per fit keeps everything in private
+// memory, and a six-parameter fit in LM_NPMAX = 14 arrays moves five times the
+// bytes it needs.
+template <int NP>
+struct lm_state_n {
+    double x[NP], xt[NP], diag[NP], R[NP * NP], qtf[NP], step[NP];
+    double fnorm, xnorm, delta, par, gnorm, pnorm;
+    double ftol, xtol, gtol, factor;
+    double xi[NP], xti[NP], lo[NP], hi[NP], xstep[NP], hstep[NP];
+    int32_t ipvt[NP];
+    int32_t n, iter, nfev, njev, info, phase, maxfev, mode, bounded, pad_;
+};
+
 // Pivoted Cholesky of A = J^T J with qrfac's pivot rule (largest remaining
 // column norm first): A P = (QR)^T (QR) P  ->  R^T R = P^T A P.
-// Returns R (upper, n x n in an LM_NPMAX-strided array), ipvt, and
+// Returns R (upper, n x n in an NP-strided array), ipvt, and
 // acnorm[j] = |J[:, j]|.
+template <int NP = LM_NPMAX>
 NGMIX_HD void factor_normal(int n, const double *A, double *R, int32_t *ipvt,
                             double *acnorm)
 {
-    double S[LM_NPMAX * LM_NPMAX];
+    double S[NP * NP];
     for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) S[i * LM_NPMAX + j] = A[i * LM_NPMAX + j];
+        for (int j = 0; j < n; j++) S[i * NP + j] = A[i * NP + j];
     for (int j = 0; j < n; j++) {
         ipvt[j] = j;
-        const double d = A[j * LM_NPMAX + j];
+        const double d = A[j * NP + j];
         acnorm[j] = d > 0.0 ? sqrt(d) : 0.0;
     }
-    // (only the leading n x n block of the LM_NPMAX-strided arrays is ever read)
+    // (only the leading n x n block of the NP-strided arrays is ever read)
     for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) R[i * LM_NPMAX + j] = 0.0;
+        for (int j = 0; j < n; j++) R[i * NP + j] = 0.0;
     // S is kept in the permuted order: row/col k of S <-> parameter ipvt[k]
     for (int k = 0; k < n; k++) {
         int kmax = k;
         for (int j = k + 1; j < n; j++)
-            if (S[j * LM_NPMAX + j] > S[kmax * LM_NPMAX + kmax]) kmax = j;
+            if (S[j * NP + j] > S[kmax * NP + kmax]) kmax = j;
         if (kmax != k) {
             for (int i = 0; i < n; i++) {
-                const double t = S[i * LM_NPMAX + k];
-                S[i * LM_NPMAX + k] = S[i * LM_NPMAX + kmax];
-                S[i * LM_NPMAX + kmax] = t;
+                const double t = S[i * NP + k];
+                S[i * NP + k] = S[i * NP + kmax];
+                S[i * NP + kmax] = t;
             }
             for (int j = 0; j < n; j++) {
-                const double t = S[k * LM_NPMAX + j];
-                S[k * LM_NPMAX + j] = S[kmax * LM_NPMAX + j];
-                S[kmax * LM_NPMAX + j] = t;
+                const double t = S[k * NP + j];
+                S[k * NP + j] = S[kmax * NP + j];
+                S[kmax * NP + j] = t;
             }
             for (int i = 0; i < k; i++) {
-                const double t = R[i * LM_NPMAX + k];
-                R[i * LM_NPMAX + k] = R[i * LM_NPMAX + kmax];
-                R[i * LM_NPMAX + kmax] = t;
+                const double t = R[i * NP + k];
+                R[i * NP + k] = R[i * NP + kmax];
+                R[i * NP + kmax] = t;
             }
             const int32_t ti = ipvt[k];
             ipvt[k] = ipvt[kmax];
             ipvt[kmax] = ti;
         }
-        const double d = S[k * LM_NPMAX + k];
+        const double d = S[k * NP + k];
         if (!(d > 0.0)) {
             // rank deficient: the remaining columns are (numerically) in the
             // span of the first k; qrfac leaves rdiag = 0 there
-            for (int j = k; j < n; j++) R[k * LM_NPMAX + j] = 0.0;
+            for (int j = k; j < n; j++) R[k * NP + j] = 0.0;
             for (int kk = k + 1; kk < n; kk++)
-                for (int j = kk; j < n; j++) R[kk * LM_NPMAX + j] = 0.0;
+                for (int j = kk; j < n; j++) R[kk * NP + j] = 0.0;
             return;
         }
         const double rkk = sqrt(d);
-        R[k * LM_NPMAX + k] = rkk;
-        for (int j = k + 1; j < n; j++) R[k * LM_NPMAX + j] = S[k * LM_NPMAX + j] / rkk;
+        R[k * NP + k] = rkk;
+        for (int j = k + 1; j < n; j++) R[k * NP + j] = S[k * NP + j] / rkk;
         for (int i = k + 1; i < n; i++)
             for (int j = i; j < n; j++) {
-                const double v = S[i * LM_NPMAX + j] -
-                                 R[k * LM_NPMAX + i] * R[k * LM_NPMAX + j];
-                S[i * LM_NPMAX + j] = v;
-                S[j * LM_NPMAX + i] = v;
+                const double v = S[i * NP + j] -
+                                 R[k * NP + i] * R[k * NP + j];
+                S[i * NP + j] = v;
+                S[j * NP + i] = v;
             }
     }
 }
 
 // first n components of Q^T f:  R^T qtf = P^T g
+template <int NP = LM_NPMAX>
 NGMIX_HD void qtf_from_gradient(int n, const double *R, const int32_t *ipvt,
                                 const double *g, double *qtf)
 {
     for (int j = 0; j < n; j++) {
         double s = g[ipvt[j]];
-        for (int i = 0; i < j; i++) s -= R[i * LM_NPMAX + j] * qtf[i];
-        const double rjj = R[j * LM_NPMAX + j];
+        for (int i = 0; i < j; i++) s -= R[i * NP + j] * qtf[i];
+        const double rjj = R[j * NP + j];
         qtf[j] = rjj != 0.0 ? s / rjj : 0.0;
     }
 }
@@ -141,12 +159,13 @@ NGMIX_HD void qtf_from_gradient(int n, const double *R, const int32_t *ipvt,
 // MINPACK qrsolv.  r: n x n with the upper triangle holding R; on output the
 // strict lower triangle holds the strict upper triangle of S transposed and
 // sdiag the diagonal of S.
+template <int NP = LM_NPMAX>
 NGMIX_HD void qrsolv(int n, double *r, const int32_t *ipvt, const double *diag,
                      const double *qtb, double *x, double *sdiag, double *wa)
 {
     for (int j = 0; j < n; j++) {
-        for (int i = j; i < n; i++) r[i * LM_NPMAX + j] = r[j * LM_NPMAX + i];
-        x[j] = r[j * LM_NPMAX + j];
+        for (int i = j; i < n; i++) r[i * NP + j] = r[j * NP + i];
+        x[j] = r[j * NP + j];
         wa[j] = qtb[j];
     }
     for (int j = 0; j < n; j++) {
@@ -158,7 +177,7 @@ NGMIX_HD void qrsolv(int n, double *r, const int32_t *ipvt, const double *diag,
             for (int k = j; k < n; k++) {
                 if (sdiag[k] == 0.0) continue;
                 double cs, sn;
-                const double rkk = r[k * LM_NPMAX + k];
+                const double rkk = r[k * NP + k];
                 if (fabs(rkk) < fabs(sdiag[k])) {
                     const double cotan = rkk / sdiag[k];
                     sn = 0.5 / sqrt(0.25 + 0.25 * (cotan * cotan));
@@ -168,19 +187,19 @@ NGMIX_HD void qrsolv(int n, double *r, const int32_t *ipvt, const double *diag,
                     cs = 0.5 / sqrt(0.25 + 0.25 * (tn * tn));
                     sn = cs * tn;
                 }
-                r[k * LM_NPMAX + k] = cs * rkk + sn * sdiag[k];
+                r[k * NP + k] = cs * rkk + sn * sdiag[k];
                 double temp = cs * wa[k] + sn * qtbpj;
                 qtbpj = -sn * wa[k] + cs * qtbpj;
                 wa[k] = temp;
                 for (int i = k + 1; i < n; i++) {
-                    temp = cs * r[i * LM_NPMAX + k] + sn * sdiag[i];
-                    sdiag[i] = -sn * r[i * LM_NPMAX + k] + cs * sdiag[i];
-                    r[i * LM_NPMAX + k] = temp;
+                    temp = cs * r[i * NP + k] + sn * sdiag[i];
+                    sdiag[i] = -sn * r[i * NP + k] + cs * sdiag[i];
+                    r[i * NP + k] = temp;
                 }
             }
         }
-        sdiag[j] = r[j * LM_NPMAX + j];
-        r[j * LM_NPMAX + j] = x[j];
+        sdiag[j] = r[j * NP + j];
+        r[j * NP + j] = x[j];
     }
     int nsing = n;
     for (int j = 0; j < n; j++) {
@@ -190,30 +209,31 @@ NGMIX_HD void qrsolv(int n, double *r, const int32_t *ipvt, const double *diag,
     for (int k = 0; k < nsing; k++) {
         const int j = nsing - 1 - k;
         double sum = 0.0;
-        for (int i = j + 1; i < nsing; i++) sum += r[i * LM_NPMAX + j] * wa[i];
+        for (int i = j + 1; i < nsing; i++) sum += r[i * NP + j] * wa[i];
         wa[j] = (wa[j] - sum) / sdiag[j];
     }
     for (int j = 0; j < n; j++) x[ipvt[j]] = wa[j];
 }
 
 // MINPACK lmpar.  r is modified as qrsolv leaves it (upper triangle intact).
+template <int NP = LM_NPMAX>
 NGMIX_HD void lmpar(int n, double *r, const int32_t *ipvt, const double *diag,
                     const double *qtb, double delta, double &par, double *x,
                     double *sdiag)
 {
-    double wa1[LM_NPMAX], wa2[LM_NPMAX];
+    double wa1[NP], wa2[NP];
     // gauss-newton direction
     int nsing = n;
     for (int j = 0; j < n; j++) {
         wa1[j] = qtb[j];
-        if (r[j * LM_NPMAX + j] == 0.0 && nsing == n) nsing = j;
+        if (r[j * NP + j] == 0.0 && nsing == n) nsing = j;
         if (nsing < n) wa1[j] = 0.0;
     }
     for (int k = 0; k < nsing; k++) {
         const int j = nsing - 1 - k;
-        wa1[j] /= r[j * LM_NPMAX + j];
+        wa1[j] /= r[j * NP + j];
         const double temp = wa1[j];
-        for (int i = 0; i < j; i++) wa1[i] -= r[i * LM_NPMAX + j] * temp;
+        for (int i = 0; i < j; i++) wa1[i] -= r[i * NP + j] * temp;
     }
     for (int j = 0; j < n; j++) x[ipvt[j]] = wa1[j];
 
@@ -234,8 +254,8 @@ NGMIX_HD void lmpar(int n, double *r, const int32_t *ipvt, const double *diag,
         }
         for (int j = 0; j < n; j++) {
             double sum = 0.0;
-            for (int i = 0; i < j; i++) sum += r[i * LM_NPMAX + j] * wa1[i];
-            wa1[j] = (wa1[j] - sum) / r[j * LM_NPMAX + j];
+            for (int i = 0; i < j; i++) sum += r[i * NP + j] * wa1[i];
+            wa1[j] = (wa1[j] - sum) / r[j * NP + j];
         }
         const double temp = enorm(n, wa1);
         parl = ((fp / delta) / temp) / temp;
@@ -243,7 +263,7 @@ NGMIX_HD void lmpar(int n, double *r, const int32_t *ipvt, const double *diag,
     // upper bound
     for (int j = 0; j < n; j++) {
         double sum = 0.0;
-        for (int i = 0; i <= j; i++) sum += r[i * LM_NPMAX + j] * qtb[i];
+        for (int i = 0; i <= j; i++) sum += r[i * NP + j] * qtb[i];
         wa1[j] = sum / diag[ipvt[j]];
     }
     const double gnorm = enorm(n, wa1);
@@ -258,7 +278,7 @@ NGMIX_HD void lmpar(int n, double *r, const int32_t *ipvt, const double *diag,
         if (par == 0.0) par = fmax(DWARF, 0.001 * paru);
         double temp = sqrt(par);
         for (int j = 0; j < n; j++) wa1[j] = temp * diag[j];
-        qrsolv(n, r, ipvt, wa1, qtb, x, sdiag, wa2);
+        qrsolv<NP>(n, r, ipvt, wa1, qtb, x, sdiag, wa2);
         for (int j = 0; j < n; j++) wa2[j] = diag[j] * x[j];
         dxnorm = enorm(n, wa2);
         temp = fp;
@@ -274,7 +294,7 @@ NGMIX_HD void lmpar(int n, double *r, const int32_t *ipvt, const double *diag,
         for (int j = 0; j < n; j++) {
             wa1[j] /= sdiag[j];
             temp = wa1[j];
-            for (int i = j + 1; i < n; i++) wa1[i] -= r[i * LM_NPMAX + j] * temp;
+            for (int i = j + 1; i < n; i++) wa1[i] -= r[i * NP + j] * temp;
         }
         temp = enorm(n, wa1);
         const double parc = ((fp / delta) / temp) / temp;
@@ -314,7 +334,8 @@ NGMIX_HD double i2e_grad(double v, double lo, double hi)
 
 // the external trial point from the internal one, and fdjac2's points
 // (h = sqrt(eps) |x_j|, sqrt(eps) at 0, in the internal parameters)
-NGMIX_HD void set_trial(lm_state &s)
+template <class State>
+NGMIX_HD void set_trial(State &s)
 {
     constexpr double EPS = 1.4901161193847656e-08;  // sqrt(machine epsilon)
     for (int j = 0; j < s.n; j++) {
@@ -330,13 +351,14 @@ NGMIX_HD void set_trial(lm_state &s)
 
 // lmpar on the stored factor, trial point, and the quantities the ratio test
 // needs afterwards (lmder: the body of the inner loop up to the evaluation)
-NGMIX_HD void propose(lm_state &s)
+template <int NP = LM_NPMAX, class State = lm_state>
+NGMIX_HD void propose(State &s)
 {
     const int n = s.n;
-    double r[LM_NPMAX * LM_NPMAX], sdiag[LM_NPMAX], p[LM_NPMAX], wa3[LM_NPMAX];
+    double r[NP * NP], sdiag[NP], p[NP], wa3[NP];
     for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) r[i * LM_NPMAX + j] = s.R[i * LM_NPMAX + j];
-    lmpar(n, r, s.ipvt, s.diag, s.qtf, s.delta, s.par, p, sdiag);
+        for (int j = 0; j < n; j++) r[i * NP + j] = s.R[i * NP + j];
+    lmpar<NP>(n, r, s.ipvt, s.diag, s.qtf, s.delta, s.par, p, sdiag);
     for (int j = 0; j < n; j++) {
         s.step[j] = -p[j];
         s.xti[j] = s.xi[j] + s.step[j];
@@ -350,14 +372,15 @@ NGMIX_HD void propose(lm_state &s)
 // the outer-loop head of lmder at the point whose normal equations are
 // (A, g): factor, scale, gradient test, then the first proposal.
 // Returns true when the fit has terminated (info set).
-NGMIX_HD bool new_jacobian(lm_state &s, const double *A, const double *g)
+template <int NP = LM_NPMAX, class State = lm_state>
+NGMIX_HD bool new_jacobian(State &s, const double *A, const double *g)
 {
     const int n = s.n;
-    double acnorm[LM_NPMAX];
+    double acnorm[NP];
     s.njev++;
-    factor_normal(n, A, s.R, s.ipvt, acnorm);
+    factor_normal<NP>(n, A, s.R, s.ipvt, acnorm);
     if (s.iter == 1) {
-        double wa3[LM_NPMAX];
+        double wa3[NP];
         for (int j = 0; j < n; j++) {
             s.diag[j] = acnorm[j];
             if (acnorm[j] == 0.0) s.diag[j] = 1.0;
@@ -367,7 +390,7 @@ NGMIX_HD bool new_jacobian(lm_state &s, const double *A, const double *g)
         s.delta = s.factor * s.xnorm;
         if (s.delta == 0.0) s.delta = s.factor;
     }
-    qtf_from_gradient(n, s.R, s.ipvt, g, s.qtf);
+    qtf_from_gradient<NP>(n, s.R, s.ipvt, g, s.qtf);
     // norm of the scaled gradient
     s.gnorm = 0.0;
     if (s.fnorm != 0.0) {
@@ -375,7 +398,7 @@ NGMIX_HD bool new_jacobian(lm_state &s, const double *A, const double *g)
             const int l = s.ipvt[j];
             if (acnorm[l] == 0.0) continue;
             double sum = 0.0;
-            for (int i = 0; i <= j; i++) sum += s.R[i * LM_NPMAX + j] * (s.qtf[i] / s.fnorm);
+            for (int i = 0; i <= j; i++) sum += s.R[i * NP + j] * (s.qtf[i] / s.fnorm);
             s.gnorm = fmax(s.gnorm, fabs(sum / acnorm[l]));
         }
     }
@@ -385,7 +408,7 @@ NGMIX_HD bool new_jacobian(lm_state &s, const double *A, const double *g)
         return true;
     }
     for (int j = 0; j < n; j++) s.diag[j] = fmax(s.diag[j], acnorm[j]);
-    propose(s);
+    propose<NP>(s);
     return false;
 }
 
@@ -429,25 +452,26 @@ NGMIX_HD void lm_init(lm_state &s, int n, const double *x0, double ftol, double 
 }
 
 // Consume the evaluation at s.xt:  ff = |f|^2, g = J^T f, A = J^T J
-// (A, g in LM_NPMAX-strided / LM_NPMAX-long arrays).  ff may be +inf (the
+// (A, g in NP-strided / NP-long arrays).  ff may be +inf (the
 // model was out of range at xt: the reference's calc_fdiff returns -inf
 // residuals there); A and g are then ignored.
-NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g_in, const double *A_in)
+template <int NP = LM_NPMAX, class State = lm_state>
+NGMIX_HD void lm_advance(State &s, double ff, const double *g_in, const double *A_in)
 {
     const int n = s.n;
     if (s.phase == LM_PHASE_DONE) return;
     // analytic jacobians are with respect to the external parameters: the
     // wrapped Dfun of leastsqbound.py:485-489 scales column j by d xt_j / d xti_j
     // (forward differences are taken in the internal parameters already)
-    double gs[LM_NPMAX], As[LM_NPMAX * LM_NPMAX];
+    double gs[NP], As[NP * NP];
     const double *g = g_in, *A = A_in;
     if (s.bounded && s.mode == NGMIX_LM_MODE_ANALYTIC) {
-        double sc[LM_NPMAX];
+        double sc[NP];
         for (int j = 0; j < n; j++) sc[j] = i2e_grad(s.xti[j], s.lo[j], s.hi[j]);
         for (int j = 0; j < n; j++) {
             gs[j] = g_in[j] * sc[j];
             for (int k = 0; k < n; k++)
-                As[j * LM_NPMAX + k] = A_in[j * LM_NPMAX + k] * sc[j] * sc[k];
+                As[j * NP + k] = A_in[j * NP + k] * sc[j] * sc[k];
         }
         g = gs;
         A = As;
@@ -457,7 +481,7 @@ NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g_in, const doubl
         // n evaluations (fdjac2); then the outer-loop head
         s.nfev += n;
         s.phase = LM_PHASE_TRIAL;
-        new_jacobian(s, A, g);
+        new_jacobian<NP>(s, A, g);
         return;
     }
     if (s.phase == LM_PHASE_INIT) {
@@ -477,7 +501,7 @@ NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g_in, const doubl
             return;
         }
         s.phase = LM_PHASE_TRIAL;
-        new_jacobian(s, A, g);
+        new_jacobian<NP>(s, A, g);
         return;
     }
 
@@ -493,11 +517,11 @@ NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g_in, const doubl
         actred = 1.0 - t * t;
     }
     // predicted reduction and directional derivative
-    double wa3[LM_NPMAX];
+    double wa3[NP];
     for (int j = 0; j < n; j++) wa3[j] = 0.0;
     for (int j = 0; j < n; j++) {
         const double temp = s.step[s.ipvt[j]];
-        for (int i = 0; i <= j; i++) wa3[i] += s.R[i * LM_NPMAX + j] * temp;
+        for (int i = 0; i <= j; i++) wa3[i] += s.R[i * NP + j] * temp;
     }
     const double temp1 = enorm(n, wa3) / s.fnorm;
     const double temp2 = (sqrt(s.par) * s.pnorm) / s.fnorm;
@@ -518,7 +542,7 @@ NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g_in, const doubl
     }
     const bool accepted = ratio >= 1.0e-4;
     if (accepted) {
-        double w[LM_NPMAX];
+        double w[NP];
         for (int j = 0; j < n; j++) {
             s.x[j] = s.xt[j];
             s.xi[j] = s.xti[j];
@@ -547,14 +571,14 @@ NGMIX_HD void lm_advance(lm_state &s, double ff, const double *g_in, const doubl
         return;
     }
     if (!accepted) {
-        propose(s);  // same factor, smaller region
+        propose<NP>(s);  // same factor, smaller region
     } else if (s.mode == NGMIX_LM_MODE_FD) {
         // ask for the jacobian at the new point
         for (int j = 0; j < n; j++) s.xti[j] = s.xi[j];
         set_trial(s);
         s.phase = LM_PHASE_JAC;
     } else {
-        new_jacobian(s, A, g);  // the trial point's jacobian is the new one
+        new_jacobian<NP>(s, A, g);  // the trial point's jacobian is the new one
     }
 }
 

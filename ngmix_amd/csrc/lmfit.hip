@@ -20,6 +20,7 @@
 #include "device_utils.hpp"
 #include "launch.hpp"
 #include "lm_core.hpp"
+#include "lm_core_reg.hpp"
 
 
 namespace ngmix {
@@ -30,16 +31,37 @@ __constant__ double c_fexp_coef_lm[9] = NGMIX_FEXP_COEF;
 
 constexpr int LM_NSUM = NGMIX_LM_NSUM;  // 21 + 6 + 1
 
-// one composed gaussian, staged in LDS
+// One composed gaussian, staged in LDS.  For gauss / exp / dev every object
+// gaussian is the same ellipse scaled by its own T_k (gmix_fill_simple,
+// gmix_nb.py:307-351), so d(irr, irc, icc)_k / d(g1, g2, T) = T_k * u_a with
+// three stamp-wide vectors u_a (results.py:955-1010): the record carries T_k
+// and the pixel pass accumulates, per pixel,
+//     N11 = sum_k T_k (ec_k qv_k^2    - e_k w11_k)
+//     N12 = sum_k T_k (ec_k qv_k qu_k - e_k w12_k)
+//     N22 = sum_k T_k (ec_k qu_k^2    - e_k w22_k)
+// from which the three shape derivatives (derivs_nb.py:113-125) are the
+// stamp-wide combinations h_a . (N11, N12, N22) -- ten instructions per pair
+// instead of eighteen, seven doubles per gaussian instead of twenty.
 struct DerivGauss {
     double row, col;
     double w11, w12, w22;  // Q = Sigma^-1
     double pa;             // norm * area
-    double d[3][3];        // halved d(irr,irc,icc)/d(g1,g2,T), middle entry doubled
-    double trh[3];         // tr(Q dSigma_a) / 2
+    double tk;             // irr + icc of the object's gaussian before the psf
+    double pad_;
     PixBox box;
 };
-static_assert(sizeof(DerivGauss) == 160, "DerivGauss");
+static_assert(sizeof(DerivGauss) == 80, "DerivGauss");
+
+// one record per 8x8 tile (as the fused pixel-pass kernels, pixpass.hip)
+struct LmTile {
+    double bv, bu;  // (v, u) of the tile's first pixel
+    int off;        // byte offset of the tile's first pixel inside the stamp
+    int r0, c0;     // its row / column
+    int pad_;
+};
+static_assert(sizeof(LmTile) == 32, "LmTile");
+
+constexpr int LM_TILE_CAP = 1024;  // tile records kept in LDS (<= 256 x 256 px)
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_row_shr_zero(double x)
@@ -61,23 +83,97 @@ __device__ __forceinline__ double row16_sum(double x)
     return x;
 }
 
+// x, y hold one partial per lane of two sums; rows of 16 lanes r0..r3.
+// permlane16_swap: x = [x_r0, y_r0, x_r2, y_r2], y = [x_r1, y_r1, x_r3, y_r3]
+// -> x + y = [x_r0 + x_r1, y_r0 + y_r1, x_r2 + x_r3, y_r2 + y_r3]
+__device__ __forceinline__ double swap_add16(double x, double y)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y),
+                                                     false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y),
+                                                     false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
+// permlane32_swap: x = [x_lo, y_lo], y = [x_hi, y_hi] by halves of 32 lanes
+// -> x + y = [x_lo + x_hi, y_lo + y_hi]
+__device__ __forceinline__ double swap_add32(double x, double y)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y),
+                                                     false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y),
+                                                     false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
 struct LmEvalShared {
     double tabr[16];
-    double red[LM_NSUM * 4];
-    int ctl[4];
 };
 
+// a wave-uniform double moved to SGPRs (a VOP3 instruction reads one SGPR pair
+// for free; as a VGPR pair it would cost two registers across the tile loop)
+__device__ __forceinline__ double uniform_f64(double x)
+{
+    // asm with "=s" results: the builtin readfirstlane of a value the compiler
+    // already knows to be uniform folds away and leaves it in VGPRs.  The
+    // s_nop covers the wait states gfx950 wants between a VALU write of a VGPR
+    // and a v_readfirstlane of it: the hazard recognizer does not look inside
+    // inline asm (without it the constants were stale now and then).
+    int lo, hi;
+    asm volatile("s_nop 4\n\tv_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3"
+                 : "=&s"(lo), "=s"(hi)
+                 : "v"(__double2loint(x)), "v"(__double2hiint(x)));
+    return __hiloint2double(hi, lo);
+}
+
+// fexp(-chi2/2) for 0 <= chi2 < 25 (fastexp_nb.py:223-262) straight from chi2:
+// 0.5 * chi2 is exact, so n and f are those of fexp_neg_fused(chi2 / 2)
+__device__ __forceinline__ double fexp_neg_half(double chi2, const double *tabr,
+                                                const FexpCoef &k)
+{
+    constexpr double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
+    const double t = fma(chi2, 0.5, MAGIC);
+    const int n = __double2loint(t);
+    const double nd = t - MAGIC;
+    const double f = fma(chi2, -0.5, nd);
+    const double tv = tabr[n];
+    double p = fma(f, __hiloint2double(k.c5hi, k.c5lo), k.c4);
+    p = fma(f, p, k.c3);
+    p = fma(f, p, k.c2);
+    p = fma(f, p, k.c1);
+    p = fma(f, p, k.c0);
+    return tv * p;
+}
+
+// a * b + c and a * b with the wave-uniform a read from its SGPR pair (left to
+// itself the compiler copies such constants into VGPRs outside the tile loop)
+__device__ __forceinline__ double fma_sgpr(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "s"(a), "v"(b), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ double mul_sgpr(double a, double b)
+{
+    double r;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b));
+    return r;
+}
+
+// LDS_TILES: the tile records of the stamp are staged in LDS (every batch whose
+// largest stamp has at most LM_TILE_CAP tiles); otherwise made on the fly
+template <bool LDS_TILES>
 __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
     const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
     const double *__restrict__ ierr, const ngmix_jacobian *__restrict__ jacs,
     int model, int ng0, const lm_state *__restrict__ states,
     const int32_t *__restrict__ stamp_obj, const int32_t *__restrict__ stamp_band,
     const ngmix_gauss2d *__restrict__ psf, int npsf, double *__restrict__ sums,
-    int32_t *__restrict__ status, int no_skip)
+    int32_t *__restrict__ status, int no_skip, int tile_cap)
 {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     __shared__ LmEvalShared sh;
-    DerivGauss *dg = (DerivGauss *)dyn;
 
     const int s = blockIdx.x;
     const int lane = threadIdx.x;
@@ -93,60 +189,115 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
     const bool masked = izw && st.npix_kept != nrow * ncol;
     double *out = sums + (size_t)s * LM_NSUM;
 
-    // ---- the composed mixture and its derivative data at the trial point
+    const int npsf1 = npsf > 0 ? npsf : 1;
+    const int G = ng0 * npsf1;
+    DerivGauss *dg = (DerivGauss *)dyn;
+    LmTile *te = (LmTile *)(dyn + (size_t)G * sizeof(DerivGauss));
+
+    // ---- tile records (need only the stamp's shape and jacobian)
+    const int ntx = (ncol + TILE_W - 1) / TILE_W;
+    const int nty = (nrow + TILE_H - 1) / TILE_H;
+    const int ntiles = ntx * nty;
+    // T / ntx by a multiply: exact for T * ntx < 2^32
+    const unsigned inv_ntx = ntx > 1 ? 0xFFFFFFFFu / (unsigned)ntx + 1u : 0u;
+    auto make_tile = [&](int T) {
+        LmTile e;
+        if (T < ntiles) {
+            const int ty = ntx > 1 ? (int)__umulhi((unsigned)T, inv_ntx) : T;
+            const int tx = T - ty * ntx;
+            e.r0 = ty * TILE_H;
+            e.c0 = tx * TILE_W;
+            const double rd = (double)e.r0 - jac.row0, cd = (double)e.c0 - jac.col0;
+            e.bv = fma(jac.dvdrow, rd, jac.dvdcol * cd);
+            e.bu = fma(jac.dudrow, rd, jac.dudcol * cd);
+            e.off = (e.r0 * ncol + e.c0) * 8;
+        } else {
+            // the sentinel past the last tile: no gaussian's box reaches it
+            e.r0 = 1 << 30;
+            e.c0 = 1 << 30;
+            e.bv = 0.0;
+            e.bu = 0.0;
+            e.off = 0;
+        }
+        e.pad_ = 0;
+        return e;
+    };
+    if (LDS_TILES)
+        for (int T = lane; T <= ntiles; T += WAVE) te[T] = make_tile(T);
+
+    // ---- the composed mixture and its derivative data at the trial point.
+    // The parameter prep of the reference (g1g2_to_e1e2, gmix_fill_simple,
+    // gmix_convolve_fill, gmix_set_norms: gmix_nb.py:176-218,307-351,609-678) is
+    // O(ngauss) per stamp but paid by the whole wave, so it is written for few
+    // instructions, equal to the reference's values to rounding:
+    //   e = tanh(2 atanh g) = 2 g / (1 + g^2) without the hyperbolic functions,
+    //   reciprocals / inverse square roots by v_rcp / v_rsq + Newton (~1 ulp).
     double p[6];
     for (int k = 0; k < 5; k++) p[k] = state.xt[k];
     p[5] = state.xt[5 + band];
     const double g1 = p[2], g2 = p[3], T = p[4], flux = p[5];
-    const int npsf1 = npsf > 0 ? npsf : 1;
-    const int G = ng0 * npsf1;
     int bad = 0;
     if (T == 0.0 || flux == 0.0) bad = 1;  // results.py:527-531
+    const double gsq = g1 * g1 + g2 * g2;
+    if (gsq >= 1.0) bad = 1;               // g >= 1: GMixRangeError
+    const double opg = 1.0 + gsq;
+    const double fgg = 2.0 * rcp_newton(opg);   // e / g
+    double efac = fgg;
+    if (4.0 * gsq >= opg * opg) efac = 0.99999999 / sqrt(gsq);  // e >= 1 is clamped
     FillCtx c;
-    if (fill_prepare(c_tables_lm, model, ng0, p, nullptr, c) != NGMIX_OK) bad = 1;
+    c.model = model;
+    c.ngauss = ng0;
+    c.row = p[0];
+    c.col = p[1];
+    c.e1 = efac * g1;
+    c.e2 = efac * g2;
+    c.T = T;
+    c.flux = flux;
+    c.fracdev = 0.0;
+    c.ifracdev = 1.0;
+    c.TdByTe = 1.0;
     double rowcen = 0.0, colcen = 0.0, ipsum = 1.0;
     const ngmix_gauss2d *q = psf ? psf + (size_t)s * npsf : nullptr;
     if (npsf > 0) {
-        double psum;
-        if (gmix_cen(q, npsf, rowcen, colcen, psum) != NGMIX_OK) bad = 1;
-        else ipsum = 1.0 / psum;
+        // gmix_get_cen (gmix_nb.py:108-130)
+        double psum = 0.0;
+        for (int i = 0; i < npsf; i++) {
+            const double pp = q[i].p;
+            rowcen = fma(pp, q[i].row, rowcen);
+            colcen = fma(pp, q[i].col, colcen);
+            psum += pp;
+        }
+        if (psum == 0.0) bad = 1;
+        ipsum = rcp_newton(psum);
+        rowcen *= ipsum;
+        colcen *= ipsum;
     }
     if (lane < 16) sh.tabr[lane] = c_exp_table_lm[15 - lane];
     if (!bad) {
-        // d(e1, e2)/d(g1, g2) for e = 2 g / (1 + g^2)  (results.py:985-992)
-        const double gsq = g1 * g1 + g2 * g2;
-        const double f = 2.0 / (1.0 + gsq);
-        const double dfac = -f / (1.0 + gsq);
-        const double de1dg1 = f + 2.0 * g1 * g1 * dfac;
-        const double de1dg2 = 2.0 * g1 * g2 * dfac;
-        const double de2dg1 = de1dg2;
-        const double de2dg2 = f + 2.0 * g2 * g2 * dfac;
         for (int i = lane; i < G; i += WAVE) {
             const int io = i / npsf1, ip = i - io * npsf1;
             ngmix_gauss2d g0, gc;
             fill_component(c_tables_lm, c, p, io, g0);
             if (npsf > 0) convolve_component(g0, q[ip], rowcen, colcen, ipsum, gc);
             else gc = g0;
-            if (gauss_set_norm(gc) != NGMIX_OK) bad = 1;
+            // gauss2d_set_norm (gmix_nb.py:190-218)
+            if (gc.det < LOW_DETVAL || gc.irr + gc.icc <= LOW_DETVAL) bad = 1;
+            const double idet = rcp_newton(gc.det);
+            double rs = __builtin_amdgcn_rsq(gc.det);   // 1 / sqrt(det)
+            rs = fma(0.5 * rs, fma(-gc.det * rs, rs, 1.0), rs);
+            rs = fma(0.5 * rs, fma(-gc.det * rs, rs, 1.0), rs);
+            gc.drr = gc.irr * idet;
+            gc.drc = gc.irc * idet;
+            gc.dcc = gc.icc * idet;
             DerivGauss r;
             r.row = gc.row;
             r.col = gc.col;
             r.w11 = gc.dcc;   // icc / det
             r.w12 = -gc.drc;  // -irc / det
             r.w22 = gc.drr;   // irr / det
-            r.pa = gc.pnorm * area;
-            const double Tk = g0.irr + g0.icc;
-            const double dc[3][3] = {
-                {-0.5 * Tk * de1dg1, 0.5 * Tk * de2dg1, 0.5 * Tk * de1dg1},
-                {-0.5 * Tk * de1dg2, 0.5 * Tk * de2dg2, 0.5 * Tk * de1dg2},
-                {g0.irr / T, g0.irc / T, g0.icc / T}};
-            for (int a = 0; a < 3; a++) {
-                r.d[a][0] = 0.5 * dc[a][0];
-                r.d[a][1] = dc[a][1];
-                r.d[a][2] = 0.5 * dc[a][2];
-                r.trh[a] = 0.5 * (r.w11 * dc[a][0] + 2.0 * r.w12 * dc[a][1] +
-                                  r.w22 * dc[a][2]);
-            }
+            r.pa = gc.p * (rs * 0.15915494309189535) * area;   // p / (2 pi sqrt(det))
+            r.tk = g0.irr + g0.icc;
+            r.pad_ = 0.0;
             r.box = no_skip ? full_box() : gauss_pixel_box(gc, jac);
             dg[i] = r;
         }
@@ -162,71 +313,118 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
     }
     __syncthreads();
 
+    // d(e1, e2)/d(g1, g2) for e = 2 g / (1 + g^2)  (results.py:985-992) and the
+    // stamp-wide vectors h_a = {u_a0 / 2, u_a1, u_a2 / 2}, u_a = d(irr, irc,
+    // icc)_k / d(g1 | g2 | T) / T_k
+    const double dfac = -0.5 * fgg * fgg;       // -f / (1 + g^2)
+    const double de1dg1 = fgg + 2.0 * g1 * g1 * dfac;
+    const double de1dg2 = 2.0 * g1 * g2 * dfac;
+    const double de2dg1 = de1dg2;
+    const double de2dg2 = fgg + 2.0 * g2 * g2 * dfac;
+    const double i2T = 0.5 * rcp_newton(T);
+    const double h00 = uniform_f64(-0.25 * de1dg1), h01 = uniform_f64(0.5 * de2dg1);
+    const double h10 = uniform_f64(-0.25 * de1dg2), h11 = uniform_f64(0.5 * de2dg2);
+    const double h20 = uniform_f64(0.5 * ((1.0 - c.e1) * i2T)),
+                 h21 = uniform_f64(c.e2 * i2T),
+                 h22 = uniform_f64(0.5 * ((1.0 + c.e1) * i2T));
+    const double iflux = uniform_f64(rcp_newton(flux));
+
     // ---- pixel pass: 8x8 tiles, value + 5 derivatives per pixel in registers
     const FexpCoef K = load_fexp_coef(c_fexp_coef_lm);
     const int lrow = lane / TILE_W, lcol = lane % TILE_W;
-    const int ntx = (ncol + TILE_W - 1) / TILE_W;
-    const int nty = (nrow + TILE_H - 1) / TILE_H;
-    const double *sval = val + st.pix_off;
-    const double *sierr = ierr + st.pix_off;
-    const double iflux = 1.0 / flux;
+    const double olv = fma(jac.dvdrow, (double)lrow, jac.dvdcol * (double)lcol);
+    const double olu = fma(jac.dudrow, (double)lrow, jac.dudcol * (double)lcol);
+    const unsigned lane_off = (unsigned)(lrow * ncol + lcol) * 8u;
+    const int rlim = nrow - lrow, clim = ncol - lcol;  // in bounds: r0 < rlim, c0 < clim
+    const char *bval = (const char *)(val + st.pix_off);
+    const char *bierr = (const char *)(ierr + st.pix_off);
 
     double acc[LM_NSUM];
 #pragma unroll
     for (int k = 0; k < LM_NSUM; k++) acc[k] = 0.0;
 
-    auto load_tile = [&](int ty, int tx, double &pv, double &pe) {
-        const int row = ty * TILE_H + lrow, col = tx * TILE_W + lcol;
+    auto tile = [&](int T) { return LDS_TILES ? te[T] : make_tile(T); };
+    auto load_tile = [&](int Tn, double &pv, double &pe) {
         pv = 0.0;
         pe = 0.0;
-        if (ty < nty && row < nrow && col < ncol) {
-            pv = sval[row * ncol + col];
-            pe = sierr[row * ncol + col];
+        if (Tn < ntiles) {
+            const LmTile e = tile(Tn);
+            if ((e.r0 < rlim) & (e.c0 < clim)) {
+                const unsigned off = lane_off + (unsigned)e.off;
+                pv = *(const double *)(bval + off);
+                pe = *(const double *)(bierr + off);
+            }
         }
     };
 
-    int ty = 0, tx = 0;
-    double nval, nierr;
-    load_tile(ty, tx, nval, nierr);
-    while (ty < nty) {
-        const double pval = nval, pierr = nierr;
-        int ty2 = ty, tx2 = tx + 1;
-        if (tx2 == ntx) {
-            tx2 = 0;
-            ty2++;
-        }
-        load_tile(ty2, tx2, nval, nierr);
+    // (tile, gaussian) box tests, CH tiles per ballot: lane = k * G + g holds
+    // gaussian g's box and tests it against tile T + k
+    const bool chunked = G <= 32;
+    const int CH = chunked ? WAVE / G : 0;
+    const unsigned ngmask = chunked ? (unsigned)((1ull << G) - 1ull) : 0u;
+    int k_l = 0;
+    bool lane_valid = false;
+    PixBox mybox = dg[0].box;
+    if (chunked) {
+        k_l = lane / G;
+        lane_valid = k_l < CH;
+        mybox = dg[lane - k_l * G].box;
+    }
+    unsigned long long allmask = 0ull;
+    int kc = 0;
 
-        const int r0 = ty * TILE_H, c0 = tx * TILE_W;
-        const double rowd = (double)(r0 + lrow) - jac.row0;
-        const double cold = (double)(c0 + lcol) - jac.col0;
-        const double v = fma(jac.dvdrow, rowd, jac.dvdcol * cold);
-        const double u = fma(jac.dudrow, rowd, jac.dudcol * cold);
-        double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0, o4 = 0.0, o5 = 0.0;
+    double nval, nierr;
+    load_tile(0, nval, nierr);
+    for (int Tc = 0; Tc < ntiles; Tc++) {
+        const double pval = nval, pierr = nierr;
+        load_tile(Tc + 1, nval, nierr);
+        const LmTile tc = tile(Tc);
+        const double v = tc.bv + olv, u = tc.bu + olu;
+        double o0 = 0.0, o1 = 0.0, o2 = 0.0, n11 = 0.0, n12 = 0.0, n22 = 0.0;
 
         for (int gb = 0; gb < G; gb += WAVE) {
-            // lane g tests gaussian gb+g's chi2<25 box against this tile
-            const int gi = gb + lane < G ? gb + lane : gb;
-            const PixBox box = dg[gi].box;
-            const bool hit = (gb + lane < G) & (r0 <= box.rmax) &
-                             (r0 + TILE_H - 1 >= box.rmin) & (c0 <= box.cmax) &
-                             (c0 + TILE_W - 1 >= box.cmin);
-            unsigned long long gmask = __ballot(hit);
+            unsigned long long gmask;
+            if (chunked) {
+                if (kc == 0) {
+                    int Tk = Tc + k_l;
+                    if (Tk > ntiles) Tk = ntiles;  // the sentinel
+                    const LmTile tk = tile(Tk);
+                    const bool hit = lane_valid & (tk.r0 <= mybox.rmax) &
+                                     (tk.r0 >= mybox.rmin - (TILE_H - 1)) &
+                                     (tk.c0 <= mybox.cmax) &
+                                     (tk.c0 >= mybox.cmin - (TILE_W - 1));
+                    allmask = __ballot(hit);
+                }
+                gmask = (unsigned)allmask & ngmask;
+                allmask >>= G;
+                kc = (kc + 1 == CH) ? 0 : kc + 1;
+            } else {
+                // lane g tests gaussian gb+g's chi2<25 box against this tile
+                const int gi = gb + lane < G ? gb + lane : gb;
+                const PixBox box = dg[gi].box;
+                const bool hit = (gb + lane < G) & (tc.r0 <= box.rmax) &
+                                 (tc.r0 + TILE_H - 1 >= box.rmin) & (tc.c0 <= box.cmax) &
+                                 (tc.c0 + TILE_W - 1 >= box.cmin);
+                gmask = __ballot(hit);
+            }
             while (gmask) {
                 const int g = gb + __builtin_ctzll(gmask);
                 gmask &= gmask - 1ull;
                 const DerivGauss &D = dg[g];
                 const double dv = v - D.row, du = u - D.col;
-                const double qv = fma(D.w11, dv, D.w12 * du);
-                const double qu = fma(D.w12, dv, D.w22 * du);
-                const double y = 0.5 * fma(dv, qv, du * qu);  // chi2 / 2
-                // derivs_nb.py:104-105: chi2 >= 25 or chi2 < 0 -> skip
-                if (y < 12.5 && y >= 0.0) {
-                    double e = D.pa * fexp_neg_fused(y, sh.tabr, K);
+                const double w11 = D.w11, w12 = D.w12, w22 = D.w22;
+                const double qv = fma(w11, dv, w12 * du);
+                const double qu = fma(w12, dv, w22 * du);
+                const double chi2 = fma(dv, qv, du * qu);
+                // derivs_nb.py:104-105: chi2 >= 25 or chi2 < 0 -> skip (one
+                // unsigned compare on the high word: negative, nan, inf fail)
+                if ((unsigned)__double2hiint(chi2) < 0x40390000u) {
+                    double e = D.pa * fexp_neg_half(chi2, sh.tabr, K);
                     double ec = e;
-                    if (y > 10.0) {
-                        // W and W - 2 W' of the apodisation (fastexp_nb.py:97-135)
-                        const double au = (12.5 - y) * 0.4;
+                    if ((unsigned)__double2hiint(chi2) >= 0x40340000u) {
+                        // W and W - 2 W' of the apodisation (fastexp_nb.py:97-135);
+                        // both are exactly 1 at chi2 == 20
+                        const double au = (25.0 - chi2) * 0.2;
                         const double aq = fma(au, fma(au, K.w6, K.wm15), K.w10);
                         const double w = (au * au) * (au * aq);
                         const double umu = au * (1.0 - au);
@@ -234,16 +432,15 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
                         ec = e * fma(12.0 * umu, umu, w);
                         e *= w;
                     }
+                    const double tk = D.tk;
                     o0 += e;
                     o1 = fma(ec, qv, o1);
                     o2 = fma(ec, qu, o2);
-                    const double qvv = qv * qv, qvu = qv * qu, quu = qu * qu;
-                    const double q0 = fma(qvv, D.d[0][0], fma(qvu, D.d[0][1], quu * D.d[0][2]));
-                    const double q1 = fma(qvv, D.d[1][0], fma(qvu, D.d[1][1], quu * D.d[1][2]));
-                    const double q2 = fma(qvv, D.d[2][0], fma(qvu, D.d[2][1], quu * D.d[2][2]));
-                    o3 = fma(ec, q0, fma(-e, D.trh[0], o3));
-                    o4 = fma(ec, q1, fma(-e, D.trh[1], o4));
-                    o5 = fma(ec, q2, fma(-e, D.trh[2], o5));
+                    const double t = tk * ec, mte = -(tk * e);
+                    const double tqv = t * qv, tqu = t * qu;
+                    n11 = fma(tqv, qv, fma(mte, w11, n11));
+                    n12 = fma(tqv, qu, fma(mte, w12, n12));
+                    n22 = fma(tqu, qu, fma(mte, w22, n22));
                 }
             }
         }
@@ -252,13 +449,15 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
         // outside the stamp and zero-weight pixels have ierr == 0
         if (!masked || pierr > 0.0) {
             const double f = (o0 - pval) * pierr;
+            const double m11 = n11 * pierr, m12 = n12 * pierr, m22 = n22 * pierr;
             double J[6];
             J[0] = o1 * pierr;
             J[1] = o2 * pierr;
-            J[2] = o3 * pierr;
-            J[3] = o4 * pierr;
-            J[4] = o5 * pierr;
-            J[5] = o0 * (pierr * iflux);
+            const double md = m11 - m22;   // u_a0 == -u_a2 for a = g1, g2
+            J[2] = fma_sgpr(h00, md, mul_sgpr(h01, m12));
+            J[3] = fma_sgpr(h10, md, mul_sgpr(h11, m12));
+            J[4] = fma_sgpr(h20, m11, fma_sgpr(h21, m12, mul_sgpr(h22, m22)));
+            J[5] = o0 * mul_sgpr(iflux, pierr);
             int k = 0;
 #pragma unroll
             for (int a = 0; a < 6; a++)
@@ -271,20 +470,20 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
             for (int a = 0; a < 6; a++) acc[21 + a] = fma(J[a], f, acc[21 + a]);
             acc[27] = fma(f, f, acc[27]);
         }
-        ty = ty2;
-        tx = tx2;
     }
 
-    // ---- 28 sums over the wave: DPP inside rows of 16, then 4 partials in LDS
+    // ---- 28 sums over the wave.  v_permlane16_swap / v_permlane32_swap trade
+    // rows of 16 / 32 lanes between two registers, so one add folds the rows of
+    // TWO sums at once: four sums collapse into one register whose row w holds
+    // the 16 lane-partials of sum 4 r + w (63 instructions), DPP finishes the
+    // rows (84) -- 147 instead of 28 x 12 = 336, no LDS, a fixed order.
+    static_assert(LM_NSUM % 4 == 0, "four sums per register");
 #pragma unroll
-    for (int k = 0; k < LM_NSUM; k++) {
-        const double r = row16_sum(acc[k]);
-        if ((lane & 15) == 15) sh.red[k * 4 + (lane >> 4)] = r;
-    }
-    __syncthreads();
-    if (lane < LM_NSUM) {
-        const double *r = sh.red + lane * 4;
-        out[lane] = ((r[0] + r[1]) + r[2]) + r[3];
+    for (int r = 0; r < LM_NSUM / 4; r++) {
+        const double ab = swap_add16(acc[4 * r + 0], acc[4 * r + 1]);
+        const double cd = swap_add16(acc[4 * r + 2], acc[4 * r + 3]);
+        const double t = row16_sum(swap_add32(ab, cd));
+        if ((lane & 15) == 15) out[4 * r + (lane >> 4)] = t;
     }
     if (lane == 0 && status) status[s] = NGMIX_OK;
 }
@@ -298,8 +497,10 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
 // sized for NGMIX_LM_NPMAX = 14 parameters (2.9 kB); a six-parameter fit uses a
 // fifth of it, and lm_advance_kernel moves every record in and out once per
 // round.  (Entries beyond n keep the zeros lm_init wrote.)
-__device__ __forceinline__ void lm_state_copy_live(lm_state &d, const lm_state &g)
+template <int ND, int NS, class D, class S>
+__device__ __forceinline__ void lm_state_copy_live(D &d, const S &g)
 {
+    // ND / NS: the strides of R in the destination / source
     const int n = g.n;
     d.n = n;
     d.iter = g.iter;
@@ -334,24 +535,23 @@ __device__ __forceinline__ void lm_state_copy_live(lm_state &d, const lm_state &
         d.xstep[j] = g.xstep[j];
         d.hstep[j] = g.hstep[j];
         d.ipvt[j] = g.ipvt[j];
-        for (int k = 0; k < n; k++) d.R[j * LM_NPMAX + k] = g.R[j * LM_NPMAX + k];
+        for (int k = 0; k < n; k++) d.R[j * ND + k] = g.R[j * NS + k];
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void lm_advance_kernel(
-    lm_state *states, int64_t nobj, const int64_t *__restrict__ obj_start,
+// NP >= the fit's parameter count: the stride of the thread's private copy
+template <int NP>
+__device__ __forceinline__ void lm_advance_one(
+    lm_state *states, int64_t o, const int64_t *__restrict__ obj_start,
     const int32_t *__restrict__ stamp_band, const double *__restrict__ sums, int nloc,
     const double *__restrict__ obj_sums, int32_t *nactive)
 {
-    const int64_t o = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
-    if (o >= nobj) return;
-    if (states[o].phase == LM_PHASE_DONE) return;
-    lm_state s;
-    lm_state_copy_live(s, states[o]);
+    lmcore::lm_state_n<NP> s;
+    lm_state_copy_live<NP, LM_NPMAX>(s, states[o]);
     const int ntri = nloc * (nloc + 1) / 2, nsum = ntri + nloc + 1;
-    double A[LM_NPMAX * LM_NPMAX], g[LM_NPMAX];
+    double A[NP * NP], g[NP];
     for (int i = 0; i < s.n; i++) {
-        for (int j = 0; j < s.n; j++) A[i * LM_NPMAX + j] = 0.0;
+        for (int j = 0; j < s.n; j++) A[i * NP + j] = 0.0;
         g[i] = 0.0;
     }
     double ff = 0.0;
@@ -365,8 +565,8 @@ __global__ __launch_bounds__(BLOCK) void lm_advance_kernel(
             const int ga = a < nloc - 1 ? a : nloc - 1 + band;
             for (int b = a; b < nloc; b++) {
                 const int gb = b < nloc - 1 ? b : nloc - 1 + band;
-                A[ga * LM_NPMAX + gb] += v[k];
-                if (ga != gb) A[gb * LM_NPMAX + ga] += v[k];
+                A[ga * NP + gb] += v[k];
+                if (ga != gb) A[gb * NP + ga] += v[k];
                 k++;
             }
             g[ga] += v[ntri + a];
@@ -380,17 +580,104 @@ __global__ __launch_bounds__(BLOCK) void lm_advance_kernel(
         int k = 0;
         for (int a = 0; a < n; a++) {
             for (int b = a; b < n; b++) {
-                A[a * LM_NPMAX + b] += v[k];
-                if (a != b) A[b * LM_NPMAX + a] += v[k];
+                A[a * NP + b] += v[k];
+                if (a != b) A[b * NP + a] += v[k];
                 k++;
             }
             g[a] += v[nt + a];
         }
         ff += v[nt + n];
     }
-    lmcore::lm_advance(s, ff, g, A);
-    lm_state_copy_live(states[o], s);
+    lmcore::lm_advance<NP>(s, ff, g, A);
+    lm_state_copy_live<LM_NPMAX, NP>(states[o], s);
     if (s.phase != LM_PHASE_DONE && nactive) atomicAdd(nactive, 1);
+}
+
+// The same step for fits of exactly N parameters with every array in registers
+// (lm_core_reg.hpp).  A stamp's sums are over its local parameters; global
+// parameter G is local G for the shared shape parameters and the stamp's band
+// puts its flux at G = nloc - 1 + band.
+template <int N>
+__device__ __forceinline__ void lm_advance_one_reg(
+    lm_state *states, int64_t o, const int64_t *__restrict__ obj_start,
+    const int32_t *__restrict__ stamp_band, const double *__restrict__ sums, int nloc,
+    const double *__restrict__ obj_sums, int32_t *nactive)
+{
+    lmcore::lm_state_n<N> s;
+    lmreg::load_state<N>(s, states[o]);
+    const int ntri = nloc * (nloc + 1) / 2, nsum = ntri + nloc + 1;
+    double A[N * N], g[N];
+#pragma unroll
+    for (int i = 0; i < N * N; i++) A[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; i++) g[i] = 0.0;
+    double ff = 0.0;
+    const int64_t s0 = obj_start ? obj_start[o] : o;
+    const int64_t s1 = obj_start ? obj_start[o + 1] : o + 1;
+    for (int64_t st = s0; st < s1; st++) {
+        const double *v = sums + st * nsum;
+        const int band = stamp_band ? stamp_band[st] : 0;
+        int la[N];
+#pragma unroll
+        for (int G = 0; G < N; G++)
+            la[G] = G < nloc - 1 ? G : (G == nloc - 1 + band ? nloc - 1 : -1);
+#pragma unroll
+        for (int ga = 0; ga < N; ga++) {
+            if (la[ga] < 0) continue;
+            const int a = la[ga];
+            const int row = a * nloc - a * (a - 1) / 2;   // index of (a, a)
+#pragma unroll
+            for (int gb = ga; gb < N; gb++) {
+                if (la[gb] < 0) continue;
+                const double t = v[row + (la[gb] - a)];
+                A[ga * N + gb] += t;
+                if (ga != gb) A[gb * N + ga] += t;
+            }
+            g[ga] += v[ntri + a];
+        }
+        ff += v[ntri + nloc];
+    }
+    if (obj_sums) {
+        // rows over the object's own N parameters (the prior rows)
+        constexpr int nt = N * (N + 1) / 2;
+        const double *v = obj_sums + o * (int64_t)(nt + N + 1);
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+#pragma unroll
+            for (int b = a; b < N; b++) {
+                A[a * N + b] += v[k];
+                if (a != b) A[b * N + a] += v[k];
+                k++;
+            }
+            g[a] += v[nt + a];
+        }
+        ff += v[nt + N];
+    }
+    lmreg::lm_advance<N>(s, ff, g, A);
+    lmreg::store_state<N>(states[o], s);
+    if (s.phase != LM_PHASE_DONE && nactive) atomicAdd(nactive, 1);
+}
+
+// NP = LM_NPMAX serves any fit (the generic code, private memory); when the
+// launcher is told that every fit has 6, 7 or 8 parameters it runs the
+// register form.
+template <int NP, bool REG>
+__global__ __launch_bounds__(WAVE) void lm_advance_kernel(
+    lm_state *states, int64_t nobj, const int64_t *__restrict__ obj_start,
+    const int32_t *__restrict__ stamp_band, const double *__restrict__ sums, int nloc,
+    const double *__restrict__ obj_sums, int32_t *nactive)
+{
+    const int64_t o = blockIdx.x * (int64_t)WAVE + threadIdx.x;
+    if (o >= nobj) return;
+    if (states[o].phase == LM_PHASE_DONE) return;
+    if (REG) {
+        if (states[o].n != NP) return;   // (never: the launcher's promise was broken)
+        lm_advance_one_reg<NP>(states, o, obj_start, stamp_band, sums, nloc, obj_sums,
+                               nactive);
+    } else {
+        lm_advance_one<NP>(states, o, obj_start, stamp_band, sums, nloc, obj_sums, nactive);
+    }
 }
 
 // ===========================================================================
@@ -646,55 +933,67 @@ __global__ __launch_bounds__(WAVE) void lm_eval_fd_kernel(
 // sum(fdiff^2)/dof; flags from ier and the covariance sanity tests.
 // rec (nobj, 4 + n + 2 n^2 + n doubles):
 //   [flags, nfev, ier, dof | pars n | pars_err n | cov0 n*n | cov n*n]
-__global__ __launch_bounds__(BLOCK) void lm_finalize_kernel(
-    const lm_state *__restrict__ states, int64_t nobj,
-    const int64_t *__restrict__ npix_obj, const double *__restrict__ ff_extra,
-    double pdef, double cdef, double *rec)
+// NT > 0: the fit has exactly NT parameters -- compile-time trip counts, the
+// work matrices in registers (as lm_core_reg.hpp does for the iteration)
+template <int NT>
+__device__ __forceinline__ void lm_finalize_one(
+    const lm_state &s, int64_t o, const int64_t *__restrict__ npix_obj,
+    const double *__restrict__ ff_extra, double pdef, double cdef, double *rec)
 {
-    const int64_t o = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
-    if (o >= nobj) return;
-    const lm_state &s = states[o];
-    const int n = s.n;
+    constexpr int NS = NT > 0 ? NT : LM_NPMAX;   // stride of the work matrices
+    const int n = NT > 0 ? NT : s.n;
     double *r = rec + o * (4 + 2 * (int64_t)n + 2 * (int64_t)n * n);
     double *pars = r + 4, *perr = pars + n, *cov0 = perr + n, *cov = cov0 + n * n;
     int flags = 0;
     const int ier = s.info;
     const long long dof = (long long)npix_obj[o] - n;
+    _Pragma("unroll")
     for (int i = 0; i < n; i++) {
         pars[i] = s.x[i];
         perr[i] = cdef;
     }
+    _Pragma("unroll")
     for (int i = 0; i < n * n; i++) cov0[i] = cov[i] = cdef;
     if (ier == 0) {
         flags |= NGMIX_FLAG_LM_FUNC_NOTFINITE;
+        _Pragma("unroll")
         for (int i = 0; i < n; i++) pars[i] = pdef;
     } else if (ier > 4) {
         flags |= 1 << (ier - 5);
+        _Pragma("unroll")
         for (int i = 0; i < n; i++) pars[i] = pdef;
     } else {
         // R^-1 (upper triangular), in the pivoted order
-        double X[LM_NPMAX * LM_NPMAX];
+        double X[NS * NS];
         bool singular = false;
+        _Pragma("unroll")
         for (int j = 0; j < n; j++) {
             const double d = s.R[j * LM_NPMAX + j];
             if (d == 0.0 || !(fabs(d) < INFINITY)) singular = true;
         }
         if (!singular) {
-            for (int i = 0; i < LM_NPMAX * LM_NPMAX; i++) X[i] = 0.0;
+            _Pragma("unroll")
+            for (int i = 0; i < NS * NS; i++) X[i] = 0.0;
+            _Pragma("unroll")
             for (int j = 0; j < n; j++) {
-                X[j * LM_NPMAX + j] = 1.0 / s.R[j * LM_NPMAX + j];
+                X[j * NS + j] = 1.0 / s.R[j * LM_NPMAX + j];
+                _Pragma("unroll")
                 for (int i = j - 1; i >= 0; i--) {
                     double acc = 0.0;
+                    _Pragma("unroll")
                     for (int k = i + 1; k <= j; k++)
-                        acc += s.R[i * LM_NPMAX + k] * X[k * LM_NPMAX + j];
-                    X[i * LM_NPMAX + j] = -acc / s.R[i * LM_NPMAX + i];
+                        acc += s.R[i * LM_NPMAX + k] * X[k * NS + j];
+                    X[i * NS + j] = -acc / s.R[i * LM_NPMAX + i];
                 }
             }
+            _Pragma("unroll")
             for (int a = 0; a < n; a++)
+                _Pragma("unroll")
                 for (int b = 0; b < n; b++) {
                     double acc = 0.0;
+                    _Pragma("unroll")
                     for (int k = (a > b ? a : b); k < n; k++)
-                        acc += X[a * LM_NPMAX + k] * X[b * LM_NPMAX + k];
+                        acc += X[a * NS + k] * X[b * NS + k];
                     // internal -> external: fjac columns over the transform's
                     // gradient at the solution (leastsqbound.py:535-538)
                     const int pa = s.ipvt[a], pb = s.ipvt[b];
@@ -707,6 +1006,7 @@ __global__ __launch_bounds__(BLOCK) void lm_finalize_kernel(
         }
         if (singular) {
             flags |= NGMIX_FLAG_LM_SINGULAR_MATRIX;
+            _Pragma("unroll")
             for (int i = 0; i < n * n; i++) cov0[i] = cdef;
         } else if (dof == 0) {
             flags |= NGMIX_FLAG_ZERO_DOF;
@@ -714,6 +1014,7 @@ __global__ __launch_bounds__(BLOCK) void lm_finalize_kernel(
             const double s_sq =
                 (s.fnorm * s.fnorm - (ff_extra ? ff_extra[o] : 0.0)) / (double)dof;
             bool finite = true;
+            _Pragma("unroll")
             for (int i = 0; i < n * n; i++) {
                 cov[i] = cov0[i] * s_sq;
                 if (!(fabs(cov[i]) < INFINITY)) finite = false;
@@ -723,20 +1024,26 @@ __global__ __launch_bounds__(BLOCK) void lm_finalize_kernel(
                 cflags |= NGMIX_FLAG_EIG_NOTFINITE;
             } else {
                 // a negative eigenvalue <=> a negative pivot of LDL^T (inertia)
-                double A[LM_NPMAX * LM_NPMAX];
+                double A[NS * NS];
+                _Pragma("unroll")
                 for (int a = 0; a < n; a++)
-                    for (int b = 0; b < n; b++) A[a * LM_NPMAX + b] = cov[a * n + b];
+                    _Pragma("unroll")
+                    for (int b = 0; b < n; b++) A[a * NS + b] = cov[a * n + b];
                 bool neg = false, negdiag = false;
+                _Pragma("unroll")
                 for (int a = 0; a < n; a++)
                     if (cov[a * n + a] < 0.0) negdiag = true;
+                _Pragma("unroll")
                 for (int k = 0; k < n; k++) {
-                    const double d = A[k * LM_NPMAX + k];
+                    const double d = A[k * NS + k];
                     if (d < 0.0) neg = true;
                     const double safe = d != 0.0 ? d : 1.0;
+                    _Pragma("unroll")
                     for (int a = k + 1; a < n; a++) {
-                        const double c = A[a * LM_NPMAX + k] / safe;
+                        const double c = A[a * NS + k] / safe;
+                        _Pragma("unroll")
                         for (int b = k + 1; b < n; b++)
-                            A[a * LM_NPMAX + b] -= c * A[k * LM_NPMAX + b];
+                            A[a * NS + b] -= c * A[k * NS + b];
                     }
                 }
                 if (neg) cflags |= NGMIX_FLAG_LM_NEG_COV_EIG;
@@ -744,6 +1051,7 @@ __global__ __launch_bounds__(BLOCK) void lm_finalize_kernel(
             }
             flags |= cflags;
             if (cflags == 0)
+                _Pragma("unroll")
                 for (int a = 0; a < n; a++) perr[a] = sqrt(cov[a * n + a]);
         }
     }
@@ -751,6 +1059,22 @@ __global__ __launch_bounds__(BLOCK) void lm_finalize_kernel(
     r[1] = ier == 0 ? -1.0 : (double)s.nfev;
     r[2] = (double)ier;
     r[3] = (double)dof;
+}
+
+__global__ __launch_bounds__(WAVE) void lm_finalize_kernel(
+    const lm_state *__restrict__ states, int64_t nobj,
+    const int64_t *__restrict__ npix_obj, const double *__restrict__ ff_extra,
+    double pdef, double cdef, double *rec)
+{
+    const int64_t o = blockIdx.x * (int64_t)WAVE + threadIdx.x;
+    if (o >= nobj) return;
+    const lm_state &s = states[o];
+    // (the fits of a batch have one parameter count: a uniform branch)
+    const int n = s.n;
+    if (n == 6) lm_finalize_one<6>(s, o, npix_obj, ff_extra, pdef, cdef, rec);
+    else if (n == 7) lm_finalize_one<7>(s, o, npix_obj, ff_extra, pdef, cdef, rec);
+    else if (n == 8) lm_finalize_one<8>(s, o, npix_obj, ff_extra, pdef, cdef, rec);
+    else lm_finalize_one<0>(s, o, npix_obj, ff_extra, pdef, cdef, rec);
 }
 
 __global__ __launch_bounds__(BLOCK) void lm_prior_sums_kernel(
@@ -829,8 +1153,8 @@ int launch_lm_finalize(const lm_state *states, int64_t nobj, const int64_t *npix
                        hipStream_t s)
 {
     if (nobj <= 0) return NGMIX_OK;
-    hipLaunchKernelGGL(lm_finalize_kernel, dim3((unsigned)((nobj + BLOCK - 1) / BLOCK)),
-                       dim3(BLOCK), 0, s, states, nobj, npix_obj, ff_extra, pdef, cdef, rec);
+    hipLaunchKernelGGL(lm_finalize_kernel, dim3((unsigned)((nobj + WAVE - 1) / WAVE)),
+                       dim3(WAVE), 0, s, states, nobj, npix_obj, ff_extra, pdef, cdef, rec);
     NGMIX_HIP_CHECK(hipGetLastError());
     return NGMIX_OK;
 }
@@ -881,19 +1205,34 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *stat
             set_last_error_msg("lm_eval: the analytic jacobian exists for gauss, exp, dev");
             return NGMIX_ERR_BAD_ARG;
         }
-        const size_t lds = (size_t)G * sizeof(DerivGauss);
+        // one 32-byte record per 8x8 tile next to the gaussians (exact when the
+        // batch carries its largest stamp shape); beyond LM_TILE_CAP tiles the
+        // kernel makes the records on the fly
+        int tile_cap = b->max_npix / 8 + 1;
+        if (b->max_nrow > 0 && b->max_ncol > 0)
+            tile_cap = ((b->max_nrow + TILE_H - 1) / TILE_H) *
+                       ((b->max_ncol + TILE_W - 1) / TILE_W);
+        tile_cap += 1;
+        const bool lds_tiles = tile_cap <= LM_TILE_CAP;
+        if (!lds_tiles) tile_cap = 0;
+        const size_t lds = (size_t)G * sizeof(DerivGauss) + (size_t)tile_cap * sizeof(LmTile);
         if (lds > 96 * 1024) {
             set_last_error_msg("lm_eval: too many composed gaussians for LDS");
             return NGMIX_ERR_BAD_ARG;
         }
+        const void *kern = lds_tiles ? (const void *)lm_eval_kernel<true>
+                                     : (const void *)lm_eval_kernel<false>;
         if (lds > 48 * 1024)
             NGMIX_HIP_CHECK(hipFuncSetAttribute(
-                (const void *)lm_eval_kernel,
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(lm_eval_kernel, grid, block, lds, s, b->stamps, b->val,
-                           b->ierr, b->jac, model, ng0, states, stamp_obj, stamp_band,
-                           psf, npsf, sums, status, no_skip);
-        NGMIX_HIP_CHECK(hipGetLastError());
+                kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const ngmix_stamp *a_stamps = b->stamps;
+        const double *a_val = b->val, *a_ierr = b->ierr;
+        const ngmix_jacobian *a_jac = b->jac;
+        int a_model = model, a_ng0 = ng0, a_npsf = npsf, a_ns = no_skip;
+        void *args[] = {&a_stamps, &a_val, &a_ierr, &a_jac, &a_model, &a_ng0, &states,
+                        &stamp_obj, &stamp_band, &psf, &a_npsf, &sums, &status, &a_ns,
+                        &tile_cap};
+        NGMIX_HIP_CHECK(hipLaunchKernel(kern, grid, block, args, lds, s));
         return NGMIX_OK;
     }
     const size_t lds = (size_t)(nloc + 1) * G * sizeof(FdGauss) + (size_t)G * sizeof(PixBox);
@@ -927,11 +1266,26 @@ int launch_lm_advance(lm_state *states, int64_t nobj, const int64_t *obj_start,
                       const double *obj_sums, int32_t *nactive, hipStream_t s)
 {
     if (nobj <= 0) return NGMIX_OK;
-    if (nloc < 2 || nloc > LM_NPMAX) return NGMIX_ERR_BAD_ARG;
+    // nloc + 256 * npars: the fits' parameter count, if the caller says
+    const int npars = (nloc >> 8) & 0xff;
+    nloc &= 0xff;
+    if (nloc < 2 || nloc > LM_NPMAX || npars > LM_NPMAX) return NGMIX_ERR_BAD_ARG;
+    if (npars != 0 && npars < nloc) return NGMIX_ERR_BAD_ARG;
     if (nactive) NGMIX_HIP_CHECK(hipMemsetAsync(nactive, 0, sizeof(int32_t), s));
-    hipLaunchKernelGGL(lm_advance_kernel, dim3((unsigned)((nobj + BLOCK - 1) / BLOCK)),
-                       dim3(BLOCK), 0, s, states, nobj, obj_start, stamp_band, sums, nloc,
-                       obj_sums, nactive);
+    const dim3 grid((unsigned)((nobj + WAVE - 1) / WAVE)), block(WAVE);
+    static const bool generic = getenv("NGMIX_LM_GENERIC") != nullptr;   // A/B knob
+    if (npars == 6 && !generic)
+        hipLaunchKernelGGL((lm_advance_kernel<6, true>), grid, block, 0, s, states, nobj,
+                           obj_start, stamp_band, sums, nloc, obj_sums, nactive);
+    else if (npars == 7 && !generic)
+        hipLaunchKernelGGL((lm_advance_kernel<7, true>), grid, block, 0, s, states, nobj,
+                           obj_start, stamp_band, sums, nloc, obj_sums, nactive);
+    else if (npars == 8 && !generic)
+        hipLaunchKernelGGL((lm_advance_kernel<8, true>), grid, block, 0, s, states, nobj,
+                           obj_start, stamp_band, sums, nloc, obj_sums, nactive);
+    else
+        hipLaunchKernelGGL((lm_advance_kernel<LM_NPMAX, false>), grid, block, 0, s, states,
+                           nobj, obj_start, stamp_band, sums, nloc, obj_sums, nactive);
     NGMIX_HIP_CHECK(hipGetLastError());
     return NGMIX_OK;
 }

@@ -126,6 +126,24 @@ def test_batch_matches_per_object_fitter(model):
     assert np.all(np.abs(pull) < 6.0)
 
 
+@pytest.mark.parametrize("nsplit", [2, 3])
+def test_batch_in_pieces_on_streams_is_the_same_fit(nsplit, monkeypatch):
+    """LMBatchFitter.nsplit: the batch advanced in pieces on separate streams,
+    and the generic lm_advance (NGMIX_LM_GENERIC is read once per process, so
+    here only the pieces are compared): every result to the bit"""
+    rng = np.random.RandomState(77)
+    n = 50
+    pars, guess, images, weights, jac, sb, psf = _make_objects(n, "exp", rng)
+    whole = LMBatchFitter("exp").go(sb, guess, psf=psf)
+    f = LMBatchFitter("exp")
+    f.nsplit = nsplit
+    pieces = f.go(sb, guess, psf=psf)
+    assert f.nsplit_used == nsplit
+    for key in ("flags", "nfev", "njev", "ier", "pars", "pars_err", "pars_cov", "lnprob",
+                "s2n", "dof"):
+        np.testing.assert_array_equal(np.asarray(whole[key]), np.asarray(pieces[key]), key)
+
+
 def test_batch_out_of_range_start_and_masked():
     rng = np.random.RandomState(5)
     n = 6

@@ -401,3 +401,84 @@ def test_batch_prior_equals_the_reference_prior(golden, tag):
         assert k == 4 + nband
         np.testing.assert_allclose(r[:k], g[tag + "_prior_rows"][i], rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(l[0], g[tag + "_prior_lnp"][i], rtol=1e-12)
+
+
+@pytest.mark.parametrize("n", [6, 7, 8])
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("bounded", [False, True])
+def test_register_form_equals_generic_form_bit_for_bit(n, mode, bounded, monkeypatch):
+    """lm_core_reg.hpp (compile-time parameter count, arrays in registers: what
+    the device runs for 6-8 parameters) against lm_core.hpp: the same state
+    record, byte for byte, after every step of every fit -- including a
+    rank-deficient jacobian and rejected steps"""
+    L = _lib.lib()
+    rng = np.random.RandomState(100 * n + 10 * mode + int(bounded))
+    nfit, m = 12, 40
+    t = np.linspace(0.0, 1.0, m)
+
+    def model(p):
+        # a sum of smooth bumps whose widths / heights are the parameters
+        out = np.zeros(m)
+        for k in range(n // 2):
+            out += p[2 * k] * np.exp(-0.5 * (t - (k + 0.5) / (n // 2)) ** 2 /
+                                     (0.05 + p[2 * k + 1] ** 2))
+        if n % 2:
+            out += p[n - 1] * t
+        return out
+    truth = rng.uniform(0.5, 1.5, size=(nfit, n))
+    data = np.array([model(p) for p in truth]) + 0.01 * rng.normal(size=(nfit, m))
+    x0 = truth * rng.uniform(0.7, 1.3, size=truth.shape)
+    lo = hi = None
+    if bounded:
+        lo = np.full(n, 0.05)
+        hi = np.full(n, np.inf)
+        hi[0] = 3.0
+        lo[1] = -np.inf
+    states = {}
+    for form in ("generic", "register"):
+        if form == "generic":
+            monkeypatch.setenv("NGMIX_LM_GENERIC", "1")
+        else:
+            monkeypatch.delenv("NGMIX_LM_GENERIC", raising=False)
+        st = np.zeros(nfit, dtype=_lib.LM_STATE_DTYPE)
+        assert L.ngmix_lm_init(_lib.ptr(st), nfit, n, _lib.ptr(x0), 1e-8, 1e-8, 0.0,
+                               60, 100.0, mode,
+                               None if lo is None else _lib.ptr(lo),
+                               None if hi is None else _lib.ptr(hi)) == 0
+        history = []
+        for rounds in range(400):
+            if np.all(st["phase"] == _lib.LM_PHASE_DONE):
+                break
+            ff = np.zeros(nfit)
+            g = np.zeros((nfit, NP))
+            A = np.zeros((nfit, NP, NP))
+            for i in range(nfit):
+                xt = st["xt"][i, :n]
+                f = model(xt) - data[i]
+                ff[i] = f @ f
+                J = np.zeros((m, n))
+                for j in range(n):
+                    xp = xt.copy()
+                    if mode == 1:
+                        xp[j] = st["xstep"][i, j] if st["hstep"][i, j] != 0 else xt[j] + 1e-7
+                        h = st["hstep"][i, j] if st["hstep"][i, j] != 0 else 1e-7
+                    else:
+                        h = 1e-7
+                        xp[j] = xt[j] + h
+                    J[:, j] = (model(xp) - f - data[i]) / h
+                if i == 3:
+                    J[:, n - 1] = J[:, 0]          # a rank-deficient jacobian
+                if i == 5 and rounds == 2:
+                    ff[i] = np.inf                 # an out-of-range trial
+                g[i, :n] = J.T @ f
+                A[i, :n, :n] = J.T @ J
+            L.ngmix_lm_advance_host(_lib.ptr(st), nfit, _lib.ptr(ff), _lib.ptr(g),
+                                    _lib.ptr(A))
+            history.append(st.copy().tobytes())
+        assert np.all(st["phase"] == _lib.LM_PHASE_DONE)
+        states[form] = history
+    assert len(states["generic"]) == len(states["register"])
+    for r, (a, b) in enumerate(zip(states["generic"], states["register"])):
+        assert a == b, "state records differ after step %d" % r
+    # the fits did something: several steps, several outcomes
+    assert len(states["generic"]) > 4
