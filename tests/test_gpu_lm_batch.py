@@ -144,6 +144,48 @@ def test_batch_in_pieces_on_streams_is_the_same_fit(nsplit, monkeypatch):
         np.testing.assert_array_equal(np.asarray(whole[key]), np.asarray(pieces[key]), key)
 
 
+@pytest.mark.parametrize("npars,mode,bounds", [
+    (6, 0, False), (6, 0, True), (7, 1, False), (8, 1, True), (14, 1, False)])
+def test_device_init_equals_host_init(npars, mode, bounds):
+    """ngmix_lm_init_batch (memset + the non-zero fields written in place)
+    against ngmix_lm_init (lmcore::lm_init): the same records, byte for byte"""
+    import torch
+    from ngmix_amd.batch import _dptr, _stream
+    L = _lib.lib()
+    rng = np.random.RandomState(npars * 10 + mode)
+    n = 300
+    x0 = rng.uniform(0.2, 2.0, size=(n, npars))
+    x0[5, 0] = 0.0           # fdjac2's step at zero
+    lo = hi = None
+    if bounds:
+        lo = np.full(npars, -np.inf)
+        hi = np.full(npars, np.inf)
+        lo[0], hi[0] = -1.0, 4.0
+        lo[2] = 0.01
+        hi[3] = 9.0
+    host = np.zeros(n, dtype=_lib.LM_STATE_DTYPE)
+    host.view(np.uint8)[:] = 0xAB        # lm_init must define every byte it owns
+    args = (1e-7, 1e-9, 0.0, 123, 50.0, mode,
+            None if lo is None else _lib.ptr(lo), None if hi is None else _lib.ptr(hi))
+    assert L.ngmix_lm_init(_lib.ptr(host), n, npars, _lib.ptr(x0), *args) == 0
+    dev = torch.full((n, _lib.LM_STATE_DTYPE.itemsize), 0xCD, dtype=torch.uint8,
+                     device="cuda")
+    d_x0 = torch.from_numpy(x0).cuda()
+    assert L.ngmix_lm_init_batch(_dptr(dev), n, npars, _dptr(d_x0), *args,
+                                 _stream()) == 0
+    torch.cuda.synchronize()
+    got = dev.cpu().numpy().reshape(-1).view(_lib.LM_STATE_DTYPE)
+    # with bounds the transforms go through asin / sin / sqrt: device and host
+    # libm differ by an ulp or two there, everything else is the same bytes
+    libm = ("x", "xt", "xi", "xti", "xstep", "hstep") if bounds else ()
+    for name in _lib.LM_STATE_DTYPE.names:
+        if name in libm:
+            np.testing.assert_allclose(got[name], host[name], rtol=1e-14, atol=0,
+                                       err_msg=name)
+        else:
+            np.testing.assert_array_equal(got[name], host[name], name)
+
+
 def test_batch_out_of_range_start_and_masked():
     rng = np.random.RandomState(5)
     n = 6
