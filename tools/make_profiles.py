@@ -39,7 +39,8 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
 lines = ["# rocprofv3 --pmc passes (tools/run_prof.sh), mean per launch, "
          "%d stamps per launch" % nstamps]
 traffic = {"nstamps": nstamps, "source": "profiles/%s_pmc_summary.txt" % tag,
-           "method": "HBM bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch; "
+           "method": "HBM bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch (median "
+                     "over the launches of the PMC pass); "
                      "the factor 2 is MI355X_MICROARCH.md's gfx950 correction "
                      "(FETCH_SIZE = TCC_EA0_RDREQ x 64 B while the requests are "
                      "128 B), confirmed here: TCC_EA0_RDREQ_sum x 128 B equals the "
@@ -49,8 +50,11 @@ for k, cs in sorted(acc.items()):
         lines.append("%-36s %-26s n=%d mean %.6g" % (k, c, len(vals),
                                                      sum(vals) / len(vals)))
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-        fetch = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"])
-        write = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
+        # median, not mean: the workload builder's own fresh render (the
+        # overwriting form, which never reads the image) is a launch of the
+        # same symbol and must not dilute the accumulate-into launches
+        fetch = sorted(cs["FETCH_SIZE"])[len(cs["FETCH_SIZE"]) // 2]
+        write = sorted(cs["WRITE_SIZE"])[len(cs["WRITE_SIZE"]) // 2]
         name = {"pixpass_wave_kernel<0, false, 8>": "loglike",
                 "pixpass_wave_kernel7<0, false, 8>": "loglike",
                 "pixpass_wave_kernel<2, false, 16>": "render"}.get(k)
