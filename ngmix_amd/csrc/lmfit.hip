@@ -17,6 +17,8 @@
 //   lm_advance_kernel  one THREAD per object: folds the object's stamps
 //                    (epochs / bands) into its (5+nband)-parameter system and
 //                    runs one step of the lmder logic (lm_core.hpp).
+#include <type_traits>
+
 #include "device_utils.hpp"
 #include "launch.hpp"
 #include "lm_core.hpp"
@@ -696,7 +698,11 @@ struct FdGauss {
 static_assert(sizeof(FdGauss) == 48, "FdGauss");
 
 template <int NLOC>
-__global__ __launch_bounds__(WAVE) void lm_eval_fd_kernel(
+// three waves per SIMD up to ten parameters (168 VGPRs, no spills; measured
+// 9.0 -> 8.1 ms per 20k 'bdf' fits against two), two beyond
+__global__ __launch_bounds__(WAVE)
+__attribute__((amdgpu_waves_per_eu(NLOC <= 10 ? 3 : 2, NLOC <= 10 ? 3 : 2)))
+void lm_eval_fd_kernel(
     const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
     const double *__restrict__ ierr, const ngmix_jacobian *__restrict__ jacs,
     int model, int ng0, const lm_state *__restrict__ states,
@@ -708,11 +714,16 @@ __global__ __launch_bounds__(WAVE) void lm_eval_fd_kernel(
     constexpr int NSUM = NTRI + NLOC + 1;
     constexpr int NSETS = NLOC + 1;
     static_assert(NLOC + 1 <= 16, "the normal equations are one 16 x 16 MFMA tile");
+    constexpr bool PACKED = NLOC + 1 <= 8;   // two pixel groups per MFMA (below)
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     __shared__ double tabr[16];
     // one tile's rows [J_0 .. J_{NLOC-1}, f, 0 ..] per pixel, 17 doubles apart
     constexpr int JSTRIDE = 17;
     __shared__ double jbuf[WAVE * JSTRIDE];
+    // 1 / h_j and the three centres: wave-uniform, read back per tile with
+    // broadcast ds_reads (as registers they pushed the kernel past three waves
+    // per SIMD)
+    __shared__ double unif[NLOC + 6];
 
     const int s = blockIdx.x;
     const int lane = threadIdx.x;
@@ -720,7 +731,6 @@ __global__ __launch_bounds__(WAVE) void lm_eval_fd_kernel(
     const lm_state &state = states[obj];
     if (state.phase == LM_PHASE_DONE) return;
     const bool want_jac = state.phase != LM_PHASE_TRIAL;
-    const int nsets = want_jac ? NSETS : 1;
     const int band = stamp_band ? stamp_band[s] : 0;
     const ngmix_stamp st = stamps[s];
     const ngmix_jacobian jac = jacs[s];
@@ -736,21 +746,34 @@ __global__ __launch_bounds__(WAVE) void lm_eval_fd_kernel(
 
     // local parameters and the fdjac2 points the state prepared (xstep /
     // hstep: the step is taken in leastsqbound's internal parameters)
-    double p0[NLOC], ps[NLOC], ih[NLOC];
+    double p0[NLOC], ps[NLOC];
 #pragma unroll
     for (int k = 0; k < NLOC; k++) {
         const int gk = k < NLOC - 1 ? k : NLOC - 1 + band;
         p0[k] = state.xt[gk];
         ps[k] = state.xstep[gk];
-        ih[k] = 1.0 / state.hstep[gk];
+        if (lane == 0) unif[k] = 1.0 / state.hstep[gk];
     }
+    // The model is linear in the flux (the last local parameter of every model
+    // but coellip, gmix_nb.py:307-558: p_i = flux * pval_i, nothing else depends
+    // on it), so the set shifted in flux is the base set times (flux + h) / flux:
+    // its column of the jacobian is m_0 (h / flux) / h without a pixel pass.
+    const bool lin_flux = model != NGMIX_MODEL_COELLIP && p0[NLOC - 1] != 0.0;
+    const double flux_rel = lin_flux ? (ps[NLOC - 1] - p0[NLOC - 1]) / p0[NLOC - 1] : 0.0;
+    const int nsets = want_jac ? (lin_flux ? NSETS - 1 : NSETS) : 1;
     double rowcen = 0.0, colcen = 0.0, ipsum = 1.0;
     const ngmix_gauss2d *q = psf ? psf + (size_t)s * npsf : nullptr;
     int bad = 0;
+    // every gaussian of a set has one centre when the psf's components do (the
+    // object's always do): dv^2, du^2, dv du are then formed once per pixel and
+    // centre -- the base one, and the two of the sets shifted in cen1 / cen2
+    bool cocen = true;
     if (npsf > 0) {
         double psum;
         if (gmix_cen(q, npsf, rowcen, colcen, psum) != NGMIX_OK) bad = 1;
         else ipsum = 1.0 / psum;
+        for (int ip = 1; ip < npsf; ip++)
+            if (q[ip].row != q[0].row || q[ip].col != q[0].col) cocen = false;
     }
     if (lane < 16) tabr[lane] = c_exp_table_lm[15 - lane];
     for (int w = lane; w < nsets * G && !bad; w += WAVE) {
@@ -801,6 +824,18 @@ __global__ __launch_bounds__(WAVE) void lm_eval_fd_kernel(
     const int nty = (nrow + TILE_H - 1) / TILE_H;
     const double *sval = val + st.pix_off;
     const double *sierr = ierr + st.pix_off;
+    // (coellip of one gaussian has NLOC == 6 too, and no cen-shifted sets to
+    // speak of beyond k = 1, 2: the centres are local parameters 0 and 1 of
+    // every model)
+    if (lane == 0) {
+        unif[NLOC + 0] = ev[0].row;
+        unif[NLOC + 1] = ev[0].col;
+        unif[NLOC + 2] = want_jac ? ev[G].row : ev[0].row;
+        unif[NLOC + 3] = want_jac ? ev[G].col : ev[0].col;
+        unif[NLOC + 4] = want_jac ? ev[2 * G].row : ev[0].row;
+        unif[NLOC + 5] = want_jac ? ev[2 * G].col : ev[0].col;
+    }
+    __syncthreads();
 
     // J^T J, J^T f and f.f are X^T X for X = [J | f] (pixels x 16): a sum of
     // outer products over the pixels -- v_mfma_f64_16x16x4_f64, four pixels
@@ -827,81 +862,138 @@ __global__ __launch_bounds__(WAVE) void lm_eval_fd_kernel(
         }
     };
 
-    int ty = 0, tx = 0;
-    double nval, nierr;
-    load_tile(ty, tx, nval, nierr);
-    while (ty < nty) {
-        const double pval = nval, pierr = nierr;
-        int ty2 = ty, tx2 = tx + 1;
-        if (tx2 == ntx) {
-            tx2 = 0;
-            ty2++;
-        }
-        load_tile(ty2, tx2, nval, nierr);
+    // the tile loop; COCEN: one centre per set (see above)
+    auto tiles = [&](auto cocen_c) {
+        constexpr bool COCEN = decltype(cocen_c)::value;
+        int ty = 0, tx = 0;
+        double nval, nierr;
+        load_tile(ty, tx, nval, nierr);
+        while (ty < nty) {
+            const double pval = nval, pierr = nierr;
+            int ty2 = ty, tx2 = tx + 1;
+            if (tx2 == ntx) {
+                tx2 = 0;
+                ty2++;
+            }
+            load_tile(ty2, tx2, nval, nierr);
 
-        const int r0 = ty * TILE_H, c0 = tx * TILE_W;
-        const double rowd = (double)(r0 + lrow) - jac.row0;
-        const double cold = (double)(c0 + lcol) - jac.col0;
-        const double v = fma(jac.dvdrow, rowd, jac.dvdcol * cold);
-        const double u = fma(jac.dudrow, rowd, jac.dudcol * cold);
-        double m[NSETS];
+            const int r0 = ty * TILE_H, c0 = tx * TILE_W;
+            const double rowd = (double)(r0 + lrow) - jac.row0;
+            const double cold = (double)(c0 + lcol) - jac.col0;
+            const double v = fma(jac.dvdrow, rowd, jac.dvdcol * cold);
+            const double u = fma(jac.dudrow, rowd, jac.dudcol * cold);
+            // dv^2, du^2, dv du about the three centres
+            double q0[3] = {0.0, 0.0, 0.0}, q1[3] = {0.0, 0.0, 0.0}, q2[3] = {0.0, 0.0, 0.0};
+            if (COCEN) {
+                const double dv0 = v - unif[NLOC + 0], du0 = u - unif[NLOC + 1];
+                q0[0] = dv0 * dv0;
+                q0[1] = du0 * du0;
+                q0[2] = dv0 * du0;
+                if (want_jac) {
+                    const double dv1 = v - unif[NLOC + 2], du1 = u - unif[NLOC + 3];
+                    q1[0] = dv1 * dv1;
+                    q1[1] = du1 * du1;
+                    q1[2] = dv1 * du1;
+                    const double dv2 = v - unif[NLOC + 4], du2 = u - unif[NLOC + 5];
+                    q2[0] = dv2 * dv2;
+                    q2[1] = du2 * du2;
+                    q2[2] = dv2 * du2;
+                }
+            }
+            double m[NSETS];
 #pragma unroll
-        for (int k = 0; k < NSETS; k++) m[k] = 0.0;
+            for (int k = 0; k < NSETS; k++) m[k] = 0.0;
 
-        for (int gb = 0; gb < G; gb += WAVE) {
-            const int gi = gb + lane < G ? gb + lane : gb;
-            const PixBox box = boxes[gi];
-            const bool hit = (gb + lane < G) & (r0 <= box.rmax) &
-                             (r0 + TILE_H - 1 >= box.rmin) & (c0 <= box.cmax) &
-                             (c0 + TILE_W - 1 >= box.cmin);
-            unsigned long long gmask = __ballot(hit);
-            while (gmask) {
-                const int g = gb + __builtin_ctzll(gmask);
-                gmask &= gmask - 1ull;
+            for (int gb = 0; gb < G; gb += WAVE) {
+                const int gi = gb + lane < G ? gb + lane : gb;
+                const PixBox box = boxes[gi];
+                const bool hit = (gb + lane < G) & (r0 <= box.rmax) &
+                                 (r0 + TILE_H - 1 >= box.rmin) & (c0 <= box.cmax) &
+                                 (c0 + TILE_W - 1 >= box.cmin);
+                unsigned long long gmask = __ballot(hit);
+                while (gmask) {
+                    const int g = gb + __builtin_ctzll(gmask);
+                    gmask &= gmask - 1ull;
 #pragma unroll
-                for (int k = 0; k < NSETS; k++) {
-                    if (k >= nsets) break;
-                    const FdGauss &E = ev[k * G + g];
-                    const double dv = v - E.row, du = u - E.col;
-                    const double y = fma(E.a, dv * dv, fma(E.b, du * du, E.c * (dv * du)));
-                    if (y < 12.5 && y >= 0.0) {
-                        double e = fexp_neg_fused(y, tabr, K);
-                        if (y > 10.0) {
-                            const double au = (12.5 - y) * 0.4;
-                            const double aq = fma(au, fma(au, K.w6, K.wm15), K.w10);
-                            e *= (au * au) * (au * aq);
+                    for (int k = 0; k < NSETS; k++) {
+                        if (k >= nsets) break;
+                        const FdGauss &E = ev[k * G + g];
+                        double y;
+                        if (COCEN) {
+                            const double *qq = k == 1 ? q1 : (k == 2 ? q2 : q0);
+                            y = fma(E.a, qq[0], fma(E.b, qq[1], E.c * qq[2]));
+                        } else {
+                            const double dv = v - E.row, du = u - E.col;
+                            y = fma(E.a, dv * dv, fma(E.b, du * du, E.c * (dv * du)));
                         }
-                        m[k] = fma(E.pa, e, m[k]);
+                        // 0 <= chi2 < 25 <=> y in [+0, 12.5): one unsigned compare on
+                        // the high word (the forms are positive definite after
+                        // gauss_set_norm; negative, nan, inf fail as they fail the
+                        // reference's test)
+                        if ((unsigned)__double2hiint(y) < 0x40290000u) {
+                            double e = fexp_neg_fused(y, tabr, K);
+                            // the apodised band 20 <= chi2 < 25: under a wave-level
+                            // branch (left to itself the compiler predicates the
+                            // nine instructions into every evaluation)
+                            const bool band = (unsigned)__double2hiint(y) >= 0x40240000u;
+                            if (__ballot(band) != 0ull) {
+                                if (band) {
+                                    const double au = (12.5 - y) * 0.4;
+                                    const double aq = fma(au, fma(au, K.w6, K.wm15), K.w10);
+                                    e *= (au * au) * (au * aq);
+                                }
+                            }
+                            m[k] = fma(E.pa, e, m[k]);
+                        }
                     }
                 }
             }
-        }
 
-        // a pixel outside the stamp or of zero weight has ierr == 0: its row
-        // is zero, except that a masked pixel may hold a non-finite value
-        const bool live = !masked || pierr > 0.0;
-        const double f = live ? (m[0] - pval) * pierr : 0.0;
-        if (!want_jac) {
-            ff = fma(f, f, ff);
-        } else {
-            double *jb = jbuf + lane * JSTRIDE;
+            // a pixel outside the stamp or of zero weight has ierr == 0: its row
+            // is zero, except that a masked pixel may hold a non-finite value
+            const bool live = !masked || pierr > 0.0;
+            const double f = live ? (m[0] - pval) * pierr : 0.0;
+            if (!want_jac) {
+                ff = fma(f, f, ff);
+            } else {
+                double *jb = jbuf + lane * JSTRIDE;
 #pragma unroll
-            for (int j = 0; j < NLOC; j++)
-                jb[j] = live ? (m[j + 1] - m[0]) * (pierr * ih[j]) : 0.0;
-            jb[NLOC] = f;
-            __syncthreads();   // one wave: orders the LDS traffic, no s_barrier
-            // A[i][k] = B[k][i] = X[pixel 4 t + k][i]: lane (i, k) reads one double
-            const double *src = jbuf + (lane >> 4) * JSTRIDE + (lane & 15);
+                for (int j = 0; j < NLOC; j++) {
+                    double d = m[j + 1] - m[0];
+                    if (j == NLOC - 1 && lin_flux) d = m[0] * flux_rel;
+                    jb[j] = live ? d * (pierr * unif[j]) : 0.0;
+                }
+                jb[NLOC] = f;
+                __syncthreads();   // one wave: orders the LDS traffic, no s_barrier
+                if (PACKED) {
+                    // X has at most 8 columns: two groups of four pixels side by
+                    // side, X' = [X_a | X_b] -- the diagonal 8 x 8 blocks of
+                    // X'^T X' are X_a^T X_a and X_b^T X_b (added at the end), and
+                    // eight instructions cover the tile instead of sixteen
+                    const double *src = jbuf + ((lane >> 4) + ((lane >> 1) & 4)) * JSTRIDE +
+                                        (lane & 7);
 #pragma unroll
-            for (int t = 0; t < 16; t++) {
-                const double x = src[4 * t * JSTRIDE];
-                M = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, M, 0, 0, 0);
+                    for (int t = 0; t < 8; t++) {
+                        const double x = src[8 * t * JSTRIDE];
+                        M = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, M, 0, 0, 0);
+                    }
+                } else {
+                    // A[i][k] = B[k][i] = X[pixel 4 t + k][i]: lane (i, k) reads one double
+                    const double *src = jbuf + (lane >> 4) * JSTRIDE + (lane & 15);
+#pragma unroll
+                    for (int t = 0; t < 16; t++) {
+                        const double x = src[4 * t * JSTRIDE];
+                        M = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, M, 0, 0, 0);
+                    }
+                }
+                __syncthreads();
             }
-            __syncthreads();
+            ty = ty2;
+            tx = tx2;
         }
-        ty = ty2;
-        tx = tx2;
-    }
+    };
+    if (cocen) tiles(std::true_type{});
+    else tiles(std::false_type{});
 
     if (!want_jac) {
         const double tot = wave_total(ff);
@@ -909,6 +1001,12 @@ __global__ __launch_bounds__(WAVE) void lm_eval_fd_kernel(
         if (lane == 0) out[NSUM - 1] = tot;
     } else {
         const int col = lane & 15;
+        if (PACKED) {
+            // entry (row, col) += entry (row + 8, col + 8): eight lanes up, two
+            // registers on
+            M[0] += __shfl_down(M[2], 8, WAVE);
+            M[1] += __shfl_down(M[3], 8, WAVE);
+        }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = (lane >> 4) + 4 * r;
