@@ -76,14 +76,13 @@ class AdmomResult(dict):
         self.update(result)
 
     def get_gmix(self):
-        if self["flags"] != 0:
+        """the fitted gaussian, unit flux: the moment ratios M1/T, M2/T are an
+        (e1, e2) ellipticity, which the mixture wants as a reduced shear"""
+        if self["flags"]:
             raise RuntimeError("cannot create gmix, fit failed")
-        pars = self["pars"].copy()
-        pars[5] = 1.0
-        g1, g2 = e1e2_to_g1g2(pars[2] / pars[4], pars[3] / pars[4])
-        pars[2] = g1
-        pars[3] = g2
-        return GMixModel(pars, "gauss")
+        row, col, m1, m2, T = self["pars"][:5]
+        g1, g2 = e1e2_to_g1g2(m1 / T, m2 / T)
+        return GMixModel(np.array([row, col, g1, g2, T, 1.0]), "gauss")
 
     def make_image(self):
         if self["flags"] != 0:
@@ -139,15 +138,16 @@ class AdmomFitter(object):
         return self.rng
 
     def _generate_guess(self, obs, Tguess):
-        # RNG call order as the reference: cen(2), g(2), T(1) (admom.py:398-400)
-        rng = self._get_rng()
-        scale = obs.jacobian.get_scale()
-        pars = np.zeros(6)
-        pars[0:2] = rng.uniform(low=-0.5 * scale, high=0.5 * scale, size=2)
-        pars[2:4] = rng.uniform(low=-0.3, high=0.3, size=2)
-        pars[4] = Tguess * (1.0 + rng.uniform(low=-0.1, high=0.1))
-        pars[5] = 1.0
-        return GMixModel(pars, "gauss")
+        """a random round-ish unit-flux gaussian around the canonical centre.
+        The ORDER of the draws is part of the contract (a seeded reference run
+        must see the same stream, admom.py:398-400): the centre pair within
+        half a pixel, the shape pair within 0.3, then T within 10 %."""
+        draw = self._get_rng().uniform
+        half_pixel = 0.5 * obs.jacobian.get_scale()
+        cen = draw(-half_pixel, half_pixel, 2)
+        shape = draw(-0.3, 0.3, 2)
+        T = Tguess * (1.0 + draw(-0.1, 0.1))
+        return GMixModel(np.concatenate([cen, shape, [T, 1.0]]), "gauss")
 
 
 def get_result(ares, jac_area, wgt_norm):

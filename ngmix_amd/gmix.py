@@ -160,22 +160,22 @@ class GMix(object):
     """
 
     def __init__(self, ngauss=None, pars=None):
-        self._model = GMIX_FULL
-        self._model_name = "full"
-        if ngauss is None and pars is None:
-            raise ValueError("send ngauss= or pars=")
-        if pars is not None:
-            npars = len(pars)
-            if (npars % 6) != 0:
-                raise ValueError("len(pars) must be mutiple of 6 got %s" % npars)
-            self._ngauss = npars // 6
-            self._npars = npars
-            self.reset()
-            self._fill(pars)
-        else:
-            self._ngauss = ngauss
-            self._npars = 6 * ngauss
-            self.reset()
+        self._model, self._model_name = GMIX_FULL, "full"
+        if pars is None:
+            if ngauss is None:
+                raise ValueError("send ngauss= or pars=")
+            self._allocate(ngauss, 6 * ngauss)
+            return
+        count, leftover = divmod(len(pars), 6)
+        if leftover:
+            raise ValueError("len(pars) must be mutiple of 6 got %s" % len(pars))
+        self._allocate(count, len(pars))
+        self._fill(pars)
+
+    def _allocate(self, ngauss, npars):
+        """size the parameter vector and the gauss2d record array (zeroed)"""
+        self._ngauss, self._npars = ngauss, npars
+        self.reset()
 
     # ---- storage
     def reset(self):
@@ -221,16 +221,13 @@ class GMix(object):
         self._data["col"] += col - col0
 
     def _second_moments(self):
+        """flux-weighted covariance of the whole mixture about its centroid: the
+        mean of the components' own covariances plus the scatter of their centres"""
         gm = self._data
-        row, col = self.get_cen()
-        rowdiff = gm["row"] - row
-        coldiff = gm["col"] - col
-        p = gm["p"]
-        ipsum = 1.0 / p.sum()
-        irr = ((gm["irr"] + rowdiff ** 2) * p).sum() * ipsum
-        irc = ((gm["irc"] + rowdiff * coldiff) * p).sum() * ipsum
-        icc = ((gm["icc"] + coldiff ** 2) * p).sum() * ipsum
-        return irr, irc, icc
+        w = gm["p"] / gm["p"].sum()
+        dr = gm["row"] - w @ gm["row"]
+        dc = gm["col"] - w @ gm["col"]
+        return w @ (gm["irr"] + dr * dr), w @ (gm["irc"] + dr * dc), w @ (gm["icc"] + dc * dc)
 
     def get_T(self):
         irr, _, icc = self._second_moments()
@@ -452,15 +449,15 @@ class GMix(object):
 class GMixModel(GMix):
     """mixture built from model parameters, e.g. GMixModel(pars, 'exp')"""
 
+    _KNOWN = frozenset(("gauss", "turb", "exp", "dev", "bd", "bdf", "cm", "coellip", "full"))
+
     def __init__(self, pars, model):
-        self._model = get_model_num(model)
-        self._model_name = get_model_name(self._model)
-        if self._model_name not in ("gauss", "turb", "exp", "dev", "bd", "bdf",
-                                    "cm", "coellip", "full"):
-            raise ValueError("bad model: '%s'" % self._model_name)
-        self._ngauss = get_model_ngauss(self._model)
-        self._npars = get_model_npars(self._model)
-        self.reset()
+        num = get_model_num(model)
+        name = get_model_name(num)
+        if name not in self._KNOWN:
+            raise ValueError("bad model: '%s'" % name)
+        self._model, self._model_name = num, name
+        self._allocate(get_model_ngauss(num), get_model_npars(num))
         self.fill(pars)
 
     def copy(self):
@@ -504,15 +501,12 @@ class GMixCoellip(GMixModel):
     """co-centric, co-elliptical gaussians: [cen1,cen2,g1,g2,T1..,F1..]"""
 
     def __init__(self, pars):
-        self._model = GMIX_COELLIP
-        self._model_name = "coellip"
-        npars = len(pars)
-        if ((npars - 4) % 2) != 0:
-            raise ValueError("coellip must have len(pars)==4+2*ngauss, got %s"
-                             % npars)
-        self._ngauss = (npars - 4) // 2
-        self._npars = npars
-        self.reset()
+        # four shared parameters, then one (T, F) pair per gaussian
+        pairs, odd = divmod(len(pars) - 4, 2)
+        if odd:
+            raise ValueError("coellip must have len(pars)==4+2*ngauss, got %s" % len(pars))
+        self._model, self._model_name = GMIX_COELLIP, "coellip"
+        self._allocate(pairs, len(pars))
         self._fill(pars)
 
     def copy(self):

@@ -42,57 +42,59 @@ def get_step(pars, ipar, nband):
 
 def apply_noise_cov(fit_model, result):
     """replace the chi^2-scaled covariance of a successful fit with the
-    sandwich covariance (noise_cov.py:36-88); result is modified in place"""
+    sandwich covariance (noise_cov.py:36-88); result is modified in place.
+    A fit that failed, or whose curvature is not finite, is left alone; a
+    sandwich that cannot be evaluated (a central-difference step left the
+    model's domain) or is not finite is reported through the covariance flags
+    exactly as a negative-definite one is, with the default errors."""
     from .fitting import _test_cov, _get_def_stuff
-    if result["flags"] != 0:
-        return
-    pcov0 = result.get("pars_cov0")
-    if pcov0 is None or not np.all(np.isfinite(pcov0)):
+    curvature = result.get("pars_cov0") if result["flags"] == 0 else None
+    if curvature is None or not np.isfinite(curvature).all():
         return
     npars = result["pars"].size
-    try:
-        cov = calc_noise_cov(fit_model=fit_model, pars=result["pars"], pars_cov0=pcov0)
-    except GMixRangeError:
-        cov = np.full((npars, npars), np.nan)
-    if not np.all(np.isfinite(cov)):
-        cflags = _test_cov(np.diag(np.full(npars, -1.0)))
-    else:
-        cflags = _test_cov(cov)
-    if cflags != 0:
-        result["flags"] |= cflags
+    cov = _sandwich_or_none(fit_model, result["pars"], curvature)
+    bits = _test_cov(cov if cov is not None else -np.eye(npars))
+    if bits:
+        result["flags"] |= bits
         result["errmsg"] = "bad noise covariance matrix"
-        _, result["pars_cov"], result["pars_err"] = _get_def_stuff(npars)
-    else:
-        result["pars_cov"] = cov
-        result["pars_err"] = np.sqrt(np.diag(cov))
+        result["pars_cov"], result["pars_err"] = _get_def_stuff(npars)[1:]
+        return
+    result["pars_cov"] = cov
+    result["pars_err"] = np.sqrt(cov.diagonal())
+
+
+def _sandwich_or_none(fit_model, pars, curvature):
+    try:
+        cov = calc_noise_cov(fit_model=fit_model, pars=pars, pars_cov0=curvature)
+    except GMixRangeError:
+        return None
+    return cov if np.isfinite(cov).all() else None
 
 
 def calc_noise_cov(fit_model, pars, pars_cov0):
-    """pars_cov0 B pars_cov0 with B from the per-mode noise power of every
-    epoch's attached noise image (noise_cov.py:91-137)"""
+    """pars_cov0 B pars_cov0 (noise_cov.py:91-137).  B sums, over every epoch,
+    the noise power spectrum P = |FFT(noise image)|^2 weighted by the transforms
+    K_a = FFT(weight * d model / d p_a) of the epoch's derivative images:
+    B_ab += Re sum_k conj(K_a) K_b P / npix^2, a and b running over the shape
+    parameters and the epoch's own band flux."""
     npars = pars.size
     nband = fit_model.nband
     nshape = npars - nband
-    all_images = _dmodel_images_all(fit_model, pars)
+    per_obs = iter(_dmodel_images_all(fit_model, pars))
     B = np.zeros((npars, npars))
-    i = 0
     for band in range(nband):
-        kpars = list(range(nshape)) + [nshape + band]
+        idx = np.r_[np.arange(nshape), nshape + band]
         for obs in fit_model.obs[band]:
-            dimages = all_images[i]
-            i += 1
+            dimages = next(per_obs)
             if not obs.has_noise():
                 raise ValueError("use_noise_image needs a noise image in every "
                                  "observation")
-            kernels = [np.fft.fft2(obs.weight * dim) for dim in dimages]
-            p = np.abs(np.fft.fft2(obs.noise)) ** 2
-            n = obs.image.size
-            for ia in range(len(kpars)):
-                for ib in range(ia, len(kpars)):
-                    val = np.sum(np.conj(kernels[ia]) * kernels[ib] * p).real / n ** 2
-                    B[kpars[ia], kpars[ib]] += val
-                    if ib != ia:
-                        B[kpars[ib], kpars[ia]] += val
+            K = np.fft.fft2(obs.weight[None, :, :] * np.asarray(dimages), axes=(1, 2))
+            power = np.abs(np.fft.fft2(obs.noise)) ** 2
+            # the upper triangle, mirrored: B stays exactly symmetric
+            block = np.einsum("aij,bij,ij->ab", K.conj(), K, power).real
+            block = np.triu(block) + np.triu(block, 1).T
+            B[np.ix_(idx, idx)] += block / float(obs.image.size) ** 2
     return pars_cov0 @ B @ pars_cov0
 
 
@@ -139,19 +141,21 @@ def _dmodel_images_all(fit_model, pars, force_fd=False):
 
 
 def _dmodel(fit_model, pars, ipar, band, obs):
-    """central difference derivative image of the convolved model with respect
-    to one parameter (noise_cov.py:200-224): two fast renders"""
-    step = get_step(pars=pars, ipar=ipar, nband=fit_model.nband)
-    ims = []
-    for sign in (1, -1):
-        p = pars.copy()
-        p[ipar] += sign * step
-        band_pars = fit_model.get_band_pars(pars=p, band=band)
-        gm = gmix_mod.make_gmix_model(band_pars, fit_model.model)
+    """d(convolved model image) / d(parameter ipar) by a central difference of
+    two fast renders -- the exponential and apodised truncation of the fit's own
+    objective (noise_cov.py:200-224); the step is get_step's"""
+    h = get_step(pars=pars, ipar=ipar, nband=fit_model.nband)
+
+    def render_at(offset):
+        shifted = np.array(pars, dtype="f8")
+        shifted[ipar] += offset
+        mix = gmix_mod.make_gmix_model(fit_model.get_band_pars(pars=shifted, band=band),
+                                       fit_model.model)
         if obs.has_psf_gmix():
-            gm = gm.convolve(obs.psf.gmix)
-        ims.append(gm.make_image(obs.image.shape, jacobian=obs.jacobian, fast_exp=True))
-    return (ims[0] - ims[1]) / (2 * step)
+            mix = mix.convolve(obs.psf.gmix)
+        return mix.make_image(obs.image.shape, jacobian=obs.jacobian, fast_exp=True)
+
+    return (render_at(h) - render_at(-h)) / (2 * h)
 
 
 # ---------------------------------------------------------------------------

@@ -63,19 +63,18 @@ class Observation(MetadataMixin):
         self._writeable = False
         self._ignore_zero_weight = ignore_zero_weight
         self._store_pixels = store_pixels
-        self._pixels = None
-        self._stamp = None
-        self.set_image(image, update_pixels=False)
-        self.set_weight(weight, update_pixels=False)
-        self.set_jacobian(jacobian, update_pixels=False)
+        self._pixels = self._stamp = None
+        # image, weight and jacobian define the pixel list: set all three, then
+        # derive it once; the rest are plain attributes
+        for setter, value in ((self.set_image, image), (self.set_weight, weight),
+                              (self.set_jacobian, jacobian)):
+            setter(value, update_pixels=False)
         self.update_pixels()
-        self.set_meta(meta)
-        self.set_bmask(bmask)
-        self.set_ormask(ormask)
-        self.set_noise(noise)
-        self.set_gmix(gmix)
-        self.set_psf(psf)
-        self.set_mfrac(mfrac)
+        for setter, value in ((self.set_meta, meta), (self.set_bmask, bmask),
+                              (self.set_ormask, ormask), (self.set_noise, noise),
+                              (self.set_gmix, gmix), (self.set_psf, psf),
+                              (self.set_mfrac, mfrac)):
+            setter(value)
 
     # ---- views
     def _get_view(self, data):
@@ -179,14 +178,15 @@ class Observation(MetadataMixin):
         self.set_weight(weight)
 
     def set_weight(self, weight, update_pixels=True):
-        image = self._image
-        if weight is not None:
-            weight = np.asarray(weight, dtype="f8")
-            assert len(weight.shape) == 2, "weight must be 2d"
-            assert weight.shape == image.shape, "image and weight must be same shape"
+        """the weight map, same shape as the image; None means unit weights"""
+        shape = self._image.shape
+        if weight is None:
+            wt = np.ones(shape)
         else:
-            weight = np.zeros(image.shape) + 1.0
-        self._weight = weight
+            wt = np.asarray(weight, dtype="f8")
+            assert wt.ndim == 2, "weight must be 2d"
+            assert wt.shape == shape, "image and weight must be same shape"
+        self._weight = wt
         if update_pixels:
             self.update_pixels()
 
