@@ -1069,7 +1069,8 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
 
     // ---- the stamp, once from HBM
     double pv[PPT], pu[PPT], pval[PPT];
-    unsigned kept = 0u;
+    // one kept bit per slot, slots 32 .. PPT-1 in a second word
+    unsigned kept = 0u, kept_hi = 0u;
     int my_last = -1, my_zero = 0;
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
@@ -1078,7 +1079,8 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
         if (p < n) {
             double a, val, ierr;
             if (src.load(p, pv[k], pu[k], a, val, ierr)) {
-                kept |= 1u << k;
+                if (k < 32) kept |= 1u << k;
+                else kept_hi |= 1u << (k - 32);
                 pval[k] = val;
                 my_last = p;
                 if (ierr * ierr == 0.0) my_zero = 1;  // admom_nb.py:146
@@ -1089,7 +1091,7 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
     const FexpCoef K = load_fexp_coef(c_fexp_coef_m);
     const int last_pos = group_max_int<NT>(my_last, sh.iscratch);
     const int has_zero = group_max_int<NT>(my_zero, sh.iscratch);
-    const int npix = group_sum_int<NT>(__popc(kept), sh.iscratch);
+    const int npix = group_sum_int<NT>(__popc(kept) + __popc(kept_hi), sh.iscratch);
     const double area = src.area;
     int phase = 0;
 
@@ -1187,9 +1189,11 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
                 // (the bit is extracted by a volatile asm: as plain C the
                 // sixteen (double) conversions are hoisted out of the iteration
                 // loop and pin 32 registers)
-                unsigned kbit = (kept >> k) & 1u;
+                const unsigned kword = k < 32 ? kept : kept_hi;
+                const int kpos = k & 31;
+                unsigned kbit = (kword >> kpos) & 1u;
                 if (ALLCHUNKS)
-                    asm volatile("v_bfe_u32 %0, %1, %2, 1" : "=v"(kbit) : "v"(kept), "v"(k));
+                    asm volatile("v_bfe_u32 %0, %1, %2, 1" : "=v"(kbit) : "v"(kword), "v"(kpos));
                 a[7] = fma(weight, (double)kbit, a[7]);
                 if (ALLCHUNKS)
                     asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]),
@@ -1304,7 +1308,7 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
             if (want_cov) {
                 const double weight = weight_fused(chi2, used_pa, sh.tab, K);
                 double w2var = 0.0;
-                if ((kept >> k) & 1u) {
+                if (((k < 32 ? kept : kept_hi) >> (k & 31)) & 1u) {
                     const double ierr = src.ierr[p];
                     w2var = weight * weight * (1.0 / (ierr * ierr));
                 }
@@ -1382,12 +1386,21 @@ __global__ __launch_bounds__(NT) void admom_grid_kernel(
         // (nearly) every register slot holds a pixel: evaluate all PPT slots --
         // an empty slot has val == 0 and kept bit 0 and adds exactly nothing
         const int nchunk = (st.nrow * st.ncol + NT - 1) / NT;
-        if (NT == WAVE && nchunk * 8 >= PPT * 7)
-            admom_fused_body<NT, PPT, NT == WAVE>(src, conf, wt + st.gm_off, res + s,
+        // More than sixteen slots per lane (36 x 64 and 18 x 128 = 48 x 48, the
+        // north-star stamp): only the compile-time form -- the run-time indexed
+        // one would put its arrays in private memory.
+        constexpr bool kOnlyUnrolled = PPT > 16;
+        if constexpr (kOnlyUnrolled) {
+            admom_fused_body<NT, PPT, true>(src, conf, wt + st.gm_off, res + s,
                                             status ? status + s : nullptr, sh);
-        else
-            admom_fused_body<NT, PPT, false>(src, conf, wt + st.gm_off, res + s,
-                                             status ? status + s : nullptr, sh);
+        } else {
+            if (NT == WAVE && nchunk * 8 >= PPT * 7)
+                admom_fused_body<NT, PPT, NT == WAVE>(src, conf, wt + st.gm_off, res + s,
+                                                status ? status + s : nullptr, sh);
+            else
+                admom_fused_body<NT, PPT, false>(src, conf, wt + st.gm_off, res + s,
+                                                 status ? status + s : nullptr, sh);
+        }
     } else {
         // stamps too large for registers: streaming passes, reference order
         __shared__ AdmomShared sh;
@@ -1426,11 +1439,18 @@ int launch_admom_grid(const ngmix_admom_conf *conf, const ngmix_batch *b,
     int nt = 0;
     if (const char *e = getenv("NGMIX_ADMOM_NT")) nt = atoi(e);
     const int np = b->max_npix;
-    if (nt == 0) nt = np <= 16 * 64 ? 64 : (np <= 16 * 128 ? 128 : 256);
+    // (48 x 48 = 36 x 64 runs as ONE wave, every slot in registers: 9.6 ms per
+    // 100k stamps against 11.6 with two waves and 18.7 with four; 64 x 64 = 32 x
+    // 128 as two: 8.9 ms per 50k against 12.7 with four)
+    if (nt == 0)
+        nt = np <= 16 * 64 ? 64
+             : (np <= 16 * 128 ? 128 : (np <= 36 * 64 ? 64 : (np <= 32 * 128 ? 128 : 256)));
     if (nt == 64 && np <= 8 * 64) admom_launch<64, 8>(conf, b, wt, res, status, s);
     else if (nt == 64 && np <= 16 * 64) admom_launch<64, 16>(conf, b, wt, res, status, s);
     else if (nt <= 128 && np <= 8 * 128) admom_launch<128, 8>(conf, b, wt, res, status, s);
     else if (nt <= 128 && np <= 16 * 128) admom_launch<128, 16>(conf, b, wt, res, status, s);
+    else if (nt == 64 && np <= 36 * 64) admom_launch<64, 36>(conf, b, wt, res, status, s);
+    else if (nt == 128 && np <= 32 * 128) admom_launch<128, 32>(conf, b, wt, res, status, s);
     else if (np <= 4 * BLOCK) admom_launch<BLOCK, 4>(conf, b, wt, res, status, s);
     else if (np <= 8 * BLOCK) admom_launch<BLOCK, 8>(conf, b, wt, res, status, s);
     else if (np <= 16 * BLOCK) admom_launch<BLOCK, 16>(conf, b, wt, res, status, s);

@@ -429,6 +429,60 @@ def test_em_multi_wave_vs_reference_order_kernel(dim, kind):
         np.testing.assert_allclose(c1[f], c2[f], rtol=1e-9, atol=1e-11, err_msg=f)
 
 
+@pytest.mark.parametrize("shape", [(25, 25), (32, 32), (40, 44), (45, 47), (48, 48), (56, 60),
+                                   (64, 64), (72, 70)])
+def test_admom_kernel_variants_vs_oracle(shape):
+    """the kernel is chosen by the batch's largest stamp: one batch per shape
+    class runs each variant on its own -- one wave with 16 or 36 register
+    slots per lane (<= 32x32, 48x48), two waves with 16 or 32 (<= 2048 px,
+    64x64), four waves, the streaming kernel -- against the oracle: exact
+    numiter and flags, the record to 1e-10"""
+    import ngmix_amd as ngmix
+    from ngmix_amd.batch import StampBatch, GMixBatch, records_to_numpy
+    from oracle import oracle as ora
+    nrow, ncol = shape
+    rng = np.random.RandomState(nrow * 100 + ncol)
+    scale = 0.263
+    nst = 5
+    obs, jrecs, Ts = [], [], []
+    for k in range(nst):
+        jac = ngmix.DiagonalJacobian(row=(nrow - 1) / 2.0 + rng.uniform(-0.4, 0.4),
+                                     col=(ncol - 1) / 2.0 + rng.uniform(-0.4, 0.4), scale=scale)
+        T = 0.3 + 0.012 * min(nrow, ncol) * rng.uniform(0.7, 1.2)
+        gm = ngmix.GMixModel([rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05),
+                              rng.uniform(-0.15, 0.15), rng.uniform(-0.15, 0.15), T, 40.0],
+                             "gauss")
+        im = gm.make_image((nrow, ncol), jacobian=jac)
+        im += 0.003 * rng.normal(size=im.shape)
+        wt = np.full(im.shape, 1.0 / 0.003 ** 2)
+        if k % 2:
+            wt[nrow // 3, ncol // 2] = 0.0      # a masked pixel in every other stamp
+        obs.append(ngmix.Observation(im, weight=wt, jacobian=jac))
+        jrecs.append(jac.get_data().view(np.float64).reshape(8))
+        Ts.append(T)
+    sb = StampBatch.from_observations(obs)
+    guess = np.zeros((nst, 6))
+    guess[:, 4] = np.array(Ts) * rng.uniform(0.85, 1.2, size=nst)
+    guess[:, 5] = 1.0
+    wt, _ = GMixBatch.from_pars(guess, "gauss")
+    wt_in = wt.to_numpy()
+    res, status = sb.admom(wt)
+    assert int(status.abs().sum()) == 0
+    res = records_to_numpy(res, _lib.ADMOM_RESULT_DTYPE)
+    wt_out = wt.to_numpy()
+    conf = np.zeros(1, dtype=ora.ADMOM_CONF_DTYPE)
+    conf["maxiter"], conf["shiftmax"], conf["etol"], conf["Ttol"] = 200, 5.0, 1e-5, 1e-3
+    for i, o in enumerate(obs):
+        j = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+        j[0] = tuple(jrecs[i])
+        pix = ora.make_pixels(o.image, o.weight, j, True)
+        w = conv_rec(wt_in[i], ora.GAUSS2D_DTYPE)
+        r = np.zeros(1, dtype=ora.ADMOM_RESULT_DTYPE)
+        assert ora.admom(conf, w, pix, r) == 0
+        assert r["flags"][0] == 0 and 2 <= r["numiter"][0] < 60
+        _check_admom("shape %s stamp %d" % (shape, i), res[i:i + 1], wt_out[i], r, w)
+
+
 def test_admom_and_em_ragged_shapes_vs_oracle():
     """one batch holding tiny, odd-shaped and > 4096-pixel stamps (every
     kernel variant: one / two / four waves per stamp and the generic
