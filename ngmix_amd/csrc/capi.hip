@@ -633,7 +633,7 @@ int ngmix_simple_sep_prior_eval(const ngmix_simple_sep_prior *prior, const doubl
 int64_t ngmix_lm_advance_host(ngmix_lm_state *states, int64_t nobj, const double *ff,
                               const double *g, const double *A)
 {
-    // fits of 6, 7 or 8 parameters run the code the device runs for them
+    // fits of 6 .. 10 parameters run the code the device runs for them
     // (NGMIX_LM_GENERIC: the generic code, for comparing the two)
     const bool generic = getenv("NGMIX_LM_GENERIC") != nullptr;
     int64_t running = 0;
@@ -641,10 +641,12 @@ int64_t ngmix_lm_advance_host(ngmix_lm_state *states, int64_t nobj, const double
         const double *gi = g + i * NGMIX_LM_NPMAX;
         const double *Ai = A + i * NGMIX_LM_NPMAX * NGMIX_LM_NPMAX;
         const int n = states[i].n;
-        if (generic || n < 6 || n > 8) lmcore::lm_advance(states[i], ff[i], gi, Ai);
+        if (generic || n < 6 || n > 10) lmcore::lm_advance(states[i], ff[i], gi, Ai);
         else if (n == 6) lm_advance_host_reg<6>(states[i], ff[i], gi, Ai);
         else if (n == 7) lm_advance_host_reg<7>(states[i], ff[i], gi, Ai);
-        else lm_advance_host_reg<8>(states[i], ff[i], gi, Ai);
+        else if (n == 8) lm_advance_host_reg<8>(states[i], ff[i], gi, Ai);
+        else if (n == 9) lm_advance_host_reg<9>(states[i], ff[i], gi, Ai);
+        else lm_advance_host_reg<10>(states[i], ff[i], gi, Ai);
         if (states[i].phase != NGMIX_LM_PHASE_DONE) running++;
     }
     return running;

@@ -403,12 +403,12 @@ def test_batch_prior_equals_the_reference_prior(golden, tag):
         np.testing.assert_allclose(l[0], g[tag + "_prior_lnp"][i], rtol=1e-12)
 
 
-@pytest.mark.parametrize("n", [6, 7, 8])
+@pytest.mark.parametrize("n", [6, 7, 8, 9, 10])
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("bounded", [False, True])
 def test_register_form_equals_generic_form_bit_for_bit(n, mode, bounded, monkeypatch):
     """lm_core_reg.hpp (compile-time parameter count, arrays in registers: what
-    the device runs for 6-8 parameters) against lm_core.hpp: the same state
+    the device runs for 6-10 parameters) against lm_core.hpp: the same state
     record, byte for byte, after every step of every fit -- including a
     rank-deficient jacobian and rejected steps"""
     L = _lib.lib()
