@@ -137,7 +137,7 @@ __device__ __forceinline__ void em_wave_body(
     // ---- the stamp, once from HBM, into registers
     const int n = src.count();
     double pv[PPT], pu[PPT], pval[PPT];
-    unsigned kept = 0u, zw = 0u;
+    unsigned long long kept = 0ull, zw = 0ull;   // one bit per slot (PPT <= 64)
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
         const int p = lane + k * NT;
@@ -145,13 +145,13 @@ __device__ __forceinline__ void em_wave_body(
         if (p < n) {
             double a, ierr;
             if (src.load(p, pv[k], pu[k], a, pval[k], ierr)) {
-                kept |= 1u << k;
-                if (ierr <= 0.0) zw |= 1u << k;
+                kept |= 1ull << k;
+                if (ierr <= 0.0) zw |= 1ull << k;
             }
         }
     }
     const double area = src.area;
-    double cnt[1] = {(double)__popc(kept)};
+    double cnt[1] = {(double)__popcll(kept)};
 
     if (lane < 16) {
         sh.tab[lane] = c_exp_table_e[lane];
@@ -241,10 +241,10 @@ __device__ __forceinline__ void em_wave_body(
 
         // fill_zero_weight_pixels overwrites val of the zero-weight pixels
         // with sky + model, as the reference does in its pixel copy
-        if (fill_zero_weight && zw != 0u) {
+        if (fill_zero_weight && zw != 0ull) {
 #pragma unroll
             for (int k = 0; k < PPT; k++)
-                if (zw & (1u << k))
+                if (zw & (1ull << k))
                     pval[k] = em_fill_value(conv, nconv, pv[k], pu[k], area, sky, sh.tab);
         }
 
@@ -255,7 +255,7 @@ __device__ __forceinline__ void em_wave_body(
 
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
-            if (!(kept & (1u << k))) continue;
+            if (!(kept & (1ull << k))) continue;
             const double v = pv[k], u = pu[k];
             const double val_pix = pval[k];
             if constexpr (NPSF1) {
@@ -502,6 +502,15 @@ static void em_wave_launch(const ngmix_em_conf *conf, const ngmix_batch *b,
     if (np <= 16 * WAVE)
         em_wave_launch_nt<WAVE, 16, KIND, NG>(conf, b, gmix, psf, npsf, conv, sky_in, fzw,
                                               out, status, s);
+    else if (KIND == NGMIX_EM_FULL && np > 16 * 2 * WAVE && np <= 18 * 2 * WAVE)
+        // 48 x 48 = 18 x 128: two waves, 18 register slots per lane, like the
+        // two-wave kernel of <= 2048 pixels (9.6 ms per 50k 45 x 45 stamps) instead
+        // of four waves with 16 (20 ms per 50k).  One wave with 36 slots was
+        // measured too: 18 ms -- its 270-340 registers leave one wave per SIMD to
+        // a serial per-pixel chain.  (The full run only: every (kind, ngauss,
+        // psf) combination is a kernel of its own.)
+        em_wave_launch_nt<2 * WAVE, (KIND == NGMIX_EM_FULL ? 18 : 16), KIND, NG>(
+            conf, b, gmix, psf, npsf, conv, sky_in, fzw, out, status, s);
     else if (np <= 16 * 2 * WAVE)
         em_wave_launch_nt<2 * WAVE, 16, KIND, NG>(conf, b, gmix, psf, npsf, conv, sky_in,
                                                   fzw, out, status, s);

@@ -483,6 +483,71 @@ def test_admom_kernel_variants_vs_oracle(shape):
         _check_admom("shape %s stamp %d" % (shape, i), res[i:i + 1], wt_out[i], r, w)
 
 
+@pytest.mark.parametrize("shape", [(25, 25), (32, 32), (40, 44), (45, 47), (48, 48), (56, 60)])
+@pytest.mark.parametrize("ngauss", [1, 2])
+def test_em_kernel_variants_vs_oracle(shape, ngauss):
+    """one batch per shape class, so that each EM kernel variant runs on its own
+    (one wave / two waves with 16 or 18 register slots / four waves): em_run with
+    one and two gaussians against the oracle, exact numiter, mixtures to 1e-9"""
+    import ngmix_amd as ngmix
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    from oracle import oracle as ora
+    nrow, ncol = shape
+    rng = np.random.RandomState(nrow * 10 + ncol + ngauss)
+    scale, sky, nst = 0.263, 0.01, 4
+    obs, jrecs, Ts = [], [], []
+    for k in range(nst):
+        jac = ngmix.DiagonalJacobian(row=(nrow - 1) / 2.0 + rng.uniform(-0.4, 0.4),
+                                     col=(ncol - 1) / 2.0 + rng.uniform(-0.4, 0.4), scale=scale)
+        T = 0.3 + 0.01 * min(nrow, ncol) * rng.uniform(0.8, 1.2)
+        gm = ngmix.GMixModel([rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05),
+                              rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1), T, 30.0], "exp")
+        im = gm.make_image((nrow, ncol), jacobian=jac) + sky
+        im += 0.001 * rng.normal(size=im.shape)
+        wt = np.full(im.shape, 1.0 / 0.001 ** 2)
+        if k % 2:
+            wt[nrow // 4, ncol // 3] = 0.0
+        obs.append(ngmix.Observation(im, weight=wt, jacobian=jac))
+        jrecs.append(jac.get_data().view(np.float64).reshape(8))
+        Ts.append(T)
+    sb = StampBatch.from_observations(obs)
+    full = np.zeros((nst, ngauss, 6))
+    for i in range(ngauss):
+        full[:, i, 0] = 30.0 * scale ** 2 / ngauss * rng.uniform(0.9, 1.1, size=nst)
+        full[:, i, 1:3] = rng.uniform(-0.03, 0.03, size=(nst, 2))
+        full[:, i, 3] = 0.5 * np.array(Ts) * (0.6 + 0.9 * i)
+        full[:, i, 5] = 0.5 * np.array(Ts) * (0.6 + 0.9 * i)
+    gm0, _ = GMixBatch.from_pars(full.reshape(nst, -1), "full", ngauss=ngauss)
+    delta = np.zeros((nst, 6))
+    delta[:, 5] = 1.0
+    psf, _ = GMixBatch.from_pars(delta, "gauss")
+    gm_in = gm0.to_numpy().reshape(nst, ngauss)
+    psf_in = psf.to_numpy()
+    out, status, conv = sb.em(gm0, psf, sky=sky, miniter=20, maxiter=60, tol=1e-6)
+    assert int(status.abs().sum()) == 0
+    out = out.cpu().numpy()
+    gm_out = gm0.to_numpy().reshape(nst, ngauss)
+    econf = np.zeros(1, dtype=ora.EM_CONF_DTYPE)
+    econf["tol"], econf["maxiter"], econf["miniter"], econf["sky"] = 1e-6, 60, 20, sky
+    for i, o in enumerate(obs):
+        j = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+        j[0] = tuple(jrecs[i])
+        pix = ora.make_pixels(o.image, o.weight, j, True)
+        g = np.zeros(ngauss, dtype=ora.GAUSS2D_DTYPE)
+        for k in range(ngauss):
+            g[k] = conv_rec(gm_in[i, k], ora.GAUSS2D_DTYPE)[0]
+        p = conv_rec(psf_in[i], ora.GAUSS2D_DTYPE)
+        c = np.zeros(ngauss, dtype=ora.GAUSS2D_DTYPE)
+        ora.gmix_convolve_fill(c, g, p)
+        sums = np.zeros((ngauss, ora.EM_SUMS_NDOUBLE[0]))
+        st, numiter, frac, _ = ora.em_run(0, econf, pix, sums, g, p, c)
+        assert st == 0
+        assert int(out[i, 0]) == numiter, (shape, i)
+        for f in ("p", "row", "col", "irr", "irc", "icc"):
+            np.testing.assert_allclose(gm_out[i][f], g[f], rtol=1e-9, atol=1e-12,
+                                       err_msg="%s stamp %d %s" % (shape, i, f))
+
+
 def test_admom_and_em_ragged_shapes_vs_oracle():
     """one batch holding tiny, odd-shaped and > 4096-pixel stamps (every
     kernel variant: one / two / four waves per stamp and the generic
