@@ -391,6 +391,133 @@ def test_batch_forward_difference_mode(model):
         assert np.all(np.abs(pull) < 6.0)
 
 
+def _multi_gauss_psf(n, ngauss, offset, rng):
+    """n psf mixtures of ngauss gaussians (flux 1), co-centred or with offset
+    components, as 'full' parameter rows and as a GMixBatch"""
+    full = np.zeros((n, ngauss, 6))
+    frac = np.array([0.55, 0.25, 0.12, 0.05, 0.03])[:ngauss]
+    frac = frac / frac.sum()
+    for i in range(ngauss):
+        full[:, i, 0] = frac[i]
+        if offset:
+            full[:, i, 1:3] = rng.uniform(-0.04, 0.04, size=(n, 2)) * (i > 0)
+        sig2 = 0.135 * (1.0 + 0.9 * i)
+        full[:, i, 3] = sig2 * (1.0 + 0.05 * i)
+        full[:, i, 4] = 0.01 * sig2 * (-1) ** i
+        full[:, i, 5] = sig2
+    gm, st = GMixBatch.from_pars(full.reshape(n, -1), "full", ngauss=ngauss)
+    assert int(st.abs().sum()) == 0
+    return full.reshape(n, -1), gm
+
+
+def _objects_with_psf(n, model, psf, rng, dim=40, scale=0.263, noise=0.01, extra=None):
+    pars = np.zeros((n, 6))
+    pars[:, 0:2] = rng.uniform(-0.5, 0.5, size=(n, 2)) * scale
+    pars[:, 2:4] = rng.normal(scale=0.1, size=(n, 2))
+    pars[:, 4] = rng.uniform(0.3, 0.8, size=n)
+    pars[:, 5] = rng.uniform(80.0, 200.0, size=n)
+    if extra is not None:
+        pars = np.column_stack([pars[:, :5], extra, pars[:, 5]])
+    cen = (dim - 1) / 2.0
+    jac = np.array([cen, cen, scale, 0.0, 0.0, scale, scale ** 2, scale])
+    gm0, _ = GMixBatch.from_pars(pars, model)
+    gm, _ = gm0.convolve(psf)
+    geom = StampBatch.from_images(np.zeros((n, dim, dim)), None, jac)
+    truth, _ = geom.render(gm)
+    images = truth.cpu().numpy().reshape(n, dim, dim) + noise * rng.normal(size=(n, dim, dim))
+    weights = np.full((n, dim, dim), 1.0 / noise ** 2)
+    sb = StampBatch.from_images(images, weights, jac)
+    guess = pars * rng.uniform(0.93, 1.07, size=pars.shape)
+    guess[:, 0:2] = pars[:, 0:2] + rng.uniform(-0.04, 0.04, size=(n, 2))
+    guess[:, 2:4] = pars[:, 2:4] + rng.uniform(-0.02, 0.02, size=(n, 2))
+    jobj = ngmix.Jacobian(row=jac[0], col=jac[1], dvdrow=jac[2], dvdcol=jac[3],
+                          dudrow=jac[4], dudcol=jac[5])
+    return pars, guess, images, weights, jobj, sb
+
+
+def _fit_one_psf(model, image, weight, jobj, psf_full_row, guess, analytic):
+    pobs = ngmix.Observation(np.zeros((5, 5)), jacobian=jobj, gmix=ngmix.GMix(pars=psf_full_row))
+    obs = ngmix.Observation(image, weight=weight, jacobian=jobj, psf=pobs)
+    return ngmix.fitting.Fitter(model=model, analytic_jacobian=analytic).go(obs=obs, guess=guess)
+
+
+@pytest.mark.parametrize("model,npsf,offset", [("dev", 4, False), ("dev", 5, True),
+                                               ("exp", 3, True)])
+def test_analytic_fits_with_many_psf_gaussians(model, npsf, offset):
+    """lm_eval_kernel with more than 32 composed gaussians (dev (x) 4 or 5: the
+    per-tile box tests instead of the ten-tiles-per-ballot ones) and with psf
+    components off the psf centre, against the per-object Fitter"""
+    rng = np.random.RandomState(100 + npsf)
+    n = 6
+    psf_rows, psf = _multi_gauss_psf(n, npsf, offset, rng)
+    pars, guess, images, weights, jobj, sb = _objects_with_psf(n, model, psf, rng)
+    res = LMBatchFitter(model).go(sb, guess, psf=psf)
+    assert np.all(res["flags"] == 0)
+    for i in range(n):
+        one = _fit_one_psf(model, images[i], weights[i], jobj, psf_rows[i], guess[i], True)
+        assert one["flags"] == 0 and res["ier"][i] == one["ier"]
+        assert abs(int(res["nfev"][i]) - int(one["nfev"])) <= 1
+        assert np.all(np.abs(res["pars"][i] - one["pars"]) <= 1e-4 * one["pars_err"]), i
+        np.testing.assert_allclose(res["pars_err"][i], one["pars_err"], rtol=1e-3)
+        np.testing.assert_allclose(res["lnprob"][i], one["lnprob"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("model,npsf,offset", [("bdf", 2, False), ("bdf", 2, True),
+                                               ("turb", 3, True), ("exp", 1, False)])
+def test_forward_difference_fits_psf_centres_and_zero_flux_guess(model, npsf, offset):
+    """lm_eval_fd_kernel: the one-centre-per-set path (co-centred psf) and the
+    per-gaussian-centre path (psf components off centre), with the flux column
+    taken from the base model -- and, for one object, a guess with flux exactly
+    0 (that shortcut is then off) -- against the per-object Fitter's lmdif"""
+    rng = np.random.RandomState(300 + npsf + int(offset))
+    n = 6
+    psf_rows, psf = _multi_gauss_psf(n, npsf, offset, rng)
+    extra = rng.uniform(0.3, 0.7, size=n) if model == "bdf" else None
+    pars, guess, images, weights, jobj, sb = _objects_with_psf(n, model, psf, rng, extra=extra)
+    guess[0, -1] = 0.0
+    res = LMBatchFitter(model, analytic_jacobian=False).go(sb, guess, psf=psf)
+    checked = 0
+    for i in range(n):
+        one = _fit_one_psf(model, images[i], weights[i], jobj, psf_rows[i], guess[i], False)
+        if one["flags"] != 0 or res["flags"][i] != 0:
+            assert (one["flags"] != 0) == (res["flags"][i] != 0), i
+            continue
+        checked += 1
+        assert np.all(np.abs(res["pars"][i] - one["pars"]) <= 2e-2 * one["pars_err"]), (i, model)
+        np.testing.assert_allclose(res["pars_err"][i], one["pars_err"], rtol=2e-2)
+        np.testing.assert_allclose(res["lnprob"][i], one["lnprob"], rtol=1e-4)
+    assert checked >= n - 1
+
+
+def test_analytic_fit_of_a_stamp_with_more_tiles_than_lds_records():
+    """a 264 x 264 stamp has 1089 8x8 tiles, more than the tile records the
+    analytic LM kernel keeps in LDS: the kernel makes them on the fly"""
+    rng = np.random.RandomState(9)
+    dim, scale = 264, 0.263
+    pars = np.array([[0.05, -0.03, 0.1, -0.05, 20.0, 5000.0],
+                     [-0.1, 0.08, -0.08, 0.12, 35.0, 9000.0]])
+    psf_rows, psf = _multi_gauss_psf(2, 1, False, rng)
+    cen = (dim - 1) / 2.0
+    jac = np.array([cen, cen, scale, 0.0, 0.0, scale, scale ** 2, scale])
+    gm0, _ = GMixBatch.from_pars(pars, "gauss")
+    gm, _ = gm0.convolve(psf)
+    geom = StampBatch.from_images(np.zeros((2, dim, dim)), None, jac)
+    truth, _ = geom.render(gm)
+    images = truth.cpu().numpy().reshape(2, dim, dim) + 0.001 * rng.normal(size=(2, dim, dim))
+    weights = np.full((2, dim, dim), 1.0e6)
+    sb = StampBatch.from_images(images, weights, jac)
+    guess = pars * np.array([1.0, 1.0, 0.9, 1.1, 1.05, 0.95])
+    res = LMBatchFitter("gauss").go(sb, guess, psf=psf)
+    assert np.all(res["flags"] == 0)
+    jobj = ngmix.Jacobian(row=jac[0], col=jac[1], dvdrow=jac[2], dvdcol=jac[3],
+                          dudrow=jac[4], dudcol=jac[5])
+    for i in range(2):
+        one = _fit_one_psf("gauss", images[i], weights[i], jobj, psf_rows[i], guess[i], True)
+        assert one["flags"] == 0 and res["ier"][i] == one["ier"]
+        assert np.all(np.abs(res["pars"][i] - one["pars"]) <= 1e-4 * one["pars_err"]), i
+        np.testing.assert_allclose(res["lnprob"][i], one["lnprob"], rtol=1e-6)
+
+
 def test_bootstrap_batch_multiband_multiepoch():
     """objects with 2 bands x 2 epochs, different psf per epoch, sub-pixel
     offsets per epoch: one bootstrap_batch call recovers shape, size and both
