@@ -90,7 +90,7 @@ template <int N>
 static void lm_advance_host_reg(ngmix_lm_state &st, double ff, const double *g,
                                 const double *A)
 {
-    lmcore::lm_state_n<N> s;
+    lmreg::lm_state_n<N> s;
     lmreg::load_state<N>(s, st);
     double gc[N], Ac[N * N];
     for (int i = 0; i < N; i++) {

@@ -22,7 +22,23 @@ namespace lmreg {
 
 using lmcore::DWARF;
 using lmcore::EPSMCH;
-using lmcore::lm_state_n;
+
+// The live part of an ngmix_lm_state record in registers.  The arrays the step
+// only writes (x on an accepted step; xstep / hstep of forward-difference mode)
+// or reads under a bounds transform (lo, hi) are NOT copied: they are reached
+// through pointers into the record itself -- fifty doubles per ten parameters
+// that would otherwise sit in registers (or spill) for nothing.
+template <int N>
+struct lm_state_n {
+    double xt[N], diag[N], R[N * N], qtf[N], step[N];
+    double fnorm, xnorm, delta, par, gnorm, pnorm;
+    double ftol, xtol, gtol, factor;
+    double xi[N], xti[N];
+    double *x, *xstep, *hstep;   // into the record
+    const double *lo, *hi;       // into the record
+    int32_t ipvt[N];
+    int32_t n, iter, nfev, njev, info, phase, maxfev, mode, bounded;
+};
 
 #define LMREG_UNROLL _Pragma("unroll")
 
@@ -525,7 +541,7 @@ NGMIX_HD void lm_advance(lm_state_n<N> &s, double ff, const double (&g_in)[N],
 
 // between the ngmix_lm_state record (arrays of LM_NPMAX) and the compact state
 template <int N>
-NGMIX_HD void load_state(lm_state_n<N> &d, const lm_state &g)
+NGMIX_HD void load_state(lm_state_n<N> &d, lm_state &g)
 {
     d.n = g.n;
     d.iter = g.iter;
@@ -536,7 +552,6 @@ NGMIX_HD void load_state(lm_state_n<N> &d, const lm_state &g)
     d.maxfev = g.maxfev;
     d.mode = g.mode;
     d.bounded = g.bounded;
-    d.pad_ = g.pad_;
     d.fnorm = g.fnorm;
     d.xnorm = g.xnorm;
     d.delta = g.delta;
@@ -547,25 +562,26 @@ NGMIX_HD void load_state(lm_state_n<N> &d, const lm_state &g)
     d.xtol = g.xtol;
     d.gtol = g.gtol;
     d.factor = g.factor;
+    d.x = g.x;
+    d.xstep = g.xstep;
+    d.hstep = g.hstep;
+    d.lo = g.lo;
+    d.hi = g.hi;
     LMREG_UNROLL
     for (int j = 0; j < N; j++) {
-        d.x[j] = g.x[j];
         d.xt[j] = g.xt[j];
         d.diag[j] = g.diag[j];
         d.qtf[j] = g.qtf[j];
         d.step[j] = g.step[j];
         d.xi[j] = g.xi[j];
         d.xti[j] = g.xti[j];
-        d.lo[j] = g.lo[j];
-        d.hi[j] = g.hi[j];
-        d.xstep[j] = g.xstep[j];
-        d.hstep[j] = g.hstep[j];
         d.ipvt[j] = g.ipvt[j];
         LMREG_UNROLL
         for (int k = 0; k < N; k++) d.R[j * N + k] = g.R[j * LM_NPMAX + k];
     }
 }
 
+// (x, xstep, hstep were written in place)
 template <int N>
 NGMIX_HD void store_state(lm_state &d, const lm_state_n<N> &g)
 {
@@ -582,15 +598,12 @@ NGMIX_HD void store_state(lm_state &d, const lm_state_n<N> &g)
     d.pnorm = g.pnorm;
     LMREG_UNROLL
     for (int j = 0; j < N; j++) {
-        d.x[j] = g.x[j];
         d.xt[j] = g.xt[j];
         d.diag[j] = g.diag[j];
         d.qtf[j] = g.qtf[j];
         d.step[j] = g.step[j];
         d.xi[j] = g.xi[j];
         d.xti[j] = g.xti[j];
-        d.xstep[j] = g.xstep[j];
-        d.hstep[j] = g.hstep[j];
         d.ipvt[j] = g.ipvt[j];
         LMREG_UNROLL
         for (int k = 0; k < N; k++) d.R[j * LM_NPMAX + k] = g.R[j * N + k];

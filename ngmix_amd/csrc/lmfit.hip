@@ -605,7 +605,7 @@ __device__ __forceinline__ void lm_advance_one_reg(
     const int32_t *__restrict__ stamp_band, const double *__restrict__ sums, int nloc,
     const double *__restrict__ obj_sums, int32_t *nactive)
 {
-    lmcore::lm_state_n<N> s;
+    lmreg::lm_state_n<N> s;
     lmreg::load_state<N>(s, states[o]);
     const int ntri = nloc * (nloc + 1) / 2, nsum = ntri + nloc + 1;
     double A[N * N], g[N];
@@ -1173,6 +1173,8 @@ __global__ __launch_bounds__(WAVE) void lm_finalize_kernel(
     if (n == 6) lm_finalize_one<6>(s, o, npix_obj, ff_extra, pdef, cdef, rec);
     else if (n == 7) lm_finalize_one<7>(s, o, npix_obj, ff_extra, pdef, cdef, rec);
     else if (n == 8) lm_finalize_one<8>(s, o, npix_obj, ff_extra, pdef, cdef, rec);
+    else if (n == 9) lm_finalize_one<9>(s, o, npix_obj, ff_extra, pdef, cdef, rec);
+    else if (n == 10) lm_finalize_one<10>(s, o, npix_obj, ff_extra, pdef, cdef, rec);
     else lm_finalize_one<0>(s, o, npix_obj, ff_extra, pdef, cdef, rec);
 }
 
