@@ -38,24 +38,34 @@ def _e1e2_to_g1g2(e1, e2):
     return e1 * fac, e2 * fac
 
 
-def _admom_gaussians(stamps, Tguess, rng):
-    """admom on every stamp from a round guess of size Tguess; returns the
-    converged weight gaussians (a dict of host arrays row, col, irr, irc,
-    icc), the result flags and the kernel status.  Only those columns leave
-    the device, not the 584-byte result records."""
+def _admom_launch(stamps, Tguess, rng, **conf):
+    """start admom on every stamp from a round guess of size Tguess (conf: the
+    tolerances / maxiter of StampBatch.admom); nothing is waited for"""
     n = stamps.n
     guess = np.zeros((n, 6))
     guess[:, 0:2] = rng.uniform(-0.1, 0.1, size=(n, 2)) * np.sqrt(Tguess / 2.0)
     guess[:, 4] = Tguess
     guess[:, 5] = 1.0
     wt, _ = GMixBatch.from_pars(guess, "gauss", device=stamps.device)
-    res, status = stamps.admom(wt)
+    res, status = stamps.admom(wt, **conf)
+    return wt, res, status
+
+
+def _admom_collect(launched):
+    """the converged weight gaussians (a dict of host arrays row, col, irr,
+    irc, icc), the result flags and the kernel status.  Only those columns
+    leave the device, not the 584-byte result records."""
+    import torch
+    wt, res, status = launched
     cols = wt.data[:, 1:6].cpu().numpy()  # row, col, irr, irc, icc of the record
     w = {"row": cols[:, 0], "col": cols[:, 1], "irr": cols[:, 2], "irc": cols[:, 3],
          "icc": cols[:, 4]}
-    import torch
     flags = res[:, 0].contiguous().view(torch.int32)[::2].cpu().numpy()
     return w, {"flags": flags}, status.cpu().numpy()
+
+
+def _admom_gaussians(stamps, Tguess, rng, **conf):
+    return _admom_collect(_admom_launch(stamps, Tguess, rng, **conf))
 
 
 # starting mixtures of the EM psf fit: flux fractions and size factors relative
@@ -164,7 +174,7 @@ def _coellip_psf_once(psf_stamps, ngauss, T0, cen, g, rng):
 def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None,
                     fit_pars=None, rng=None, psf_ngauss=1, em_pars=None, prior=None,
                     stamp_obj=None, stamp_band=None, ntry=1, psf_fitter="em",
-                    psf_ntry=1):
+                    psf_ntry=1, guess_admom=None):
     """
     stamps, psf_stamps: StampBatch of the object images and of their psf images
         (stamp i of one belongs to stamp i of the other)
@@ -178,6 +188,8 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
         gaussians (the reference's CoellipFitter psf runners)
     prior: a batch prior for the object fits (prior_batch.PriorSimpleSepBatch ...)
     psf_ntry: attempts per psf fit (psf_fitter='coellip'; PSFRunner's ntry)
+    guess_admom: dict of etol / Ttol / maxiter for the adaptive moments of the
+        guess stage (defaults 1e-4 / 1e-2: a starting point, not a measurement)
     ntry: fits that end with flags != 0 are repeated from a perturbed guess up
         to ntry times in all, as Runner does object by object
         (runners.py:95-150); 'ntry' of the result counts the attempts
@@ -198,8 +210,22 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
     if Tguess is None:
         Tguess = 2.0 * psf_Tguess
 
-    # 1. psf: one gaussian per stamp from its adaptive moments
-    pw, prec, pst = _admom_gaussians(psf_stamps, psf_Tguess, rng)
+    # the guess stage's tolerances: it only has to put the fit inside its basin
+    # -- ten times the measurement defaults stop the iteration two or three
+    # passes earlier and the LM needs no more rounds for it
+    gconf = dict(etol=1.0e-4, Ttol=1.0e-2)
+    gconf.update(guess_admom or {})
+
+    # 1. psf: one gaussian per stamp from its adaptive moments.  With a
+    # one-gaussian psf nothing between here and the object's adaptive moments
+    # draws random numbers or needs the psf result, so that launch (and the pixel
+    # sums of the flux guess) are queued right behind: the device works through
+    # them while the host turns the psf moments into mixtures
+    p_launched = _admom_launch(psf_stamps, psf_Tguess, rng)
+    o_launched = _admom_launch(stamps, Tguess, rng, **gconf) if psf_ngauss == 1 else None
+    same_size = bool(np.all(stamps.npix == stamps.npix[0]))
+    d_flux = stamps.val.reshape(n, -1).sum(dim=1) if same_size else None
+    pw, prec, pst = _admom_collect(p_launched)
     psf_bad = (prec["flags"] != 0) | (pst != 0)
     psf_T = np.where(psf_bad, psf_Tguess, pw["irr"] + pw["icc"])
     pe1 = np.where(psf_bad, 0.0, (pw["icc"] - pw["irr"]) / psf_T)
@@ -220,15 +246,17 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
         psf_bad = psf_bad | (em_flags != 0)
 
     # 2. guess: adaptive moments of the object, psf size taken out
-    ow, orec, ost = _admom_gaussians(stamps, Tguess, rng)
+    if o_launched is None:
+        o_launched = _admom_launch(stamps, Tguess, rng, **gconf)
+    ow, orec, ost = _admom_collect(o_launched)
     gbad = (orec["flags"] != 0) | (ost != 0)
     T_obs = np.where(gbad, 2.0 * psf_T, ow["irr"] + ow["icc"])
     e1 = np.where(gbad, 0.0, (ow["icc"] - ow["irr"]) / T_obs)
     e2 = np.where(gbad, 0.0, 2.0 * ow["irc"] / T_obs)
     g1, g2 = _e1e2_to_g1g2(e1, e2)
     npix = stamps.npix.astype(np.int64)
-    if np.all(npix == npix[0]):
-        flux = stamps.val.reshape(n, -1).sum(dim=1).cpu().numpy()
+    if d_flux is not None:
+        flux = d_flux.cpu().numpy()
     else:
         cs = np.concatenate([[0], np.cumsum(npix)])
         v = stamps.val.cpu().numpy()
