@@ -518,6 +518,52 @@ def test_analytic_fit_of_a_stamp_with_more_tiles_than_lds_records():
         np.testing.assert_allclose(res["lnprob"][i], one["lnprob"], rtol=1e-6)
 
 
+@pytest.mark.parametrize("model,fd,npsf,offset", [("exp", 0, 1, False), ("dev", 0, 3, True),
+                                                  ("bdf", 1, 2, True), ("turb", 1, 1, False)])
+def test_lm_eval_skipping_is_exact(model, fd, npsf, offset):
+    """the (tile, gaussian) pairs the LM kernels skip -- the bounding box of the
+    chi2 < 25 ellipse -- contribute exactly nothing: the normal-equation
+    sums with NGMIX_BATCH_NO_SKIP are the same, bit for bit (sheared mixtures,
+    off-centre objects and psf components, both kernels)"""
+    import ctypes
+    import torch
+    from ngmix_amd.batch import _dptr, _stream
+    from ngmix_amd.gmix import get_model_num
+    L = _lib.lib()
+    rng = np.random.RandomState(500 + npsf + fd)
+    n = 64
+    psf_rows, psf = _multi_gauss_psf(n, npsf, offset, rng)
+    extra = rng.uniform(0.3, 0.7, size=n) if model == "bdf" else None
+    pars, guess, images, weights, jobj, sb = _objects_with_psf(n, model, psf, rng, dim=48,
+                                                              extra=extra)
+    # strongly sheared, off-centre trial points: thin ellipses across the tiles
+    guess[:, 2] = rng.uniform(-0.6, 0.6, size=n)
+    guess[:, 3] = rng.uniform(-0.6, 0.6, size=n)
+    guess[:, 0:2] += rng.uniform(-1.5, 1.5, size=(n, 2))
+    npars = guess.shape[1]
+    nsum = npars * (npars + 1) // 2 + npars + 1
+    out = []
+    for no_skip in (False, True):
+        st = torch.empty((n, _lib.LM_STATE_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+        dg = torch.from_numpy(np.ascontiguousarray(guess)).cuda()
+        _lib.check(L.ngmix_lm_init_batch(_dptr(st), n, npars, _dptr(dg), 1e-8, 1e-8, 0.0, 100,
+                                         100.0, _lib.LM_MODE_FD if fd else _lib.LM_MODE_ANALYTIC,
+                                         None, None, _stream()), "init")
+        sobj = torch.arange(n, dtype=torch.int32, device="cuda")
+        sband = torch.zeros(n, dtype=torch.int32, device="cuda")
+        sums = torch.zeros((n, nsum), dtype=torch.float64, device="cuda")
+        status = torch.zeros(n, dtype=torch.int32, device="cuda")
+        b = sb._batch(1, no_skip=no_skip)
+        _lib.check(L.ngmix_lm_eval_batch(ctypes.byref(b), get_model_num(model), fd, _dptr(st),
+                                         _dptr(sobj), _dptr(sband), _dptr(psf.data), npsf,
+                                         _dptr(sums), _dptr(status), _stream()), "eval")
+        torch.cuda.synchronize()
+        assert int(status.abs().sum()) == 0
+        out.append(sums.cpu().numpy())
+    assert np.all(np.isfinite(out[0])) and np.abs(out[0]).max() > 0
+    np.testing.assert_array_equal(out[0], out[1])
+
+
 def test_bootstrap_batch_multiband_multiepoch():
     """objects with 2 bands x 2 epochs, different psf per epoch, sub-pixel
     offsets per epoch: one bootstrap_batch call recovers shape, size and both
