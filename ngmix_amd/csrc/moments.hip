@@ -261,13 +261,39 @@ __device__ __forceinline__ void wsums_pass(const GridSrc &src, const EvalGauss *
     int lastp = -1;
     bool zero_div = false;
 
-    for (int r0 = 0; r0 < nrow; r0 += TILE_H) {
-        for (int c0 = 0; c0 < ncol; c0 += TILE_W) {
-            const int row = r0 + lrow, col = c0 + lcol;
-            if (!(row < nrow && col < ncol)) continue;
-            const int p = row * ncol + col;
-            const double val = src.val[p], ierr = src.ierr[p];
-            if (src.izw && !(ierr > 0.0)) continue;  // not in the pixel list
+    // Tiles in row-major order, two per loop trip, each one's val / ierr requested
+    // a tile ahead: with the load at the top of its own tile every wave spent
+    // 80 % of its life waiting for memory (a tile is only ~100 instructions).  The loads are unconditional -- a lane
+    // outside the stamp reads pixel 0 and ignores it -- because a branch around
+    // a load makes the compiler drain every outstanding load right there.
+    const int ntx = (ncol + TILE_W - 1) / TILE_W, nty = (nrow + TILE_H - 1) / TILE_H;
+    const int ntiles = ntx * nty;
+    struct Tile {
+        double val, ierr;
+        int row, col;
+        bool inb;
+    };
+    int f_ty = 0, f_tx = 0, f_T = 0;   // the next tile to request
+    auto fetch = [&]() {
+        Tile t;
+        t.row = f_ty * TILE_H + lrow;
+        t.col = f_tx * TILE_W + lcol;
+        t.inb = f_T < ntiles && t.row < nrow && t.col < ncol;
+        const int p = t.inb ? t.row * ncol + t.col : 0;
+        t.val = src.val[p];
+        t.ierr = src.ierr[p];
+        f_T++;
+        if (++f_tx == ntx) {
+            f_tx = 0;
+            f_ty++;
+        }
+        return t;
+    };
+    auto eval = [&](const Tile &t) {
+        if (!t.inb) return;
+        const int row = t.row, col = t.col, p = row * ncol + col;
+        const double val = t.val, ierr = t.ierr;
+        if (src.izw && !(ierr > 0.0)) return;  // not in the pixel list
             double v, u;
             {
                 const double rd = (double)row - src.jac.row0, cd = (double)col - src.jac.col0;
@@ -278,11 +304,11 @@ __device__ __forceinline__ void wsums_pass(const GridSrc &src, const EvalGauss *
             const double rad2 = fma(umod, umod, vmod * vmod);
             bool take = rad2 < maxrad2;
             if (NMOM == 6) take = take && ierr > 0.0;  // gmix_nb.py:713
-            if (!take) continue;
+            if (!take) return;
             const double ierr2 = ierr * ierr;
             if (ierr2 == 0.0) {
                 zero_div = true;  // gmix_nb.py:775: 1/ierr^2
-                continue;
+                return;
             }
             double weight = 0.0;
             for (int g = 0; g < ng; g++) {
@@ -316,7 +342,15 @@ __device__ __forceinline__ void wsums_pass(const GridSrc &src, const EvalGauss *
                 acc[NCOV + NMOM + 1] += 1.0;
             }
             lastp = p > lastp ? p : lastp;
-        }
+    };
+    // two register sets, each overwritten right after it has been evaluated (no
+    // copies): B's loads are in flight while A is evaluated and vice versa
+    Tile ta = fetch(), tb = fetch();
+    for (int T = 0; T < ntiles; T += 2) {
+        eval(ta);
+        ta = fetch();
+        eval(tb);
+        tb = fetch();
     }
     if (__ballot(zero_div) != 0ull && lane == 0) sh.err = NGMIX_ERR_ZERO_DIV;
     // wave totals: DPP inside rows of 16 lanes, the 4 row sums through LDS
