@@ -112,6 +112,9 @@ typedef struct {
     int32_t maxiter;
     double shiftmax, etol, Ttol;
     uint8_t cenonly;
+    uint8_t no_cov; /* batch extension, in the reference record's padding (0 there):
+                       skip the 7 x 7 covariance sums (sums_cov stays 0) -- for runs
+                       that only want the converged weight, e.g. a fit's guess */
 } ngmix_admom_conf; /* 40 B */
 
 typedef struct {

@@ -63,6 +63,7 @@ JACOBIAN_DTYPE = np.dtype([
 ADMOM_CONF_DTYPE = np.dtype([
     ("maxiter", "i4"), ("shiftmax", "f8"), ("etol", "f8"), ("Ttol", "f8"),
     ("cenonly", bool),
+    ("no_cov", bool),   # batch extension in the reference record's padding
 ], align=True)
 ADMOM_RESULT_DTYPE = np.dtype([
     ("flags", "i4"), ("numiter", "i4"), ("npix", "i4"), ("wsum", "f8"),

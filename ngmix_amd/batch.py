@@ -533,12 +533,14 @@ class StampBatch(object):
         return res, status
 
     def admom(self, wt, maxiter=200, shiftmax=5.0, etol=1.0e-5, Ttol=1.0e-3,
-              cenonly=False, res=None, status=None):
+              cenonly=False, res=None, status=None, no_cov=False):
         """
         adaptive moments of every stamp (admom_nb.py:13-108) in one launch.
         wt: GMixBatch with ONE gaussian per stamp, the guess; updated in place
         (it is the weight, as in the reference).  Returns (res, status) with
         res an (N, 73) float64 tensor of 584-byte result records.
+        no_cov: skip the 7 x 7 covariance sums (sums_cov stays zero) -- for runs
+        that only want the converged weight gaussian, e.g. a fit's guess.
         """
         torch = _torch()
         assert wt.n == self.n and wt.ngauss == 1
@@ -548,6 +550,7 @@ class StampBatch(object):
         conf["etol"] = etol
         conf["Ttol"] = Ttol
         conf["cenonly"] = cenonly
+        conf["no_cov"] = no_cov
         if res is None:
             res = torch.zeros((self.n, 73), dtype=torch.float64, device=self.device)
         if status is None:

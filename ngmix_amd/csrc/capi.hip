@@ -420,7 +420,11 @@ int ngmix_admom(const ngmix_admom_conf *conf, ngmix_gauss2d *wt,
     if (npix > 0)
         NGMIX_HIP_CHECK(hipMemcpy(d_px, pixels, npix * sizeof(ngmix_pixel), hipMemcpyHostToDevice));
     NGMIX_HIP_CHECK(hipMemcpy(d_res, res, sizeof(ngmix_admom_result), hipMemcpyHostToDevice));
-    int st = launch_admom_list(conf, d_px, npix, d_wt, d_res, d_st, nullptr);
+    // the seam form takes the reference's record: whatever sits in its padding,
+    // the batch extension is off
+    ngmix_admom_conf seam_conf = *conf;
+    seam_conf.no_cov = 0;
+    int st = launch_admom_list(&seam_conf, d_px, npix, d_wt, d_res, d_st, nullptr);
     if (st) return st;
     int32_t kst = 0;
     NGMIX_HIP_CHECK(hipMemcpy(&kst, d_st, 4, hipMemcpyDeviceToHost));

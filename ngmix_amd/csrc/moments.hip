@@ -931,7 +931,7 @@ __device__ __forceinline__ void admom_body(const Src &src,
     if (sh.mom_ran) {
         const EvalGauss e = make_eval(sh.wt_used);
         const double vcen = sh.wt_used.row, ucen = sh.wt_used.col;
-        const bool want_cov = sh.res_is_mom != 0 && sh.status == NGMIX_OK;
+        const bool want_cov = sh.res_is_mom != 0 && sh.status == NGMIX_OK && !conf.no_cov;
         double c[49];
 #pragma unroll
         for (int i = 0; i < 49; i++) c[i] = 0.0;
@@ -1315,7 +1315,7 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
     // F scratch of its last pixel.  sums_cov[i,j] and [j,i] differ in the
     // reference only by the rounding of (w2var*F[i])*F[j] vs (w2var*F[j])*F[i];
     // one triangle is accumulated and mirrored.
-    const bool want_cov = last_kind == 2 && st == NGMIX_OK;
+    const bool want_cov = last_kind == 2 && st == NGMIX_OK && !conf.no_cov;
     double c[28];
 #pragma unroll
     for (int i = 0; i < 28; i++) c[i] = 0.0;
@@ -1343,8 +1343,10 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
                 const double weight = weight_fused(chi2, used_pa, sh.tab, K);
                 double w2var = 0.0;
                 if (((k < 32 ? kept : kept_hi) >> (k & 31)) & 1u) {
+                    // (v_rcp + Newton, ~1 ulp: the fused kernels' contract; the
+                    // IEEE division was a quarter of this pass)
                     const double ierr = src.ierr[p];
-                    w2var = weight * weight * (1.0 / (ierr * ierr));
+                    w2var = weight * weight * rcp_newton(ierr * ierr);
                 }
                 int idx = 0;
 #pragma unroll

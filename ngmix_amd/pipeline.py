@@ -213,7 +213,7 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
     # the guess stage's tolerances: it only has to put the fit inside its basin
     # -- ten times the measurement defaults stop the iteration two or three
     # passes earlier and the LM needs no more rounds for it
-    gconf = dict(etol=1.0e-4, Ttol=1.0e-2)
+    gconf = dict(etol=1.0e-4, Ttol=1.0e-2, no_cov=True)   # (only the weight is read)
     gconf.update(guess_admom or {})
 
     # 1. psf: one gaussian per stamp from its adaptive moments.  With a

@@ -25,7 +25,8 @@ RTOL = 1e-10
 def conv_rec(a, dtype):
     out = np.zeros(a.size, dtype=dtype)
     for n in dtype.names:
-        out[n] = a[n]
+        if n in a.dtype.names:   # (a reference record has no batch-extension fields)
+            out[n] = a[n]
     return out
 
 
@@ -546,6 +547,43 @@ def test_em_kernel_variants_vs_oracle(shape, ngauss):
         for f in ("p", "row", "col", "irr", "irc", "icc"):
             np.testing.assert_allclose(gm_out[i][f], g[f], rtol=1e-9, atol=1e-12,
                                        err_msg="%s stamp %d %s" % (shape, i, f))
+
+
+@pytest.mark.parametrize("shape", [(32, 32), (48, 48), (64, 64), (90, 80)])
+def test_admom_no_cov_changes_nothing_but_the_covariance(shape):
+    """conf.no_cov (the batch extension in the reference record's padding): the
+    iteration, the weight, the sums and the flags are the same bytes; only
+    sums_cov (and what get_result derives from it) stays zero"""
+    from ngmix_amd.batch import StampBatch, GMixBatch, records_to_numpy
+    import ngmix_amd as ngmix
+    nrow, ncol = shape
+    rng = np.random.RandomState(nrow + ncol)
+    obs = []
+    for k in range(4):
+        jac = ngmix.DiagonalJacobian(row=(nrow - 1) / 2.0 + rng.uniform(-0.3, 0.3),
+                                     col=(ncol - 1) / 2.0 + rng.uniform(-0.3, 0.3), scale=0.263)
+        T = 0.3 + 0.01 * min(nrow, ncol)
+        gm = ngmix.GMixModel([0.0, 0.0, rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1), T, 50.0],
+                             "gauss")
+        im = gm.make_image((nrow, ncol), jacobian=jac) + 0.002 * rng.normal(size=(nrow, ncol))
+        obs.append(ngmix.Observation(im, weight=np.full(im.shape, 2.5e5), jacobian=jac))
+    sb = StampBatch.from_observations(obs)
+    guess = np.zeros((4, 6))
+    guess[:, 4] = 0.3 + 0.011 * min(nrow, ncol)
+    guess[:, 5] = 1.0
+    out = {}
+    for no_cov in (False, True):
+        wt, _ = GMixBatch.from_pars(guess, "gauss")
+        res, status = sb.admom(wt, no_cov=no_cov)
+        assert int(status.abs().sum()) == 0
+        out[no_cov] = (records_to_numpy(res, _lib.ADMOM_RESULT_DTYPE), wt.to_numpy())
+    (full, wfull), (lean, wlean) = out[False], out[True]
+    assert np.all(full["flags"] == 0) and np.abs(full["sums_cov"]).max() > 0
+    for name in ("flags", "numiter", "npix", "wsum", "sums", "pars", "rho4", "F"):
+        np.testing.assert_array_equal(lean[name], full[name], name)
+    assert np.all(lean["sums_cov"] == 0.0)
+    for f in wfull.dtype.names:
+        np.testing.assert_array_equal(wlean[f], wfull[f], f)
 
 
 def test_admom_and_em_ragged_shapes_vs_oracle():
