@@ -15,7 +15,7 @@ from .observation import Observation
 
 logger = logging.getLogger(__name__)
 
-__all__ = ["GaussMom", "GaussMomBatch"]
+__all__ = ["GaussMom", "GaussMomBatch", "MomBatchResult"]
 
 
 def _make_weight(fwhm):
@@ -67,11 +67,51 @@ class GaussMom(object):
         return _remove_area(res, obs.jacobian.area)
 
 
+class MomBatchResult(object):
+    """
+    The weighted moments of N stamps.  By key, arrays over the stamps --
+    res["T"] is (N,), res["e"] (N, 2), res["sums_cov"] (N, nm, nm): every key of
+    GaussMom.go's dict but the flag strings (moments.make_mom_result_batch, one
+    vectorised pass); by position, res[i] is exactly the dict GaussMom.go returns
+    for stamp i (built on request).  len() and iteration are over the stamps.
+    """
+
+    def __init__(self, arrays, records, area):
+        self._arrays = arrays
+        self._records = records
+        self._area = area
+
+    def __len__(self):
+        return self._records.size
+
+    def keys(self):
+        return self._arrays.keys()
+
+    def __contains__(self, key):
+        return key in self._arrays
+
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            return self._arrays[key]
+        i = int(key)
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(key)
+        r = get_weighted_moments_stats(self._records[i])
+        if r["flags"] == 0:
+            _remove_area(r, self._area[i])
+        return r
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 class GaussMomBatch(object):
     """
-    GaussMom over a StampBatch: one weighted-sums launch for all stamps, the
-    per-stamp statistics (make_mom_result, O(1) scalar work) on the host.
-    go() returns a list of the same result dicts GaussMom.go returns.
+    GaussMom over a StampBatch: one weighted-sums launch for all stamps and
+    one vectorised pass of make_mom_result's statistics.  go() returns a
+    MomBatchResult: arrays by key, GaussMom.go's dict by stamp index.
     """
 
     def __init__(self, fwhm, with_higher_order=False):
@@ -91,10 +131,18 @@ class GaussMomBatch(object):
         res, status = stamps.weighted_sums(wtb, maxrad, nmom=nmom)
         rec = records_to_numpy(res, _lib.moments_result_dtype(nmom))
         area = stamps.jac[:, 6].abs().cpu().numpy()
-        out = []
-        for i in range(n):
-            r = get_weighted_moments_stats(rec[i])
-            if r["flags"] == 0:
-                _remove_area(r, area[i])
-            out.append(r)
-        return out
+        arrays = moments.make_mom_result_batch(rec["sums"], rec["sums_cov"], rec["wsum"])
+        arrays["npix"] = rec["npix"].copy()
+        arrays["wsum"] = rec["wsum"].copy()
+        # the record's own flags (the kernel's) are 0 in the reference's record too;
+        # the pixel area out of the flux-like quantities of the successful ones
+        # (gaussmom.py:62-74)
+        good = arrays["flags"] == 0
+        fac = np.where(good, 1.0 / area, 1.0)
+        for key in ("flux", "flux_err", "sums_norm", "wsum"):
+            arrays[key] = arrays[key] * fac
+        arrays["pars"][:, 5] *= fac
+        arrays["sums"] = arrays["sums"] * fac[:, None]
+        arrays["sums_err"] = arrays["sums_err"] * fac[:, None]
+        arrays["sums_cov"] = arrays["sums_cov"] * (fac ** 2)[:, None, None]
+        return MomBatchResult(arrays, rec, area)

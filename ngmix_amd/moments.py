@@ -214,3 +214,112 @@ def make_mom_result(sums, sums_cov, sums_norm=None):
             res[name] = np.nan
             res[err_name] = np.nan
     return res
+
+
+def _ratio_error_arrays(a, b, var_a, var_b, cov_ab, where):
+    """get_ratio_error over arrays, evaluated only where `where` (elsewhere nan);
+    util.get_ratio_var's expression (equal to the scalar routine to the last
+    bit or two: numpy squares arrays by multiplying and scalars through pow)"""
+    out = np.full(np.shape(a), np.nan)
+    if np.any(where):
+        aw, bw = a[where], b[where]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            var = (aw / bw) ** 2 * (var_a[where] / aw ** 2 + var_b[where] / bw ** 2 -
+                                    2 * cov_ab[where] / (aw * bw))
+            out[where] = np.sqrt(np.clip(var, 0.0, np.inf))
+    return out
+
+
+def make_mom_result_batch(sums, sums_cov, sums_norm=None):
+    """
+    make_mom_result for N objects at once: sums (N, 6 | 17), sums_cov (N, nm, nm),
+    sums_norm (N,).  Returns a dict of arrays with make_mom_result's keys --
+    flags / flux_flags / T_flags (N,) ints, flux, flux_err, s2n, T, T_err, e1,
+    e2 (N,), e, e_err (N, 2), e_cov (N, 2, 2), pars (N, 6; nan where the scalar
+    routine sets none), sums_err (N, 6), the named moments M.. and M.._err --
+    the values make_mom_result(sums[i], sums_cov[i], sums_norm[i]) gives (flags and
+    ratios identical, the propagated errors to the last bit or two; the flag
+    strings are left to the per-object view).
+    """
+    sums = np.asarray(sums, dtype="f8")
+    sums_cov = np.asarray(sums_cov, dtype="f8")
+    n, nm = sums.shape
+    if nm not in (6, 17) or sums_cov.shape != (n, nm, nm):
+        raise ValueError("sums must be (N, 6 | 17) and sums_cov (N, nm, nm)")
+    iv, iu, i1, i2, it, iflux = 0, 1, 2, 3, 4, 5
+    nan = np.full(n, np.nan)
+    flux = sums[:, iflux].copy()
+    var_f = sums_cov[:, iflux, iflux]
+    var_t = sums_cov[:, it, it]
+    flags = np.zeros(n, dtype=np.int64)
+    flux_flags = np.zeros(n, dtype=np.int64)
+    T_flags = np.zeros(n, dtype=np.int64)
+
+    fpos = var_f > 0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        flux_err = np.where(fpos, np.sqrt(np.where(fpos, var_f, 1.0)), np.nan)
+        s2n = np.where(fpos, flux / flux_err, np.nan)
+    flux_flags[~fpos] |= ngflags.NONPOS_VAR
+
+    both = fpos & (var_t > 0)
+    t_ok = both & (flux > 0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        T = np.where(t_ok, sums[:, it] / np.where(t_ok, flux, 1.0), np.nan)
+    T_err = _ratio_error_arrays(sums[:, it], flux, var_t, var_f, sums_cov[:, it, iflux], t_ok)
+    T_flags[both & ~(flux > 0)] |= ngflags.NONPOS_FLUX
+    T_flags[~both] |= ngflags.NONPOS_VAR
+
+    diag = np.diagonal(sums_cov, axis1=1, axis2=2)
+    dpos = np.all(diag > 0, axis=1)
+    # (N, nm): sqrt(diag) where every diagonal entry is positive, else nan
+    sums_err = np.where(dpos[:, None], np.sqrt(np.where(diag > 0, diag, 1.0)), np.nan)
+    flags[~dpos] |= ngflags.NONPOS_VAR
+
+    ok = flags == 0
+    with np.errstate(invalid="ignore"):
+        shape_ok = ok & (flux > 0) & (T > 0)
+    flags[ok & ~(flux > 0)] |= ngflags.NONPOS_FLUX
+    with np.errstate(invalid="ignore"):
+        flags[ok & (flux > 0) & ~(T > 0)] |= ngflags.NONPOS_SIZE
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mt = np.where(shape_ok, sums[:, it], 1.0)
+        e1 = np.where(shape_ok, sums[:, i1] / mt, np.nan)
+        e2 = np.where(shape_ok, sums[:, i2] / mt, np.nan)
+    pars = np.full((n, 6), np.nan)
+    pars[shape_ok] = np.stack([sums[:, iv], sums[:, iu], e1, e2, T, flux], axis=1)[shape_ok]
+    e1_err = _ratio_error_arrays(sums[:, i1], sums[:, it], sums_cov[:, i1, i1], var_t,
+                                 sums_cov[:, i1, it], shape_ok)
+    e2_err = _ratio_error_arrays(sums[:, i2], sums[:, it], sums_cov[:, i2, i2], var_t,
+                                 sums_cov[:, i2, it], shape_ok)
+    err_ok = shape_ok & np.isfinite(e1_err) & np.isfinite(e2_err)
+    flags[shape_ok & ~err_ok] |= ngflags.NONPOS_SHAPE_VAR
+    e_err = np.full((n, 2), np.nan)
+    e_err[err_ok, 0], e_err[err_ok, 1] = e1_err[err_ok], e2_err[err_ok]
+    e_cov = np.full((n, 2, 2), np.nan)
+    e_cov[:, 0, 1] = e_cov[:, 1, 0] = 0.0
+    e_cov[err_ok, 0, 0] = e1_err[err_ok] ** 2
+    e_cov[err_ok, 1, 1] = e2_err[err_ok] ** 2
+    # (np.diag(nan2) of the scalar routine: nan on the diagonal, zeros off it)
+
+    res = {
+        "flags": flags, "flux_flags": flux_flags, "T_flags": T_flags,
+        "flux": flux, "flux_err": flux_err, "s2n": s2n, "T": T, "T_err": T_err,
+        "e1": e1, "e2": e2, "e": np.stack([e1, e2], axis=1), "e_err": e_err, "e_cov": e_cov,
+        "pars": pars, "sums": sums, "sums_cov": sums_cov,
+        "sums_norm": np.asarray(sums_norm, dtype="f8") if sums_norm is not None else nan.copy(),
+        "sums_err": sums_err,
+    }
+    with np.errstate(invalid="ignore"):
+        fsum_err = np.sqrt(var_f)
+    fgood = flux > 0
+    for name, ind in MOMENTS_NAME_MAP.items():
+        if ind > nm - 1:
+            continue
+        if name in ("MF", "M00"):
+            res[name], res[name + "_err"] = flux.copy(), fsum_err
+            continue
+        with np.errstate(invalid="ignore", divide="ignore"):
+            res[name] = np.where(fgood, sums[:, ind] / np.where(fgood, flux, 1.0), np.nan)
+        res[name + "_err"] = _ratio_error_arrays(sums[:, ind], flux, sums_cov[:, ind, ind],
+                                                 var_f, sums_cov[:, ind, iflux], fgood)
+    return res

@@ -378,3 +378,39 @@ def test_noise_cov_steps():
     got = [get_step(pars, i, 2) for i in range(pars.size)]
     assert got == [1e-3, 1e-3, 1e-4, 1e-4, 8e-4, 4e-4, 2.0, 1e-6]
     assert get_step(np.array([0, 0, 0, 0, 1e-3, 5.0]), 4, 1) == 1e-4
+
+
+@pytest.mark.parametrize("nm", [6, 17])
+def test_make_mom_result_batch_equals_the_per_object_routine(nm):
+    """moments.make_mom_result_batch (one vectorised pass over N objects)
+    against make_mom_result object by object, every flag path included: flags
+    and ratios identical, propagated errors to the last bit or two"""
+    from ngmix_amd import moments
+    rng = np.random.RandomState(nm)
+    N = 600
+    sums = rng.normal(size=(N, nm))
+    sums[:, 5] = rng.normal(1.0, 1.0, size=N)      # some non-positive fluxes
+    sums[:, 4] = rng.normal(0.5, 0.6, size=N)      # some non-positive sizes
+    A = rng.normal(size=(N, nm, nm))
+    cov = np.einsum("nij,nkj->nik", A, A) * 0.01
+    cov[::7, 5, 5] = -1.0                          # NONPOS_VAR on the flux
+    cov[1::11, 4, 4] = 0.0                         # ... on T
+    cov[2::13, 2, 2] = -0.5                        # ... on a shape moment
+    norm = rng.uniform(1, 2, size=N)
+    b = moments.make_mom_result_batch(sums, cov, norm)
+    assert len(np.unique(b["flags"])) >= 3 and len(np.unique(b["T_flags"])) >= 2
+    for i in range(N):
+        r = moments.make_mom_result(sums[i].copy(), cov[i].copy(), norm[i])
+        for k, v in b.items():
+            if k == "pars" and "pars" not in r:
+                assert np.all(np.isnan(v[i]))
+                continue
+            rv = np.asarray(r[k], dtype="f8")
+            vv = np.asarray(v[i], dtype="f8")
+            if k == "sums_err" and rv.size != vv.size:
+                vv = vv[:rv.size]                  # the scalar routine's 6 nans
+            if k.endswith("_err") or k == "e_cov":
+                np.testing.assert_allclose(vv, rv, rtol=4e-15, atol=0, equal_nan=True,
+                                           err_msg=k)
+            else:
+                assert np.array_equal(vv, rv, equal_nan=True), (k, i)
