@@ -258,9 +258,16 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
     if d_flux is not None:
         flux = d_flux.cpu().numpy()
     else:
-        cs = np.concatenate([[0], np.cumsum(npix)])
-        v = stamps.val.cpu().numpy()
-        flux = np.array([v[cs[i]:cs[i + 1]].sum() for i in range(n)])
+        # ragged stamps: a segmented sum on the device
+        import torch
+        vals = stamps.val
+        if not stamps._packed():
+            # (a selection shares its parent's pixel arrays: gather its own pixels)
+            start = np.concatenate([[0], np.cumsum(npix)[:-1]])
+            flat = np.repeat(stamps.pix_off - start, npix) + np.arange(int(npix.sum()))
+            vals = vals[torch.from_numpy(flat).to(stamps.device)]
+        flux = torch.segment_reduce(
+            vals, "sum", lengths=torch.from_numpy(npix).to(stamps.device)).cpu().numpy()
     if stamp_obj is None:
         sobj = np.arange(n, dtype=np.int64)
         sband = np.zeros(n, dtype=np.int64)

@@ -564,6 +564,37 @@ def test_lm_eval_skipping_is_exact(model, fd, npsf, offset):
     np.testing.assert_array_equal(out[0], out[1])
 
 
+def test_bootstrap_batch_on_ragged_and_selected_stamps():
+    """the flux guess of bootstrap_batch on stamps of different shapes (a
+    segmented sum on the device) and on a selection that shares its parent's
+    pixel arrays: the pixel sums of the stamps themselves"""
+    from ngmix_amd.pipeline import bootstrap_batch
+    rng = np.random.RandomState(12)
+    scale = 0.263
+    shapes = [(32, 32), (40, 36), (32, 32), (36, 40), (48, 48), (32, 32)]
+    obs, pobs = [], []
+    for nrow, ncol in shapes:
+        jac = ngmix.DiagonalJacobian(row=(nrow - 1) / 2.0, col=(ncol - 1) / 2.0, scale=scale)
+        pgm = ngmix.GMixModel([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], "gauss")
+        gm = ngmix.GMixModel([0.02, -0.03, 0.08, -0.05, 0.6, rng.uniform(80, 160)], "exp")
+        im = gm.convolve(pgm).make_image((nrow, ncol), jacobian=jac, fast_exp=True)
+        im += 0.01 * rng.normal(size=im.shape)
+        obs.append(ngmix.Observation(im, weight=np.full(im.shape, 1e4), jacobian=jac))
+        pj = ngmix.DiagonalJacobian(row=12.0, col=12.0, scale=scale)
+        pim = pgm.make_image((25, 25), jacobian=pj) + 1e-5 * rng.normal(size=(25, 25))
+        pobs.append(ngmix.Observation(pim, weight=np.full((25, 25), 1e8), jacobian=pj))
+    sb = StampBatch.from_observations(obs)
+    psb = StampBatch.from_observations(pobs)
+    res = bootstrap_batch(sb, psb, model="exp")
+    assert np.all(res["flags"] == 0)
+    sums = np.array([o.image.sum() for o in obs])
+    np.testing.assert_allclose(res["guess"][:, 5], sums, rtol=1e-12)
+    idx = np.array([4, 1, 3])
+    sub = bootstrap_batch(sb.select(idx), psb.select(idx), model="exp")
+    np.testing.assert_allclose(sub["guess"][:, 5], sums[idx], rtol=1e-12)
+    assert np.all(sub["flags"] == 0)
+
+
 def test_bootstrap_batch_multiband_multiepoch():
     """objects with 2 bands x 2 epochs, different psf per epoch, sub-pixel
     offsets per epoch: one bootstrap_batch call recovers shape, size and both
