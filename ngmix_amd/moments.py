@@ -220,14 +220,12 @@ def _ratio_error_arrays(a, b, var_a, var_b, cov_ab, where):
     """get_ratio_error over arrays, evaluated only where `where` (elsewhere nan);
     util.get_ratio_var's expression (equal to the scalar routine to the last
     bit or two: numpy squares arrays by multiplying and scalars through pow)"""
-    out = np.full(np.shape(a), np.nan)
-    if np.any(where):
-        aw, bw = a[where], b[where]
-        with np.errstate(divide="ignore", invalid="ignore"):
-            var = (aw / bw) ** 2 * (var_a[where] / aw ** 2 + var_b[where] / bw ** 2 -
-                                    2 * cov_ab[where] / (aw * bw))
-            out[where] = np.sqrt(np.clip(var, 0.0, np.inf))
-    return out
+    # evaluated everywhere (masked gathers cost more than the arithmetic), kept
+    # where asked: the elementwise values do not depend on their neighbours
+    with np.errstate(divide="ignore", invalid="ignore"):
+        var = (a / b) ** 2 * (var_a / a ** 2 + var_b / b ** 2 - 2 * cov_ab / (a * b))
+        err = np.sqrt(np.clip(var, 0.0, np.inf))
+    return np.where(where, err, np.nan)
 
 
 def make_mom_result_batch(sums, sums_cov, sums_norm=None):
@@ -248,9 +246,17 @@ def make_mom_result_batch(sums, sums_cov, sums_norm=None):
         raise ValueError("sums must be (N, 6 | 17) and sums_cov (N, nm, nm)")
     iv, iu, i1, i2, it, iflux = 0, 1, 2, 3, 4, 5
     nan = np.full(n, np.nan)
-    flux = sums[:, iflux].copy()
-    var_f = sums_cov[:, iflux, iflux]
-    var_t = sums_cov[:, it, it]
+    # The columns the statistics read, each as a contiguous (N,) vector (the
+    # inputs are usually strided views of a record array: arithmetic on 448-byte
+    # strides costs ten times the arithmetic): sums by moment, and of the
+    # covariance its diagonal and the columns of MF and MT.
+    sT = np.ascontiguousarray(sums.T)
+    diagT = np.ascontiguousarray(np.diagonal(sums_cov, axis1=1, axis2=2).T)
+    cov_fT = np.ascontiguousarray(sums_cov[:, :, iflux].T)
+    cov_tT = np.ascontiguousarray(sums_cov[:, :, it].T)
+    flux = sT[iflux].copy()
+    var_f = diagT[iflux]
+    var_t = diagT[it]
     flags = np.zeros(n, dtype=np.int64)
     flux_flags = np.zeros(n, dtype=np.int64)
     T_flags = np.zeros(n, dtype=np.int64)
@@ -264,15 +270,14 @@ def make_mom_result_batch(sums, sums_cov, sums_norm=None):
     both = fpos & (var_t > 0)
     t_ok = both & (flux > 0)
     with np.errstate(invalid="ignore", divide="ignore"):
-        T = np.where(t_ok, sums[:, it] / np.where(t_ok, flux, 1.0), np.nan)
-    T_err = _ratio_error_arrays(sums[:, it], flux, var_t, var_f, sums_cov[:, it, iflux], t_ok)
+        T = np.where(t_ok, sT[it] / np.where(t_ok, flux, 1.0), np.nan)
+    T_err = _ratio_error_arrays(sT[it], flux, var_t, var_f, cov_fT[it], t_ok)
     T_flags[both & ~(flux > 0)] |= ngflags.NONPOS_FLUX
     T_flags[~both] |= ngflags.NONPOS_VAR
 
-    diag = np.diagonal(sums_cov, axis1=1, axis2=2)
-    dpos = np.all(diag > 0, axis=1)
+    dpos = np.all(diagT > 0, axis=0)
     # (N, nm): sqrt(diag) where every diagonal entry is positive, else nan
-    sums_err = np.where(dpos[:, None], np.sqrt(np.where(diag > 0, diag, 1.0)), np.nan)
+    sums_err = np.where(dpos[:, None], np.sqrt(np.where(diagT > 0, diagT, 1.0)).T, np.nan)
     flags[~dpos] |= ngflags.NONPOS_VAR
 
     ok = flags == 0
@@ -282,15 +287,13 @@ def make_mom_result_batch(sums, sums_cov, sums_norm=None):
     with np.errstate(invalid="ignore"):
         flags[ok & (flux > 0) & ~(T > 0)] |= ngflags.NONPOS_SIZE
     with np.errstate(invalid="ignore", divide="ignore"):
-        mt = np.where(shape_ok, sums[:, it], 1.0)
-        e1 = np.where(shape_ok, sums[:, i1] / mt, np.nan)
-        e2 = np.where(shape_ok, sums[:, i2] / mt, np.nan)
+        mt = np.where(shape_ok, sT[it], 1.0)
+        e1 = np.where(shape_ok, sT[i1] / mt, np.nan)
+        e2 = np.where(shape_ok, sT[i2] / mt, np.nan)
     pars = np.full((n, 6), np.nan)
-    pars[shape_ok] = np.stack([sums[:, iv], sums[:, iu], e1, e2, T, flux], axis=1)[shape_ok]
-    e1_err = _ratio_error_arrays(sums[:, i1], sums[:, it], sums_cov[:, i1, i1], var_t,
-                                 sums_cov[:, i1, it], shape_ok)
-    e2_err = _ratio_error_arrays(sums[:, i2], sums[:, it], sums_cov[:, i2, i2], var_t,
-                                 sums_cov[:, i2, it], shape_ok)
+    pars[shape_ok] = np.stack([sT[iv], sT[iu], e1, e2, T, flux], axis=1)[shape_ok]
+    e1_err = _ratio_error_arrays(sT[i1], sT[it], diagT[i1], var_t, cov_tT[i1], shape_ok)
+    e2_err = _ratio_error_arrays(sT[i2], sT[it], diagT[i2], var_t, cov_tT[i2], shape_ok)
     err_ok = shape_ok & np.isfinite(e1_err) & np.isfinite(e2_err)
     flags[shape_ok & ~err_ok] |= ngflags.NONPOS_SHAPE_VAR
     e_err = np.full((n, 2), np.nan)
@@ -319,7 +322,7 @@ def make_mom_result_batch(sums, sums_cov, sums_norm=None):
             res[name], res[name + "_err"] = flux.copy(), fsum_err
             continue
         with np.errstate(invalid="ignore", divide="ignore"):
-            res[name] = np.where(fgood, sums[:, ind] / np.where(fgood, flux, 1.0), np.nan)
-        res[name + "_err"] = _ratio_error_arrays(sums[:, ind], flux, sums_cov[:, ind, ind],
-                                                 var_f, sums_cov[:, ind, iflux], fgood)
+            res[name] = np.where(fgood, sT[ind] / np.where(fgood, flux, 1.0), np.nan)
+        res[name + "_err"] = _ratio_error_arrays(sT[ind], flux, diagT[ind], var_f,
+                                                 cov_fT[ind], fgood)
     return res
