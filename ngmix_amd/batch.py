@@ -246,18 +246,18 @@ class StampBatch(object):
         """ragged batch from Observation objects (any mix of shapes)"""
         torch = _torch()
         dev = _require_cuda(device)
-        n = len(obs_list)
-        nrow = np.array([o.image.shape[0] for o in obs_list], dtype=np.int32)
-        ncol = np.array([o.image.shape[1] for o in obs_list], dtype=np.int32)
+        # the Observations' own arrays (their public properties hand out
+        # read-only views and a COPY of the jacobian: 10 us per object, more than
+        # the packing itself)
+        imgs = [o._image for o in obs_list]
+        nrow = np.array([im.shape[0] for im in imgs], dtype=np.int32)
+        ncol = np.array([im.shape[1] for im in imgs], dtype=np.int32)
         npix = nrow.astype(np.int64) * ncol
         off = np.concatenate([[0], np.cumsum(npix)[:-1]]).astype(np.int64)
-        val = np.concatenate([np.asarray(o.image, dtype="f8").ravel()
-                              for o in obs_list])
-        wt = np.concatenate([np.asarray(o.weight, dtype="f8").ravel()
-                             for o in obs_list])
-        jac = np.stack([o.jacobian.get_data().view(np.float64).reshape(8)
-                        for o in obs_list])
-        izw = np.array([o.ignore_zero_weight for o in obs_list], dtype=bool)
+        val = np.concatenate([np.asarray(im, dtype="f8").ravel() for im in imgs])
+        wt = np.concatenate([np.asarray(o._weight, dtype="f8").ravel() for o in obs_list])
+        jac = np.stack([o._jacobian._data.view(np.float64).reshape(8) for o in obs_list])
+        izw = np.array([o._ignore_zero_weight for o in obs_list], dtype=bool)
         dval = _as_device_f64(val, dev)
         dw = _as_device_f64(wt, dev)
         ierr = torch.empty_like(dw)
