@@ -1095,7 +1095,7 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
                                                  ngmix_gauss2d *wt_io,
                                                  ngmix_admom_result *res_io,
                                                  int32_t *status,
-                                                 AdmomFusedShared &sh)
+                                                 AdmomFusedShared &sh, double *lds_ierr)
 {
     const int tid = threadIdx.x;
     const int n = src.count();
@@ -1106,6 +1106,23 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
     // one kept bit per slot, slots 32 .. PPT-1 in a second word
     unsigned kept = 0u, kept_hi = 0u;
     int my_last = -1, my_zero = 0;
+    // The loop below asks for one slot's val / ierr and tests ierr at once: left
+    // alone that is sixteen to thirty-six SERIAL round trips to HBM per stamp.
+    // This pass touches every slot first -- independent loads, issued back to
+    // back, folded into a sum nobody needs -- so that the loop finds its lines in
+    // cache.  (Holding the values themselves in registers until they are used
+    // was tried: the run-time indexed pixel loops of the 16-slot kernels then
+    // spill to private memory.)
+    {
+        double touch = 0.0;
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            const int p = tid + k * NT;
+            const int pc = p < n ? p : 0;
+            touch += src.val[pc] + src.ierr[pc];
+        }
+        if (touch == 1.2345678e300) my_zero = 1;   // (never: keeps the loads alive)
+    }
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
         const int p = tid + k * NT;
@@ -1113,6 +1130,9 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
         if (p < n) {
             double a, val, ierr;
             if (src.load(p, pv[k], pu[k], a, val, ierr)) {
+                // ierr waits in LDS for the covariance pass (read back from HBM
+                // there, each load was waited for on the spot)
+                lds_ierr[k * NT + tid] = ierr;
                 if (k < 32) kept |= 1u << k;
                 else kept_hi |= 1u << (k - 32);
                 pval[k] = val;
@@ -1345,7 +1365,7 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
                 if (((k < 32 ? kept : kept_hi) >> (k & 31)) & 1u) {
                     // (v_rcp + Newton, ~1 ulp: the fused kernels' contract; the
                     // IEEE division was a quarter of this pass)
-                    const double ierr = src.ierr[p];
+                    const double ierr = lds_ierr[k * NT + tid];
                     w2var = weight * weight * rcp_newton(ierr * ierr);
                 }
                 int idx = 0;
@@ -1419,6 +1439,7 @@ __global__ __launch_bounds__(NT) void admom_grid_kernel(
     src.izw = (st.flags & NGMIX_STAMP_IGNORE_ZERO_WEIGHT) != 0;
     if constexpr (PPT > 0) {
         __shared__ AdmomFusedShared sh;
+        __shared__ double lds_ierr[NT * PPT];
         // (nearly) every register slot holds a pixel: evaluate all PPT slots --
         // an empty slot has val == 0 and kept bit 0 and adds exactly nothing
         const int nchunk = (st.nrow * st.ncol + NT - 1) / NT;
@@ -1428,14 +1449,14 @@ __global__ __launch_bounds__(NT) void admom_grid_kernel(
         constexpr bool kOnlyUnrolled = PPT > 16;
         if constexpr (kOnlyUnrolled) {
             admom_fused_body<NT, PPT, true>(src, conf, wt + st.gm_off, res + s,
-                                            status ? status + s : nullptr, sh);
+                                            status ? status + s : nullptr, sh, lds_ierr);
         } else {
             if (NT == WAVE && nchunk * 8 >= PPT * 7)
                 admom_fused_body<NT, PPT, NT == WAVE>(src, conf, wt + st.gm_off, res + s,
-                                                status ? status + s : nullptr, sh);
+                                                status ? status + s : nullptr, sh, lds_ierr);
             else
                 admom_fused_body<NT, PPT, false>(src, conf, wt + st.gm_off, res + s,
-                                                 status ? status + s : nullptr, sh);
+                                                 status ? status + s : nullptr, sh, lds_ierr);
         }
     } else {
         // stamps too large for registers: streaming passes, reference order
