@@ -1062,12 +1062,19 @@ __device__ __forceinline__ void lm_finalize_one(
         _Pragma("unroll")
         for (int i = 0; i < n; i++) pars[i] = pdef;
     } else {
-        // R^-1 (upper triangular), in the pivoted order
+        // R^-1 (upper triangular), in the pivoted order.  The factor is read
+        // once into a local copy: straight from the record every use was a load
+        // waited for on the spot (a thousand of them in the unrolled form)
         double X[NS * NS];
+        double Rl[NS * NS];
+        _Pragma("unroll")
+        for (int i = 0; i < n; i++)
+            _Pragma("unroll")
+            for (int k = i; k < n; k++) Rl[i * NS + k] = s.R[i * LM_NPMAX + k];
         bool singular = false;
         _Pragma("unroll")
         for (int j = 0; j < n; j++) {
-            const double d = s.R[j * LM_NPMAX + j];
+            const double d = Rl[j * NS + j];
             if (d == 0.0 || !(fabs(d) < INFINITY)) singular = true;
         }
         if (!singular) {
@@ -1075,14 +1082,14 @@ __device__ __forceinline__ void lm_finalize_one(
             for (int i = 0; i < NS * NS; i++) X[i] = 0.0;
             _Pragma("unroll")
             for (int j = 0; j < n; j++) {
-                X[j * NS + j] = 1.0 / s.R[j * LM_NPMAX + j];
+                X[j * NS + j] = 1.0 / Rl[j * NS + j];
                 _Pragma("unroll")
                 for (int i = j - 1; i >= 0; i--) {
                     double acc = 0.0;
                     _Pragma("unroll")
                     for (int k = i + 1; k <= j; k++)
-                        acc += s.R[i * LM_NPMAX + k] * X[k * NS + j];
-                    X[i * NS + j] = -acc / s.R[i * LM_NPMAX + i];
+                        acc += Rl[i * NS + k] * X[k * NS + j];
+                    X[i * NS + j] = -acc / Rl[i * NS + i];
                 }
             }
             _Pragma("unroll")
