@@ -416,8 +416,7 @@ NGMIX_HD bool new_jacobian(lm_state_n<N> &s, const double (&A)[N * N], const dou
     }
     LMREG_UNROLL
     for (int j = 0; j < N; j++) s.diag[j] = fmax(s.diag[j], acnorm[j]);
-    propose<N>(s);
-    return false;
+    return false;   // the caller proposes (ONE copy of lmpar / qrsolv in the code)
 }
 
 // lmcore::lm_advance for a fit of exactly N parameters (s.n == N)
@@ -443,13 +442,16 @@ NGMIX_HD void lm_advance(lm_state_n<N> &s, double ff, const double (&g_in)[N],
         LMREG_UNROLL
         for (int i = 0; i < N * N; i++) A[i] = A_in[i];
     }
+    // The three places lmder factors a new jacobian (and the two where it
+    // proposes a step) set a flag and meet at ONE call site each at the end:
+    // inlined at every site the step was 45,000 instructions for six parameters,
+    // four copies of lmpar / qrsolv that no instruction cache holds.
+    bool want_jacobian = false, want_proposal = false;
     if (s.phase == LM_PHASE_JAC) {
         s.nfev += N;
         s.phase = LM_PHASE_TRIAL;
-        new_jacobian<N>(s, A, g);
-        return;
-    }
-    if (s.phase == LM_PHASE_INIT) {
+        want_jacobian = true;
+    } else if (s.phase == LM_PHASE_INIT) {
         s.nfev = s.mode == NGMIX_LM_MODE_FD ? 1 + N : 1;
         s.fnorm = sqrt(ff);
         s.par = 0.0;
@@ -461,9 +463,8 @@ NGMIX_HD void lm_advance(lm_state_n<N> &s, double ff, const double (&g_in)[N],
             return;
         }
         s.phase = LM_PHASE_TRIAL;
-        new_jacobian<N>(s, A, g);
-        return;
-    }
+        want_jacobian = true;
+    } else {
 
     // ---- LM_PHASE_TRIAL: the rest of lmder's inner loop
     s.nfev++;
@@ -528,15 +529,18 @@ NGMIX_HD void lm_advance(lm_state_n<N> &s, double ff, const double (&g_in)[N],
         return;
     }
     if (!accepted) {
-        propose<N>(s);
+        want_proposal = true;   // same factor, smaller region
     } else if (s.mode == NGMIX_LM_MODE_FD) {
         LMREG_UNROLL
         for (int j = 0; j < N; j++) s.xti[j] = s.xi[j];
         set_trial<N>(s);
         s.phase = LM_PHASE_JAC;
     } else {
-        new_jacobian<N>(s, A, g);
+        want_jacobian = true;   // the trial point's jacobian is the new one
     }
+    }
+    if (want_jacobian) want_proposal = !new_jacobian<N>(s, A, g);
+    if (want_proposal) propose<N>(s);
 }
 
 // between the ngmix_lm_state record (arrays of LM_NPMAX) and the compact state
