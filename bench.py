@@ -328,6 +328,7 @@ def run_c2(args, rank, world, device, backend):
         },
         "roofline": {
             "bound": "hbm",
+            "dominant": dominant,
             "kernel": syms.get(dominant, "pixpass_%s_kernel (%s)" % (
                 "grid" if args.exact else "wave", dominant)),
             "achieved": achieved,
