@@ -277,18 +277,40 @@ def build(verbose=False, force=False):
 _lib = None
 
 
+class _build_lock(object):
+    """exclusive advisory lock (fcntl.flock) on csrc/.build.lock around the
+    staleness check + make: concurrent forced rebuilds would write the same
+    .o / .so.tmp files"""
+
+    def __enter__(self):
+        import fcntl
+        self._f = open(os.path.join(_CSRC, ".build.lock"), "w")
+        fcntl.flock(self._f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self._f, fcntl.LOCK_UN)
+        self._f.close()
+        return False
+
+
 def lib():
     """load the HIP library; raises (never falls back) if unavailable"""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            build()
-        elif library_is_stale():
-            # never run kernels that do not correspond to the sources
-            build(force=True)
-            if library_is_stale():
-                raise RuntimeError("libngmix_hip.so does not match ngmix_amd/csrc "
-                                   "and could not be rebuilt")
+        if not os.path.exists(LIB_PATH) or library_is_stale():
+            # never run kernels that do not correspond to the sources.  The
+            # ranks of one job all get here together (launch_local_ranks):
+            # one of them builds under the lock, the others find it done
+            with _build_lock():
+                if not os.path.exists(LIB_PATH):
+                    build()
+                elif library_is_stale():
+                    build(force=True)
+                if library_is_stale():
+                    raise RuntimeError("libngmix_hip.so does not match ngmix_amd/csrc "
+                                       "and could not be rebuilt")
         # One HIP runtime per process: PyTorch-ROCm ships its own
         # libamdhip64; importing torch first makes our library bind to that
         # copy (same SONAME) instead of initialising a second runtime that

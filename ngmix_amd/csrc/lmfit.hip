@@ -675,7 +675,15 @@ __global__ __launch_bounds__(WAVE) void lm_advance_kernel(
     if (o >= nobj) return;
     if (states[o].phase == LM_PHASE_DONE) return;
     if (REG) {
-        if (states[o].n != NP) return;   // (never: the launcher's promise was broken)
+        if (states[o].n != NP) {
+            // the caller's parameter-count hint (nloc + 256 npars) was wrong for
+            // this fit: end it as MINPACK ends a call with improper input
+            // (info = 0 -> LM_FUNC_NOTFINITE and default pars in the record)
+            // instead of leaving it un-advanced for finalize to package
+            states[o].info = 0;
+            states[o].phase = LM_PHASE_DONE;
+            return;
+        }
         lm_advance_one_reg<NP>(states, o, obj_start, stamp_band, sums, nloc, obj_sums,
                                nactive);
     } else {

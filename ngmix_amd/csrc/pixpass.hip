@@ -1189,7 +1189,8 @@ __global__ __launch_bounds__(BLOCK) void weight_to_ierr_kernel(const double *w,
 {
     for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * BLOCK) {
-        double ivar = w[i];
+        // (no weight map: unit weights, Observation's default, observation.py:97-100)
+        double ivar = w ? w[i] : 1.0;
         if (ivar < 0.0) ivar = 0.0;
         ierr[i] = sqrt(ivar);
     }

@@ -11,6 +11,7 @@
 //    gather entry points fail loudly there.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <stdint.h>
 #include <string.h>
 
 #include <new>
@@ -44,12 +45,9 @@ struct Rccl {
     bool ok = false;
 };
 
-static Rccl &rccl()
+static Rccl bind_rccl()
 {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
+    Rccl r;
     // RTLD_NOLOAD first: a host that already carries RCCL (PyTorch-ROCm ships
     // its own copy) must not get a second one
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -69,6 +67,14 @@ static Rccl &rccl()
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather &&
            r.GetErrorString;
+    return r;
+}
+
+// bound once: the initialiser of a function-local static runs exactly once
+// even when two host threads make their first comm call together
+static Rccl &rccl()
+{
+    static Rccl r = bind_rccl();
     return r;
 }
 
@@ -103,6 +109,11 @@ int ngmix_batch_create(ngmix_batch **out, int64_t nstamps, const int32_t *nrow,
         return NGMIX_ERR_BAD_ARG;
     }
     *out = nullptr;
+    if (nstamps * (int64_t)ngauss > INT32_MAX) {
+        // ngmix_stamp.gm_off is an int32 index into the mixture array
+        set_last_error_msg("ngmix_batch_create: nstamps * ngauss exceeds 2^31 - 1");
+        return NGMIX_ERR_BAD_ARG;
+    }
     Store *s = new (std::nothrow) Store();
     if (!s) return NGMIX_ERR_HIP;
     memset(&s->b, 0, sizeof(s->b));
@@ -198,8 +209,9 @@ int ngmix_batch_upload(ngmix_batch *b, const double *images, const double *weigh
         NGMIX_HIP_CHECK(hipMemcpyAsync(s->host_stamps.data(), s->d_stamps,
                                        n * sizeof(ngmix_stamp), hipMemcpyDeviceToHost, q));
     } else {
-        std::vector<double> ones((size_t)s->total_pix, 1.0);
-        NGMIX_HIP_CHECK(hipMemcpy(s->d_ierr, ones.data(), pixbytes, hipMemcpyHostToDevice));
+        // unit ierr, filled on the device on the caller's stream
+        int st = launch_weight_to_ierr(nullptr, s->d_ierr, s->total_pix, q);
+        if (st) return st;
     }
     NGMIX_HIP_CHECK(hipStreamSynchronize(q));
     int32_t masked = 0;

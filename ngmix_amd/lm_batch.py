@@ -82,6 +82,55 @@ class LMBatchResult(dict):
         self._lazy.pop(key, None)
         dict.__setitem__(self, key, value)
 
+    def __delitem__(self, key):
+        if self._lazy.pop(key, None) is None:
+            dict.__delitem__(self, key)
+
+    # every whole-mapping view counts the lazy keys and reads through them, so
+    # that items() / dict(res) / {**res} / copy / pickle see one ordinary dict
+    def materialize(self):
+        for key in list(self._lazy):
+            self[key]
+        return self
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._lazy)
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def pop(self, key, *default):
+        if key in self:
+            value = self[key]
+            dict.__delitem__(self, key)
+            return value
+        if default:
+            return default[0]
+        raise KeyError(key)
+
+    def copy(self):
+        return LMBatchResult(self.items())
+
+    __copy__ = copy
+
+    def __eq__(self, other):
+        return dict.__eq__(self.materialize(), other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        return dict.__repr__(self.materialize())
+
+    def __reduce__(self):
+        # the fetchers are closures over device tensors: pickle the values
+        return (LMBatchResult, (dict(self.items()),))
+
 
 class LMBatchFitter(object):
     """

@@ -320,6 +320,9 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
         sub = fitter.go(stamps.select(sidx), g2_, psf=sub_psf, stamp_obj=sub_obj,
                         stamp_band=sband[sidx].astype(np.int32))
         tries[redo] += 1
+        # (items() reads through the keys an LMBatchResult keeps on the
+        # device, pars_cov0 among them: the retried objects take every array
+        # of their new fit)
         for k, v in sub.items():
             if isinstance(v, np.ndarray) and v.shape[:1] == (redo.size,) and k in res:
                 if not res[k].flags.writeable:

@@ -166,7 +166,17 @@ class PSFFluxBatch(object):
     def _solve(stamps, model, norm, stamp_obj):
         """flux = sum(m I w) / sum(m m w) per object, chi2 of the scaled
         template, and the flags / errors of PSFFluxFitModel.go
-        (results.py:700-770) for every object at once"""
+        (results.py:700-770) for every object at once.
+
+        Weights: the stamp store keeps ierr = sqrt(max(w, 0)) (pixels_nb.py:49-52)
+        and not the raw weight map, so w here is ierr * ierr: equal to the
+        reference's obs.weight to one rounding (sqrt then square, <= 1 ulp per
+        pixel; the goldens hold to 1e-11), and a NEGATIVE weight counts as zero
+        where the reference's sums would subtract it -- the reference's own
+        pixel arrays (ierr) make the same clamp for every other fitter, and
+        Observation rejects nothing here either.  Whether the epochs carry
+        mixtures or templates is decided by the first epoch, as the reference
+        does (results.py:778-789)."""
         import torch
         dev = stamps.device
         ns = stamps.n

@@ -694,6 +694,17 @@ def test_select_and_bootstrap_retries():
     assert np.all(three["ntry"][~failed] == 1) and np.all(three["ntry"][failed] >= 2)
     np.testing.assert_array_equal(three["pars"][~failed], one["pars"][~failed])
     assert (three["flags"] != 0).sum() <= failed.sum()
+    # the merge of a retry covers the keys that stay on the device until read
+    # (pars_cov0): a retried object that ends well carries ITS fit's matrix,
+    # pars_cov = pars_cov0 * chi2 / dof (run_leastsq, fitters.py:312-330)
+    fixed = failed & (three["flags"] == 0)
+    assert fixed.any()
+    assert "pars_cov0" in dict(three) and len(three) == len(three.keys())
+    ratio = three["pars_cov"][fixed] / three["pars_cov0"][fixed]
+    np.testing.assert_allclose(ratio, np.broadcast_to(
+        three["chi2per"][fixed][:, None, None], ratio.shape), rtol=1e-6)
+    ok = (~failed) & (three["flags"] == 0)
+    np.testing.assert_array_equal(three["pars_cov0"][ok], one["pars_cov0"][ok])
 
 
 @pytest.mark.parametrize("model", ["turb", "bdf", "dev", "bd"])

@@ -623,7 +623,30 @@ def test_cabi_stamp_store_and_rccl_gather():
     zero = np.zeros(48 * 48)
     assert L.ngmix_batch_upload(pb2, _lib.ptr(flat_im[:48 * 48].copy()), _lib.ptr(zero),
                                 _lib.ptr(jac[:1].copy()), None) == _lib.ERR_BAD_ARG
+    # no weight map (NULL): unit weights, filled on the device on the stream
+    # given -- the same loglike as an explicit map of ones
+    ones = np.ones(48 * 48)
+    got = []
+    for wt in (None, _lib.ptr(ones)):
+        _lib.check(L.ngmix_batch_upload(pb2, _lib.ptr(flat_im[:48 * 48].copy()), wt,
+                                        _lib.ptr(jac[:1].copy()), None), "upload")
+        gm1 = GMixBatch.from_numpy(gmh[:1, :1].copy())
+        o1 = torch.empty((1, 4), dtype=torch.float64, device="cuda")
+        s1 = torch.empty(1, dtype=torch.int32, device="cuda")
+        _lib.check(L.ngmix_loglike_batch(pb2, ctypes.c_void_p(gm1.data.data_ptr()),
+                                         ctypes.c_void_p(o1.data_ptr()),
+                                         ctypes.c_void_p(s1.data_ptr()), None), "loglike")
+        torch.cuda.synchronize()
+        got.append(o1.cpu().numpy())
+    assert got[0][0, 3] == 48 * 48
+    np.testing.assert_array_equal(got[0], got[1])
     L.ngmix_batch_free(pb2)
+    # stamp.gm_off is an int32 index: a store whose mixtures would not fit is
+    # refused before anything is allocated
+    pb3 = ctypes.POINTER(_lib.Batch)()
+    assert L.ngmix_batch_create(ctypes.byref(pb3), 2, _lib.ptr(nrow[:2].copy()),
+                                _lib.ptr(ncol[:2].copy()), 2 ** 30, 1) == _lib.ERR_BAD_ARG
+    assert "2^31" in _lib.last_error()
 
 
 @pytest.mark.parametrize("exact", [False, True], ids=["fused", "exact"])
