@@ -1185,6 +1185,27 @@ void ora_render_loglike_batch(const ora_gauss2d *gm_all, int64_t ng,
     (void)nthreads;
 }
 
+/* config-5 cpu_baseline leg: get_loglike (gmix_nb.py:824-874) of every epoch
+   stamp of the batch, stamps in parallel; the object sum is the caller's */
+void ora_loglike_batch(const ora_gauss2d *gm_all, int64_t ng,
+                       const ora_pixel *pixels_all, int64_t npix, int64_t nstamps,
+                       double *loglike_out, int nthreads)
+{
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+    for (int64_t s = 0; s < nstamps; s++) {
+        ora_gauss2d gm[64];
+        int64_t n = ng < 64 ? ng : 64;
+        memcpy(gm, gm_all + s * ng, n * sizeof(ora_gauss2d));
+        double ll, sn, sd;
+        int64_t np;
+        ora_get_loglike(gm, n, pixels_all + s * npix, npix, &ll, &sn, &sd, &np);
+        loglike_out[s] = ll;
+    }
+    (void)nthreads;
+}
+
 /* config-4 cpu_baseline legs: one admom / one 1-gaussian em_run per stamp over
    the reference's AoS pixel arrays, stamps in parallel (bench.py --cpu-baselines) */
 void ora_admom_batch(const ora_admom_conf *conf, ora_gauss2d *wt_all,

@@ -156,6 +156,9 @@ void ora_em_batch(const ora_em_conf *conf, ora_pixel *pixels_all, int64_t npix,
                   int64_t nstamps, ora_gauss2d *gmix_all, int64_t ngauss,
                   ora_gauss2d *psf_all, int64_t npsf, ora_gauss2d *conv_all,
                   int32_t *numiter_out, int32_t *status_out, int nthreads);
+void ora_loglike_batch(const ora_gauss2d *gm_all, int64_t ng,
+                       const ora_pixel *pixels_all, int64_t npix, int64_t nstamps,
+                       double *loglike_out, int nthreads);
 int ora_num_threads(void);
 void ora_render_loglike_batch(const ora_gauss2d *gm_all, int64_t ng,
                               const ora_pixel *pixels_all,

@@ -337,6 +337,19 @@ def render_loglike_batch(gm_all, pixels_all, coords_all, images_all, nthreads):
     return out
 
 
+def loglike_batch(gm_all, pixels_all, nthreads):
+    """cpu_baseline leg (config 5): gm_all (nstamps, ng) gauss2d with norms
+    set; pixels_all (nstamps, npix).  Returns loglike per stamp."""
+    _check_c(gm_all, GAUSS2D_DTYPE)
+    _check_c(pixels_all, PIXEL_DTYPE)
+    nstamps, ng = gm_all.shape
+    out = np.zeros(nstamps)
+    lib().ora_loglike_batch(_p(gm_all), _i64(ng), _p(pixels_all),
+                            _i64(pixels_all.shape[1]), _i64(nstamps), _p(out),
+                            ctypes.c_int(int(nthreads)))
+    return out
+
+
 def admom_batch(conf, wt_all, pixels_all, res_all, nthreads):
     """cpu_baseline leg: one admom per stamp; wt_all (n,) gauss2d guesses
     (updated), pixels_all (n, npix), res_all (n,) result records"""

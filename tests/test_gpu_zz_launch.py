@@ -46,6 +46,9 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert "pixpass_wave_kernel" in d["roofline"]["kernel"], d["roofline"]["kernel"]
     assert d["roofline"]["dominant"] in ("loglike", "render")
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    # every rank's own time per step rides in rank 0's line (skew at N = 8)
+    assert len(d["per_rank_ms_per_step"]) == 2 and min(d["per_rank_ms_per_step"]) > 0
+    assert max(d["per_rank_ms_per_step"]) <= d["ms_per_step"] * 1.001
     # the same launch under torch.distributed.run, and for config 4
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29541",
@@ -66,6 +69,14 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["bad_status"] == 0 and d["unit"] == "fits/s"
     assert d["roofline"]["kernel"] == "ngmix::lm_eval_kernel<true>" and d["roofline"]["frac"] > 0
+    # config 5 (multi-epoch objects: every epoch of an object on one rank)
+    cmd5 = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "C5",
+            "--steps", "2", "--warmup", "1", "--settle-steps", "0", "--nstamps", "300"]
+    p = subprocess.run(cmd5, env=env, capture_output=True, text=True, timeout=280, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["bad_status"] == 0 and d["value"] > 0
+    assert d["roofline"]["bound"] == "hbm" and len(d["per_rank_ms_per_step"]) == 2
     # a world size other than --gpus is refused, not mislabelled
     cmd[cmd.index("--gpus") + 1] = "4"
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=root)
