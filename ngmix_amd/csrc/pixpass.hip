@@ -393,6 +393,15 @@ __device__ __forceinline__ void wait_vm(double &a, double &b)
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
 
+// vmcnt(0) with every look-ahead register tied to it: nothing that uses them
+// can be scheduled above the wait
+__device__ __forceinline__ void wait_vm_all(double &a, double &b, double &c, double &d,
+                                            double &e, double &f, double &g, double &h)
+{
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
+
 // The tile loop of one stamp.  FAST = every gaussian of the stamp is positive
 // definite and shares one centre.
 template <int OP, bool MASKED, bool FAST, bool FULL, int TW>
@@ -613,20 +622,28 @@ __device__ __forceinline__ void wave_tiles(
         prefetch(2, in2, va2, ie2);
         prefetch(3, in3, va3, ie3);
     }
+    // No exit from the middle of a group of four: the tiles past the last one
+    // are SKIPPED (forward branches) while their look-ahead loads are still
+    // issued (with EXEC = 0), so every path through the loop issues the same
+    // loads in the same order and the hand-counted waits are provable on the
+    // machine code (tools/isa_hazards.py follows every load to its s_waitcnt
+    // over the control-flow graph; with `break`s inside the group the compiler
+    // routed the exits back through the loop header, where no static count
+    // holds).
     while (T < ntiles) {
         compute(Y3{}, T, in0, va0, ie0);
-        if (T + 1 >= ntiles) break;
-        compute(Y2{}, T + 1, in1, va1, ie1);
+        if (T + 1 < ntiles) compute(Y2{}, T + 1, in1, va1, ie1);
         prefetch(T + 4, in0, va0, ie0);
         prefetch(T + 5, in1, va1, ie1);
-        if (T + 2 >= ntiles) break;
-        compute(Y3{}, T + 2, in2, va2, ie2);
-        if (T + 3 >= ntiles) break;
-        compute(Y2{}, T + 3, in3, va3, ie3);
+        if (T + 2 < ntiles) compute(Y3{}, T + 2, in2, va2, ie2);
+        if (T + 3 < ntiles) compute(Y2{}, T + 3, in3, va3, ie3);
         prefetch(T + 6, in2, va2, ie2);
         prefetch(T + 7, in3, va3, ie3);
         T += 4;
     }
+    // every look-ahead load has landed from here on (those past the last tile
+    // were issued with EXEC = 0 and return at once): the registers are free
+    if (full) wait_vm_all(va0, ie0, va1, ie1, va2, ie2, va3, ie3);
 }
 
 template <int OP, bool MASKED, int TW>
@@ -710,6 +727,11 @@ __device__ __forceinline__ void pixpass_wave_body(
     const bool overwrite = OP == OP_RENDER_FAST && (no_skip & 4);
     const int stcode = lazy_norms<WAVE>(L, gm, ng);
     if (stcode != NGMIX_OK || (overwrite && ng == 0)) {
+        // the look-ahead registers are dead on this path and the compiler may
+        // reuse them: not before their loads have landed
+        // (no operands: tying the dead values to the asm made the compiler
+        // copy them into fresh registers BEFORE the wait)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // (an overwriting render leaves a defined image: zeros for a stamp the
         // reference would have raised on, and for an empty mixture)
         if (overwrite)
@@ -736,6 +758,11 @@ __device__ __forceinline__ void pixpass_wave_body(
         if (!(t.dcc > 0.0 && t.drr > 0.0 && detq > 0.0)) L.ctl[3] = 0;
     }
     __syncthreads();
+    // The first tiles have landed by now (the staging above waited for its own,
+    // younger loads); saying so makes every later copy, select or reuse of
+    // these registers provably safe on every static path -- the dispatch
+    // below copies them into the loop's register sets (tools/isa_hazards.py)
+    wait_vm_all(pv[0], pe[0], pv[1], pe[1], pv[2], pe[2], pv[3], pe[3]);
     const bool fast = L.ctl[2] != 0 && L.ctl[3] != 0;
     const bool masked = MASKED && izw && st.npix_kept != npix;
     if (OP == OP_FDIFF && masked) build_rank_tables<WAVE>(L.cmask, L.cpre, sierr, npix);

@@ -215,6 +215,44 @@ def test_kernel_resource_guard():
     assert any("outside the validated occupancy band" in p for p in problems)
 
 
+def test_isa_hazard_guard(tmp_path):
+    """tools/isa_hazards.py (run by `make` on every object): the dataflow that
+    follows each load to its s_waitcnt and the wait-state rules fire on every
+    deliberately broken kernel of tests/helpers/hazard_cases.hip and on none of
+    the repaired ones; the shipped library's fused pixel-pass kernels -- the
+    ones with hand-counted vmcnt waits -- and the LM evaluation kernel with
+    its inline-asm readfirstlanes pass"""
+    import importlib.util
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(
+        "isa_hazards", os.path.join(root, "tools", "isa_hazards.py"))
+    ih = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ih)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    obj = str(tmp_path / "hazard_cases.o")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-c",
+                    os.path.join(root, "tests", "helpers", "hazard_cases.hip"), "-o", obj],
+                   check=True, capture_output=True)
+    problems, stats = ih.check([obj])
+    flagged = {p.split(":")[0] for p in problems}
+    assert flagged == {"bad_wait_count", "bad_loop_exit", "bad_readfirstlane", "bad_dpp",
+                       "bad_sgpr_base"}, problems
+    assert stats["functions"] == 9
+    assert any("may be in flight" in p for p in problems)
+    assert any("v_readlane/v_readfirstlane (1)" in p for p in problems)
+    assert any("DPP read (2)" in p for p in problems)
+    assert any("VMEM read of it (5)" in p for p in problems)
+    # the shipped kernels
+    problems, stats = ih.check([_lib.LIB_PATH], only=["pixpass_wave_kernel", "lm_eval_kernel"])
+    assert problems == []
+    assert stats["functions"] >= 10 and stats["loads"] > 1000 and stats["readlanes"] > 50
+
+
 def test_library_matches_sources():
     """the loaded library was built from the sources in csrc/ (the digest `make`
     leaves next to it); _lib.lib() rebuilds or refuses otherwise"""
