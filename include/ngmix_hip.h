@@ -492,11 +492,16 @@ int64_t ngmix_lm_advance_host(ngmix_lm_state *states, int64_t nobj,
    sums: (nstamps, NGMIX_LM_NSUMS(nloc)), nloc = the model's npars (6, bdf 7,
    bd 8); status: per stamp (NGMIX_ERR_G_RANGE: model out of range at the
    trial point, sums then carry ff = +inf like the reference's LOWVAL
-   residuals) */
+   residuals).  stamp_stats (may be NULL; fd = 0 only): (nstamps, 2), the
+   s2n_numer and s2n_denom sums of get_loglike (gmix_nb.py:862-864) at the
+   trial point -- they fall out of the normal-equation sums, so that the
+   statistics of FitModel.set_fit_result (results.py:45-72) need no pixel
+   pass of their own after the fit */
 int ngmix_lm_eval_batch(const ngmix_batch *batch, int model, int fd,
                         const ngmix_lm_state *states, const int32_t *stamp_obj,
                         const int32_t *stamp_band, const ngmix_gauss2d *psf,
-                        int npsf, double *sums, int32_t *status, void *stream);
+                        int npsf, double *sums, int32_t *status,
+                        double *stamp_stats, void *stream);
 /* DEVICE: fold stamps obj_start[i]..obj_start[i+1] (NULL: stamp i) into
    object i's normal equations and advance its state; *nactive (device int32,
    may be NULL) receives the number of fits still running.  obj_sums (may be
@@ -506,11 +511,17 @@ int ngmix_lm_eval_batch(const ngmix_batch *batch, int model, int fd,
    in forward-difference mode their jacobian is by the state's xstep / hstep.
    nloc may carry the fits' parameter count as nloc + 256 * npars (npars =
    nloc - 1 + the number of bands; 0 = not said): the step then runs with a
-   private state sized for npars instead of NGMIX_LM_NPMAX */
+   private state sized for npars instead of NGMIX_LM_NPMAX.
+   stamp_stats / obj_stats (both or neither, may be NULL): whenever a fit
+   moves to its trial point (lmder counts an iteration; the starting point on
+   the first call) obj_stats[i] (nobj, 2) takes the sum of its stamps'
+   stamp_stats rows from ngmix_lm_eval_batch: when the fit ends they are
+   s2n_numer / s2n_denom at the solution, and lnprob = -fnorm^2 / 2 */
 int ngmix_lm_advance_batch(ngmix_lm_state *states, int64_t nobj,
                            const int64_t *obj_start, const int32_t *stamp_band,
                            const double *sums, int nloc, const double *obj_sums,
-                           int32_t *nactive, void *stream);
+                           int32_t *nactive, const double *stamp_stats,
+                           double *obj_stats, void *stream);
 
 /* The separable joint prior of the reference's PriorSimpleSep
    (joint_prior.py:10-120) in a form a kernel can evaluate: gaussian centre

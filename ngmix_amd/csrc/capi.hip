@@ -659,19 +659,20 @@ int64_t ngmix_lm_advance_host(ngmix_lm_state *states, int64_t nobj, const double
 int ngmix_lm_eval_batch(const ngmix_batch *batch, int model, int fd,
                         const ngmix_lm_state *states, const int32_t *stamp_obj,
                         const int32_t *stamp_band, const ngmix_gauss2d *psf, int npsf,
-                        double *sums, int32_t *status, void *stream)
+                        double *sums, int32_t *status, double *stamp_stats, void *stream)
 {
     return launch_lm_eval(batch, model, fd, states, stamp_obj, stamp_band, psf, npsf,
-                          sums, status, (hipStream_t)stream);
+                          sums, status, stamp_stats, (hipStream_t)stream);
 }
 
 int ngmix_lm_advance_batch(ngmix_lm_state *states, int64_t nobj,
                            const int64_t *obj_start, const int32_t *stamp_band,
                            const double *sums, int nloc, const double *obj_sums,
-                           int32_t *nactive, void *stream)
+                           int32_t *nactive, const double *stamp_stats, double *obj_stats,
+                           void *stream)
 {
     return launch_lm_advance(states, nobj, obj_start, stamp_band, sums, nloc, obj_sums,
-                             nactive, (hipStream_t)stream);
+                             nactive, stamp_stats, obj_stats, (hipStream_t)stream);
 }
 
 int ngmix_lm_finalize_batch(const ngmix_lm_state *states, int64_t nobj,

@@ -110,6 +110,8 @@ __device__ __forceinline__ double swap_add32(double x, double y)
 
 struct LmEvalShared {
     double tabr[16];
+    double raw[LM_NSUM];   // the reduced sums in the raw basis (below)
+    double hc[6][3];       // the rows of the raw -> parameter map, 3 terms each
 };
 
 // a wave-uniform double moved to SGPRs (a VOP3 instruction reads one SGPR pair
@@ -172,7 +174,8 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
     int model, int ng0, const lm_state *__restrict__ states,
     const int32_t *__restrict__ stamp_obj, const int32_t *__restrict__ stamp_band,
     const ngmix_gauss2d *__restrict__ psf, int npsf, double *__restrict__ sums,
-    int32_t *__restrict__ status, int no_skip, int tile_cap)
+    int32_t *__restrict__ status, int no_skip, int tile_cap,
+    double *__restrict__ stamp_stats)
 {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     __shared__ LmEvalShared sh;
@@ -310,6 +313,10 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
             for (int k = 0; k < LM_NSUM - 1; k++) out[k] = 0.0;
             out[LM_NSUM - 1] = INFINITY;
             if (status) status[s] = NGMIX_ERR_G_RANGE;
+            if (stamp_stats) {
+                stamp_stats[2 * (size_t)s] = 0.0;
+                stamp_stats[2 * (size_t)s + 1] = 0.0;
+            }
         }
         return;
     }
@@ -448,28 +455,32 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
         }
 
         // residual and jacobian row of this pixel (results.py:556-563); lanes
-        // outside the stamp and zero-weight pixels have ierr == 0
+        // outside the stamp and zero-weight pixels have ierr == 0.  The row is
+        // LINEAR in B = ierr * (o1, o2, N11, N12, N22, o0) with stamp-wide
+        // coefficients (the h_a above, 1 / flux): J = H B.  So the normal
+        // equations are accumulated in the raw basis -- B B^T, B f, f^2: the
+        // same 28 fused accumulates, without the nine instructions per pixel
+        // of the map -- and mapped once per stamp after the reduction:
+        // J^T J = H (sum B B^T) H^T, J^T f = H (sum B f).
         if (!masked || pierr > 0.0) {
             const double f = (o0 - pval) * pierr;
-            const double m11 = n11 * pierr, m12 = n12 * pierr, m22 = n22 * pierr;
-            double J[6];
-            J[0] = o1 * pierr;
-            J[1] = o2 * pierr;
-            const double md = m11 - m22;   // u_a0 == -u_a2 for a = g1, g2
-            J[2] = fma_sgpr(h00, md, mul_sgpr(h01, m12));
-            J[3] = fma_sgpr(h10, md, mul_sgpr(h11, m12));
-            J[4] = fma_sgpr(h20, m11, fma_sgpr(h21, m12, mul_sgpr(h22, m22)));
-            J[5] = o0 * mul_sgpr(iflux, pierr);
+            double B[6];
+            B[0] = o1 * pierr;
+            B[1] = o2 * pierr;
+            B[2] = n11 * pierr;
+            B[3] = n12 * pierr;
+            B[4] = n22 * pierr;
+            B[5] = o0 * pierr;
             int k = 0;
 #pragma unroll
             for (int a = 0; a < 6; a++)
 #pragma unroll
                 for (int b = a; b < 6; b++) {
-                    acc[k] = fma(J[a], J[b], acc[k]);
+                    acc[k] = fma(B[a], B[b], acc[k]);
                     k++;
                 }
 #pragma unroll
-            for (int a = 0; a < 6; a++) acc[21 + a] = fma(J[a], f, acc[21 + a]);
+            for (int a = 0; a < 6; a++) acc[21 + a] = fma(B[a], f, acc[21 + a]);
             acc[27] = fma(f, f, acc[27]);
         }
     }
@@ -485,9 +496,74 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
         const double ab = swap_add16(acc[4 * r + 0], acc[4 * r + 1]);
         const double cd = swap_add16(acc[4 * r + 2], acc[4 * r + 3]);
         const double t = row16_sum(swap_add32(ab, cd));
-        if ((lane & 15) == 15) out[4 * r + (lane >> 4)] = t;
+        if ((lane & 15) == 15) sh.raw[4 * r + (lane >> 4)] = t;
     }
-    if (lane == 0 && status) status[s] = NGMIX_OK;
+    // ---- raw basis -> parameters.  Row a of H has at most three terms,
+    // (column, coefficient): cen1 = B0, cen2 = B1, g1 / g2 = h_a0 (B2 - B4) +
+    // h_a1 B3 (u_a0 == -u_a2 for the shears), T = h20 B2 + h21 B3 + h22 B4,
+    // flux = B5 / flux.  Lane k < 21 owns (J^T J)[a][b], lanes 21..26 (J^T f)[a].
+    if (lane == 0) {
+        const double z = 0.0;
+        const double rows[6][3] = {{1.0, z, z},    {1.0, z, z},    {h00, h01, -h00},
+                                   {h10, h11, -h10}, {h20, h21, h22}, {iflux, z, z}};
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int t = 0; t < 3; t++) sh.hc[a][t] = rows[a][t];
+    }
+    __syncthreads();
+    if (lane < LM_NSUM) {
+        // the columns of row a's terms: {0}, {1}, {2, 3, 4} x 3, {5}
+        auto col0 = [](int a) { return a < 2 ? a : (a < 5 ? 2 : 5); };
+        // index of raw (i, j), i <= j, in the packed upper triangle
+        auto tri = [](int i, int j) { return i * 6 - i * (i - 1) / 2 + (j - i); };
+        double r;
+        if (lane < 21) {
+            int a = 0, rem = lane;
+            while (rem >= 6 - a) {
+                rem -= 6 - a;
+                a++;
+            }
+            const int b = a + rem;
+            const int ca = col0(a), cb = col0(b);
+            r = 0.0;
+#pragma unroll
+            for (int ta = 0; ta < 3; ta++) {
+                double inner = 0.0;
+#pragma unroll
+                for (int tb = 0; tb < 3; tb++) {
+                    // (padding terms carry a zero coefficient and re-read a
+                    // valid column)
+                    const int i = (a >= 2 && a < 5) ? ca + ta : ca;
+                    const int j = (b >= 2 && b < 5) ? cb + tb : cb;
+                    const double sij = sh.raw[i <= j ? tri(i, j) : tri(j, i)];
+                    inner = fma(sh.hc[b][tb], sij, inner);
+                }
+                r = fma(sh.hc[a][ta], inner, r);
+            }
+        } else if (lane < 27) {
+            const int a = lane - 21, ca = col0(a);
+            r = 0.0;
+#pragma unroll
+            for (int ta = 0; ta < 3; ta++) {
+                const int i = (a >= 2 && a < 5) ? ca + ta : ca;
+                r = fma(sh.hc[a][ta], sh.raw[21 + i], r);
+            }
+        } else {
+            r = sh.raw[27];
+        }
+        out[lane] = r;
+    }
+    // the sums of get_loglike's statistics at this trial point come with the
+    // raw basis for free (gmix_nb.py:862-864): s2n_denom = sum (model ierr)^2
+    // = (B B^T)[5][5], s2n_numer = sum val model ivar = that - sum (model ierr) f
+    if (lane == 0) {
+        if (stamp_stats) {
+            stamp_stats[2 * (size_t)s] = sh.raw[20] - sh.raw[26];
+            stamp_stats[2 * (size_t)s + 1] = sh.raw[20];
+        }
+        if (status) status[s] = NGMIX_OK;
+    }
 }
 
 // One thread per object: gather its stamps' sums into the (nloc-1+nband)-
@@ -661,6 +737,12 @@ __device__ __forceinline__ void lm_advance_one_reg(
     if (s.phase != LM_PHASE_DONE && nactive) atomicAdd(nactive, 1);
 }
 
+template <int NP, bool REG>
+__device__ __forceinline__ void lm_advance_dispatch(
+    lm_state *states, int64_t o, const int64_t *__restrict__ obj_start,
+    const int32_t *__restrict__ stamp_band, const double *__restrict__ sums, int nloc,
+    const double *__restrict__ obj_sums, int32_t *nactive);
+
 // NP = LM_NPMAX serves any fit (the generic code, private memory); when the
 // launcher is told that every fit has 6 .. 10 parameters it runs the
 // register form (9 and 10 spill part of their arrays to fixed private slots and
@@ -669,11 +751,39 @@ template <int NP, bool REG>
 __global__ __launch_bounds__(WAVE) void lm_advance_kernel(
     lm_state *states, int64_t nobj, const int64_t *__restrict__ obj_start,
     const int32_t *__restrict__ stamp_band, const double *__restrict__ sums, int nloc,
-    const double *__restrict__ obj_sums, int32_t *nactive)
+    const double *__restrict__ obj_sums, int32_t *nactive,
+    const double *__restrict__ stamp_stats, double *__restrict__ obj_stats)
 {
     const int64_t o = blockIdx.x * (int64_t)WAVE + threadIdx.x;
     if (o >= nobj) return;
     if (states[o].phase == LM_PHASE_DONE) return;
+    // lmder moves to the trial point exactly when it counts an iteration
+    // (and the starting point is where it stands after the first call)
+    const int iter0 = states[o].iter, phase0 = states[o].phase;
+    lm_advance_dispatch<NP, REG>(states, o, obj_start, stamp_band, sums, nloc, obj_sums,
+                                 nactive);
+    if (stamp_stats && obj_stats &&
+        (phase0 == LM_PHASE_INIT || states[o].iter != iter0)) {
+        // the loglike statistics of the point the fit now stands at: the sums
+        // lm_eval made at this trial point, over the object's stamps
+        const int64_t s0 = obj_start ? obj_start[o] : o;
+        const int64_t s1 = obj_start ? obj_start[o + 1] : o + 1;
+        double a = 0.0, b = 0.0;
+        for (int64_t st = s0; st < s1; st++) {
+            a += stamp_stats[2 * st];
+            b += stamp_stats[2 * st + 1];
+        }
+        obj_stats[2 * o] = a;
+        obj_stats[2 * o + 1] = b;
+    }
+}
+
+template <int NP, bool REG>
+__device__ __forceinline__ void lm_advance_dispatch(
+    lm_state *states, int64_t o, const int64_t *__restrict__ obj_start,
+    const int32_t *__restrict__ stamp_band, const double *__restrict__ sums, int nloc,
+    const double *__restrict__ obj_sums, int32_t *nactive)
+{
     if (REG) {
         if (states[o].n != NP) {
             // the caller's parameter-count hint (nloc + 256 npars) was wrong for
@@ -1339,7 +1449,7 @@ static int model_ngauss_npars(int model, int &ng0, int &nloc)
 int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *states,
                    const int32_t *stamp_obj, const int32_t *stamp_band,
                    const ngmix_gauss2d *psf, int npsf, double *sums, int32_t *status,
-                   hipStream_t s)
+                   double *stamp_stats, hipStream_t s)
 {
     if (b->nstamps <= 0) return NGMIX_OK;
     int ng0, nloc;
@@ -1384,9 +1494,14 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *stat
         int a_model = model, a_ng0 = ng0, a_npsf = npsf, a_ns = no_skip;
         void *args[] = {&a_stamps, &a_val, &a_ierr, &a_jac, &a_model, &a_ng0, &states,
                         &stamp_obj, &stamp_band, &psf, &a_npsf, &sums, &status, &a_ns,
-                        &tile_cap};
+                        &tile_cap, &stamp_stats};
         NGMIX_HIP_CHECK(hipLaunchKernel(kern, grid, block, args, lds, s));
         return NGMIX_OK;
+    }
+    if (stamp_stats) {
+        set_last_error_msg("lm_eval: the loglike statistics come with the analytic "
+                           "kernel only (stamp_stats must be NULL in forward-difference mode)");
+        return NGMIX_ERR_BAD_ARG;
     }
     const size_t lds = (size_t)(nloc + 1) * G * sizeof(FdGauss) + (size_t)G * sizeof(PixBox);
     if (lds > 128 * 1024) {
@@ -1416,7 +1531,8 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *stat
 
 int launch_lm_advance(lm_state *states, int64_t nobj, const int64_t *obj_start,
                       const int32_t *stamp_band, const double *sums, int nloc,
-                      const double *obj_sums, int32_t *nactive, hipStream_t s)
+                      const double *obj_sums, int32_t *nactive, const double *stamp_stats,
+                      double *obj_stats, hipStream_t s)
 {
     if (nobj <= 0) return NGMIX_OK;
     // nloc + 256 * npars: the fits' parameter count, if the caller says
@@ -1429,22 +1545,28 @@ int launch_lm_advance(lm_state *states, int64_t nobj, const int64_t *obj_start,
     static const bool generic = getenv("NGMIX_LM_GENERIC") != nullptr;   // A/B knob
     if (npars == 6 && !generic)
         hipLaunchKernelGGL((lm_advance_kernel<6, true>), grid, block, 0, s, states, nobj,
-                           obj_start, stamp_band, sums, nloc, obj_sums, nactive);
+                           obj_start, stamp_band, sums, nloc, obj_sums, nactive, stamp_stats,
+                           obj_stats);
     else if (npars == 7 && !generic)
         hipLaunchKernelGGL((lm_advance_kernel<7, true>), grid, block, 0, s, states, nobj,
-                           obj_start, stamp_band, sums, nloc, obj_sums, nactive);
+                           obj_start, stamp_band, sums, nloc, obj_sums, nactive, stamp_stats,
+                           obj_stats);
     else if (npars == 8 && !generic)
         hipLaunchKernelGGL((lm_advance_kernel<8, true>), grid, block, 0, s, states, nobj,
-                           obj_start, stamp_band, sums, nloc, obj_sums, nactive);
+                           obj_start, stamp_band, sums, nloc, obj_sums, nactive, stamp_stats,
+                           obj_stats);
     else if (npars == 9 && !generic)
         hipLaunchKernelGGL((lm_advance_kernel<9, true>), grid, block, 0, s, states, nobj,
-                           obj_start, stamp_band, sums, nloc, obj_sums, nactive);
+                           obj_start, stamp_band, sums, nloc, obj_sums, nactive, stamp_stats,
+                           obj_stats);
     else if (npars == 10 && !generic)
         hipLaunchKernelGGL((lm_advance_kernel<10, true>), grid, block, 0, s, states, nobj,
-                           obj_start, stamp_band, sums, nloc, obj_sums, nactive);
+                           obj_start, stamp_band, sums, nloc, obj_sums, nactive, stamp_stats,
+                           obj_stats);
     else
         hipLaunchKernelGGL((lm_advance_kernel<LM_NPMAX, false>), grid, block, 0, s, states,
-                           nobj, obj_start, stamp_band, sums, nloc, obj_sums, nactive);
+                           nobj, obj_start, stamp_band, sums, nloc, obj_sums, nactive,
+                           stamp_stats, obj_stats);
     NGMIX_HIP_CHECK(hipGetLastError());
     return NGMIX_OK;
 }

@@ -189,6 +189,20 @@ class LMBatchFitter(object):
         torch = _torch()
         L = _lib.lib()
         dev = stamps.device
+        # fitter.time_phases = True: wall-clock per phase of this call, each
+        # phase closed by a device synchronisation (a diagnostic: it removes
+        # the overlap between phases)
+        import time as _time
+        phases = {} if getattr(self, "time_phases", False) else None
+        tmark = [_time.perf_counter()]
+
+        def mark(name):
+            if phases is not None:
+                torch.cuda.synchronize(dev)
+                now = _time.perf_counter()
+                phases[name] = phases.get(name, 0.0) + (now - tmark[0]) * 1e3
+                tmark[0] = now
+        self.phase_ms = phases
         guess = np.ascontiguousarray(np.atleast_2d(guess), dtype="f8")
         nobj, npars = guess.shape
         nshape = self.nloc - 1
@@ -257,6 +271,14 @@ class LMBatchFitter(object):
         d_sums = torch.zeros((ns, nsum), dtype=torch.float64, device=dev)
         d_status = torch.zeros(ns, dtype=torch.int32, device=dev)
         d_nact = torch.zeros(1, dtype=torch.int32, device=dev)
+        # the loglike statistics of set_fit_result ride with the analytic
+        # kernel's sums (lnprob = -fnorm^2 / 2 has no prior term to add)
+        loop_stats = not self.fd and self.prior is None and \
+            not getattr(self, "stats_pass", False)
+        d_sstats = d_ostats = None
+        if loop_stats:
+            d_sstats = torch.empty((ns, 2), dtype=torch.float64, device=dev)
+            d_ostats = torch.zeros((nobj, 2), dtype=torch.float64, device=dev)
         b = stamps._batch(1)
         modnum = get_model_num(self.model)
         if self.ngauss is not None:
@@ -318,6 +340,7 @@ class LMBatchFitter(object):
             })
         rounds = 0
         import time
+        mark("setup")
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         # time_kernels: HIP events around every pixel-pass launch (bench.py),
@@ -336,7 +359,8 @@ class LMBatchFitter(object):
                 ctypes.byref(sub["batch"]), modnum, int(self.fd), _dptr(d_states),
                 off(d_sobj, 4 * s_lo), off(d_sband, 4 * s_lo),
                 off(psf.data, 104 * npsf * s_lo) if psf is not None else None,
-                npsf, off(d_sums, 8 * nsum * s_lo), off(d_status, 4 * s_lo), _stream()),
+                npsf, off(d_sums, 8 * nsum * s_lo), off(d_status, 4 * s_lo),
+                off(d_sstats, 16 * s_lo), _stream()),
                 "ngmix_lm_eval_batch")
             if ev is not None:
                 ev[-1][1].record()
@@ -356,7 +380,8 @@ class LMBatchFitter(object):
                 off(d_states, isz * o_lo), o_hi - o_lo, off(d_start, 8 * o_lo),
                 _dptr(d_sband), _dptr(d_sums), self.nloc + 256 * npars,
                 off(osums, 8 * wosum * o_lo) if osums is not None else None,
-                _dptr(sub["nact"]), _stream()),
+                _dptr(sub["nact"]), _dptr(d_sstats) if loop_stats else None,
+                off(d_ostats, 16 * o_lo), _stream()),
                 "ngmix_lm_advance_batch")
 
         osums_box = [None]
@@ -396,6 +421,7 @@ class LMBatchFitter(object):
             self.eval_ms = float(np.mean(ms))
             self.eval_ms_total = float(np.sum(ms))
             self.eval_stamps_total = float(np.sum([w for _, _, w in ev]))
+        mark("loop")
         self.nsplit_used = nsplit
         self._d_states = d_states
         self.rounds = rounds
@@ -429,48 +455,85 @@ class LMBatchFitter(object):
                 _dptr(d_states), nobj, _dptr(d_npix),
                 _dptr(d_ffx) if d_ffx is not None else None, float(PDEF), float(CDEF),
                 _dptr(d_rec), _stream()), "ngmix_lm_finalize_batch")
-        # the record array comes back through pinned memory on a side stream
-        # (PyTorch's caching host allocator: no hipHostMalloc after the first
-        # call) while the statistics pass below runs on the launch stream
-        # (pars_cov0, 40 % of the record, stays on the device until it is asked for)
+        mark("finalize")
+        # Two downloads through pinned memory on a side stream (PyTorch's
+        # caching host allocator: no hipHostMalloc after the first call):
+        #   * the head -- pars, pars_err, flags / nfev / ier / dof / njev and
+        #     the seven statistics columns, 2 n + 12 doubles per fit -- which
+        #     go() waits for;
+        #   * pars_cov (n^2 per fit, three quarters of the bytes), which keeps
+        #     flowing after go() has returned and is waited for when it is
+        #     first read (LMBatchResult lazy key; so are the blocks cut from it).
+        # pars_cov0 stays on the device until it is asked for.
         c0, c1 = 4 + 2 * n, 4 + 2 * n + n * n
-        d_head = d_rec[:, :4].to(torch.int64)       # flags, nfev, ier, dof
-        d_eager = torch.cat([d_rec[:, 4:c0], d_rec[:, c1:]], dim=1)
-        d_cov0 = d_rec[:, c0:c1].contiguous()
-        h_rec = torch.empty((nobj, width - n * n - 4), dtype=torch.float64, pin_memory=True)
+        d_cov0 = d_rec[:, c0:c1]
+        d_cov = d_rec[:, c1:].contiguous()
+        side = self._side_stream(dev)
+        d_ok = d_rec[:, 0] == 0.0
+        self._fit_ctx = (stamps, psf, sobj, sband, d_rec, d_ok, n)
+        self._gmix = None
+        if loop_stats:
+            # lnprob = -|f|^2 / 2 at the point the fit stands at; the s2n sums
+            # the advance kernel kept for that point
+            fn = sview[:, fields["fnorm"][1] // 8]
+            tot = torch.stack([-0.5 * fn * fn, d_ostats[:, 0], d_ostats[:, 1],
+                               d_npix.to(torch.float64)], dim=1)
+        else:
+            tot = self._loglike_at_solutions(stamps, psf, sobj, sband, obj_start)
+        d_stats = self._stats_columns(tot, d_ok, n)
+        njev = d_states.view(torch.int32).reshape(nobj, -1)[
+            :, _lib.LM_STATE_DTYPE.fields["njev"][1] // 4]
+        d_headblk = torch.cat([d_rec[:, 4:c0], d_rec[:, :4],
+                               njev.to(torch.float64)[:, None], d_stats], dim=1)
+        h_head = torch.empty(d_headblk.shape, dtype=torch.float64, pin_memory=True)
+        h_cov = torch.empty((nobj, n * n), dtype=torch.float64, pin_memory=True)
         ready = torch.cuda.Event()
         ready.record()
-        side = self._side_stream(dev)
         with torch.cuda.stream(side):
             side.wait_event(ready)
-            h_rec.copy_(d_eager, non_blocking=True)
+            h_head.copy_(d_headblk, non_blocking=True)
             copied = torch.cuda.Event()
             copied.record()
-        d_eager.record_stream(side)
-        stats = self._device_stats(stamps, psf, sobj, sband, obj_start, d_rec, n)
-        njev = d_states.view(torch.int32).reshape(nobj, -1)[
-            :, _lib.LM_STATE_DTYPE.fields["njev"][1] // 4].cpu().numpy()
-        head = d_head.t().contiguous().cpu().numpy()   # (4, nobj): contiguous columns
+            h_cov.copy_(d_cov, non_blocking=True)
+            cov_copied = torch.cuda.Event()
+            cov_copied.record()
+        d_headblk.record_stream(side)
+        d_cov.record_stream(side)
+        mark("enqueue_copy")
         copied.synchronize()
-        rec = h_rec.numpy()
+        mark("download")
+        rec = h_head.numpy()
+        ints = np.ascontiguousarray(rec[:, 2 * n:2 * n + 5].T).astype(np.int64)
         res = LMBatchResult({
             "model": self.model,
-            "flags": head[0],
-            "nfev": head[1],
-            "njev": njev.astype(np.int64),
-            "ier": head[2],
-            # views of the record array (no copies)
+            "flags": ints[0],
+            "nfev": ints[1],
+            "njev": ints[4],
+            "ier": ints[2],
+            # views of the downloaded block (no copies)
             "pars": rec[:, 0:n],
             "pars_err": rec[:, n:2 * n],
-            "pars_cov": np.lib.stride_tricks.as_strided(
-                rec[:, 2 * n:], shape=(nobj, n, n),
-                strides=(rec.strides[0], n * 8, 8), writeable=False),
             "npix": npix_obj,
-            "dof": head[3],
+            "dof": ints[3],
         })
+
+        def fetch_cov():
+            cov_copied.synchronize()
+            a = h_cov.numpy().reshape(nobj, n, n)
+            a.flags.writeable = False
+            return a
+        res.set_lazy("pars_cov", fetch_cov)
         res.set_lazy("pars_cov0", lambda: d_cov0.cpu().numpy().reshape(nobj, n, n))
-        self._add_stats(res, stats, nband)
+        self._add_stats(res, rec[:, 2 * n + 5:], nband)
+        mark("package")
         return res
+
+    @property
+    def gmix(self):
+        """the fitted (pre-psf) mixtures of the last go(), one per stamp"""
+        if self._gmix is None:
+            self._fitted_mixtures()
+        return self._gmix
 
     def _side_stream(self, dev, which=0):
         torch = _torch()
@@ -541,16 +604,15 @@ class LMBatchFitter(object):
         """the raw ngmix_lm_state records of the last go() (debugging)"""
         return self._d_states.cpu().numpy().reshape(-1).view(_lib.LM_STATE_DTYPE)
 
-    def _device_stats(self, stamps, psf, sobj, sband, obj_start, d_rec, n):
-        """the device half of FitModel.set_fit_result (results.py:45-72,
-        398-408): one batched get_loglike at the solutions, folded per object
-        on the device; returns the (nobj, 4) array lnprob, s2n_numer,
-        s2n_denom, npix (one small download)"""
+    def _fitted_mixtures(self):
+        """the mixtures at the solutions of the last go(): (pre-psf, convolved),
+        one per stamp; a harmless model stands in for failed fits (their
+        statistics are not reported)"""
         torch = _torch()
+        stamps, psf, sobj, sband, d_rec, d_ok, n = self._fit_ctx
         dev = stamps.device
         nobj = d_rec.shape[0]
         nshape = self.nloc - 1
-        # a harmless model for failed fits (their statistics are not reported)
         default = np.zeros(n)
         default[4] = 1.0
         if self.model == "bdf":
@@ -560,7 +622,6 @@ class LMBatchFitter(object):
         default[nshape:] = 1.0
         if self.model == "coellip":
             default[4:] = 1.0
-        d_ok = d_rec[:, 0] == 0.0
         usable = torch.where(d_ok[:, None], d_rec[:, 4:4 + n],
                              torch.from_numpy(default).to(dev)[None, :])
         if stamps.n == nobj and np.all(sband == 0):
@@ -578,7 +639,19 @@ class LMBatchFitter(object):
         gm = gm0
         if psf is not None:
             gm, _ = gm0.convolve(psf)
-        self.gmix = gm0  # the fitted (pre-psf) mixtures, one per stamp
+        self._gmix = gm0
+        return gm, usable
+
+    def _loglike_at_solutions(self, stamps, psf, sobj, sband, obj_start):
+        """the device half of FitModel.set_fit_result (results.py:45-72,
+        398-408) when the lock-step loop did not carry the statistics
+        (forward-difference fits, fits with a prior): one batched get_loglike
+        at the solutions, folded per object on the device; (nobj, 4) lnprob,
+        s2n_numer, s2n_denom, npix"""
+        torch = _torch()
+        dev = stamps.device
+        gm, usable = self._fitted_mixtures()
+        nobj = usable.shape[0]
         out, st1 = stamps.loglike(gm)
         if stamps.n == nobj:
             tot = out
@@ -590,9 +663,14 @@ class LMBatchFitter(object):
             # calc_lnprob adds the joint prior (results.py:410-437)
             tot = tot.clone()
             tot[:, 0] += self.prior.get_lnprob_batch(usable.contiguous())
-        # lnprob, s2n_numer, s2n_denom, npix, dof, chi2per, s2n -- NaN for the
-        # fits that failed, as set_fit_result leaves those keys out
-        nan = torch.full((nobj,), float("nan"), dtype=torch.float64, device=dev)
+        return tot
+
+    @staticmethod
+    def _stats_columns(tot, d_ok, n):
+        """lnprob, s2n_numer, s2n_denom, npix, dof, chi2per, s2n per object --
+        NaN for the fits that failed, as set_fit_result leaves those keys out"""
+        torch = _torch()
+        nan = torch.full_like(tot[:, 0], float("nan"))
         npix = torch.round(tot[:, 3])
         dof = npix - float(n)
         s2n = torch.where(tot[:, 2] > 0, tot[:, 1] / torch.sqrt(tot[:, 2]),
@@ -601,7 +679,7 @@ class LMBatchFitter(object):
                 torch.where(d_ok, tot[:, 2], nan), npix, dof,
                 torch.where(d_ok, tot[:, 0] / (-0.5) / dof, nan),
                 torch.where(d_ok, s2n, nan)]
-        return torch.stack(cols, dim=1).cpu().numpy()
+        return torch.stack(cols, dim=1)
 
     def _add_stats(self, res, out, nband):
         """the host half: the keys FitModel.set_fit_result adds for fits with
@@ -617,21 +695,22 @@ class LMBatchFitter(object):
         res["chi2per"] = out[:, 5]
         res["s2n_w"] = out[:, 6]
         res["s2n"] = res["s2n_w"]
-        with np.errstate(all="ignore"):
-            pc = res["pars_cov"]
-            res["g"] = pars[:, 2:4]
-            res["g_cov"] = pc[:, 2:4, 2:4]
-            res["g_err"] = res["pars_err"][:, 2:4]
-            if self.model == "coellip":
-                # CoellipFitModel._set_flux is a no-op (results.py:648-652)
-                return
-            res["T"] = pars[:, 4]
-            res["T_err"] = np.sqrt(pc[:, 4, 4])
-            if nband == 1:
-                res["flux"] = pars[:, nshape]
-                res["flux_err"] = np.sqrt(pc[:, nshape, nshape])
-            else:
-                res["flux"] = pars[:, nshape:]
-                res["flux_cov"] = pc[:, nshape:, nshape:]
-                res["flux_err"] = np.sqrt(np.diagonal(res["flux_cov"], axis1=1,
-                                                      axis2=2))
+        perr = res["pars_err"]
+        res["g"] = pars[:, 2:4]
+        res["g_err"] = perr[:, 2:4]
+        # (blocks of pars_cov: read when asked for, like pars_cov itself)
+        res.set_lazy("g_cov", lambda: res["pars_cov"][:, 2:4, 2:4])
+        if self.model == "coellip":
+            # CoellipFitModel._set_flux is a no-op (results.py:648-652)
+            return
+        # pars_err is sqrt(diag(pars_cov)) (fitters.py:333-339), made by the
+        # finalize kernel with the same IEEE square root
+        res["T"] = pars[:, 4]
+        res["T_err"] = perr[:, 4]
+        if nband == 1:
+            res["flux"] = pars[:, nshape]
+            res["flux_err"] = perr[:, nshape]
+        else:
+            res["flux"] = pars[:, nshape:]
+            res.set_lazy("flux_cov", lambda: res["pars_cov"][:, nshape:, nshape:])
+            res["flux_err"] = perr[:, nshape:]

@@ -556,7 +556,7 @@ def test_lm_eval_skipping_is_exact(model, fd, npsf, offset):
         b = sb._batch(1, no_skip=no_skip)
         _lib.check(L.ngmix_lm_eval_batch(ctypes.byref(b), get_model_num(model), fd, _dptr(st),
                                          _dptr(sobj), _dptr(sband), _dptr(psf.data), npsf,
-                                         _dptr(sums), _dptr(status), _stream()), "eval")
+                                         _dptr(sums), _dptr(status), None, _stream()), "eval")
         torch.cuda.synchronize()
         assert int(status.abs().sum()) == 0
         out.append(sums.cpu().numpy())

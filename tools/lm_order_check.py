@@ -51,7 +51,7 @@ def sums_at_guess(sbx, gx, psfx):
     b = sbx._batch(1)
     _lib.check(L.ngmix_lm_eval_batch(ctypes.byref(b), get_model_num("exp"), 0, _dptr(st),
                                      _dptr(sobj), _dptr(sband), _dptr(psfx.data), 1,
-                                     _dptr(sums), _dptr(status), _stream()), "eval")
+                                     _dptr(sums), _dptr(status), None, _stream()), "eval")
     torch.cuda.synchronize()
     return sums.cpu().numpy(), st
 

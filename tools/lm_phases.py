@@ -1,0 +1,44 @@
+"""where a LMBatchFitter.go() call spends its time (config 3): wall-clock per
+phase with a device sync after each, next to the un-instrumented call
+python tools/lm_phases.py [nstamps]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import bench  # noqa: E402
+from ngmix_amd.batch import GMixBatch  # noqa: E402
+from ngmix_amd.lm_batch import LMBatchFitter  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+dev = torch.device("cuda", 0)
+sb, _, pars = bench.make_workload(n, seed=1000, device=dev)
+rng = np.random.RandomState(7)
+guess = pars * rng.uniform(0.9, 1.1, size=pars.shape)
+psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (n, 1)), "gauss",
+                             device=dev)
+fitter = LMBatchFitter("exp")
+for _ in range(3):
+    fitter.go(sb, guess, psf=psf)
+torch.cuda.synchronize()
+best = 1e9
+for _ in range(7):
+    t0 = time.perf_counter()
+    res = fitter.go(sb, guess, psf=psf)
+    res["pars"]
+    torch.cuda.synchronize()
+    best = min(best, time.perf_counter() - t0)
+print("plain go(): best of 7 %.3f ms (loop %.3f ms, %d rounds)" % (
+    best * 1e3, fitter.loop_seconds * 1e3, fitter.rounds))
+fitter.time_phases = True
+acc = {}
+for _ in range(5):
+    fitter.go(sb, guess, psf=psf)
+    for k, v in fitter.phase_ms.items():
+        acc.setdefault(k, []).append(v)
+print("phases (ms, min of 5, each closed by a sync):",
+      {k: round(min(v), 3) for k, v in acc.items()},
+      "sum %.3f" % sum(min(v) for v in acc.values()))
