@@ -451,7 +451,7 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
                            "records" % world,
         },
         "roofline": {
-            "bound": "hbm", "kernel": "ngmix::lm_eval_kernel<true>",
+            "bound": "hbm", "kernel": "ngmix::lm_eval_kernel<true, true>",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_launch": eval_bytes * stamps_per_launch,

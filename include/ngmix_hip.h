@@ -570,6 +570,23 @@ int ngmix_lm_finalize_batch(const ngmix_lm_state *states, int64_t nobj,
                             const int64_t *npix_obj, const double *ff_extra,
                             double pdef, double cdef, double *rec, void *stream);
 
+/* DEVICE: the statistics of FitModel.set_fit_result (results.py:45-72,
+   398-408) and the integer columns of the records above, laid out for one
+   contiguous download.  rec: the records of ngmix_lm_finalize_batch
+   (npars = states[i].n for every i).  The loglike sums at the solutions come
+   either from obj_stats (nobj, 2) kept by ngmix_lm_advance_batch (lnprob is
+   then -fnorm^2 / 2 and npix = npix_obj) or from tot (nobj, 4) = lnprob,
+   s2n_numer, s2n_denom, npix of a get_loglike pass (exactly one of the two is
+   not NULL).  head: (nobj, 2 npars) = pars | pars_err; cols:
+   (NGMIX_LM_NCOLS, nobj) column-major = flags, nfev, ier, dof (of the fit),
+   njev, lnprob, s2n_numer, s2n_denom, npix, dof, chi2per, s2n -- the seven
+   statistics are NaN where flags != 0, as set_fit_result leaves them out */
+#define NGMIX_LM_NCOLS 12
+int ngmix_lm_pack_batch(const ngmix_lm_state *states, int64_t nobj, int npars,
+                        const double *rec, const double *obj_stats,
+                        const double *tot, const int64_t *npix_obj, double *head,
+                        double *cols, void *stream);
+
 /* ======================================================================
  * (4) MULTI-GPU: one process per GPU; objects are sharded by contiguous
  * blocks and nothing crosses ranks except the per-object RESULT RECORDS

@@ -229,7 +229,9 @@ SIGNATURES = {
     "ngmix_lm_advance_batch": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
                                       _vp]),
     "ngmix_lm_finalize_batch": (_i32, [_vp, _i64, _vp, _vp, _f64, _f64, _vp, _vp]),
+    "ngmix_lm_pack_batch": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
+LM_NCOLS = 12
 
 
 def _makefile_list(name):

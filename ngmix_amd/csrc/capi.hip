@@ -683,4 +683,12 @@ int ngmix_lm_finalize_batch(const ngmix_lm_state *states, int64_t nobj,
                               (hipStream_t)stream);
 }
 
+int ngmix_lm_pack_batch(const ngmix_lm_state *states, int64_t nobj, int npars,
+                        const double *rec, const double *obj_stats, const double *tot,
+                        const int64_t *npix_obj, double *head, double *cols, void *stream)
+{
+    return launch_lm_pack(states, nobj, npars, rec, obj_stats, tot, npix_obj, head, cols,
+                          (hipStream_t)stream);
+}
+
 }  // extern "C"

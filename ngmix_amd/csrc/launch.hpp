@@ -60,4 +60,8 @@ int launch_lm_finalize(const ngmix_lm_state *states, int64_t nobj,
                        const int64_t *npix_obj, const double *ff_extra, double pdef,
                        double cdef, double *rec, hipStream_t s);
 
+int launch_lm_pack(const ngmix_lm_state *states, int64_t nobj, int npars, const double *rec,
+                   const double *obj_stats, const double *tot, const int64_t *npix_obj,
+                   double *head, double *cols, hipStream_t s);
+
 }  // namespace ngmix

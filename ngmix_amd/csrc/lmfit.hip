@@ -167,7 +167,10 @@ __device__ __forceinline__ double mul_sgpr(double a, double b)
 
 // LDS_TILES: the tile records of the stamp are staged in LDS (every batch whose
 // largest stamp has at most LM_TILE_CAP tiles); otherwise made on the fly
-template <bool LDS_TILES>
+// RAW: the normal equations are accumulated in the raw basis and mapped after
+// the reduction (the default); false keeps the per-pixel map (NGMIX_LM_JBASIS,
+// the A/B knob: no statistics then)
+template <bool LDS_TILES, bool RAW = true>
 __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
     const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
     const double *__restrict__ ierr, const ngmix_jacobian *__restrict__ jacs,
@@ -465,12 +468,23 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
         if (!masked || pierr > 0.0) {
             const double f = (o0 - pval) * pierr;
             double B[6];
-            B[0] = o1 * pierr;
-            B[1] = o2 * pierr;
-            B[2] = n11 * pierr;
-            B[3] = n12 * pierr;
-            B[4] = n22 * pierr;
-            B[5] = o0 * pierr;
+            if (RAW) {
+                B[0] = o1 * pierr;
+                B[1] = o2 * pierr;
+                B[2] = n11 * pierr;
+                B[3] = n12 * pierr;
+                B[4] = n22 * pierr;
+                B[5] = o0 * pierr;
+            } else {
+                const double m11 = n11 * pierr, m12 = n12 * pierr, m22 = n22 * pierr;
+                B[0] = o1 * pierr;
+                B[1] = o2 * pierr;
+                const double md = m11 - m22;   // u_a0 == -u_a2 for a = g1, g2
+                B[2] = fma_sgpr(h00, md, mul_sgpr(h01, m12));
+                B[3] = fma_sgpr(h10, md, mul_sgpr(h11, m12));
+                B[4] = fma_sgpr(h20, m11, fma_sgpr(h21, m12, mul_sgpr(h22, m22)));
+                B[5] = o0 * mul_sgpr(iflux, pierr);
+            }
             int k = 0;
 #pragma unroll
             for (int a = 0; a < 6; a++)
@@ -496,7 +510,14 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
         const double ab = swap_add16(acc[4 * r + 0], acc[4 * r + 1]);
         const double cd = swap_add16(acc[4 * r + 2], acc[4 * r + 3]);
         const double t = row16_sum(swap_add32(ab, cd));
-        if ((lane & 15) == 15) sh.raw[4 * r + (lane >> 4)] = t;
+        if ((lane & 15) == 15) {
+            if (RAW) sh.raw[4 * r + (lane >> 4)] = t;
+            else out[4 * r + (lane >> 4)] = t;
+        }
+    }
+    if (!RAW) {
+        if (lane == 0 && status) status[s] = NGMIX_OK;
+        return;
     }
     // ---- raw basis -> parameters.  Row a of H has at most three terms,
     // (column, coefficient): cen1 = B0, cen2 = B1, g1 / g2 = h_a0 (B2 - B4) +
@@ -1422,6 +1443,69 @@ int launch_lm_finalize(const lm_state *states, int64_t nobj, const int64_t *npix
     return NGMIX_OK;
 }
 
+// FitModel.set_fit_result's statistics (results.py:45-72, 398-408) and the
+// integer columns of run_leastsq's packaging, one thread per fit, laid out for
+// ONE contiguous download: head (nobj, 2 n) = pars | pars_err row-major, then
+// cols (NGMIX_LM_NCOLS, nobj) column-major -- every host array is then a
+// contiguous view of the downloaded buffer
+__global__ __launch_bounds__(256) void lm_pack_kernel(
+    const lm_state *__restrict__ states, int64_t nobj, int n, const double *__restrict__ rec,
+    const double *__restrict__ obj_stats, const double *__restrict__ tot,
+    const int64_t *__restrict__ npix_obj, double *__restrict__ head,
+    double *__restrict__ cols)
+{
+    const int64_t o = blockIdx.x * (int64_t)256 + threadIdx.x;
+    if (o >= nobj) return;
+    const double *r = rec + o * (4 + 2 * (int64_t)n + 2 * (int64_t)n * n);
+    for (int k = 0; k < 2 * n; k++) head[o * 2 * n + k] = r[4 + k];
+    const bool ok = r[0] == 0.0;
+    double lnprob, numer, denom, npix;
+    if (obj_stats) {
+        // the loop carried them: lnprob = -|f|^2 / 2 where the fit stands
+        const double fn = states[o].fnorm;
+        lnprob = -0.5 * fn * fn;
+        numer = obj_stats[2 * o];
+        denom = obj_stats[2 * o + 1];
+        npix = (double)npix_obj[o];
+    } else {
+        lnprob = tot[4 * o];
+        numer = tot[4 * o + 1];
+        denom = tot[4 * o + 2];
+        npix = rint(tot[4 * o + 3]);
+    }
+    const double dof = npix - (double)n;
+    const double s2n = denom > 0.0 ? numer / sqrt(denom) : 0.0;
+    double *c = cols + o;
+    c[0 * nobj] = r[0];                       // flags
+    c[1 * nobj] = r[1];                       // nfev
+    c[2 * nobj] = r[2];                       // ier
+    c[3 * nobj] = r[3];                       // dof of run_leastsq
+    c[4 * nobj] = (double)states[o].njev;
+    c[5 * nobj] = ok ? lnprob : NAN;
+    c[6 * nobj] = ok ? numer : NAN;
+    c[7 * nobj] = ok ? denom : NAN;
+    c[8 * nobj] = npix;
+    c[9 * nobj] = dof;
+    c[10 * nobj] = ok ? lnprob / (-0.5) / dof : NAN;   // results.py:64
+    c[11 * nobj] = ok ? s2n : NAN;
+}
+
+int launch_lm_pack(const lm_state *states, int64_t nobj, int npars, const double *rec,
+                   const double *obj_stats, const double *tot, const int64_t *npix_obj,
+                   double *head, double *cols, hipStream_t s)
+{
+    if (nobj <= 0) return NGMIX_OK;
+    if (!states || !rec || !head || !cols || npars < 1 || npars > LM_NPMAX ||
+        (obj_stats ? !npix_obj : !tot)) {
+        set_last_error_msg("lm_pack: bad argument");
+        return NGMIX_ERR_BAD_ARG;
+    }
+    hipLaunchKernelGGL(lm_pack_kernel, dim3((unsigned)((nobj + 255) / 256)), dim3(256), 0, s,
+                       states, nobj, npars, rec, obj_stats, tot, npix_obj, head, cols);
+    NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
+}
+
 static int model_ngauss_npars(int model, int &ng0, int &nloc)
 {
     switch (model) {
@@ -1483,8 +1567,16 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *stat
             set_last_error_msg("lm_eval: too many composed gaussians for LDS");
             return NGMIX_ERR_BAD_ARG;
         }
-        const void *kern = lds_tiles ? (const void *)lm_eval_kernel<true>
-                                     : (const void *)lm_eval_kernel<false>;
+        static const bool jbasis = getenv("NGMIX_LM_JBASIS") != nullptr;   // A/B knob
+        if (jbasis && stamp_stats) {
+            set_last_error_msg("lm_eval: NGMIX_LM_JBASIS carries no statistics");
+            return NGMIX_ERR_BAD_ARG;
+        }
+        const void *kern =
+            jbasis ? (lds_tiles ? (const void *)lm_eval_kernel<true, false>
+                                : (const void *)lm_eval_kernel<false, false>)
+                   : (lds_tiles ? (const void *)lm_eval_kernel<true, true>
+                                : (const void *)lm_eval_kernel<false, true>);
         if (lds > 48 * 1024)
             NGMIX_HIP_CHECK(hipFuncSetAttribute(
                 kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

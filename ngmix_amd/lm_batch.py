@@ -60,11 +60,16 @@ class LMBatchResult(dict):
         self._lazy = {}
 
     def set_lazy(self, key, fetch):
+        """fetch(result) -> value, called once when `key` is first read (it is
+        handed the result instead of closing over it: a closure would make a
+        reference cycle, and the pinned download buffers behind the arrays
+        would wait for the cyclic collector instead of going back to the
+        allocator when the result is dropped)"""
         self._lazy[key] = fetch
 
     def __missing__(self, key):
         if key in self._lazy:
-            value = self._lazy.pop(key)()
+            value = self._lazy.pop(key)(self)
             self[key] = value
             return value
         raise KeyError(key)
@@ -198,7 +203,8 @@ class LMBatchFitter(object):
 
         def mark(name):
             if phases is not None:
-                torch.cuda.synchronize(dev)
+                if self.time_phases != "nosync":
+                    torch.cuda.synchronize(dev)
                 now = _time.perf_counter()
                 phases[name] = phases.get(name, 0.0) + (now - tmark[0]) * 1e3
                 tmark[0] = now
@@ -274,7 +280,8 @@ class LMBatchFitter(object):
         # the loglike statistics of set_fit_result ride with the analytic
         # kernel's sums (lnprob = -fnorm^2 / 2 has no prior term to add)
         loop_stats = not self.fd and self.prior is None and \
-            not getattr(self, "stats_pass", False)
+            not getattr(self, "stats_pass", False) and \
+            not os.environ.get("NGMIX_LM_JBASIS")
         d_sstats = d_ostats = None
         if loop_stats:
             d_sstats = torch.empty((ns, 2), dtype=torch.float64, device=dev)
@@ -337,6 +344,9 @@ class LMBatchFitter(object):
                 "stream": self._side_stream(dev, 1 + k) if nsplit > 1 else None,
                 "nact": torch.zeros(1, dtype=torch.int32, device=dev),
                 "live": True, "active": o_hi - o_lo,
+                "ring": [torch.zeros(1, dtype=torch.int32, pin_memory=True)
+                         for _ in range(3)],
+                "pend": [], "launched": 0, "ev_idx": [],
             })
         rounds = 0
         import time
@@ -351,9 +361,12 @@ class LMBatchFitter(object):
         def enqueue(sub):
             (o_lo, o_hi), (s_lo, s_hi) = sub["o"], sub["s"]
             if ev is not None:
-                ev.append((torch.cuda.Event(enable_timing=True),
+                # (the stamps this launch still has to evaluate are known when
+                # the previous round's counter is read: filled in then)
+                ev.append([torch.cuda.Event(enable_timing=True),
                            torch.cuda.Event(enable_timing=True),
-                           sub["active"] * nstamp_obj))
+                           sub["active"] * nstamp_obj if not sub["launched"] else None])
+                sub["ev_idx"].append(len(ev) - 1)
                 ev[-1][0].record()
             _lib.check(L.ngmix_lm_eval_batch(
                 ctypes.byref(sub["batch"]), modnum, int(self.fd), _dptr(d_states),
@@ -383,6 +396,14 @@ class LMBatchFitter(object):
                 _dptr(sub["nact"]), _dptr(d_sstats) if loop_stats else None,
                 off(d_ostats, 16 * o_lo), _stream()),
                 "ngmix_lm_advance_batch")
+            # the count of fits still running, on its way to the host behind
+            # the round that made it
+            h = sub["ring"][sub["launched"] % len(sub["ring"])]
+            h.copy_(sub["nact"], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            sub["pend"].append((done, h))
+            sub["launched"] += 1
 
         osums_box = [None]
         with torch.cuda.device(dev):
@@ -392,15 +413,29 @@ class LMBatchFitter(object):
                 start.record(main)
                 for sub in subs:
                     sub["stream"].wait_event(start)
+            # One round is kept in flight AHEAD of the counter being read: the
+            # host reads round r's count of running fits (a 4-byte pinned copy
+            # behind that round) while round r + 1 already runs, so the GPU
+            # never waits for the host between rounds.  When the count is zero
+            # the round in flight finds every fit finished and both its kernels
+            # return at once (~30 us, once per call).
+            depth = 1 if check_every == 1 else 0
             while any(sub["live"] for sub in subs):
                 for sub in subs:
                     if not sub["live"]:
                         continue
                     with torch.cuda.stream(sub["stream"] or main):
-                        if rounds > 0 and (rounds % check_every == 0 or rounds > 2 * maxfev):
-                            # the fits of this piece still running (waits for its
-                            # last lm_advance only; the other piece keeps the GPU busy)
-                            sub["active"] = int(sub["nact"].item())
+                        if len(sub["pend"]) > depth and (
+                                sub["launched"] % check_every == 0 or
+                                sub["launched"] > 2 * maxfev):
+                            while len(sub["pend"]) > depth:
+                                done, h = sub["pend"].pop(0)
+                            done.synchronize()
+                            sub["active"] = int(h[0])
+                            # (that count is what the launch after it evaluates)
+                            k = sub["launched"] - len(sub["pend"])
+                            if ev is not None and k < len(sub["ev_idx"]):
+                                ev[sub["ev_idx"][k]][2] = sub["active"] * nstamp_obj
                             if sub["active"] == 0:
                                 sub["live"] = False
                                 continue
@@ -408,7 +443,8 @@ class LMBatchFitter(object):
                 rounds += 1
                 if rounds > 2 * maxfev + 5:
                     raise RuntimeError("batched LM did not terminate")
-            rounds -= 1   # the last trip only read the counters
+            # rounds that had fits to advance (not the one in flight at the end)
+            rounds = max(sub["launched"] - len(sub["pend"]) for sub in subs)
             if nsplit > 1:
                 for sub in subs:
                     main.wait_stream(sub["stream"])
@@ -417,6 +453,13 @@ class LMBatchFitter(object):
         self.loop_seconds = time.perf_counter() - t0
         if ev is not None:
             # per-launch mean, and the whole fit: stamps evaluated / time spent
+            # (a launch whose count was never read -- check_every > 1 -- keeps
+            # the last count known before it)
+            last = 0.0
+            for rec_ in ev:
+                if rec_[2] is None:
+                    rec_[2] = last
+                last = rec_[2]
             ms = [a.elapsed_time(b) for a, b, _ in ev]
             self.eval_ms = float(np.mean(ms))
             self.eval_ms_total = float(np.sum(ms))
@@ -472,59 +515,63 @@ class LMBatchFitter(object):
         d_ok = d_rec[:, 0] == 0.0
         self._fit_ctx = (stamps, psf, sobj, sband, d_rec, d_ok, n)
         self._gmix = None
-        if loop_stats:
-            # lnprob = -|f|^2 / 2 at the point the fit stands at; the s2n sums
-            # the advance kernel kept for that point
-            fn = sview[:, fields["fnorm"][1] // 8]
-            tot = torch.stack([-0.5 * fn * fn, d_ostats[:, 0], d_ostats[:, 1],
-                               d_npix.to(torch.float64)], dim=1)
-        else:
-            tot = self._loglike_at_solutions(stamps, psf, sobj, sband, obj_start)
-        d_stats = self._stats_columns(tot, d_ok, n)
-        njev = d_states.view(torch.int32).reshape(nobj, -1)[
-            :, _lib.LM_STATE_DTYPE.fields["njev"][1] // 4]
-        d_headblk = torch.cat([d_rec[:, 4:c0], d_rec[:, :4],
-                               njev.to(torch.float64)[:, None], d_stats], dim=1)
-        h_head = torch.empty(d_headblk.shape, dtype=torch.float64, pin_memory=True)
+        tot = None
+        if not loop_stats:
+            tot = self._loglike_at_solutions(stamps, psf, sobj, sband,
+                                             obj_start).contiguous()
+        # pars | pars_err rows, then twelve contiguous columns (integers and
+        # statistics): one kernel, one download, contiguous host views
+        ncols = _lib.LM_NCOLS
+        d_flat = torch.empty(nobj * (2 * n + ncols), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.ngmix_lm_pack_batch(
+                _dptr(d_states), nobj, n, _dptr(d_rec), _dptr(d_ostats) if loop_stats else None,
+                _dptr(tot), _dptr(d_npix), _dptr(d_flat),
+                ctypes.c_void_p(d_flat.data_ptr() + 8 * nobj * 2 * n), _stream()),
+                "ngmix_lm_pack_batch")
+        mark("pack")
+        h_flat = torch.empty(d_flat.shape, dtype=torch.float64, pin_memory=True)
         h_cov = torch.empty((nobj, n * n), dtype=torch.float64, pin_memory=True)
+        mark("pinned_alloc")
         ready = torch.cuda.Event()
         ready.record()
         with torch.cuda.stream(side):
             side.wait_event(ready)
-            h_head.copy_(d_headblk, non_blocking=True)
+            h_flat.copy_(d_flat, non_blocking=True)
             copied = torch.cuda.Event()
             copied.record()
             h_cov.copy_(d_cov, non_blocking=True)
             cov_copied = torch.cuda.Event()
             cov_copied.record()
-        d_headblk.record_stream(side)
+        d_flat.record_stream(side)
         d_cov.record_stream(side)
         mark("enqueue_copy")
         copied.synchronize()
         mark("download")
-        rec = h_head.numpy()
-        ints = np.ascontiguousarray(rec[:, 2 * n:2 * n + 5].T).astype(np.int64)
+        flat = h_flat.numpy()
+        rec = flat[:nobj * 2 * n].reshape(nobj, 2 * n)
+        cols = flat[nobj * 2 * n:].reshape(ncols, nobj)
         res = LMBatchResult({
             "model": self.model,
-            "flags": ints[0],
-            "nfev": ints[1],
-            "njev": ints[4],
-            "ier": ints[2],
+            "flags": cols[0].astype(np.int64),
+            "nfev": cols[1].astype(np.int64),
+            "njev": cols[4].astype(np.int64),
+            "ier": cols[2].astype(np.int64),
             # views of the downloaded block (no copies)
             "pars": rec[:, 0:n],
             "pars_err": rec[:, n:2 * n],
             "npix": npix_obj,
-            "dof": ints[3],
+            "dof": cols[3].astype(np.int64),
         })
 
-        def fetch_cov():
+        def fetch_cov(_):
             cov_copied.synchronize()
             a = h_cov.numpy().reshape(nobj, n, n)
             a.flags.writeable = False
             return a
         res.set_lazy("pars_cov", fetch_cov)
-        res.set_lazy("pars_cov0", lambda: d_cov0.cpu().numpy().reshape(nobj, n, n))
-        self._add_stats(res, rec[:, 2 * n + 5:], nband)
+        res.set_lazy("pars_cov0", lambda _: d_cov0.cpu().numpy().reshape(nobj, n, n))
+        self._add_stats(res, cols[5:], nband)
         mark("package")
         return res
 
@@ -665,41 +712,26 @@ class LMBatchFitter(object):
             tot[:, 0] += self.prior.get_lnprob_batch(usable.contiguous())
         return tot
 
-    @staticmethod
-    def _stats_columns(tot, d_ok, n):
-        """lnprob, s2n_numer, s2n_denom, npix, dof, chi2per, s2n per object --
-        NaN for the fits that failed, as set_fit_result leaves those keys out"""
-        torch = _torch()
-        nan = torch.full_like(tot[:, 0], float("nan"))
-        npix = torch.round(tot[:, 3])
-        dof = npix - float(n)
-        s2n = torch.where(tot[:, 2] > 0, tot[:, 1] / torch.sqrt(tot[:, 2]),
-                          torch.zeros_like(nan))
-        cols = [torch.where(d_ok, tot[:, 0], nan), torch.where(d_ok, tot[:, 1], nan),
-                torch.where(d_ok, tot[:, 2], nan), npix, dof,
-                torch.where(d_ok, tot[:, 0] / (-0.5) / dof, nan),
-                torch.where(d_ok, s2n, nan)]
-        return torch.stack(cols, dim=1)
-
     def _add_stats(self, res, out, nband):
         """the host half: the keys FitModel.set_fit_result adds for fits with
-        flags == 0 (NaN elsewhere); g / T / flux blocks are VIEWS of the
-        record array"""
+        flags == 0 (NaN elsewhere); out: the seven statistics columns of
+        ngmix_lm_pack_batch (contiguous rows); g / T / flux blocks are VIEWS
+        of the downloaded arrays"""
         pars = res["pars"]
         nshape = self.nloc - 1
-        res["lnprob"] = out[:, 0]
-        res["s2n_numer"] = out[:, 1]
-        res["s2n_denom"] = out[:, 2]
-        res["npix"] = out[:, 3].astype(np.int64)
-        res["dof"] = out[:, 4].astype(np.int64)
-        res["chi2per"] = out[:, 5]
-        res["s2n_w"] = out[:, 6]
+        res["lnprob"] = out[0]
+        res["s2n_numer"] = out[1]
+        res["s2n_denom"] = out[2]
+        res["npix"] = out[3].astype(np.int64)
+        res["dof"] = out[4].astype(np.int64)
+        res["chi2per"] = out[5]
+        res["s2n_w"] = out[6]
         res["s2n"] = res["s2n_w"]
         perr = res["pars_err"]
         res["g"] = pars[:, 2:4]
         res["g_err"] = perr[:, 2:4]
         # (blocks of pars_cov: read when asked for, like pars_cov itself)
-        res.set_lazy("g_cov", lambda: res["pars_cov"][:, 2:4, 2:4])
+        res.set_lazy("g_cov", lambda r: r["pars_cov"][:, 2:4, 2:4])
         if self.model == "coellip":
             # CoellipFitModel._set_flux is a no-op (results.py:648-652)
             return
@@ -712,5 +744,5 @@ class LMBatchFitter(object):
             res["flux_err"] = perr[:, nshape]
         else:
             res["flux"] = pars[:, nshape:]
-            res.set_lazy("flux_cov", lambda: res["pars_cov"][:, nshape:, nshape:])
+            res.set_lazy("flux_cov", lambda r: r["pars_cov"][:, nshape:, nshape:])
             res["flux_err"] = perr[:, nshape:]

@@ -68,7 +68,7 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["bad_status"] == 0 and d["unit"] == "fits/s"
-    assert d["roofline"]["kernel"] == "ngmix::lm_eval_kernel<true>" and d["roofline"]["frac"] > 0
+    assert d["roofline"]["kernel"].startswith("ngmix::lm_eval_kernel<") and d["roofline"]["frac"] > 0
     # config 5 (multi-epoch objects: every epoch of an object on one rank)
     cmd5 = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "C5",
             "--steps", "2", "--warmup", "1", "--settle-steps", "0", "--nstamps", "300"]

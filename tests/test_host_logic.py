@@ -428,7 +428,7 @@ def test_lm_batch_result_lazy_keys_are_ordinary_keys():
     def make():
         calls = []
         r = LMBatchResult(a=np.arange(3))
-        r.set_lazy("c", lambda: calls.append(1) or np.ones(3))
+        r.set_lazy("c", lambda _: calls.append(1) or np.ones(3))
         return r, calls
 
     r, calls = make()
@@ -453,3 +453,17 @@ def test_lm_batch_result_lazy_keys_are_ordinary_keys():
     assert "c" not in r and not calls
     with pytest.raises(KeyError):
         r["c"]
+    # a fetcher is handed the result (no closure over it, hence no reference
+    # cycle: dropping the result frees what its arrays hold at once)
+    import gc
+    import weakref
+    r, calls = make()
+    r.set_lazy("d", lambda res: res["a"] * 2)
+    w = weakref.ref(r)
+    assert np.all(r["d"] == 2 * np.arange(3))
+    gc.disable()
+    try:
+        del r
+        assert w() is None
+    finally:
+        gc.enable()

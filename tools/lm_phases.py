@@ -25,14 +25,18 @@ for _ in range(3):
     fitter.go(sb, guess, psf=psf)
 torch.cuda.synchronize()
 best = 1e9
-for _ in range(7):
+allt = []
+for _ in range(12):
     t0 = time.perf_counter()
     res = fitter.go(sb, guess, psf=psf)
     res["pars"]
+    t1 = time.perf_counter()
     torch.cuda.synchronize()
-    best = min(best, time.perf_counter() - t0)
-print("plain go(): best of 7 %.3f ms (loop %.3f ms, %d rounds)" % (
-    best * 1e3, fitter.loop_seconds * 1e3, fitter.rounds))
+    t2 = time.perf_counter()
+    allt.append((round((t1 - t0) * 1e3, 2), round((t2 - t1) * 1e3, 2)))
+    best = min(best, t2 - t0)
+print("plain go(): best of 12 %.3f ms (loop %.3f ms, %d rounds); (go, trailing sync) ms: %s" % (
+    best * 1e3, fitter.loop_seconds * 1e3, fitter.rounds, allt))
 fitter.time_phases = True
 acc = {}
 for _ in range(5):
@@ -42,3 +46,15 @@ for _ in range(5):
 print("phases (ms, min of 5, each closed by a sync):",
       {k: round(min(v), 3) for k, v in acc.items()},
       "sum %.3f" % sum(min(v) for v in acc.values()))
+
+fitter.time_phases = "nosync"
+acc = {}
+for _ in range(5):
+    t0 = time.perf_counter()
+    res = fitter.go(sb, guess, psf=psf)
+    dt = (time.perf_counter() - t0) * 1e3
+    for k, v in fitter.phase_ms.items():
+        acc.setdefault(k, []).append(v)
+    acc.setdefault("total", []).append(dt)
+print("host time per phase without syncs (ms, all 5):",
+      {k: [round(x, 2) for x in v] for k, v in acc.items()})

@@ -1,0 +1,58 @@
+"""lm_eval_kernel alone on the C3 workload: the launch at every fit's starting
+point, HIP events over 30 launches (NGMIX_LM_JBASIS=1 selects the per-pixel
+map for A/B)
+python tools/time_lm_eval.py [nstamps]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import bench  # noqa: E402
+from ngmix_amd import _lib  # noqa: E402
+from ngmix_amd.batch import GMixBatch, _dptr, _stream  # noqa: E402
+from ngmix_amd.gmix import get_model_num  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+dev = torch.device("cuda", 0)
+sb, _, pars = bench.make_workload(n, seed=1000, device=dev)
+rng = np.random.RandomState(7)
+guess = pars * rng.uniform(0.9, 1.1, size=pars.shape)
+psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (n, 1)), "gauss",
+                             device=dev)
+L = _lib.lib()
+st = torch.empty((n, _lib.LM_STATE_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+dg = torch.from_numpy(np.ascontiguousarray(guess)).to(dev)
+_lib.check(L.ngmix_lm_init_batch(_dptr(st), n, 6, _dptr(dg), 1e-8, 1e-8, 0.0, 700, 100.0,
+                                 _lib.LM_MODE_ANALYTIC, None, None, _stream()), "init")
+sums = torch.zeros((n, 28), dtype=torch.float64, device=dev)
+status = torch.zeros(n, dtype=torch.int32, device=dev)
+stats = None if os.environ.get("NGMIX_LM_JBASIS") else \
+    torch.zeros((n, 2), dtype=torch.float64, device=dev)
+b = sb._batch(1)
+
+
+def launch():
+    _lib.check(L.ngmix_lm_eval_batch(ctypes.byref(b), get_model_num("exp"), 0, _dptr(st),
+                                     None, None, _dptr(psf.data), 1, _dptr(sums),
+                                     _dptr(status), _dptr(stats), _stream()), "eval")
+
+
+for _ in range(60):
+    launch()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+best = []
+for rep in range(5):
+    e0.record()
+    for _ in range(30):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    best.append(e0.elapsed_time(e1) / 30)
+print("lm_eval %s: %.4f ms per launch of %d stamps (min of 5 x 30; all %s)" % (
+    "J basis" if stats is None else "raw basis", min(best), n,
+    [round(x, 4) for x in best]))
+print("checksum", float(sums.sum()), int(status.abs().sum()))
