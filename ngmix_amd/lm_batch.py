@@ -274,8 +274,9 @@ class LMBatchFitter(object):
             d_sband = torch.from_numpy(sband).to(dev)
             d_start = torch.from_numpy(obj_start).to(dev)
         nsum = self.nloc * (self.nloc + 1) // 2 + self.nloc + 1
-        d_sums = torch.zeros((ns, nsum), dtype=torch.float64, device=dev)
-        d_status = torch.zeros(ns, dtype=torch.int32, device=dev)
+        # (every row is written by the first round's launch)
+        d_sums = torch.empty((ns, nsum), dtype=torch.float64, device=dev)
+        d_status = torch.empty(ns, dtype=torch.int32, device=dev)
         d_nact = torch.zeros(1, dtype=torch.int32, device=dev)
         # the loglike statistics of set_fit_result ride with the analytic
         # kernel's sums (lnprob = -fnorm^2 / 2 has no prior term to add)
@@ -464,6 +465,7 @@ class LMBatchFitter(object):
             self.eval_ms = float(np.mean(ms))
             self.eval_ms_total = float(np.sum(ms))
             self.eval_stamps_total = float(np.sum([w for _, _, w in ev]))
+            self.eval_launches = [(float(t), float(w)) for t, (_, _, w) in zip(ms, ev)]
         mark("loop")
         self.nsplit_used = nsplit
         self._d_states = d_states

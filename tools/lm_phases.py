@@ -58,3 +58,17 @@ for _ in range(5):
     acc.setdefault("total", []).append(dt)
 print("host time per phase without syncs (ms, all 5):",
       {k: [round(x, 2) for x in v] for k, v in acc.items()})
+
+# per-launch times of the pixel pass in one fit (HIP events) and the stamps
+# each launch still had to evaluate
+fitter.time_phases = False
+fitter.time_kernels = True
+guess2 = guess.copy()
+guess2[:, 0:2] = pars[:, 0:2] + rng.uniform(-0.05, 0.05, size=(n, 2))
+guess2[:, 2:4] = pars[:, 2:4] + rng.uniform(-0.03, 0.03, size=(n, 2))
+for g, name in ((guess, "guess = truth x U(0.9, 1.1)"), (guess2, "+ centre / shear offsets (bench C3)")):
+    fitter.go(sb, g, psf=psf)
+    import ngmix_amd.lm_batch as lb
+    print(name, "rounds", fitter.rounds, "loop %.3f ms" % (fitter.loop_seconds * 1e3),
+          "eval total %.3f ms over %.0f stamp evaluations" % (
+              fitter.eval_ms_total, fitter.eval_stamps_total), [(round(t, 3), int(w)) for t, w in fitter.eval_launches])

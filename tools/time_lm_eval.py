@@ -56,3 +56,30 @@ print("lm_eval %s: %.4f ms per launch of %d stamps (min of 5 x 30; all %s)" % (
     "J basis" if stats is None else "raw basis", min(best), n,
     [round(x, 4) for x in best]))
 print("checksum", float(sums.sum()), int(status.abs().sum()))
+
+# the same launch timed one by one, alone and with an lm_advance-sized kernel
+# between the launches (a copy of the states is advanced, the evaluated one
+# stays at the starting point)
+st2 = st.clone()
+nact = torch.zeros(1, dtype=torch.int32, device=dev)
+
+
+def advance():
+    _lib.check(L.ngmix_lm_advance_batch(_dptr(st2), n, None, None, _dptr(sums), 6 + 256 * 6,
+                                        None, _dptr(nact), None, None, _stream()), "advance")
+
+
+for label, between in (("alone", None), ("advance between", advance)):
+    ts = []
+    for _ in range(20):
+        if between is not None:
+            st2.copy_(st)
+            between()
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        launch()
+        b_.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b_))
+    print("one launch per event pair, %s: median %.4f min %.4f ms" % (
+        label, float(np.median(ts)), min(ts)))
