@@ -3,6 +3,8 @@
 // parameters (a separate translation unit: 72 kernel instantiations).
 // Reference: ngmix/em/em_nb.py (em_run and its fixcen / fixcov / fluxonly
 // variants); the generic reference-order kernel is in em.hip.
+#include <type_traits>
+
 #include "em_common.hpp"
 #include "launch_iter.hpp"
 
@@ -266,6 +268,12 @@ __device__ __forceinline__ void em_wave_body(
         for (int k = 0; k < NV; k++) acc[k] = 0.0;
         bool bad = false;
 
+        // The pixel pass, with and without the logL term: the one-gaussian
+        // one-wave kernels (config 4, every one-gaussian psf fit) run the
+        // second form while elogL cannot be seen (above) -- five instructions
+        // per pixel of 43.  Two copies of the loop, one register budget.
+        auto pixel_pass = [&](auto with_logl) {
+            constexpr bool LOGL = decltype(with_logl)::value;
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
             if (!(kept & (1ull << k))) continue;
@@ -298,8 +306,8 @@ __device__ __forceinline__ void em_wave_body(
                         // (one component in all: val (K - y) / gsum with
                         // gsum == val is K - y to three roundings -- no product,
                         // no reciprocal)
-                        if (use_logl && NG == 1) logL = val != 0.0 ? c.K - y : 0.0;
-                        if (use_logl && NG > 1) logL = fma(val, c.K - y, logL);
+                        if (LOGL && NG == 1) logL = val != 0.0 ? c.K - y : 0.0;
+                        if (LOGL && NG > 1) logL = fma(val, c.K - y, logL);
                     }
                     gi[ii] = val;
                     gsum = ii == 0 ? val : gsum + val;
@@ -309,9 +317,9 @@ __device__ __forceinline__ void em_wave_body(
                     bad = true;  // GMixRangeError('gtot == 0')
                     continue;
                 }
-                if (use_logl && NG > 1) logL = (gsum == 0.0) ? 0.0 : logL * fast_rcp(gsum);
+                if (LOGL && NG > 1) logL = (gsum == 0.0) ? 0.0 : logL * fast_rcp(gsum);
                 const double factor = val_pix * fast_rcp(gtot);
-                acc[6 * NG + 0] += logL;
+                if (LOGL) acc[6 * NG + 0] += logL;
                 acc[6 * NG + 1] = fma(sky, factor, acc[6 * NG + 1]);
 #pragma unroll
                 for (int ii = 0; ii < NG; ii++) {
@@ -357,19 +365,19 @@ __device__ __forceinline__ void em_wave_body(
                                 tuv[ii] = fma(uv, val, tuv[ii]);
                                 tu2[ii] = fma(u2, val, tu2[ii]);
                             }
-                            if (use_logl) logL = fma(val, c.K - y, logL);
+                            if (LOGL) logL = fma(val, c.K - y, logL);
                         }
                     }
                 }
             }
-            if (use_logl) logL = (gsum == 0.0) ? 0.0 : logL * fast_rcp(gsum);
+            if (LOGL) logL = (gsum == 0.0) ? 0.0 : logL * fast_rcp(gsum);
             const double gtot = gsum + sky;
             if (gtot == 0.0) {
                 bad = true;  // GMixRangeError('gtot == 0')
                 continue;
             }
             const double factor = val_pix * fast_rcp(gtot);
-            acc[6 * NG + 0] += logL;
+            if (LOGL) acc[6 * NG + 0] += logL;
             acc[6 * NG + 1] = fma(sky, factor, acc[6 * NG + 1]);
 #pragma unroll
             for (int ii = 0; ii < NG; ii++) {
@@ -387,6 +395,11 @@ __device__ __forceinline__ void em_wave_body(
                 }
             }
         }
+
+        };
+        constexpr bool kTwoForms = NT == WAVE && NG == 1 && NPSF1 && use_logl;
+        if (kTwoForms && !need_logl) pixel_pass(std::integral_constant<bool, false>{});
+        else pixel_pass(std::integral_constant<bool, use_logl>{});
 
         const bool anybad = __syncthreads_or(bad ? 1 : 0) != 0;
         em_group_reduce<NT, NV>(acc, sh.red, sh.part, sh.tot);
