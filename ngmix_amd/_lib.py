@@ -268,7 +268,9 @@ def library_is_stale():
 
 def build(verbose=False, force=False):
     """compile libngmix_hip.so in-tree for gfx950 (hipcc)"""
-    res = subprocess.run(["make", "-C", _CSRC, "-j4"] + (["-B"] if force else []),
+    jobs = max(2, min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity")
+                      else (os.cpu_count() or 4)))
+    res = subprocess.run(["make", "-C", _CSRC, "-j%d" % jobs] + (["-B"] if force else []),
                          capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout[-4000:])

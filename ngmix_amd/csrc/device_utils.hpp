@@ -210,10 +210,11 @@ template <int NV>
 __device__ __forceinline__ void wave_reduce_lds(const double (&acc)[NV], double *red,
                                                 double *tot)
 {
-    constexpr int NVP = NV <= 2 ? 2 : NV <= 4 ? 4 : NV <= 8 ? 8 : NV <= 16 ? 16 : 32;
+    constexpr int NVP = NV <= 2 ? 2 : NV <= 4 ? 4 : NV <= 8 ? 8 : NV <= 16 ? 16
+                        : NV <= 32 ? 32 : 64;
     constexpr int SEGS = WAVE / NVP;   // lanes per value
     constexpr int SEGLEN = WAVE / SEGS;
-    static_assert(NV <= 32, "wave_reduce_lds: too many sums");
+    static_assert(NV <= 64, "wave_reduce_lds: too many sums");
     const int lane = threadIdx.x & (WAVE - 1);
 #pragma unroll
     for (int k = 0; k < NV; k++) red[k * WAVE_RED_STRIDE + lane] = acc[k];

@@ -549,6 +549,82 @@ def test_em_kernel_variants_vs_oracle(shape, ngauss):
                                        err_msg="%s stamp %d %s" % (shape, i, f))
 
 
+@pytest.mark.parametrize("shape", [(25, 25), (32, 32), (45, 47), (48, 48), (56, 60)])
+@pytest.mark.parametrize("ngauss,npsf,kind", [(3, 1, 0), (4, 1, 0), (5, 1, 0), (6, 1, 0),
+                                              (4, 3, 0), (6, 3, 0), (4, 1, 1), (5, 1, 2),
+                                              (6, 1, 3), (1, 3, 0), (2, 3, 1)])
+def test_em_many_gaussians_vs_oracle(shape, ngauss, npsf, kind):
+    """em_run is general in the gaussian counts (em_nb.py:160-246, 284-354): the
+    fused kernels for four to six object gaussians (em_wave_hi.hip: one wave up
+    to 32x32, two up to 48x48; the 56x60 stamps run the generic kernel), with
+    one- and three-gaussian psfs and every run kind, against the oracle --
+    exact numiter, mixtures to 1e-9"""
+    import ngmix_amd as ngmix
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    from oracle import oracle as ora
+    nrow, ncol = shape
+    rng = np.random.RandomState(nrow * 7 + ncol + 31 * ngauss + npsf + 5 * kind)
+    scale, sky, nst = 0.263, 0.01, 3
+    obs, jrecs, Ts = [], [], []
+    for k in range(nst):
+        jac = ngmix.DiagonalJacobian(row=(nrow - 1) / 2.0 + rng.uniform(-0.4, 0.4),
+                                     col=(ncol - 1) / 2.0 + rng.uniform(-0.4, 0.4), scale=scale)
+        T = 0.3 + 0.01 * min(nrow, ncol) * rng.uniform(0.8, 1.2)
+        gm = ngmix.GMixModel([rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05),
+                              rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1), T, 30.0], "dev")
+        im = gm.make_image((nrow, ncol), jacobian=jac) + sky
+        im += 0.001 * rng.normal(size=im.shape)
+        wt = np.full(im.shape, 1.0 / 0.001 ** 2)
+        if k % 2:
+            wt[nrow // 4, ncol // 3] = 0.0
+        obs.append(ngmix.Observation(im, weight=wt, jacobian=jac))
+        jrecs.append(jac.get_data().view(np.float64).reshape(8))
+        Ts.append(T)
+    sb = StampBatch.from_observations(obs)
+    full = np.zeros((nst, ngauss, 6))
+    for i in range(ngauss):
+        full[:, i, 0] = 30.0 * scale ** 2 / ngauss * rng.uniform(0.9, 1.1, size=nst)
+        full[:, i, 1:3] = rng.uniform(-0.03, 0.03, size=(nst, 2))
+        full[:, i, 3] = 0.5 * np.array(Ts) * (0.3 + 0.5 * i)
+        full[:, i, 5] = 0.5 * np.array(Ts) * (0.3 + 0.5 * i)
+    gm0, _ = GMixBatch.from_pars(full.reshape(nst, -1), "full", ngauss=ngauss)
+    if npsf == 1:
+        ppars = np.tile([0.0, 0.0, 0.0, 0.0, 0.05, 1.0], (nst, 1))
+        psf, _ = GMixBatch.from_pars(ppars, "gauss")
+    else:
+        ppars = np.tile([0.0, 0.0, 0.01, -0.02, 0.06, 1.0], (nst, 1))
+        psf, _ = GMixBatch.from_pars(ppars, "turb")
+    gm_in = gm0.to_numpy().reshape(nst, ngauss)
+    psf_in = psf.to_numpy().reshape(nst, npsf)
+    miniter = 20 if kind != 3 else 5
+    out, status, conv = sb.em(gm0, psf, sky=sky, kind=kind, miniter=miniter, maxiter=40,
+                              tol=1e-6)
+    assert int(status.abs().sum()) == 0
+    out = out.cpu().numpy()
+    gm_out = gm0.to_numpy().reshape(nst, ngauss)
+    econf = np.zeros(1, dtype=ora.EM_CONF_DTYPE)
+    econf["tol"], econf["maxiter"], econf["miniter"], econf["sky"] = 1e-6, 40, miniter, sky
+    for i, o in enumerate(obs):
+        j = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+        j[0] = tuple(jrecs[i])
+        pix = ora.make_pixels(o.image, o.weight, j, True)
+        g = np.zeros(ngauss, dtype=ora.GAUSS2D_DTYPE)
+        for k in range(ngauss):
+            g[k] = conv_rec(gm_in[i, k], ora.GAUSS2D_DTYPE)[0]
+        p = np.zeros(npsf, dtype=ora.GAUSS2D_DTYPE)
+        for k in range(npsf):
+            p[k] = conv_rec(psf_in[i, k], ora.GAUSS2D_DTYPE)[0]
+        c = np.zeros(ngauss * npsf, dtype=ora.GAUSS2D_DTYPE)
+        ora.gmix_convolve_fill(c, g, p)
+        sums = np.zeros((ngauss, ora.EM_SUMS_NDOUBLE[kind]))
+        st, numiter, frac, _ = ora.em_run(kind, econf, pix, sums, g, p, c)
+        assert st == 0
+        assert int(out[i, 0]) == numiter, (shape, i)
+        for f in ("p", "row", "col", "irr", "irc", "icc"):
+            np.testing.assert_allclose(gm_out[i][f], g[f], rtol=1e-9, atol=1e-12,
+                                       err_msg="%s stamp %d %s" % (shape, i, f))
+
+
 @pytest.mark.parametrize("shape", [(32, 32), (48, 48), (64, 64), (90, 80)])
 def test_admom_no_cov_changes_nothing_but_the_covariance(shape):
     """conf.no_cov (the batch extension in the reference record's padding): the
