@@ -65,48 +65,7 @@ static_assert(sizeof(LmTile) == 32, "LmTile");
 
 constexpr int LM_TILE_CAP = 1024;  // tile records kept in LDS (<= 256 x 256 px)
 
-template <int CTRL>
-__device__ __forceinline__ double dpp_row_shr_zero(double x)
-{
-    // row_shr within each row of 16 lanes; lanes without a source read 0
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
-// sum of x over each row of 16 lanes, valid in the row's last lane
-__device__ __forceinline__ double row16_sum(double x)
-{
-    x += dpp_row_shr_zero<0x111>(x);
-    x += dpp_row_shr_zero<0x112>(x);
-    x += dpp_row_shr_zero<0x114>(x);
-    x += dpp_row_shr_zero<0x118>(x);
-    return x;
-}
-
-// x, y hold one partial per lane of two sums; rows of 16 lanes r0..r3.
-// permlane16_swap: x = [x_r0, y_r0, x_r2, y_r2], y = [x_r1, y_r1, x_r3, y_r3]
-// -> x + y = [x_r0 + x_r1, y_r0 + y_r1, x_r2 + x_r3, y_r2 + y_r3]
-__device__ __forceinline__ double swap_add16(double x, double y)
-{
-    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y),
-                                                     false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y),
-                                                     false, false);
-    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-
-// permlane32_swap: x = [x_lo, y_lo], y = [x_hi, y_hi] by halves of 32 lanes
-// -> x + y = [x_lo + x_hi, y_lo + y_hi]
-__device__ __forceinline__ double swap_add32(double x, double y)
-{
-    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y),
-                                                     false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y),
-                                                     false, false);
-    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
+// (dpp_row_shr_zero / row16_sum / swap_add16 / swap_add32: device_utils.hpp)
 
 struct LmEvalShared {
     double tabr[16];

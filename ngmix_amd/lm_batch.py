@@ -264,11 +264,14 @@ class LMBatchFitter(object):
                 _lib.ptr(lo) if lo is not None else None,
                 _lib.ptr(hi) if hi is not None else None, _stream()),
                 "ngmix_lm_init_batch")
+        d_sobj = d_sband = d_start = None
         if trivial_map:
-            # made on the device: three uploads less on the common path
-            d_sobj = torch.arange(ns, dtype=torch.int32, device=dev)
-            d_sband = torch.zeros(ns, dtype=torch.int32, device=dev)
-            d_start = torch.arange(nobj + 1, dtype=torch.int64, device=dev)
+            # stamp i is object i in band 0: the kernels take NULL for the three
+            # maps (as pieces on several streams they need the absolute indices)
+            if self._nsplit_wanted() > 1:
+                d_sobj = torch.arange(ns, dtype=torch.int32, device=dev)
+                d_sband = torch.zeros(ns, dtype=torch.int32, device=dev)
+                d_start = torch.arange(nobj + 1, dtype=torch.int64, device=dev)
         else:
             d_sobj = torch.from_numpy(sobj).to(dev)
             d_sband = torch.from_numpy(sband).to(dev)
@@ -318,11 +321,7 @@ class LMBatchFitter(object):
         # per fit, latency bound -- runs under another piece's pixel pass.
         # Measured on 100k fits: 6.65 against 6.70 ms for the loop once lm_advance
         # runs from registers, so the default is one piece.
-        nsplit = getattr(self, "nsplit", None)
-        if nsplit is None and os.environ.get("NGMIX_LM_NSPLIT"):
-            nsplit = int(os.environ["NGMIX_LM_NSPLIT"])   # A/B knob
-        if nsplit is None:
-            nsplit = 1
+        nsplit = self._nsplit_wanted()
         if self.prior is not None and prior_desc is None:
             nsplit = 1
         nsplit = max(1, min(int(nsplit), nobj))
@@ -583,6 +582,12 @@ class LMBatchFitter(object):
         if self._gmix is None:
             self._fitted_mixtures()
         return self._gmix
+
+    def _nsplit_wanted(self):
+        nsplit = getattr(self, "nsplit", None)
+        if nsplit is None and os.environ.get("NGMIX_LM_NSPLIT"):
+            nsplit = int(os.environ["NGMIX_LM_NSPLIT"])   # A/B knob
+        return 1 if nsplit is None else int(nsplit)
 
     def _side_stream(self, dev, which=0):
         torch = _torch()

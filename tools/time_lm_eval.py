@@ -83,3 +83,25 @@ for label, between in (("alone", None), ("advance between", advance)):
         ts.append(a.elapsed_time(b_))
     print("one launch per event pair, %s: median %.4f min %.4f ms" % (
         label, float(np.median(ts)), min(ts)))
+
+
+def reinit():
+    _lib.check(L.ngmix_lm_init_batch(_dptr(st), n, 6, _dptr(dg), 1e-8, 1e-8, 0.0, 700, 100.0,
+                                     _lib.LM_MODE_ANALYTIC, None, None, _stream()), "init")
+
+
+big = torch.empty(64 * 1024 * 1024, dtype=torch.float64, device=dev)   # 512 MB
+for label, between in (("states re-initialised before each launch (as go() does)", reinit),
+                       ("512 MB of unrelated memory written before each launch",
+                        lambda: big.fill_(1.0))):
+    ts = []
+    for _ in range(20):
+        between()
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        launch()
+        b_.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b_))
+    print("one launch per event pair, %s: median %.4f min %.4f ms" % (
+        label, float(np.median(ts)), min(ts)))
