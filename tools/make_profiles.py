@@ -74,6 +74,10 @@ if "FETCH_SIZE" in c5acc and "WRITE_SIZE" in c5acc:
                                                  "WRITE_SIZE", len(c5acc["WRITE_SIZE"]), write))
     traffic["c5_loglike_hbm_bytes_per_launch"] = 2 * fetch * 1024 + write * 1024
     traffic["c5_nstamps"] = 200000
+    for c, vals in sorted(c5acc.items()):
+        if c not in ("FETCH_SIZE", "WRITE_SIZE"):
+            lines.append("%-36s %-26s n=%d mean %.6g" % (
+                "pixpass_wave_kernel7<0, false, 8>", c, len(vals), sum(vals) / len(vals)))
 for sub, name in (("bench_stats", "bench"), ("c3_stats", "c3"), ("c4_stats", "c4"),
                   ("c5_stats", "c5"),
                   ("iter_stats", "iter"), ("lm_stats", "lm")):

@@ -18,6 +18,10 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_stat
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_stats -o run -- python3 $ROOT/bench.py --config C5 --steps 50 --warmup 10 > $OUT/bench_c5_under_rocprof.json 2> $OUT/c5_stats.log
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_c5fetch -o run -- python3 $ROOT/bench.py --config C5 --steps 3 --warmup 1 --settle-steps 0 > /dev/null 2> $OUT/pmc_c5fetch.log
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_c5write -o run -- python3 $ROOT/bench.py --config C5 --steps 3 --warmup 1 --settle-steps 0 > /dev/null 2> $OUT/pmc_c5write.log
+# the instruction / stall counters of the same kernel on the C5 shape (64 x 64 x 16
+# gaussians: 64 tiles, 4 tiles per ballot), next to the C2 ones of run_prof.sh
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_c5sq1 -o run -- python3 $ROOT/bench.py --config C5 --steps 3 --warmup 1 --settle-steps 0 > /dev/null 2> $OUT/pmc_c5sq1.log
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_c5sq2 -o run -- python3 $ROOT/bench.py --config C5 --steps 3 --warmup 1 --settle-steps 0 > /dev/null 2> $OUT/pmc_c5sq2.log
 # 3. iterative kernels and batched LM
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/iter_stats -o run -- python3 $ROOT/tools/bench_iter.py 200000 3 > $OUT/iter.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lm_stats -o run -- python3 $ROOT/tools/bench_lm.py 100000 0 > $OUT/lm.log 2>&1
