@@ -823,3 +823,35 @@ def test_reference_coellip_four_and_five_gaussians(golden, ngauss):
     assert np.all(np.abs(one["pars"] - g[pre + "pars"]) <= 3e-2 * err)
     # the truth is recovered
     assert np.all(np.abs(res["pars"][0] - g[pre + "truth"]) <= 5.0 * err)
+
+
+def test_go_stream_pipeline_equals_go():
+    """LMBatchFitter.go_stream (finalise / download of batch i under the first
+    rounds of batch i + 1) returns, for every batch of the sequence, the
+    arrays go() returns for it -- bit for bit, in order; an empty sequence
+    and a sequence of one work too"""
+    from ngmix_amd.lm_batch import LMBatchFitter
+    rng = np.random.RandomState(91)
+    items = []
+    for k, (n, model) in enumerate([(300, "exp"), (120, "exp"), (257, "exp"), (64, "exp")]):
+        pars, guess, images, weights, jac, _, psf = _make_objects(n, model, rng)
+        sb = StampBatch.from_images(images, weights, jac)
+        items.append((sb, guess, {"psf": psf}))
+    fitter = LMBatchFitter("exp")
+    ref = [fitter.go(sb, g, **kw) for sb, g, kw in items]
+    got = list(fitter.go_stream(items))
+    assert len(got) == len(ref)
+    for a, b in zip(ref, got):
+        assert set(a.keys()) == set(b.keys())
+        for key in ("flags", "nfev", "njev", "ier", "pars", "pars_err", "pars_cov", "pars_cov0",
+                    "lnprob", "chi2per", "s2n", "npix", "dof", "g_cov", "T_err", "flux"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    assert list(fitter.go_stream([])) == []
+    one = list(fitter.go_stream(items[:1]))
+    np.testing.assert_array_equal(one[0]["pars"], ref[0]["pars"])
+    # a forward-difference fitter and a prior go through the same stages
+    fd = LMBatchFitter("exp", analytic_jacobian=False)
+    r1 = fd.go(items[1][0], items[1][1], psf=items[1][2]["psf"])
+    r2 = list(fd.go_stream(items[1:2]))[0]
+    np.testing.assert_array_equal(r1["pars"], r2["pars"])
+    np.testing.assert_array_equal(r1["lnprob"], r2["lnprob"])

@@ -105,3 +105,37 @@ for label, between in (("states re-initialised before each launch (as go() does)
         ts.append(a.elapsed_time(b_))
     print("one launch per event pair, %s: median %.4f min %.4f ms" % (
         label, float(np.median(ts)), min(ts)))
+
+# what precedes the launch: nothing, a busy kernel of lm_advance's length, an idle gap
+import time as _time
+gmx, _ = GMixBatch.from_pars(pars[:20000], "exp", device=dev)
+sub = sb.select(np.arange(20000))
+psub, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (20000, 1)), "gauss", device=dev)
+gsub, _ = gmx.convolve(psub)
+
+
+def busy():
+    sub.loglike(gsub)
+
+
+def idle():
+    torch.cuda.synchronize()
+    _time.sleep(0.0005)
+
+
+for label, between in (("a 0.14 ms loglike launch before", busy), ("0.5 ms of idle GPU before", idle),
+                       ("lm_advance before", advance)):
+    ts = []
+    for _ in range(30):
+        if between is advance:
+            st2.copy_(st)
+        between()
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        launch()
+        b_.record()
+        between() if between is not idle else None
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b_))
+    print("one launch per event pair, %s: median %.4f min %.4f ms" % (
+        label, float(np.median(ts)), min(ts)))
