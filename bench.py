@@ -394,7 +394,7 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
     a2 = copy.copy(args)
     a2.steps = steps or args.steps
     if steps is not None:
-        a2.warmup, a2.settle_steps = 1, 0
+        a2.warmup, a2.settle_steps = 2, 8
     else:
         a2.warmup = min(args.warmup, 5)
         a2.settle_steps = min(max(args.settle_steps, 0), 200)
@@ -593,7 +593,7 @@ def run_c4(args, rank, world, device, backend, nstamps=None, steps=None, quiet=F
     a2 = copy.copy(args)
     a2.steps = K
     if steps is not None:       # the short leg of a C2 run
-        a2.warmup, a2.settle_steps = 2, 0
+        a2.warmup, a2.settle_steps = 2, 5
     elapsed = timed_steps(step, a2, distributed, device)
     admom_ms = _mean_ms(ev[0], ev[1])
     em_ms = _mean_ms(ev[2], ev[3])
@@ -725,7 +725,7 @@ def run_c5(args, rank, world, device, backend, nobj=None, steps=None):
     a2 = copy.copy(args)
     a2.steps = K
     if steps is not None:
-        a2.warmup, a2.settle_steps = 2, 0
+        a2.warmup, a2.settle_steps = 5, 30
     elapsed = timed_steps(step, a2, distributed, device)
     ll_ms = _mean_ms(ev0, ev1)
     red_ms = _mean_ms(ev1, ev2)
@@ -1157,9 +1157,11 @@ def main():
             import torch
             torch.cuda.empty_cache()
             other = {}
-            for name, fn, kw in (("C3", run_c3, dict(nstamps=100000, steps=3)),
-                                 ("C4", run_c4, dict(nstamps=125000, steps=5)),
-                                 ("C5", run_c5, dict(nobj=20000, steps=10))):
+            # (short legs, but long enough for the clock governor: each runs its
+            # own settle + warm-up steps, ~0.1 s of load, before the timed ones)
+            for name, fn, kw in (("C3", run_c3, dict(nstamps=100000, steps=10)),
+                                 ("C4", run_c4, dict(nstamps=125000, steps=8)),
+                                 ("C5", run_c5, dict(nobj=20000, steps=30))):
                 try:
                     o = fn(args, rank, world, device, backend, **kw)
                     other[name] = {k: o[k] for k in (
