@@ -1017,6 +1017,59 @@ def cpu_baseline_c4(budget=1.5, usable=None, teams=None, verbose=False):
     return out
 
 
+def cpu_baseline_c3(budget=1.5, verbose=False):
+    """config-3 cpu_baseline leg: complete 'exp' (x) gaussian-psf LM fits of
+    48x48 stamps on ONE core -- scipy's MINPACK (what the reference's
+    run_leastsq calls, fitters.py:64-112) around the C port of fill_fdiff.
+    The jacobian is MINPACK's forward differences (lmdif): the port has no
+    FitModel.calc_jacobian, so a fit costs ~7 residual evaluations per
+    iteration where the reference's lmder pays one jacobian; stated in
+    `sample`."""
+    from scipy.optimize import leastsq
+    w = _CpuWorkloads(3)
+    ora = w.ora
+    gms, pix, _, pars = w.stamps(8, 48, "exp")
+    psf = np.zeros(1, dtype=ora.GAUSS2D_DTYPE)
+    ora.gmix_fill(psf, np.array([0.0, 0.0, 0.0, 0.0, 0.27, 1.0]), "gauss")
+    rng = np.random.RandomState(33)
+    nfev = []
+
+    def fit(i):
+        gm0 = np.zeros(6, dtype=ora.GAUSS2D_DTYPE)
+        gm = np.zeros(6, dtype=ora.GAUSS2D_DTYPE)
+        fd = np.zeros(pix.shape[1])
+
+        def resid(p):
+            # (out of range -> the reference's LOWVAL residual vector)
+            if p[2] * p[2] + p[3] * p[3] >= 1.0 or p[4] <= 0.0:
+                return np.full(fd.size, -9.999e9)
+            ora.gmix_fill(gm0, p, "exp")
+            ora.gmix_convolve_fill(gm, gm0, psf)
+            ora.gmix_set_norms(gm)
+            ora.fill_fdiff(gm, pix[i], fd, 0)
+            return fd.copy()
+        guess = pars[i] * rng.uniform(0.9, 1.1, size=6)
+        out = leastsq(resid, guess, full_output=1, ftol=1.49012e-8, xtol=1.49012e-8)
+        nfev.append(out[2]["nfev"])
+        return out[0]
+
+    fit(0)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < budget:
+        fit(n % pix.shape[0])
+        n += 1
+    rate = n / (time.perf_counter() - t0)
+    if verbose:
+        print("C3 'exp' LM fit 48x48 (scipy MINPACK lmdif + C fill_fdiff): 1 thread %.3g fits/s "
+              "(mean nfev %.1f)" % (rate, float(np.mean(nfev))))
+    return {"value": rate, "unit": "fits/s", "cores": 1, "kind": "port",
+            "single_core_value": rate, "mean_nfev": float(np.mean(nfev)),
+            "sample": "%d fits of 48x48 'exp' (x) gaussian-psf stamps in %.1f s on one core: "
+                      "scipy MINPACK (forward-difference jacobian) around the C port of "
+                      "fill_fdiff / gmix_fill / gmix_convolve_fill" % (n, budget)}
+
+
 def cpu_baseline_c5(budget=1.5, usable=None, nepoch=10, verbose=False):
     """config-5 cpu_baseline leg: the joint loglike of objects with 10 epochs
     of 64x64 pixels under a 16-gaussian 'bdf' (x) gaussian-psf mixture"""
@@ -1075,6 +1128,7 @@ def cpu_baseline_configs(budget=4.0):
               "%.3g pixel-gaussian evals/s" % (threads, r, 2 * r * 48 * 48 * 6))
         if threads == 1:
             print("C1 one stamp, render + loglike: %.1f us" % (1e6 / r))
+    cpu_baseline_c3(budget, verbose=True)
     cpu_baseline_c4(budget, usable, verbose=True)
     cpu_baseline_c5(budget, usable, verbose=True)
 
@@ -1179,6 +1233,7 @@ def main():
                 # the GPU figures, bounded to ~2 s per leg
                 try:
                     usable, _ = host_threads()
+                    other.setdefault("C3", {})["cpu_baseline"] = cpu_baseline_c3(budget=1.0)
                     c4 = cpu_baseline_c4(budget=1.0, usable=usable)
                     if "rooflines" in other.get("C4", {}):
                         other["C4"]["cpu_baseline"] = c4
