@@ -173,6 +173,18 @@ def test_c3_full_size(bench):
     assert np.all(np.abs(pull.mean(axis=0)) < 0.05)
     assert abs(res["chi2per"].mean() - 1.0) < 0.01
 
+    # the same batch twice through the software pipeline (go_stream: batch 2's
+    # first rounds run under batch 1's finalise / download): both results are
+    # go()'s, to the bit
+    fitter = LMBatchFitter("exp")
+    piped = list(fitter.go_stream([(sb, guess, {"psf": psf})] * 2))
+    assert len(piped) == 2
+    for r in piped:
+        for key in ("nfev", "flags", "pars", "pars_err", "lnprob", "s2n"):
+            assert np.array_equal(r[key], res[key], equal_nan=True), key
+    assert np.array_equal(piped[1]["pars_cov"], res["pars_cov"])
+    del piped
+
     # order independence of the lock-step driver: a permuted subset
     sub = np.random.RandomState(8).choice(n, size=5000, replace=False)
     r2 = LMBatchFitter("exp").go(sb.select(sub), guess[sub], psf=psf.select(sub))

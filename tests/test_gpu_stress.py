@@ -179,3 +179,40 @@ def test_c3_repeated_fits(bench):
     got = fit(perm)
     for a, b in zip(first, got):
         assert np.array_equal(a[perm], b, equal_nan=True)
+
+
+@pytest.mark.parametrize("ngauss", [4, 6])
+def test_em_many_gaussians_repeat_and_order(bench, ngauss):
+    """the fused EM kernels for four to six object gaussians on 30,000
+    config-4 stamps: five launches bit-identical, a permuted subset gives the
+    permuted results"""
+    import torch
+    from ngmix_amd.batch import GMixBatch
+    n = 30000
+    w = bench.make_c4(n, 29, "cuda")
+    sb_em = w["sb_em"]
+    rng = np.random.RandomState(ngauss)
+    full = np.zeros((n, ngauss, 6))
+    for i in range(ngauss):
+        full[:, i, 0] = 100.0 * bench.SCALE ** 2 / ngauss
+        full[:, i, 1] = full[:, i, 2] = 0.01 * (i - 0.5 * (ngauss - 1))
+        full[:, i, 3] = full[:, i, 5] = 0.25 * (1 + 0.6 * i) * rng.uniform(0.9, 1.1, size=n)
+
+    def run(sel=None):
+        pars = full if sel is None else full[sel]
+        sb = sb_em if sel is None else sb_em.select(sel)
+        psf = w["psf"] if sel is None else w["psf"].select(sel)
+        gm, _ = GMixBatch.from_pars(pars.reshape(pars.shape[0], -1), "full", ngauss=ngauss)
+        conv, _ = gm.convolve(psf)
+        out, st, _ = sb.em(gm, psf, conv=conv, sky=w["sky"], miniter=10, maxiter=30, tol=1e-5)
+        return out.clone(), st.clone(), gm.data[:, :7].clone()
+
+    first = run()
+    assert int(first[1].abs().sum()) == 0
+    _all_equal(first, run, 4)
+    sub = np.random.RandomState(2).permutation(n)[:8000]
+    got = run(sub)
+    d = torch.from_numpy(sub).cuda()
+    assert torch.equal(got[0], first[0][d])
+    assert torch.equal(got[2].reshape(len(sub), ngauss, 7),
+                       first[2].reshape(n, ngauss, 7)[d])
