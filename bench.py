@@ -608,7 +608,7 @@ def run_c4(args, rank, world, device, backend, nstamps=None, steps=None, quiet=F
     fl_admom = n * npx * (it_admom * ADMOM_FLOP_ITER_PX + ADMOM_FLOP_ONCE_PX)
     fl_em = n * npx * it_em * EM_FLOP_ITER_PX
     syms = kernel_symbols({"admom": ("admom_grid_kernel<64, 16>",),
-                           "em": ("em_wave_kernel<64, 16, 0, 1, true>",)})
+                           "em": ("em_wave_kernel<64, 16, 0, 1, 1>",)})
 
     def roof(ms, flop, key, nbytes):
         tf = flop / (ms * 1e-3) / 1e12

@@ -118,10 +118,11 @@ __device__ __forceinline__ void em_group_reduce(const double (&acc)[NV], double 
     }
 }
 
-// KIND, the number of object gaussians NG and (NPSF1) a one-gaussian psf are
+// KIND, the number of object gaussians NG and the psf's gaussian count NPSF (1:
+// the shared-X form below; 3: the general form unrolled; 0: a run-time count) are
 // compile-time: the pixel pass is straight-line code.  NT threads per stamp
 // (1, 2 or 4 waves), PPT pixels per thread in registers.
-template <int NT, int PPT, int KIND, int NG, bool NPSF1>
+template <int NT, int PPT, int KIND, int NG, int NPSF>
 __device__ __forceinline__ void em_wave_body(
     const GridSrc &src, const ngmix_em_conf conf, double sky_in,
     ngmix_gauss2d *gmix_io, ngmix_gauss2d *psf_io, int npsf_rt,
@@ -131,7 +132,8 @@ __device__ __forceinline__ void em_wave_body(
     constexpr int NV = 6 * NG + 2;
     constexpr int kind = KIND;
     constexpr int ngauss = NG;
-    const int npsf = NPSF1 ? 1 : npsf_rt;
+    constexpr bool NPSF1 = NPSF == 1;
+    const int npsf = NPSF > 0 ? NPSF : npsf_rt;
     const int lane = threadIdx.x;
     const int nconv = ngauss * npsf;
     ngmix_gauss2d *gmix = (ngmix_gauss2d *)dyn;
@@ -346,7 +348,9 @@ __device__ __forceinline__ void em_wave_body(
             for (int ii = 0; ii < NG; ii++) {
                 gi[ii] = tv[ii] = tu[ii] = tv2[ii] = tuv[ii] = tu2[ii] = 0.0;
                 {
-                    for (int i = ii * npsf; i < (ii + 1) * npsf; i++) {
+#pragma unroll
+                    for (int ip = 0; ip < (NPSF > 0 ? NPSF : npsf); ip++) {
+                        const int i = ii * npsf + ip;
                         const EmConvF c = ce[i];
                         const double vdiff = v - c.row;
                         const double udiff = u - c.col;
@@ -474,7 +478,7 @@ __device__ __forceinline__ void em_wave_body(
 
 static __constant__ double c_fexp_coef_e[9] = NGMIX_FEXP_COEF;
 
-template <int NT, int PPT, int KIND, int NG, bool NPSF1>
+template <int NT, int PPT, int KIND, int NG, int NPSF>
 __global__ __launch_bounds__(NT) void em_wave_kernel(
     ngmix_em_conf conf, const ngmix_stamp *stamps, const double *val,
     const double *ierr, const ngmix_jacobian *jacs, ngmix_gauss2d *gmix,
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(NT) void em_wave_kernel(
     src.nrow = st.nrow;
     src.ncol = st.ncol;
     src.izw = (st.flags & NGMIX_STAMP_IGNORE_ZERO_WEIGHT) != 0;
-    em_wave_body<NT, PPT, KIND, NG, NPSF1>(
+    em_wave_body<NT, PPT, KIND, NG, NPSF>(
         src, conf, sky_in[s], gmix + (size_t)s * NG, gmix_psf + (size_t)s * npsf, npsf,
         gmix_conv + (size_t)s * NG * npsf, fill_zero_weight, out + 3 * (size_t)s,
         status ? status + s : nullptr, sh, dyn, c_fexp_coef_e);
@@ -509,12 +513,19 @@ static void em_wave_launch_nt(const ngmix_em_conf *conf, const ngmix_batch *b,
     const size_t lds = (NG + npsf + nconv) * sizeof(ngmix_gauss2d) +
                        nconv * sizeof(EmConvF) + 64;
     if (npsf == 1)
-        hipLaunchKernelGGL((em_wave_kernel<NT, PPT, KIND, NG, true>),
+        hipLaunchKernelGGL((em_wave_kernel<NT, PPT, KIND, NG, 1>),
+                           dim3((unsigned)b->nstamps), dim3(NT), lds, s, *conf,
+                           b->stamps, b->val, b->ierr, b->jac, gmix, psf, npsf, conv,
+                           sky_in, fzw, out, status);
+    else if (npsf == 3 && NG <= 3 && NT == WAVE)
+        // (the 'turb' / coellip-3 psf of a galaxy fit on stamps of <= 32 x 32:
+        // the component loop unrolled)
+        hipLaunchKernelGGL((em_wave_kernel<NT, PPT, KIND, NG, (NG <= 3 && NT == WAVE) ? 3 : 0>),
                            dim3((unsigned)b->nstamps), dim3(NT), lds, s, *conf,
                            b->stamps, b->val, b->ierr, b->jac, gmix, psf, npsf, conv,
                            sky_in, fzw, out, status);
     else
-        hipLaunchKernelGGL((em_wave_kernel<NT, PPT, KIND, NG, false>),
+        hipLaunchKernelGGL((em_wave_kernel<NT, PPT, KIND, NG, 0>),
                            dim3((unsigned)b->nstamps), dim3(NT), lds, s, *conf,
                            b->stamps, b->val, b->ierr, b->jac, gmix, psf, npsf, conv,
                            sky_in, fzw, out, status);

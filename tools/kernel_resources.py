@@ -33,7 +33,7 @@ GUARDS = {
     "pixpass_wave_kernel": 84,
     # config 4's em_run: three waves per SIMD (512 / 3); at 172 registers it ran
     # 13.4 instead of 10.7 ms per 125k stamps
-    "em_wave_kernel<64, 16, 0, 1, true>": 168,
+    "em_wave_kernel<64, 16, 0, 1, 1>": 168,
 }
 # register-heavy on purpose (the stamp or the accumulators live in VGPRs):
 # only memory spills are an error
