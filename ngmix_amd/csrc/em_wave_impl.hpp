@@ -273,10 +273,12 @@ __device__ __forceinline__ void em_wave_body(
         for (int k = 0; k < NV; k++) acc[k] = 0.0;
         bool bad = false;
 
-        // The pixel pass, with and without the logL term: the one-gaussian
-        // one-wave kernels (config 4, every one-gaussian psf fit) run the
+        // The pixel pass, with and without the logL term: the one-wave kernels
+        // with a compile-time psf count and <= 3 object gaussians (config 4,
+        // every psf fit, galaxy fits under a 1- or 3-gaussian psf) run the
         // second form while elogL cannot be seen (above) -- five instructions
-        // per pixel of 43.  Two copies of the loop, one register budget.
+        // per pixel of 43 for one gaussian.  Two copies of the loop, one
+        // register budget.
         auto pixel_pass = [&](auto with_logl) {
             constexpr bool LOGL = decltype(with_logl)::value;
 #pragma unroll
@@ -404,7 +406,7 @@ __device__ __forceinline__ void em_wave_body(
         }
 
         };
-        constexpr bool kTwoForms = NT == WAVE && NG == 1 && NPSF1 && use_logl;
+        constexpr bool kTwoForms = NT == WAVE && use_logl && NG <= 3 && (NPSF1 || NPSF == 3);
         if (kTwoForms && !need_logl) pixel_pass(std::integral_constant<bool, false>{});
         else pixel_pass(std::integral_constant<bool, use_logl>{});
 
