@@ -139,3 +139,72 @@ for label, between in (("a 0.14 ms loglike launch before", busy), ("0.5 ms of id
         ts.append(a.elapsed_time(b_))
     print("one launch per event pair, %s: median %.4f min %.4f ms" % (
         label, float(np.median(ts)), min(ts)))
+
+# a 7 MB device-to-host copy beside lm_advance / beside lm_eval (the copies of
+# a batch's results are blit kernels on this platform: tools/d2h_probe.py)
+dsrc = torch.randn(7 * 1024 * 1024 // 8, dtype=torch.float64, device=dev)
+hdst = torch.empty(dsrc.shape, dtype=torch.float64, pin_memory=True)
+side = torch.cuda.Stream()
+
+
+def timed_pair(kernel, with_copy, reps=20):
+    ts = []
+    for _ in range(reps):
+        st2.copy_(st)
+        torch.cuda.synchronize()
+        t0 = _time.perf_counter()
+        if with_copy:
+            e = torch.cuda.Event()
+            e.record()
+            with torch.cuda.stream(side):
+                side.wait_event(e)
+                hdst.copy_(dsrc, non_blocking=True)
+        kernel()
+        torch.cuda.synchronize()
+        ts.append((_time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
+
+
+def copy_only():
+    with torch.cuda.stream(side):
+        hdst.copy_(dsrc, non_blocking=True)
+
+
+print("wall ms (median of 20): 7 MB copy alone %.3f; lm_advance alone %.3f, with the copy beside it %.3f; "
+      "lm_eval alone %.3f, with the copy beside it %.3f" % (
+          timed_pair(copy_only, False), timed_pair(advance, False), timed_pair(advance, True),
+          timed_pair(launch, False), timed_pair(launch, True)))
+
+for mb, chunks in ((7, 1), (19, 1), (29, 1), (48, 1), (48, 7), (48, 24)):
+    dsrc = torch.randn(mb * 1024 * 1024 // 8, dtype=torch.float64, device=dev)
+    hdst = torch.empty(dsrc.shape, dtype=torch.float64, pin_memory=True)
+    step_ = dsrc.numel() // chunks
+
+    def copies():
+        for c in range(chunks):
+            hdst[c * step_:(c + 1) * step_].copy_(dsrc[c * step_:(c + 1) * step_],
+                                                  non_blocking=True)
+
+    def both():
+        e = torch.cuda.Event()
+        e.record()
+        with torch.cuda.stream(side):
+            side.wait_event(e)
+            copies()
+        launch()
+
+    def only():
+        with torch.cuda.stream(side):
+            copies()
+
+    def wall(fn):
+        ts = []
+        for _ in range(15):
+            torch.cuda.synchronize()
+            t0 = _time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append((_time.perf_counter() - t0) * 1e3)
+        return float(np.median(ts))
+    print("%2d MB in %2d copies: alone %.3f ms; beside lm_eval (1.39 alone): %.3f ms" % (
+        mb, chunks, wall(only), wall(both)))
