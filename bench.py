@@ -407,9 +407,15 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
 
     # The steps run as a software pipeline (LMBatchFitter.go_stream): while one
     # batch's results are packed and downloaded the next batch's first rounds
-    # are already queued.  The untimed steps and the K timed steps are two
-    # separate pipelines, so that every timed batch lies wholly inside the timed
-    # region (--no-pipeline: one synchronous go() per step).
+    # are already queued (--no-pipeline: one synchronous go() per step).  ONE
+    # pipeline runs through the untimed and the timed steps, so the timed
+    # region sees its steady state at both ends: the batch in flight when the
+    # clock starts has had its set-up and first two rounds, and so has the
+    # batch after the last timed one when the clock stops -- work inside the
+    # region for a batch that is not counted, and the closing synchronisation
+    # waits for it.  (Two separate pipelines were measured first: the cold start
+    # of the timed one, 12-20 ms for its first step with fresh pinned buffers,
+    # made a 10-step leg read 1.14-1.41e7 fits/s on one box.)
     pipelined = not getattr(args, "no_pipeline", False)
     streams = {}
 
@@ -420,11 +426,10 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
     def next_result(i):
         if not pipelined:
             return fitter.go(sb, guess, psf=psf)
-        key = "timed" if i is not None else "untimed"
-        if key not in streams:
-            count = a2.steps if i is not None else a2.warmup + max(a2.settle_steps, 0)
-            streams[key] = fitter.go_stream(batches(count))
-        return next(streams[key])
+        if "all" not in streams:
+            count = a2.warmup + max(a2.settle_steps, 0) + a2.steps + 1
+            streams["all"] = fitter.go_stream(batches(count))
+        return next(streams["all"])
 
     def step(i):
         res = next_result(i)
