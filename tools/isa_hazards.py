@@ -12,8 +12,11 @@ on the machine code that ships, for EVERY function of every code object:
 
   A. vmcnt discipline.  A forward dataflow over the control-flow graph tracks,
      per VGPR/AGPR, the youngest memory load that may still be in flight into
-     it as k = the number of VMEM operations issued after it (gfx9 returns
-     VMEM loads in issue order and counts stores in the same counter).
+     it as k = the number of VMEM operations issued after it (on gfx9 loads
+     and stores share vmcnt and retire in issue order -- stores only got their
+     own counter with gfx10 -- which is the model of LLVM's SIInsertWaitcnts
+     and what the compiler's own code relies on: counting loads alone flags
+     compiler-made `load; store; s_waitcnt vmcnt(1)` sequences).
      `s_waitcnt vmcnt(N)` retires every register with k >= N.  Any instruction
      that reads or writes a register whose load may be in flight is an error
      -- a v_mov copying a look-ahead register, a spill, a wait count that is
