@@ -587,6 +587,15 @@ int ngmix_lm_pack_batch(const ngmix_lm_state *states, int64_t nobj, int npars,
                         const double *tot, const int64_t *npix_obj, double *head,
                         double *cols, void *stream);
 
+/* HOST: the launch census -- how many times each batch kernel variant has been
+   dispatched by this process, as "name<TAB>count" lines ("em_wave_kernel<64,
+   16, 0, 1, 1>\t35\n...") written to buf (NUL-terminated, truncated to
+   buflen); returns the size the full text needs.  reset != 0 clears the
+   counts afterwards.  A test asserts with it WHICH kernel served a workload:
+   a silent fall-back to a generic kernel is a performance bug no parity
+   test sees. */
+int64_t ngmix_launch_census(char *buf, int64_t buflen, int reset);
+
 /* ======================================================================
  * (4) MULTI-GPU: one process per GPU; objects are sharded by contiguous
  * blocks and nothing crosses ranks except the per-object RESULT RECORDS

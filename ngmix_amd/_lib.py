@@ -229,6 +229,7 @@ SIGNATURES = {
     "ngmix_lm_advance_batch": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
                                       _vp]),
     "ngmix_lm_finalize_batch": (_i32, [_vp, _i64, _vp, _vp, _f64, _f64, _vp, _vp]),
+    "ngmix_launch_census": (_i64, [ctypes.c_char_p, _i64, _i32]),
     "ngmix_lm_pack_batch": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 LM_NCOLS = 12
@@ -331,6 +332,19 @@ def lib():
             fn.argtypes = argtypes
         _lib = L
     return _lib
+
+
+def launch_census(reset=False):
+    """{kernel variant: launches so far in this process} (ngmix_launch_census)"""
+    L = lib()
+    n = L.ngmix_launch_census(None, 0, 0)
+    buf = ctypes.create_string_buffer(int(n) + 64)
+    L.ngmix_launch_census(buf, len(buf), 1 if reset else 0)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, _, count = line.rpartition("\t")
+        out[name] = int(count)
+    return out
 
 
 def last_error():

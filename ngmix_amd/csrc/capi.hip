@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,6 +27,15 @@ void set_last_error(const char *what, hipError_t err)
 }
 
 void set_last_error_msg(const char *msg) { g_last_error = msg; }
+
+static std::mutex g_census_mutex;
+static std::map<std::string, long long> g_census;
+
+void census(const char *kernel)
+{
+    std::lock_guard<std::mutex> lock(g_census_mutex);
+    g_census[kernel] += 1;
+}
 
 // grow-only device scratch, one set per host thread AND per device: after
 // ngmix_set_device(other) on the same thread the seam forms must not reuse
@@ -689,6 +700,21 @@ int ngmix_lm_pack_batch(const ngmix_lm_state *states, int64_t nobj, int npars,
 {
     return launch_lm_pack(states, nobj, npars, rec, obj_stats, tot, npix_obj, head, cols,
                           (hipStream_t)stream);
+}
+
+int64_t ngmix_launch_census(char *buf, int64_t buflen, int reset)
+{
+    std::lock_guard<std::mutex> lock(g_census_mutex);
+    std::string text;
+    for (const auto &kv : g_census)
+        text += kv.first + "\t" + std::to_string(kv.second) + "\n";
+    if (reset) g_census.clear();
+    if (buf && buflen > 0) {
+        const size_t n = text.size() < (size_t)buflen - 1 ? text.size() : (size_t)buflen - 1;
+        memcpy(buf, text.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)text.size() + 1;
 }
 
 }  // extern "C"

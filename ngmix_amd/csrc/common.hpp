@@ -421,6 +421,11 @@ NGMIX_HD int gmix_moms(const ngmix_gauss2d *gm, int n, double &irr, double &irc,
 namespace ngmix {
 void set_last_error(const char *what, hipError_t err);
 void set_last_error_msg(const char *msg);
+// launch census (capi.hip): every batch launcher names the kernel variant it
+// dispatches, so that a test can assert WHICH kernel served a workload (a
+// silent fall-back to a generic kernel is a performance bug no parity test
+// sees).  A mutex-protected map; a few hundred nanoseconds per launch.
+void census(const char *kernel);
 }  // namespace ngmix
 
 #define NGMIX_HIP_CHECK(expr)                                   \

@@ -12,6 +12,8 @@
 // sums; the M-step (O(ngauss) scalar work) runs on thread 0 out of LDS.
 // EM evaluates gaussians with a HARD chi2<25 cut (em_nb.py:222-227), not the
 // apodized evaluator; only the zero-weight fill uses the apodized one.
+#include <stdio.h>
+
 #include "em_common.hpp"
 #include "launch_iter.hpp"
 
@@ -340,6 +342,11 @@ static void em_grid_launch(int kind, const ngmix_em_conf *conf, const ngmix_batc
                            int npsf, ngmix_gauss2d *conv, const double *sky_in,
                            int fzw, double *out, int32_t *status, hipStream_t s)
 {
+    {
+        char name[64];
+        snprintf(name, sizeof(name), "em_grid_kernel<%d, %d, %d>", NT, PPT, NG);
+        census(name);
+    }
     hipLaunchKernelGGL((em_grid_kernel<NT, PPT, NG>), dim3((unsigned)b->nstamps),
                        dim3(NT), em_dyn_lds(ngauss, npsf), s, kind, *conf,
                        b->stamps, b->val, b->ierr, b->jac, gmix, ngauss, psf, npsf,

@@ -6,6 +6,8 @@
 // Reference: ngmix/em/em_nb.py (em_run and its fixcen / fixcov / fluxonly
 // variants); the generic reference-order kernel is in em.hip.
 #pragma once
+#include <stdio.h>
+
 #include <type_traits>
 
 #include "em_common.hpp"
@@ -514,6 +516,12 @@ static void em_wave_launch_nt(const ngmix_em_conf *conf, const ngmix_batch *b,
     const size_t nconv = (size_t)NG * npsf;
     const size_t lds = (NG + npsf + nconv) * sizeof(ngmix_gauss2d) +
                        nconv * sizeof(EmConvF) + 64;
+    {
+        char name[80];
+        snprintf(name, sizeof(name), "em_wave_kernel<%d, %d, %d, %d, %d>", NT, PPT, KIND, NG,
+                 npsf == 1 ? 1 : (npsf == 3 && NG <= 3 && NT == WAVE) ? 3 : 0);
+        census(name);
+    }
     if (npsf == 1)
         hipLaunchKernelGGL((em_wave_kernel<NT, PPT, KIND, NG, 1>),
                            dim3((unsigned)b->nstamps), dim3(NT), lds, s, *conf,

@@ -19,6 +19,8 @@
 //                    runs one step of the lmder logic (lm_core.hpp).
 #include <type_traits>
 
+#include <stdio.h>
+
 #include "device_utils.hpp"
 #include "launch.hpp"
 #include "lm_core.hpp"
@@ -1546,6 +1548,8 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *stat
         void *args[] = {&a_stamps, &a_val, &a_ierr, &a_jac, &a_model, &a_ng0, &states,
                         &stamp_obj, &stamp_band, &psf, &a_npsf, &sums, &status, &a_ns,
                         &tile_cap, &stamp_stats};
+        census(jbasis ? (lds_tiles ? "lm_eval_kernel<true, false>" : "lm_eval_kernel<false, false>")
+                      : (lds_tiles ? "lm_eval_kernel<true, true>" : "lm_eval_kernel<false, true>"));
         NGMIX_HIP_CHECK(hipLaunchKernel(kern, grid, block, args, lds, s));
         return NGMIX_OK;
     }
@@ -1561,6 +1565,7 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *stat
     }
 #define NGMIX_FD_LAUNCH(N)                                                              \
     do {                                                                                \
+        census("lm_eval_fd_kernel<" #N ">");                                            \
         if (lds > 48 * 1024)                                                            \
             NGMIX_HIP_CHECK(hipFuncSetAttribute(                                        \
                 (const void *)lm_eval_fd_kernel<N>,                                     \
@@ -1594,6 +1599,14 @@ int launch_lm_advance(lm_state *states, int64_t nobj, const int64_t *obj_start,
     if (nactive) NGMIX_HIP_CHECK(hipMemsetAsync(nactive, 0, sizeof(int32_t), s));
     const dim3 grid((unsigned)((nobj + WAVE - 1) / WAVE)), block(WAVE);
     static const bool generic = getenv("NGMIX_LM_GENERIC") != nullptr;   // A/B knob
+    {
+        char name[64];
+        if (npars >= 6 && npars <= 10 && !generic)
+            snprintf(name, sizeof(name), "lm_advance_kernel<%d, true>", npars);
+        else
+            snprintf(name, sizeof(name), "lm_advance_kernel<%d, false>", LM_NPMAX);
+        census(name);
+    }
     if (npars == 6 && !generic)
         hipLaunchKernelGGL((lm_advance_kernel<6, true>), grid, block, 0, s, states, nobj,
                            obj_start, stamp_band, sums, nloc, obj_sums, nactive, stamp_stats,

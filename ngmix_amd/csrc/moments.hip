@@ -7,6 +7,8 @@
 //
 // One work-group per stamp.  Both are compute-bound: the stamp
 // is read from HBM once and the iteration runs on chip.
+#include <stdio.h>
+
 #include "iter_common.hpp"
 #include "launch_iter.hpp"
 
@@ -649,6 +651,7 @@ int launch_weighted_sums_grid(const ngmix_batch *b, const ngmix_gauss2d *gmix,
     const int ng = b->max_ngauss > 0 ? b->max_ngauss : 1;
     if (!(b->flags & NGMIX_BATCH_EXACT)) {
         const size_t lds = (size_t)ng * sizeof(EvalGauss) + 16;
+        census(nmom == 6 ? "wsums_wave_kernel<6>" : "wsums_wave_kernel<17>");
         if (nmom == 6)
             hipLaunchKernelGGL(wsums_wave_kernel<6>, dim3((unsigned)b->nstamps),
                                dim3(WAVE), lds, s, b->stamps, b->val, b->ierr, b->jac,
@@ -660,6 +663,7 @@ int launch_weighted_sums_grid(const ngmix_batch *b, const ngmix_gauss2d *gmix,
         NGMIX_HIP_CHECK(hipGetLastError());
         return NGMIX_OK;
     }
+    census("weighted_sums_grid_kernel");
     hipLaunchKernelGGL(weighted_sums_grid_kernel, dim3((unsigned)b->nstamps),
                        dim3(BLOCK), wsums_lds(nmom, ng), s, b->stamps, b->val,
                        b->ierr, b->jac, gmix, (char *)res, nmom, maxrad, status);
@@ -1490,6 +1494,11 @@ static void admom_launch(const ngmix_admom_conf *conf, const ngmix_batch *b,
                          ngmix_gauss2d *wt, ngmix_admom_result *res, int32_t *status,
                          hipStream_t s)
 {
+    {
+        char name[64];
+        snprintf(name, sizeof(name), "admom_grid_kernel<%d, %d>", NT, PPT);
+        census(name);
+    }
     hipLaunchKernelGGL((admom_grid_kernel<NT, PPT>), dim3((unsigned)b->nstamps),
                        dim3(NT), 0, s, *conf, b->stamps, b->val, b->ierr, b->jac, wt,
                        res, status);

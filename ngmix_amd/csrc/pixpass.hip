@@ -916,6 +916,10 @@ static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
                 kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         void *args[] = {&a_stamps, &a_val, &a_ierr, &a_jac, &gmix, &out, &out_start,
                         &status, &a_ng, &a_nc, &a_ns};
+        census(OP == OP_LOGLIKE ? "pixpass_grid_kernel<loglike>"
+               : OP == OP_FDIFF ? "pixpass_grid_kernel<fdiff>"
+               : OP == OP_S2N   ? "pixpass_grid_kernel<s2n>"
+                                : "pixpass_grid_kernel<render>");
         NGMIX_HIP_CHECK(hipLaunchKernel(kern, grid, block, args, lds, s));
         return NGMIX_OK;
     }
@@ -939,6 +943,11 @@ static int launch_grid(const ngmix_batch *b, ngmix_gauss2d *gmix, double *out,
     dim3 grid((unsigned)b->nstamps), block(WAVE);
     void *args[] = {&a_stamps, &a_val, &a_ierr, &a_jac, &gmix, &out, &out_start,
                     &status, &a_ng, &a_nc, &a_ns, &a_tc};
+    census(FOP == OP_LOGLIKE ? (six_waves ? "pixpass_wave_kernel<loglike>"
+                                          : "pixpass_wave_kernel7<loglike>")
+           : FOP == OP_FDIFF ? "pixpass_wave_kernel<fdiff>"
+           : FOP == OP_S2N   ? "pixpass_wave_kernel<s2n>"
+                             : "pixpass_wave_kernel<render>");
     NGMIX_HIP_CHECK(hipLaunchKernel(kern, grid, block, args, flds, s));
     return NGMIX_OK;
 }

@@ -52,10 +52,28 @@ def _oracle_loglike(gmrow, val, ierr, jac):
     return res, fd
 
 
+def _census(run):
+    """the batch kernel variants `run()` dispatched (ngmix_launch_census)"""
+    from ngmix_amd import _lib
+    _lib.launch_census(reset=True)
+    run()
+    return _lib.launch_census(reset=True)
+
+
 def _c2_checks(bench, n, nsample):
     import torch
     sb, gm, pars = bench.make_workload(n, 11, "cuda")
     npix = 48 * 48
+    # which kernels serve config 2: the fused one-wave-per-stamp kernels with
+    # the hand-counted look-ahead (7-wave loglike build), not the 256-thread
+    # reference-order ones
+    seen = _census(lambda: (sb.loglike(gm), sb.fill_fdiff(gm), sb.render(gm),
+                            sb.model_s2n_sum(gm)))
+    assert seen.get("pixpass_wave_kernel7<loglike>", 0) == 1
+    assert seen.get("pixpass_wave_kernel<fdiff>", 0) == 1
+    assert seen.get("pixpass_wave_kernel<render>", 0) == 1
+    assert seen.get("pixpass_wave_kernel<s2n>", 0) == 1
+    assert not any(k.startswith("pixpass_grid_kernel") for k in seen), seen
     out, status = sb.loglike(gm)
     assert int(status.abs().sum()) == 0
     assert torch.all(out[:, 3] == npix)
@@ -162,7 +180,16 @@ def test_c3_full_size(bench):
     guess[:, 0:2] = pars[:, 0:2] + rng.uniform(-0.05, 0.05, size=(n, 2))
     guess[:, 2:4] = pars[:, 2:4] + rng.uniform(-0.03, 0.03, size=(n, 2))
     psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (n, 1)), "gauss")
-    res = LMBatchFitter("exp").go(sb, guess, psf=psf)
+    box = {}
+    seen = _census(lambda: box.update(res=LMBatchFitter("exp").go(sb, guess, psf=psf)))
+    res = box["res"]
+    # config 3 runs the raw-basis pixel pass with LDS tile records and the
+    # six-parameter register form of the lmder step, one launch each per round
+    # (+ the round in flight when the count reaches zero); no stats pixel pass
+    rounds = seen.get("lm_eval_kernel<true, true>", 0)
+    assert 4 <= rounds <= 8 and seen.get("lm_advance_kernel<6, true>", 0) == rounds, seen
+    assert not any(k.startswith(("pixpass", "lm_eval_fd", "lm_advance_kernel<14"))
+                   for k in seen), seen
     assert np.all(res["flags"] == 0)
     assert np.all((res["ier"] >= 1) & (res["ier"] <= 4))
     assert np.all(res["npix"] == 2304) and np.all(res["dof"] == 2304 - 6)
@@ -235,7 +262,11 @@ def test_c4_full_size(bench):
     sb, sb_em = w["sb"], w["sb_em"]
 
     wt = w["wt0"].clone()
-    res, st = sb.admom(wt)
+    box = {}
+    seen = _census(lambda: box.update(r=sb.admom(wt)))
+    res, st = box["r"]
+    # one wave per 32 x 32 stamp, sixteen register slots per lane
+    assert seen == {"admom_grid_kernel<64, 16>": 1}, seen
     assert int(st.abs().sum()) == 0
     rec = records_to_numpy(res, _lib.ADMOM_RESULT_DTYPE)
     assert np.all(rec["flags"] == 0) and np.all(rec["npix"] == 1024)
@@ -243,7 +274,10 @@ def test_c4_full_size(bench):
 
     gm = w["gm0"].clone()
     conv, _ = gm.convolve(w["psf"])
-    out_e, st_e, _ = sb_em.em(gm, w["psf"], conv=conv, sky=w["sky"])
+    seen = _census(lambda: box.update(e=sb_em.em(gm, w["psf"], conv=conv, sky=w["sky"])))
+    out_e, st_e, _ = box["e"]
+    # the fused one-wave kernel: full run, one object gaussian, one psf gaussian
+    assert seen == {"em_wave_kernel<64, 16, 0, 1, 1>": 1}, seen
     assert int(st_e.abs().sum()) == 0
     numiter = out_e[:, 0].cpu().numpy()
     assert np.all(numiter >= 40) and np.all(numiter < 500)
@@ -309,7 +343,11 @@ def test_c5_full_size(bench):
     nobj, nepoch = 20000, 10
     sb, gm, obj_start = bench.make_c5(nobj, 3, "cuda")
     ns = nobj * nepoch
-    per_obj, per_stamp, status = sb.loglike_objects(gm, obj_start)
+    box = {}
+    seen = _census(lambda: box.update(r=sb.loglike_objects(gm, obj_start)))
+    per_obj, per_stamp, status = box["r"]
+    # the same fused loglike kernel as config 2, on 64-tile stamps with 16 gaussians
+    assert seen.get("pixpass_wave_kernel7<loglike>", 0) == 1, seen
     assert int(status.abs().sum()) == 0
     assert torch.all(per_stamp[:, 3] == 4096) and torch.all(per_obj[:, 3] == 40960)
     # the per-object records are the sums of the epochs' (exact host sums)

@@ -597,8 +597,25 @@ def test_em_many_gaussians_vs_oracle(shape, ngauss, npsf, kind):
     gm_in = gm0.to_numpy().reshape(nst, ngauss)
     psf_in = psf.to_numpy().reshape(nst, npsf)
     miniter = 20 if kind != 3 else 5
+    _lib.launch_census(reset=True)
     out, status, conv = sb.em(gm0, psf, sky=sky, kind=kind, miniter=miniter, maxiter=40,
                               tol=1e-6)
+    seen = _lib.launch_census(reset=True)
+    # which kernel served it: the fused one- / two-wave kernels up to 2048 pixels
+    # (2304 in the full run, 4096 for <= 3 object gaussians) with the psf count
+    # compile-time for 1 and (one wave, <= 3 gaussians) 3; the generic beyond
+    npix = nrow * ncol
+    fused = npix <= (4096 if ngauss <= 3 else (2304 if kind == 0 else 2048))
+    assert len(seen) == 1, seen
+    name = list(seen)[0]
+    if fused:
+        nt = 64 if npix <= 1024 else (128 if npix <= 2304 and (npix <= 2048 or kind == 0)
+                                      else 256)
+        cpsf = 1 if npsf == 1 else (3 if npsf == 3 and ngauss <= 3 and nt == 64 else 0)
+        assert name.startswith("em_wave_kernel<%d, " % nt), seen
+        assert name.endswith(", %d, %d, %d>" % (kind, ngauss, cpsf)), seen
+    else:
+        assert name.startswith("em_grid_kernel<"), seen
     assert int(status.abs().sum()) == 0
     out = out.cpu().numpy()
     gm_out = gm0.to_numpy().reshape(nst, ngauss)
