@@ -394,7 +394,10 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
     a2 = copy.copy(args)
     a2.steps = steps or args.steps
     if steps is not None:
-        a2.warmup, a2.settle_steps = 2, 8
+        # (a short leg of a default C2 run: the GPU has idled through the CPU
+        # legs before it, and the clock governor needs ~0.4 s of uninterrupted
+        # launches to reach the state the timed steps should see)
+        a2.warmup, a2.settle_steps = 2, 70
     else:
         a2.warmup = min(args.warmup, 5)
         a2.settle_steps = min(max(args.settle_steps, 0), 200)
@@ -403,19 +406,17 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
     gat = Gather(world, device)
     K = steps or args.steps
     state = {"loop": 0.0, "rounds": 0, "bad": 0, "nfev": 0.0, "eval_ms": 0.0,
-             "eval_stamps": 0.0, "launches": 0}
+             "eval_stamps": 0.0, "launches": 0, "kernels": {}, "launched": 0}
 
-    # The steps run as a software pipeline (LMBatchFitter.go_stream): while one
-    # batch's results are packed and downloaded the next batch's first rounds
-    # are already queued (--no-pipeline: one synchronous go() per step).  ONE
-    # pipeline runs through the untimed and the timed steps, so the timed
-    # region sees its steady state at both ends: the batch in flight when the
-    # clock starts has had its set-up and first two rounds, and so has the
-    # batch after the last timed one when the clock stops -- work inside the
-    # region for a batch that is not counted, and the closing synchronisation
-    # waits for it.  (Two separate pipelines were measured first: the cold start
-    # of the timed one, 12-20 ms for its first step with fresh pinned buffers,
-    # made a 10-step leg read 1.14-1.41e7 fits/s on one box.)
+    # The steps run as a software pipeline (LMBatchFitter.go_stream): every
+    # batch's device work -- set-up, rounds, finalize, pack, downloads -- is
+    # queued without the host waiting for anything, and the next batch is
+    # queued before the host turns to this one's arrays (--no-pipeline: one
+    # synchronous go() per step).  ONE pipeline runs through the untimed and
+    # the timed steps, so the timed region sees its steady state at both ends:
+    # the batch after the last timed one is queued inside the region -- work
+    # for a batch that is not counted, and the closing synchronisation waits
+    # for it.
     pipelined = not getattr(args, "no_pipeline", False)
     streams = {}
 
@@ -437,7 +438,10 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
             state["loop"] += fitter.loop_seconds
             state["eval_ms"] += fitter.eval_ms_total
             state["eval_stamps"] += fitter.eval_stamps_total
-            state["launches"] += int(round(fitter.eval_ms_total / fitter.eval_ms))
+            state["launches"] += fitter.eval_launch_count
+            state["launched"] += fitter.rounds_launched
+            for k, v in getattr(fitter, "kernel_ms", {}).items():
+                state["kernels"][k] = state["kernels"].get(k, 0.0) + v
             state["nsplit"] = fitter.nsplit_used
             state["rounds"] = fitter.rounds
             state["bad"] = int((res["flags"] != 0).sum())
@@ -498,6 +502,11 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
                     "bound; bytes and time are summed over the launches of whole fits, "
                     "each launch counted with the stamps still being fitted",
         },
+        # HIP-event time of every kernel of a fit, summed per fit (mean over the
+        # timed steps): what ms_per_step is to be read against
+        "kernels_ms": {k: v / K for k, v in sorted(state["kernels"].items())},
+        "kernels_ms_sum": sum(state["kernels"].values()) / K,
+        "rounds_launched": state["launched"] / float(K),
         "device_loop_ms": loop_ms, "rounds": rounds, "pipelined": pipelined,
         "fits_per_s_device_loop": n / (loop_ms * 1e-3) if loop_ms > 0 else None,
         "mean_nfev": state["nfev"], "bad_status": state["bad"],
@@ -598,7 +607,7 @@ def run_c4(args, rank, world, device, backend, nstamps=None, steps=None, quiet=F
     a2 = copy.copy(args)
     a2.steps = K
     if steps is not None:       # the short leg of a C2 run
-        a2.warmup, a2.settle_steps = 2, 5
+        a2.warmup, a2.settle_steps = 2, 30   # ~0.45 s of load before the clock starts
     elapsed = timed_steps(step, a2, distributed, device)
     admom_ms = _mean_ms(ev[0], ev[1])
     em_ms = _mean_ms(ev[2], ev[3])
@@ -730,7 +739,7 @@ def run_c5(args, rank, world, device, backend, nobj=None, steps=None):
     a2 = copy.copy(args)
     a2.steps = K
     if steps is not None:
-        a2.warmup, a2.settle_steps = 5, 30
+        a2.warmup, a2.settle_steps = 5, 160   # ~0.45 s of load before the clock starts
     elapsed = timed_steps(step, a2, distributed, device)
     ll_ms = _mean_ms(ev0, ev1)
     red_ms = _mean_ms(ev1, ev2)
@@ -1022,57 +1031,127 @@ def cpu_baseline_c4(budget=1.5, usable=None, teams=None, verbose=False):
     return out
 
 
-def cpu_baseline_c3(budget=1.5, verbose=False):
-    """config-3 cpu_baseline leg: complete 'exp' (x) gaussian-psf LM fits of
-    48x48 stamps on ONE core -- scipy's MINPACK (what the reference's
-    run_leastsq calls, fitters.py:64-112) around the C port of fill_fdiff.
-    The jacobian is MINPACK's forward differences (lmdif): the port has no
-    FitModel.calc_jacobian, so a fit costs ~7 residual evaluations per
-    iteration where the reference's lmder pays one jacobian; stated in
-    `sample`."""
+def _c3_cpu_fits(budget, seed, nstamps=16):
+    """Complete 'exp' (x) gaussian-psf LM fits of 48x48 stamps on THIS core
+    for `budget` seconds, the reference's algorithm: scipy's MINPACK lmder
+    (what run_leastsq calls with Dfun = FitModel.calc_jacobian,
+    fitters.py:93-104) at DEFAULT_LM_PARS (ftol = xtol = 1e-5, maxfev 4000:
+    defaults.py:17) around the C port of fill_fdiff and of deriv_images
+    (results.py:439-570, derivs_nb.py:40-127).  Returns (fits, seconds, sum of
+    nfev, fits that ended with ier 1..4)."""
     from scipy.optimize import leastsq
-    w = _CpuWorkloads(3)
+    w = _CpuWorkloads(seed)
     ora = w.ora
-    gms, pix, _, pars = w.stamps(8, 48, "exp")
+    _, pix, _, pars = w.stamps(nstamps, 48, "exp")
     psf = np.zeros(1, dtype=ora.GAUSS2D_DTYPE)
     ora.gmix_fill(psf, np.array([0.0, 0.0, 0.0, 0.0, 0.27, 1.0]), "gauss")
-    rng = np.random.RandomState(33)
-    nfev = []
+    rng = np.random.RandomState(33 + seed)
+    npix = pix.shape[1]
+    vv = [np.ascontiguousarray(pix[i]["v"]) for i in range(nstamps)]
+    uu = [np.ascontiguousarray(pix[i]["u"]) for i in range(nstamps)]
+    area = [np.ascontiguousarray(pix[i]["area"]) for i in range(nstamps)]
+    ierr = [np.ascontiguousarray(pix[i]["ierr"]) for i in range(nstamps)]
+    dcov_de = np.array([[-1.0, 0.0, 1.0], [0.0, 1.0, 0.0]])
+    gm0 = np.zeros(6, dtype=ora.GAUSS2D_DTYPE)
+    gm = np.zeros(6, dtype=ora.GAUSS2D_DTYPE)
+    fd = np.zeros(npix)
+    dimg = np.zeros((6, npix))
+    jac = np.zeros((npix, 6))
+    stat = {"nfev": 0, "ok": 0}
+
+    def fill(p):
+        # out of range -> GMixRangeError in the reference
+        if p[2] * p[2] + p[3] * p[3] >= 1.0 or p[4] <= 0.0 or p[5] == 0.0:
+            return False
+        ora.gmix_fill(gm0, p, "exp")
+        ora.gmix_convolve_fill(gm, gm0, psf)
+        ora.gmix_set_norms(gm)
+        return True
 
     def fit(i):
-        gm0 = np.zeros(6, dtype=ora.GAUSS2D_DTYPE)
-        gm = np.zeros(6, dtype=ora.GAUSS2D_DTYPE)
-        fd = np.zeros(pix.shape[1])
-
         def resid(p):
-            # (out of range -> the reference's LOWVAL residual vector)
-            if p[2] * p[2] + p[3] * p[3] >= 1.0 or p[4] <= 0.0:
-                return np.full(fd.size, -9.999e9)
-            ora.gmix_fill(gm0, p, "exp")
-            ora.gmix_convolve_fill(gm, gm0, psf)
-            ora.gmix_set_norms(gm)
+            if not fill(p):
+                return np.full(npix, -9.999e9)      # LOWVAL (results.py:461-463)
             ora.fill_fdiff(gm, pix[i], fd, 0)
             return fd.copy()
+
+        def dfun(p):
+            # FitModel.calc_jacobian: composed gaussians + d cov / d(g1, g2, T)
+            # (results.py:955-1010), deriv_images, rows scaled by ierr
+            if not fill(p):
+                return np.zeros((npix, 6))
+            g1, g2, T, flux = p[2:6]
+            gpars = np.stack([gm[k] for k in ("p", "row", "col", "irr", "irc", "icc")], axis=1)
+            mcov = np.stack([gm0[k] for k in ("irr", "irc", "icc")], axis=1)
+            half_tk = 0.5 * (mcov[:, 0] + mcov[:, 2])
+            gsq = g1 * g1 + g2 * g2
+            f = 2.0 / (1.0 + gsq)
+            g = np.array([g1, g2])
+            jac_e = f * np.eye(2) + (2.0 * g[:, None] * g[None, :]) * (-f / (1.0 + gsq))
+            dcov = np.empty((6, 3, 3))
+            dcov[:, 0:2, :] = half_tk[:, None, None] * (jac_e @ dcov_de)[None, :, :]
+            dcov[:, 2, :] = mcov / T
+            dimg[:] = 0.0       # deriv_images accumulates (derivs_nb.py:107-125)
+            ora.deriv_images(gpars, dcov, vv[i], uu[i], area[i], dimg)
+            for k in range(5):
+                jac[:, k] = dimg[1 + k] * ierr[i]
+            jac[:, 5] = dimg[0] * (ierr[i] / flux)
+            return jac
         guess = pars[i] * rng.uniform(0.9, 1.1, size=6)
-        out = leastsq(resid, guess, full_output=1, ftol=1.49012e-8, xtol=1.49012e-8)
-        nfev.append(out[2]["nfev"])
-        return out[0]
+        guess[0:2] = pars[i][0:2] + rng.uniform(-0.05, 0.05, size=2)
+        guess[2:4] = pars[i][2:4] + rng.uniform(-0.03, 0.03, size=2)
+        out = leastsq(resid, guess, Dfun=dfun, full_output=1, ftol=1.0e-5, xtol=1.0e-5,
+                      maxfev=4000)
+        stat["nfev"] += out[2]["nfev"]
+        stat["ok"] += int(1 <= out[4] <= 4)
 
     fit(0)
+    stat["nfev"] = stat["ok"] = 0
     t0 = time.perf_counter()
     n = 0
     while time.perf_counter() - t0 < budget:
-        fit(n % pix.shape[0])
+        fit(n % nstamps)
         n += 1
-    rate = n / (time.perf_counter() - t0)
+    return n, time.perf_counter() - t0, stat["nfev"], stat["ok"]
+
+
+def cpu_baseline_c3(budget=1.5, usable=None, verbose=False):
+    """config-3 cpu_baseline leg, the reference's own algorithm on the host
+    cores: MINPACK lmder with the analytic jacobian at ftol = xtol = 1e-5
+    (_c3_cpu_fits), on one core and on every core the process may use -- one
+    worker PROCESS per core (MINPACK's callbacks hold the GIL, as in the
+    reference), started as fresh interpreters that never touch the GPU."""
+    if usable is None:
+        usable, _ = host_threads()
+    n1, dt1, nfev1, ok1 = _c3_cpu_fits(budget, 3)
+    single = n1 / dt1
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-c3-worker", "%g" % budget]
+    procs = [subprocess.Popen(cmd + [str(100 + k)], stdout=subprocess.PIPE, text=True, cwd=ROOT)
+             for k in range(usable)]
+    rates, nfits, nfev, ok = 0.0, 0, 0, 0
+    for pr in procs:
+        out, _ = pr.communicate(timeout=120 + 4 * budget)
+        rec = json.loads(out.strip().splitlines()[-1])
+        rates += rec["n"] / rec["seconds"]
+        nfits += rec["n"]
+        nfev += rec["nfev"]
+        ok += rec["ok"]
+    mean_nfev = nfev / float(max(nfits, 1))
     if verbose:
-        print("C3 'exp' LM fit 48x48 (scipy MINPACK lmdif + C fill_fdiff): 1 thread %.3g fits/s "
-              "(mean nfev %.1f)" % (rate, float(np.mean(nfev))))
-    return {"value": rate, "unit": "fits/s", "cores": 1, "kind": "port",
-            "single_core_value": rate, "mean_nfev": float(np.mean(nfev)),
-            "sample": "%d fits of 48x48 'exp' (x) gaussian-psf stamps in %.1f s on one core: "
-                      "scipy MINPACK (forward-difference jacobian) around the C port of "
-                      "fill_fdiff / gmix_fill / gmix_convolve_fill" % (n, budget)}
+        print("C3 'exp' LM fit 48x48 (scipy MINPACK lmder + C fill_fdiff / deriv_images, "
+              "ftol = xtol = 1e-5): 1 core %.3g fits/s (mean nfev %.2f); %d worker processes "
+              "%.3g fits/s (mean nfev %.2f, %d of %d converged)" % (
+                  single, nfev1 / float(max(n1, 1)), usable, rates, mean_nfev, ok, nfits))
+    return {"value": rates, "unit": "fits/s", "cores": int(usable), "kind": "port",
+            "single_core_value": single, "mean_nfev": mean_nfev,
+            "single_core_mean_nfev": nfev1 / float(max(n1, 1)),
+            "converged": ok, "fits": nfits,
+            "jacobian": "analytic (C port of deriv_images through Dfun, as the reference)",
+            "sample": "%d fits of 48x48 'exp' (x) gaussian-psf stamps in %.1f s on %d worker "
+                      "processes (one per usable core), and %d in %.1f s on one core: scipy "
+                      "MINPACK lmder at ftol = xtol = 1e-5 (the reference's DEFAULT_LM_PARS) "
+                      "around the C port of fill_fdiff / deriv_images / gmix_fill / "
+                      "gmix_convolve_fill" % (nfits, budget, usable, n1, dt1)}
 
 
 def cpu_baseline_c5(budget=1.5, usable=None, nepoch=10, verbose=False):
@@ -1133,7 +1212,7 @@ def cpu_baseline_configs(budget=4.0):
               "%.3g pixel-gaussian evals/s" % (threads, r, 2 * r * 48 * 48 * 6))
         if threads == 1:
             print("C1 one stamp, render + loglike: %.1f us" % (1e6 / r))
-    cpu_baseline_c3(budget, verbose=True)
+    cpu_baseline_c3(budget, usable, verbose=True)
     cpu_baseline_c4(budget, usable, verbose=True)
     cpu_baseline_c5(budget, usable, verbose=True)
 
@@ -1167,6 +1246,12 @@ def load_traffic(kernel, nstamps, key="nstamps"):
 
 
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-c3-worker":
+        # one worker of cpu_baseline_c3: a fresh interpreter, no GPU, no torch
+        n, dt, nfev, ok = _c3_cpu_fits(float(sys.argv[2]),
+                                       int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+        print(json.dumps({"n": n, "seconds": dt, "nfev": nfev, "ok": ok}))
+        return 0
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -1218,16 +1303,18 @@ def main():
             other = {}
             # (short legs, but long enough for the clock governor: each runs its
             # own settle + warm-up steps, ~0.1 s of load, before the timed ones)
-            for name, fn, kw in (("C3", run_c3, dict(nstamps=100000, steps=10)),
-                                 ("C4", run_c4, dict(nstamps=125000, steps=8)),
-                                 ("C5", run_c5, dict(nobj=20000, steps=30))):
+            for name, fn, kw in (("C3", run_c3, dict(nstamps=100000, steps=30)),
+                                 ("C4", run_c4, dict(nstamps=125000, steps=16)),
+                                 ("C5", run_c5, dict(nobj=20000, steps=60))):
                 try:
                     o = fn(args, rank, world, device, backend, **kw)
                     other[name] = {k: o[k] for k in (
                         "metric", "value", "unit", "config", "roofline", "kernels_ms",
                         "bad_status") if k in o}
                     for k in ("rooflines", "mean_numiter", "device_loop_ms", "rounds",
-                              "fits_per_s_device_loop", "mean_nfev", "ms_per_step"):
+                              "fits_per_s_device_loop", "mean_nfev", "ms_per_step",
+                              "kernels_ms_sum", "rounds_launched", "pipelined", "steps",
+                              "settle_steps"):
                         if k in o:
                             other[name][k] = o[k]
                 except Exception as e:   # never lose the headline line
@@ -1238,7 +1325,8 @@ def main():
                 # the GPU figures, bounded to ~2 s per leg
                 try:
                     usable, _ = host_threads()
-                    other.setdefault("C3", {})["cpu_baseline"] = cpu_baseline_c3(budget=1.0)
+                    other.setdefault("C3", {})["cpu_baseline"] = cpu_baseline_c3(
+                        budget=2.0, usable=usable)
                     c4 = cpu_baseline_c4(budget=1.0, usable=usable)
                     if "rooflines" in other.get("C4", {}):
                         other["C4"]["cpu_baseline"] = c4

@@ -158,7 +158,7 @@ const char *ngmix_last_error(void);
 /* sizeof() of an ABI record by its type name ("ngmix_gauss2d", "ngmix_pixel",
    "ngmix_coord", "ngmix_jacobian", "ngmix_admom_conf", "ngmix_admom_result",
    "ngmix_em_conf", "ngmix_stamp", "ngmix_batch", "ngmix_lm_state",
-   "ngmix_simple_sep_prior"), -1 for an
+   "ngmix_simple_sep_prior", "ngmix_lm_problem"), -1 for an
    unknown name: lets a binding check its own record layouts at load time */
 int64_t ngmix_abi_sizeof(const char *type_name);
 int ngmix_device_count(void);
@@ -426,12 +426,23 @@ int ngmix_deriv_images_batch(const ngmix_batch *batch, const double *gpars,
 #define NGMIX_LM_PHASE_INIT 0   /* wants |f|^2, J^T f, J^T J at xt (= the guess) */
 #define NGMIX_LM_PHASE_TRIAL 1  /* wants |f|^2 at xt (analytic mode: and J^T f, J^T J) */
 #define NGMIX_LM_PHASE_DONE 2
-#define NGMIX_LM_PHASE_JAC 3    /* forward-difference mode: wants J^T f, J^T J at xt (= x) */
+#define NGMIX_LM_PHASE_JAC 3    /* wants J^T f, J^T J at xt (= x): forward-difference mode,
+                                   and mode ANALYTIC_LAZY after an |f|^2-only trial */
 
 /* ngmix_lm_state.mode */
 #define NGMIX_LM_MODE_ANALYTIC 0 /* lmder; the jacobian comes with every evaluation */
 #define NGMIX_LM_MODE_FD 1       /* lmdif: forward-difference jacobian only at accepted
                                     points, its n evaluations counted in nfev */
+#define NGMIX_LM_MODE_ANALYTIC_LAZY 2 /* lmder, and a trial whose acceptance is predicted
+                                    to END the fit (lmder's own predicted reduction <= ftol,
+                                    or a step bound that will pass the xtol test) is
+                                    evaluated for |f|^2 alone -- state.fonly = 1 -- as lmder
+                                    itself does: it never forms the jacobian at the final
+                                    point.  A prediction that fails asks for the jacobian
+                                    at the accepted point in the next round (phase JAC),
+                                    which is lmder's own order of evaluation: nfev, njev
+                                    and every iterate are those of mode ANALYTIC, bit for
+                                    bit */
 
 /* one fit: lmder's loop variables, re-entrant (layout used by host and device) */
 typedef struct {
@@ -458,7 +469,8 @@ typedef struct {
     double hstep[NGMIX_LM_NPMAX];
     int32_t ipvt[NGMIX_LM_NPMAX]; /* 0-based */
     int32_t n, iter, nfev, njev, info, phase, maxfev, mode;
-    int32_t bounded, pad_;
+    int32_t bounded;
+    int32_t fonly; /* 1: the evaluation at xt needs |f|^2 only (mode ANALYTIC_LAZY) */
 } ngmix_lm_state;
 
 /* HOST: initialise nobj states from the guesses x0 (nobj, npars);
@@ -580,12 +592,59 @@ int ngmix_lm_finalize_batch(const ngmix_lm_state *states, int64_t nobj,
    not NULL).  head: (nobj, 2 npars) = pars | pars_err; cols:
    (NGMIX_LM_NCOLS, nobj) column-major = flags, nfev, ier, dof (of the fit),
    njev, lnprob, s2n_numer, s2n_denom, npix, dof, chi2per, s2n -- the seven
-   statistics are NaN where flags != 0, as set_fit_result leaves them out */
+   statistics are NaN where flags != 0, as set_fit_result leaves them out.
+   cov_tri (may be NULL): (nobj, npars (npars + 1) / 2), the row-major upper
+   triangle of pars_cov -- the matrix is symmetric to the bit, so the
+   triangle is all a download needs */
 #define NGMIX_LM_NCOLS 12
 int ngmix_lm_pack_batch(const ngmix_lm_state *states, int64_t nobj, int npars,
                         const double *rec, const double *obj_stats,
                         const double *tot, const int64_t *npix_obj, double *head,
-                        double *cols, void *stream);
+                        double *cols, double *cov_tri, void *stream);
+
+/* DEVICE: `nrounds` lock-step rounds queued by ONE host call -- per round
+   ngmix_lm_eval_batch, ngmix_lm_prior_sums_batch (when `prior` is set) and
+   ngmix_lm_advance_batch, nothing between them on the host.  The reference's
+   driver calls back into Python twice per LM step (leastsqbound.py:445-491);
+   here the host is not in the loop at all: a fit that has finished is skipped
+   by every later launch (its phase is read on the device), so rounds may be
+   queued blind -- a round that finds every fit finished costs two empty
+   launches.  The members of ngmix_lm_problem are the arguments of the three
+   entry points above.  counts (device int32, nrounds slots, may be NULL):
+   slot r receives the number of fits still running after round r;
+   counts_host (pinned host memory or NULL) receives one copy of all the slots
+   behind the last round.  events (may be NULL): 3 nrounds hipEvent_t recorded
+   before the pixel pass, between the pixel pass and the step, and after the
+   step of each round (ngmix_event_*: timing without a host in the loop). */
+typedef struct {
+    const ngmix_batch *batch;
+    ngmix_lm_state *states;          /* device, nobj records */
+    int64_t nobj;
+    const int32_t *stamp_obj;        /* (nstamps,) or NULL */
+    const int32_t *stamp_band;       /* (nstamps,) or NULL */
+    const int64_t *obj_start;        /* (nobj + 1,) or NULL */
+    const ngmix_gauss2d *psf;        /* nstamps * npsf records or NULL */
+    double *sums;                    /* (nstamps, NGMIX_LM_NSUMS(nloc)) */
+    int32_t *status;                 /* (nstamps,) */
+    double *stamp_stats;             /* (nstamps, 2) or NULL */
+    double *obj_stats;               /* (nobj, 2) or NULL */
+    const ngmix_simple_sep_prior *prior; /* HOST record or NULL */
+    double *obj_sums;                /* (nobj, NGMIX_LM_NSUMS(npars)) or NULL */
+    double prior_step;               /* step_rel of ngmix_lm_prior_sums_batch */
+    int32_t model, fd, npsf;
+    int32_t nloc_npars;              /* nloc + 256 * npars, as ngmix_lm_advance_batch */
+} ngmix_lm_problem;
+int ngmix_lm_rounds_batch(const ngmix_lm_problem *problem, int nrounds,
+                          int32_t *counts, int32_t *counts_host, void **events,
+                          void *stream);
+/* HOST: n timing events (hipEvent_t) for ngmix_lm_rounds_batch / to record
+   on a stream; elapsed milliseconds between two recorded events (both must
+   have completed: synchronise the stream or the later event first) */
+int ngmix_events_create(int n, void **events);
+int ngmix_events_destroy(int n, void **events);
+int ngmix_event_record(void *event, void *stream);
+int ngmix_event_synchronize(void *event);
+int ngmix_event_elapsed_ms(void *start, void *stop, float *ms);
 
 /* HOST: the launch census -- how many times each batch kernel variant has been
    dispatched by this process, as "name<TAB>count" lines ("em_wave_kernel<64,

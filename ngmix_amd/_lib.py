@@ -100,6 +100,7 @@ LM_PHASE_DONE = 2
 LM_PHASE_JAC = 3
 LM_MODE_ANALYTIC = 0
 LM_MODE_FD = 1
+LM_MODE_ANALYTIC_LAZY = 2
 # ngmix_lm_state (include/ngmix_hip.h): one re-entrant lmder iteration
 LM_STATE_DTYPE = np.dtype([
     ("x", "f8", LM_NPMAX), ("xt", "f8", LM_NPMAX), ("diag", "f8", LM_NPMAX),
@@ -114,7 +115,7 @@ LM_STATE_DTYPE = np.dtype([
     ("ipvt", "i4", LM_NPMAX),
     ("n", "i4"), ("iter", "i4"), ("nfev", "i4"), ("njev", "i4"), ("info", "i4"),
     ("phase", "i4"), ("maxfev", "i4"), ("mode", "i4"),
-    ("bounded", "i4"), ("pad_", "i4"),
+    ("bounded", "i4"), ("fonly", "i4"),
 ], align=True)
 
 
@@ -145,6 +146,31 @@ class Batch(ctypes.Structure):
         ("flags", ctypes.c_int32),
         ("max_nrow", ctypes.c_int32),
         ("max_ncol", ctypes.c_int32),
+    ]
+
+
+class LMProblem(ctypes.Structure):
+    """ngmix_lm_problem: the arguments of one lock-step round
+    (ngmix_lm_rounds_batch)"""
+    _fields_ = [
+        ("batch", ctypes.POINTER(Batch)),
+        ("states", ctypes.c_void_p),
+        ("nobj", ctypes.c_int64),
+        ("stamp_obj", ctypes.c_void_p),
+        ("stamp_band", ctypes.c_void_p),
+        ("obj_start", ctypes.c_void_p),
+        ("psf", ctypes.c_void_p),
+        ("sums", ctypes.c_void_p),
+        ("status", ctypes.c_void_p),
+        ("stamp_stats", ctypes.c_void_p),
+        ("obj_stats", ctypes.c_void_p),
+        ("prior", ctypes.c_void_p),
+        ("obj_sums", ctypes.c_void_p),
+        ("prior_step", ctypes.c_double),
+        ("model", ctypes.c_int32),
+        ("fd", ctypes.c_int32),
+        ("npsf", ctypes.c_int32),
+        ("nloc_npars", ctypes.c_int32),
     ]
 
 
@@ -230,7 +256,13 @@ SIGNATURES = {
                                       _vp]),
     "ngmix_lm_finalize_batch": (_i32, [_vp, _i64, _vp, _vp, _f64, _f64, _vp, _vp]),
     "ngmix_launch_census": (_i64, [ctypes.c_char_p, _i64, _i32]),
-    "ngmix_lm_pack_batch": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngmix_lm_pack_batch": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngmix_lm_rounds_batch": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp]),
+    "ngmix_events_create": (_i32, [_i32, _vp]),
+    "ngmix_events_destroy": (_i32, [_i32, _vp]),
+    "ngmix_event_record": (_i32, [_vp, _vp]),
+    "ngmix_event_synchronize": (_i32, [_vp]),
+    "ngmix_event_elapsed_ms": (_i32, [_vp, _vp, _vp]),
 }
 LM_NCOLS = 12
 

@@ -137,6 +137,7 @@ int64_t ngmix_abi_sizeof(const char *type_name)
     NGMIX_SIZEOF_CASE(ngmix_batch);
     NGMIX_SIZEOF_CASE(ngmix_lm_state);
     NGMIX_SIZEOF_CASE(ngmix_simple_sep_prior);
+    NGMIX_SIZEOF_CASE(ngmix_lm_problem);
 #undef NGMIX_SIZEOF_CASE
     return -1;
 }
@@ -696,10 +697,66 @@ int ngmix_lm_finalize_batch(const ngmix_lm_state *states, int64_t nobj,
 
 int ngmix_lm_pack_batch(const ngmix_lm_state *states, int64_t nobj, int npars,
                         const double *rec, const double *obj_stats, const double *tot,
-                        const int64_t *npix_obj, double *head, double *cols, void *stream)
+                        const int64_t *npix_obj, double *head, double *cols,
+                        double *cov_tri, void *stream)
 {
     return launch_lm_pack(states, nobj, npars, rec, obj_stats, tot, npix_obj, head, cols,
-                          (hipStream_t)stream);
+                          cov_tri, (hipStream_t)stream);
+}
+
+int ngmix_lm_rounds_batch(const ngmix_lm_problem *problem, int nrounds, int32_t *counts,
+                          int32_t *counts_host, void **events, void *stream)
+{
+    return launch_lm_rounds(problem, nrounds, counts, counts_host, events,
+                            (hipStream_t)stream);
+}
+
+int ngmix_events_create(int n, void **events)
+{
+    if (n < 0 || (n > 0 && !events)) return NGMIX_ERR_BAD_ARG;
+    for (int i = 0; i < n; i++) events[i] = nullptr;
+    for (int i = 0; i < n; i++) {
+        hipEvent_t e;
+        const hipError_t err = hipEventCreate(&e);
+        if (err != hipSuccess) {
+            set_last_error("hipEventCreate", err);
+            ngmix_events_destroy(i, events);
+            return NGMIX_ERR_HIP;
+        }
+        events[i] = (void *)e;
+    }
+    return NGMIX_OK;
+}
+
+int ngmix_events_destroy(int n, void **events)
+{
+    if (n < 0 || (n > 0 && !events)) return NGMIX_ERR_BAD_ARG;
+    for (int i = 0; i < n; i++) {
+        if (events[i]) (void)hipEventDestroy((hipEvent_t)events[i]);
+        events[i] = nullptr;
+    }
+    return NGMIX_OK;
+}
+
+int ngmix_event_record(void *event, void *stream)
+{
+    if (!event) return NGMIX_ERR_BAD_ARG;
+    NGMIX_HIP_CHECK(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return NGMIX_OK;
+}
+
+int ngmix_event_synchronize(void *event)
+{
+    if (!event) return NGMIX_ERR_BAD_ARG;
+    NGMIX_HIP_CHECK(hipEventSynchronize((hipEvent_t)event));
+    return NGMIX_OK;
+}
+
+int ngmix_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    if (!start || !stop || !ms) return NGMIX_ERR_BAD_ARG;
+    NGMIX_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return NGMIX_OK;
 }
 
 int64_t ngmix_launch_census(char *buf, int64_t buflen, int reset)

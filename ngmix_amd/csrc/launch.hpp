@@ -48,7 +48,9 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const ngmix_lm_state
 int launch_lm_advance(ngmix_lm_state *states, int64_t nobj, const int64_t *obj_start,
                       const int32_t *stamp_band, const double *sums, int nloc,
                       const double *obj_sums, int32_t *nactive, const double *stamp_stats,
-                      double *obj_stats, hipStream_t s);
+                      double *obj_stats, hipStream_t s, bool zero_count = true);
+int launch_lm_rounds(const ngmix_lm_problem *p, int nrounds, int32_t *counts,
+                     int32_t *counts_host, void **events, hipStream_t s);
 
 int launch_lm_prior_sums(const ngmix_lm_state *states, int64_t nobj,
                          const ngmix_simple_sep_prior *prior, double step_rel,
@@ -62,6 +64,6 @@ int launch_lm_finalize(const ngmix_lm_state *states, int64_t nobj,
 
 int launch_lm_pack(const ngmix_lm_state *states, int64_t nobj, int npars, const double *rec,
                    const double *obj_stats, const double *tot, const int64_t *npix_obj,
-                   double *head, double *cols, hipStream_t s);
+                   double *head, double *cols, double *cov_tri, hipStream_t s);
 
 }  // namespace ngmix

@@ -74,7 +74,7 @@ struct lm_state_n {
     double ftol, xtol, gtol, factor;
     double xi[NP], xti[NP], lo[NP], hi[NP], xstep[NP], hstep[NP];
     int32_t ipvt[NP];
-    int32_t n, iter, nfev, njev, info, phase, maxfev, mode, bounded, pad_;
+    int32_t n, iter, nfev, njev, info, phase, maxfev, mode, bounded, fonly;
 };
 
 // Pivoted Cholesky of A = J^T J with qrfac's pivot rule (largest remaining
@@ -367,6 +367,27 @@ NGMIX_HD void propose(State &s)
     set_trial(s);
     s.pnorm = enorm(n, wa3);
     if (s.iter == 1) s.delta = fmin(s.delta, s.pnorm);
+    s.fonly = 0;
+    if (s.mode == NGMIX_LM_MODE_ANALYTIC_LAZY) {
+        // Will accepting this trial end the fit?  lmder's predicted reduction
+        // is known before the evaluation (the same expression lm_advance forms
+        // afterwards); near the solution the actual reduction follows it, and
+        // the ftol test passes when both are <= ftol.  The xtol test compares
+        // the step bound after the update, at most pnorm / 0.5, with xnorm.
+        // If so the evaluation needs |f|^2 only -- lmder never forms the
+        // jacobian at its last point; a miss costs this fit one more round
+        // (phase JAC), never a different iterate.
+        double w3[NP];
+        for (int j = 0; j < n; j++) w3[j] = 0.0;
+        for (int j = 0; j < n; j++) {
+            const double temp = s.step[s.ipvt[j]];
+            for (int i = 0; i <= j; i++) w3[i] += s.R[i * NP + j] * temp;
+        }
+        const double temp1 = enorm(n, w3) / s.fnorm;
+        const double temp2 = (sqrt(s.par) * s.pnorm) / s.fnorm;
+        const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+        if (prered <= s.ftol || s.pnorm / 0.5 <= s.xtol * s.xnorm) s.fonly = 1;
+    }
 }
 
 // the outer-loop head of lmder at the point whose normal equations are
@@ -420,7 +441,7 @@ NGMIX_HD void lm_init(lm_state &s, int n, const double *x0, double ftol, double 
     s.n = n;
     s.mode = mode;
     s.bounded = 0;
-    s.pad_ = 0;
+    s.fonly = 0;
     for (int j = 0; j < LM_NPMAX; j++) {
         s.lo[j] = (lo && j < n) ? lo[j] : -INFINITY;
         s.hi[j] = (hi && j < n) ? hi[j] : INFINITY;
@@ -465,7 +486,7 @@ NGMIX_HD void lm_advance(State &s, double ff, const double *g_in, const double *
     // (forward differences are taken in the internal parameters already)
     double gs[NP], As[NP * NP];
     const double *g = g_in, *A = A_in;
-    if (s.bounded && s.mode == NGMIX_LM_MODE_ANALYTIC) {
+    if (s.bounded && s.mode != NGMIX_LM_MODE_FD) {
         double sc[NP];
         for (int j = 0; j < n; j++) sc[j] = i2e_grad(s.xti[j], s.lo[j], s.hi[j]);
         for (int j = 0; j < n; j++) {
@@ -478,8 +499,10 @@ NGMIX_HD void lm_advance(State &s, double ff, const double *g_in, const double *
     }
     if (s.phase == LM_PHASE_JAC) {
         // lmdif: the forward-difference jacobian at the accepted point cost
-        // n evaluations (fdjac2); then the outer-loop head
-        s.nfev += n;
+        // n evaluations (fdjac2); then the outer-loop head.  (Mode
+        // ANALYTIC_LAZY: the analytic jacobian asked for after an |f|^2-only
+        // trial -- lmder's own call with iflag = 2, counted by njev alone.)
+        if (s.mode == NGMIX_LM_MODE_FD) s.nfev += n;
         s.phase = LM_PHASE_TRIAL;
         new_jacobian<NP>(s, A, g);
         return;
@@ -572,11 +595,12 @@ NGMIX_HD void lm_advance(State &s, double ff, const double *g_in, const double *
     }
     if (!accepted) {
         propose<NP>(s);  // same factor, smaller region
-    } else if (s.mode == NGMIX_LM_MODE_FD) {
+    } else if (s.mode == NGMIX_LM_MODE_FD || s.fonly) {
         // ask for the jacobian at the new point
         for (int j = 0; j < n; j++) s.xti[j] = s.xi[j];
         set_trial(s);
         s.phase = LM_PHASE_JAC;
+        s.fonly = 0;
     } else {
         new_jacobian<NP>(s, A, g);  // the trial point's jacobian is the new one
     }

@@ -37,7 +37,7 @@ struct lm_state_n {
     double *x, *xstep, *hstep;   // into the record
     const double *lo, *hi;       // into the record
     int32_t ipvt[N];
-    int32_t n, iter, nfev, njev, info, phase, maxfev, mode, bounded;
+    int32_t n, iter, nfev, njev, info, phase, maxfev, mode, bounded, fonly;
 };
 
 #define LMREG_UNROLL _Pragma("unroll")
@@ -374,6 +374,23 @@ NGMIX_HD void propose(lm_state_n<N> &s)
     set_trial<N>(s);
     s.pnorm = enorm<N>(wa3);
     if (s.iter == 1) s.delta = fmin(s.delta, s.pnorm);
+    s.fonly = 0;
+    if (s.mode == NGMIX_LM_MODE_ANALYTIC_LAZY) {
+        // (lmcore::propose: will accepting this trial end the fit?)
+        double w3[N];
+        LMREG_UNROLL
+        for (int j = 0; j < N; j++) w3[j] = 0.0;
+        LMREG_UNROLL
+        for (int j = 0; j < N; j++) {
+            const double temp = dget<N>(s.step, s.ipvt[j]);
+            LMREG_UNROLL
+            for (int i = 0; i <= j; i++) w3[i] += s.R[i * N + j] * temp;
+        }
+        const double temp1 = enorm<N>(w3) / s.fnorm;
+        const double temp2 = (sqrt(s.par) * s.pnorm) / s.fnorm;
+        const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+        if (prered <= s.ftol || s.pnorm / 0.5 <= s.xtol * s.xnorm) s.fonly = 1;
+    }
 }
 
 // lmcore::new_jacobian
@@ -426,7 +443,7 @@ NGMIX_HD void lm_advance(lm_state_n<N> &s, double ff, const double (&g_in)[N],
 {
     if (s.phase == LM_PHASE_DONE) return;
     double g[N], A[N * N];
-    if (s.bounded && s.mode == NGMIX_LM_MODE_ANALYTIC) {
+    if (s.bounded && s.mode != NGMIX_LM_MODE_FD) {
         double sc[N];
         LMREG_UNROLL
         for (int j = 0; j < N; j++) sc[j] = lmcore::i2e_grad(s.xti[j], s.lo[j], s.hi[j]);
@@ -448,7 +465,7 @@ NGMIX_HD void lm_advance(lm_state_n<N> &s, double ff, const double (&g_in)[N],
     // four copies of lmpar / qrsolv that no instruction cache holds.
     bool want_jacobian = false, want_proposal = false;
     if (s.phase == LM_PHASE_JAC) {
-        s.nfev += N;
+        if (s.mode == NGMIX_LM_MODE_FD) s.nfev += N;
         s.phase = LM_PHASE_TRIAL;
         want_jacobian = true;
     } else if (s.phase == LM_PHASE_INIT) {
@@ -530,11 +547,12 @@ NGMIX_HD void lm_advance(lm_state_n<N> &s, double ff, const double (&g_in)[N],
     }
     if (!accepted) {
         want_proposal = true;   // same factor, smaller region
-    } else if (s.mode == NGMIX_LM_MODE_FD) {
+    } else if (s.mode == NGMIX_LM_MODE_FD || s.fonly) {
         LMREG_UNROLL
         for (int j = 0; j < N; j++) s.xti[j] = s.xi[j];
         set_trial<N>(s);
         s.phase = LM_PHASE_JAC;
+        s.fonly = 0;
     } else {
         want_jacobian = true;   // the trial point's jacobian is the new one
     }
@@ -556,6 +574,7 @@ NGMIX_HD void load_state(lm_state_n<N> &d, lm_state &g)
     d.maxfev = g.maxfev;
     d.mode = g.mode;
     d.bounded = g.bounded;
+    d.fonly = g.fonly;
     d.fnorm = g.fnorm;
     d.xnorm = g.xnorm;
     d.delta = g.delta;
@@ -594,6 +613,7 @@ NGMIX_HD void store_state(lm_state &d, const lm_state_n<N> &g)
     d.njev = g.njev;
     d.info = g.info;
     d.phase = g.phase;
+    d.fonly = g.fonly;
     d.fnorm = g.fnorm;
     d.xnorm = g.xnorm;
     d.delta = g.delta;

@@ -343,14 +343,20 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
         lane_valid = k_l < CH;
         mybox = dg[lane - k_l * G].box;
     }
+    // mode ANALYTIC_LAZY: a trial whose acceptance is predicted to end the fit
+    // asks for |f|^2 alone (ngmix_hip.h): the same per-pixel model value -- the
+    // same expressions in the same order, so f is what the full pass computes,
+    // to the bit -- without the five derivative images and their 25 sums
+    const bool fonly = __builtin_amdgcn_readfirstlane(state.fonly) != 0;
+
+    auto pixel_pass = [&](auto jac_tag) {
+    constexpr bool JAC = decltype(jac_tag)::value;
     unsigned long long allmask = 0ull;
     int kc = 0;
 
-    double nval, nierr;
-    load_tile(0, nval, nierr);
-    for (int Tc = 0; Tc < ntiles; Tc++) {
-        const double pval = nval, pierr = nierr;
-        load_tile(Tc + 1, nval, nierr);
+    // one tile: every surviving gaussian at its 64 pixels, then the pixels'
+    // terms of the sums
+    auto tile_body = [&](int Tc, double pval, double pierr) {
         const LmTile tc = tile(Tc);
         const double v = tc.bv + olv, u = tc.bu + olu;
         double o0 = 0.0, o1 = 0.0, o2 = 0.0, n11 = 0.0, n12 = 0.0, n22 = 0.0;
@@ -400,20 +406,24 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
                         const double au = (25.0 - chi2) * 0.2;
                         const double aq = fma(au, fma(au, K.w6, K.wm15), K.w10);
                         const double w = (au * au) * (au * aq);
-                        const double umu = au * (1.0 - au);
-                        // -2 W' = 60 * 0.2 * umu^2
-                        ec = e * fma(12.0 * umu, umu, w);
+                        if (JAC) {
+                            const double umu = au * (1.0 - au);
+                            // -2 W' = 60 * 0.2 * umu^2
+                            ec = e * fma(12.0 * umu, umu, w);
+                        }
                         e *= w;
                     }
-                    const double tk = D.tk;
                     o0 += e;
-                    o1 = fma(ec, qv, o1);
-                    o2 = fma(ec, qu, o2);
-                    const double t = tk * ec, mte = -(tk * e);
-                    const double tqv = t * qv, tqu = t * qu;
-                    n11 = fma(tqv, qv, fma(mte, w11, n11));
-                    n12 = fma(tqv, qu, fma(mte, w12, n12));
-                    n22 = fma(tqu, qu, fma(mte, w22, n22));
+                    if (JAC) {
+                        const double tk = D.tk;
+                        o1 = fma(ec, qv, o1);
+                        o2 = fma(ec, qu, o2);
+                        const double t = tk * ec, mte = -(tk * e);
+                        const double tqv = t * qv, tqu = t * qu;
+                        n11 = fma(tqv, qv, fma(mte, w11, n11));
+                        n12 = fma(tqv, qu, fma(mte, w12, n12));
+                        n22 = fma(tqu, qu, fma(mte, w22, n22));
+                    }
                 }
             }
         }
@@ -426,7 +436,17 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
         // same 28 fused accumulates, without the nine instructions per pixel
         // of the map -- and mapped once per stamp after the reduction:
         // J^T J = H (sum B B^T) H^T, J^T f = H (sum B f).
-        if (!masked || pierr > 0.0) {
+        if (!JAC) {
+            // B5 = model * ierr and f: the three sums the step and the
+            // statistics read, accumulated as the full pass accumulates them
+            if (!masked || pierr > 0.0) {
+                const double f = (o0 - pval) * pierr;
+                const double b5 = o0 * pierr;
+                acc[20] = fma(b5, b5, acc[20]);
+                acc[26] = fma(b5, f, acc[26]);
+                acc[27] = fma(f, f, acc[27]);
+            }
+        } else if (!masked || pierr > 0.0) {
             const double f = (o0 - pval) * pierr;
             double B[6];
             if (RAW) {
@@ -458,7 +478,58 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
             for (int a = 0; a < 6; a++) acc[21 + a] = fma(B[a], f, acc[21 + a]);
             acc[27] = fma(f, f, acc[27]);
         }
+    };
+    if (JAC) {
+        // the full pass: a tile is ~165 instructions, four waves share the SIMD
+        // -- the next tile's pixels asked for at the top of this one are there
+        // when it ends
+        double nval, nierr;
+        load_tile(0, nval, nierr);
+        for (int Tc = 0; Tc < ntiles; Tc++) {
+            const double pval = nval, pierr = nierr;
+            load_tile(Tc + 1, nval, nierr);
+            tile_body(Tc, pval, pierr);
+        }
+    } else {
+        // the |f|^2-only pass: a tile is ~75 instructions, too short to cover a
+        // trip to HBM -- the pixels are asked for a GROUP of four tiles ahead,
+        // by loads no branch goes around (a branch around a load makes the
+        // compiler drain every outstanding load there): a lane outside the
+        // stamp, or a tile past the last, reads the stamp's first pixel and
+        // ignores it
+        constexpr int PF = 4;
+        double nv[PF], ne[PF];
+        auto load_group = [&](int T0) {
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                int Tn = T0 + k;
+                if (Tn > ntiles) Tn = ntiles;       // the sentinel: out of bounds
+                const LmTile e = tile(Tn);
+                const bool inb = (e.r0 < rlim) & (e.c0 < clim);
+                const unsigned off = inb ? lane_off + (unsigned)e.off : 0u;
+                const double a = *(const double *)(bval + off);
+                const double b = *(const double *)(bierr + off);
+                nv[k] = inb ? a : 0.0;
+                ne[k] = inb ? b : 0.0;
+            }
+        };
+        load_group(0);
+        for (int Tg = 0; Tg < ntiles; Tg += PF) {
+            double cv[PF], ce[PF];
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                cv[k] = nv[k];
+                ce[k] = ne[k];
+            }
+            load_group(Tg + PF);
+#pragma unroll
+            for (int k = 0; k < PF; k++)
+                if (Tg + k < ntiles) tile_body(Tg + k, cv[k], ce[k]);
+        }
     }
+    };
+    if (RAW && fonly) pixel_pass(std::false_type{});
+    else pixel_pass(std::true_type{});
 
     // ---- 28 sums over the wave.  v_permlane16_swap / v_permlane32_swap trade
     // rows of 16 / 32 lanes between two registers, so one add folds the rows of
@@ -468,6 +539,9 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
     static_assert(LM_NSUM % 4 == 0, "four sums per register");
 #pragma unroll
     for (int r = 0; r < LM_NSUM / 4; r++) {
+        // (an |f|^2-only pass has sums 20, 26 and 27: the last two registers,
+        // folded exactly as the full pass folds them)
+        if (RAW && fonly && r < 5) continue;
         const double ab = swap_add16(acc[4 * r + 0], acc[4 * r + 1]);
         const double cd = swap_add16(acc[4 * r + 2], acc[4 * r + 3]);
         const double t = row16_sum(swap_add32(ab, cd));
@@ -478,6 +552,20 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
     }
     if (!RAW) {
         if (lane == 0 && status) status[s] = NGMIX_OK;
+        return;
+    }
+    if (fonly) {
+        // |f|^2 and the statistics; the other sums of this stamp are not read
+        // (lm_advance: a trial that carries fonly uses ff alone)
+        __syncthreads();
+        if (lane == 0) {
+            out[LM_NSUM - 1] = sh.raw[27];
+            if (stamp_stats) {
+                stamp_stats[2 * (size_t)s] = sh.raw[20] - sh.raw[26];
+                stamp_stats[2 * (size_t)s + 1] = sh.raw[20];
+            }
+            if (status) status[s] = NGMIX_OK;
+        }
         return;
     }
     // ---- raw basis -> parameters.  Row a of H has at most three terms,
@@ -571,7 +659,7 @@ __device__ __forceinline__ void lm_state_copy_live(D &d, const S &g)
     d.maxfev = g.maxfev;
     d.mode = g.mode;
     d.bounded = g.bounded;
-    d.pad_ = g.pad_;
+    d.fonly = g.fonly;
     d.fnorm = g.fnorm;
     d.xnorm = g.xnorm;
     d.delta = g.delta;
@@ -1413,12 +1501,22 @@ __global__ __launch_bounds__(256) void lm_pack_kernel(
     const lm_state *__restrict__ states, int64_t nobj, int n, const double *__restrict__ rec,
     const double *__restrict__ obj_stats, const double *__restrict__ tot,
     const int64_t *__restrict__ npix_obj, double *__restrict__ head,
-    double *__restrict__ cols)
+    double *__restrict__ cols, double *__restrict__ cov_tri)
 {
     const int64_t o = blockIdx.x * (int64_t)256 + threadIdx.x;
     if (o >= nobj) return;
     const double *r = rec + o * (4 + 2 * (int64_t)n + 2 * (int64_t)n * n);
     for (int k = 0; k < 2 * n; k++) head[o * 2 * n + k] = r[4 + k];
+    if (cov_tri) {
+        // pars_cov is symmetric to the bit (lm_finalize_one forms (a, b) and
+        // (b, a) from the same products in the same order): its upper triangle
+        // is all the host needs -- 21 instead of 36 doubles per six-parameter fit
+        const double *cov = r + 4 + 2 * (int64_t)n + (int64_t)n * n;
+        double *t = cov_tri + o * (int64_t)(n * (n + 1) / 2);
+        int k = 0;
+        for (int a = 0; a < n; a++)
+            for (int b = a; b < n; b++) t[k++] = cov[a * n + b];
+    }
     const bool ok = r[0] == 0.0;
     double lnprob, numer, denom, npix;
     if (obj_stats) {
@@ -1453,7 +1551,7 @@ __global__ __launch_bounds__(256) void lm_pack_kernel(
 
 int launch_lm_pack(const lm_state *states, int64_t nobj, int npars, const double *rec,
                    const double *obj_stats, const double *tot, const int64_t *npix_obj,
-                   double *head, double *cols, hipStream_t s)
+                   double *head, double *cols, double *cov_tri, hipStream_t s)
 {
     if (nobj <= 0) return NGMIX_OK;
     if (!states || !rec || !head || !cols || npars < 1 || npars > LM_NPMAX ||
@@ -1462,7 +1560,7 @@ int launch_lm_pack(const lm_state *states, int64_t nobj, int npars, const double
         return NGMIX_ERR_BAD_ARG;
     }
     hipLaunchKernelGGL(lm_pack_kernel, dim3((unsigned)((nobj + 255) / 256)), dim3(256), 0, s,
-                       states, nobj, npars, rec, obj_stats, tot, npix_obj, head, cols);
+                       states, nobj, npars, rec, obj_stats, tot, npix_obj, head, cols, cov_tri);
     NGMIX_HIP_CHECK(hipGetLastError());
     return NGMIX_OK;
 }
@@ -1588,7 +1686,7 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *stat
 int launch_lm_advance(lm_state *states, int64_t nobj, const int64_t *obj_start,
                       const int32_t *stamp_band, const double *sums, int nloc,
                       const double *obj_sums, int32_t *nactive, const double *stamp_stats,
-                      double *obj_stats, hipStream_t s)
+                      double *obj_stats, hipStream_t s, bool zero_count)
 {
     if (nobj <= 0) return NGMIX_OK;
     // nloc + 256 * npars: the fits' parameter count, if the caller says
@@ -1596,7 +1694,14 @@ int launch_lm_advance(lm_state *states, int64_t nobj, const int64_t *obj_start,
     nloc &= 0xff;
     if (nloc < 2 || nloc > LM_NPMAX || npars > LM_NPMAX) return NGMIX_ERR_BAD_ARG;
     if (npars != 0 && npars < nloc) return NGMIX_ERR_BAD_ARG;
-    if (nactive) NGMIX_HIP_CHECK(hipMemsetAsync(nactive, 0, sizeof(int32_t), s));
+    if ((stamp_stats == nullptr) != (obj_stats == nullptr)) {
+        // "both or neither" (ngmix_hip.h): with one of them the kernel would skip
+        // the statistics silently and lm_pack would package an unwritten buffer
+        set_last_error_msg("lm_advance: stamp_stats and obj_stats go together");
+        return NGMIX_ERR_BAD_ARG;
+    }
+    if (nactive && zero_count)
+        NGMIX_HIP_CHECK(hipMemsetAsync(nactive, 0, sizeof(int32_t), s));
     const dim3 grid((unsigned)((nobj + WAVE - 1) / WAVE)), block(WAVE);
     static const bool generic = getenv("NGMIX_LM_GENERIC") != nullptr;   // A/B knob
     {
@@ -1632,6 +1737,52 @@ int launch_lm_advance(lm_state *states, int64_t nobj, const int64_t *obj_start,
                            nobj, obj_start, stamp_band, sums, nloc, obj_sums, nactive,
                            stamp_stats, obj_stats);
     NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
+}
+
+// nrounds x {pixel pass, prior rows, lmder step} queued by one host call
+// (ngmix_lm_rounds_batch): the host is not in the lock-step loop.  A finished
+// fit is skipped by every later launch (its phase is read on the device), so
+// the caller may queue rounds blind.
+int launch_lm_rounds(const ngmix_lm_problem *p, int nrounds, int32_t *counts,
+                     int32_t *counts_host, void **events, hipStream_t s)
+{
+    if (!p || !p->batch || !p->states || !p->sums || nrounds < 0) {
+        set_last_error_msg("lm_rounds: problem, batch, states and sums are required");
+        return NGMIX_ERR_BAD_ARG;
+    }
+    if (counts_host && !counts) {
+        set_last_error_msg("lm_rounds: counts_host needs counts");
+        return NGMIX_ERR_BAD_ARG;
+    }
+    if (p->prior && !p->obj_sums) {
+        set_last_error_msg("lm_rounds: a prior needs obj_sums");
+        return NGMIX_ERR_BAD_ARG;
+    }
+    if (nrounds == 0 || p->nobj <= 0) return NGMIX_OK;
+    if (counts)
+        NGMIX_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)nrounds * sizeof(int32_t), s));
+    for (int r = 0; r < nrounds; r++) {
+        if (events) NGMIX_HIP_CHECK(hipEventRecord((hipEvent_t)events[3 * r], s));
+        int rc = launch_lm_eval(p->batch, p->model, p->fd, p->states, p->stamp_obj,
+                                p->stamp_band, p->psf, p->npsf, p->sums, p->status,
+                                p->stamp_stats, s);
+        if (rc != NGMIX_OK) return rc;
+        if (events) NGMIX_HIP_CHECK(hipEventRecord((hipEvent_t)events[3 * r + 1], s));
+        if (p->prior) {
+            rc = launch_lm_prior_sums(p->states, p->nobj, p->prior, p->prior_step,
+                                      p->obj_sums, s);
+            if (rc != NGMIX_OK) return rc;
+        }
+        rc = launch_lm_advance(p->states, p->nobj, p->obj_start, p->stamp_band, p->sums,
+                               p->nloc_npars, p->obj_sums, counts ? counts + r : nullptr,
+                               p->stamp_stats, p->obj_stats, s, false);
+        if (rc != NGMIX_OK) return rc;
+        if (events) NGMIX_HIP_CHECK(hipEventRecord((hipEvent_t)events[3 * r + 2], s));
+    }
+    if (counts_host)
+        NGMIX_HIP_CHECK(hipMemcpyAsync(counts_host, counts, (size_t)nrounds * sizeof(int32_t),
+                                       hipMemcpyDeviceToHost, s));
     return NGMIX_OK;
 }
 

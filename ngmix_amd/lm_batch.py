@@ -137,6 +137,61 @@ class LMBatchResult(dict):
         return (LMBatchResult, (dict(self.items()),))
 
 
+class _Job(object):
+    """one batch on its way through LMBatchFitter (device arrays, events)"""
+
+
+class _HipEvents(object):
+    """n hipEvent_t of the library (ngmix_events_create), destroyed with the
+    object"""
+
+    def __init__(self, n):
+        self.n = n
+        self.handles = (ctypes.c_void_p * n)()
+        _lib.check(_lib.lib().ngmix_events_create(n, self.handles), "ngmix_events_create")
+
+    def record(self, i):
+        _lib.check(_lib.lib().ngmix_event_record(self.handles[i], _stream()),
+                   "ngmix_event_record")
+
+    def elapsed_ms(self, i, j):
+        ms = ctypes.c_float()
+        _lib.check(_lib.lib().ngmix_event_elapsed_ms(self.handles[i], self.handles[j],
+                                                      ctypes.byref(ms)),
+                   "ngmix_event_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            _lib.lib().ngmix_events_destroy(self.n, self.handles)
+        except Exception:
+            pass
+
+
+class _EventPool(object):
+    """timing events handed out as ctypes arrays and taken back (bench.py's
+    time_kernels mode records ~25 events per fit: no create / destroy per fit)"""
+
+    def __init__(self):
+        self.free = []
+        self.owned = []
+
+    def take(self, n):
+        arr = (ctypes.c_void_p * n)()
+        need = n - min(n, len(self.free))
+        if need:
+            fresh = _HipEvents(need)
+            self.owned.append(fresh)
+            self.free.extend(fresh.handles[i] for i in range(need))
+        for i in range(n):
+            arr[i] = self.free.pop()
+        return arr
+
+    def give(self, arr):
+        if arr is not None:
+            self.free.extend(arr[i] for i in range(len(arr)))
+
+
 class LMBatchFitter(object):
     """
     fitter = LMBatchFitter(model='exp')
@@ -178,91 +233,8 @@ class LMBatchFitter(object):
 
     def go(self, stamps, guess, psf=None, stamp_obj=None, stamp_band=None,
            check_every=1):
-        """one batch, start to finish (see _go_stages for the arguments)"""
-        gen = self._go_stages(stamps, guess, psf, stamp_obj, stamp_band, check_every, False)
-        try:
-            while True:
-                next(gen)
-        except StopIteration as done:
-            return done.value
-
-    def go_stream(self, batches, check_every=1):
         """
-        Fit a SEQUENCE of batches as a software pipeline: a generator of result
-        dicts, one per batch, in order.  batches: an iterable of (stamps,
-        guess, kwargs) with kwargs the keyword arguments of go() (psf=...,
-        stamp_obj=..., stamp_band=...).
-
-        While batch i's results are finalised, packed, downloaded and turned
-        into arrays, batch i + 1 -- set up while batch i was still iterating --
-        already has its first rounds queued, so the GPU does not idle between
-        batches.  That matters twice: the host phases of a call (1.3 of 7.9 ms
-        on 100k fits) disappear behind kernels, and the GPU stays in the clock
-        state it only reaches under uninterrupted load (the same lm_eval
-        launch takes 1.30 ms then, 1.42-1.45 ms when the GPU idles a
-        millisecond between launches: tools/lm_eval_warm.py).  Every result is
-        what go() returns for that batch, bit for bit.
-        """
-        it = iter(batches)
-
-        def start(item):
-            stamps, guess, kw = item
-            gen = self._go_stages(stamps, guess, kw.get("psf"), kw.get("stamp_obj"),
-                                  kw.get("stamp_band"), check_every, True)
-            assert next(gen) == "ready"
-            return gen
-
-        def advance(gen, until, limit=None):
-            """run gen to its next `until` stage (at most `limit` stages);
-            returns (stage or None when it finished, result)"""
-            n = 0
-            try:
-                while True:
-                    stage = next(gen)
-                    n += 1
-                    if stage == until or (limit is not None and n >= limit):
-                        return stage, None
-            except StopIteration as done:
-                return None, done.value
-
-        try:
-            cur = start(next(it))
-        except StopIteration:
-            return
-        nxt, exhausted = None, False
-        while cur is not None:
-            # the first round of the current batch is on its way: set the next
-            # batch up behind it (its init kernels queue behind that round)
-            stage, res = advance(cur, "round", limit=1)
-            if stage is not None and nxt is None and not exhausted:
-                try:
-                    nxt = start(next(it))
-                except StopIteration:
-                    exhausted = True
-            if stage is not None:
-                stage, res = advance(cur, "copies")
-            if stage is not None:
-                # finalize / pack / downloads are queued: give the GPU the next
-                # batch's first two rounds before turning to the host work
-                if nxt is not None:
-                    advance(nxt, None, limit=2)
-                stage, res = advance(cur, None)
-            yield res
-            cur, nxt = nxt, None
-            if cur is None and not exhausted:
-                try:
-                    cur = start(next(it))
-                except StopIteration:
-                    cur = None
-
-    def _go_stages(self, stamps, guess, psf, stamp_obj, stamp_band, check_every,
-                   streaming):
-        """
-        go() as a generator of stages ("ready" after the set-up, "round" after
-        every round of launches, "copies" once the downloads are queued; the
-        result is the generator's return value), so that go_stream() can
-        interleave two batches.  streaming: no device-wide synchronisation
-        around the loop (loop_seconds is then host time).
+        one batch, start to finish
 
         stamps: StampBatch -- every observation (epoch / band) of every object
         guess: (nobj, nshape + nband) starting parameters: the model's shape
@@ -273,27 +245,72 @@ class LMBatchFitter(object):
         stamp_obj: (nstamps,) object index of each stamp, non-decreasing;
             None: stamp i is object i
         stamp_band: (nstamps,) band of each stamp; None: band 0
+        check_every: (host-driven loop only) read the count of running fits
+            every so many rounds
 
         returns a dict of arrays indexed by object
         """
+        job = self._enqueue(stamps, guess, psf, stamp_obj, stamp_band, check_every, False)
+        return self._collect(job)
+
+    def go_stream(self, batches, check_every=1):
+        """
+        Fit a SEQUENCE of batches as a software pipeline: a generator of result
+        dicts, one per batch, in order.  batches: an iterable of (stamps,
+        guess, kwargs) with kwargs the keyword arguments of go() (psf=...,
+        stamp_obj=..., stamp_band=...).
+
+        Everything a batch needs on the device -- set-up, the lock-step rounds,
+        finalize, pack, the downloads -- is queued without the host waiting for
+        anything (_enqueue), and batch i + 1 is queued before the host turns to
+        batch i's arrays: the GPU always has a whole batch of work in front of
+        it, whatever the host's pace.  That matters twice: the host phases of a
+        call disappear behind kernels, and the GPU stays in the clock state it
+        only reaches under uninterrupted load (the same lm_eval launch takes
+        1.30 ms then, 1.42-1.45 ms when the GPU idles a millisecond between
+        launches: tools/lm_eval_warm.py).  Every result is what go() returns
+        for that batch, bit for bit.
+        """
+        prev = None
+        for stamps, guess, kw in batches:
+            job = self._enqueue(stamps, guess, kw.get("psf"), kw.get("stamp_obj"),
+                                kw.get("stamp_band"), check_every, True)
+            if prev is not None:
+                yield self._collect(prev)
+            prev = job
+        if prev is not None:
+            yield self._collect(prev)
+
+    # ------------------------------------------------------------------
+    # the two halves of a fit: everything the device needs, queued; then the
+    # host's half
+    # ------------------------------------------------------------------
+
+    def _mark(self, job, name):
+        # fitter.time_phases = True: wall-clock per phase of this call, each
+        # phase closed by a device synchronisation (a diagnostic: it removes
+        # the overlap between phases); "nosync": host time only
+        import time
+        if job.phases is None:
+            return
+        if self.time_phases != "nosync":
+            _torch().cuda.synchronize(job.dev)
+        now = time.perf_counter()
+        job.phases[name] = job.phases.get(name, 0.0) + (now - job.tmark) * 1e3
+        job.tmark = now
+
+    def _enqueue(self, stamps, guess, psf, stamp_obj, stamp_band, check_every, streaming):
+        """set a batch up and queue its whole fit on the current stream; returns
+        the job _collect() turns into the result dict"""
+        import time
         torch = _torch()
         L = _lib.lib()
         dev = stamps.device
-        # fitter.time_phases = True: wall-clock per phase of this call, each
-        # phase closed by a device synchronisation (a diagnostic: it removes
-        # the overlap between phases)
-        import time as _time
-        phases = {} if getattr(self, "time_phases", False) else None
-        tmark = [_time.perf_counter()]
-
-        def mark(name):
-            if phases is not None:
-                if self.time_phases != "nosync":
-                    torch.cuda.synchronize(dev)
-                now = _time.perf_counter()
-                phases[name] = phases.get(name, 0.0) + (now - tmark[0]) * 1e3
-                tmark[0] = now
-        self.phase_ms = phases
+        job = _Job()
+        job.dev = dev
+        job.phases = {} if getattr(self, "time_phases", False) else None
+        job.tmark = time.perf_counter()
+        self.phase_ms = job.phases
         guess = np.ascontiguousarray(np.atleast_2d(guess), dtype="f8")
         nobj, npars = guess.shape
         nshape = self.nloc - 1
@@ -337,23 +354,27 @@ class LMBatchFitter(object):
         # leastsq's convention: maxfev = 0 (or absent) means 100 (n + 1) function
         # calls with an analytic jacobian, 200 (n + 1) in forward-difference mode
         maxfev = int(fp.get("maxfev", 0)) or (200 if self.fd else 100) * (npars + 1)
+        ev_init = self._timing_events(2)
         d_states = torch.empty((nobj, _lib.LM_STATE_DTYPE.itemsize), dtype=torch.uint8,
                                device=dev)
         d_guess = torch.from_numpy(guess).to(dev)
         with torch.cuda.device(dev):
+            self._record(ev_init, 0)
             _lib.check(L.ngmix_lm_init_batch(
                 _dptr(d_states), nobj, npars, _dptr(d_guess),
                 float(fp.get("ftol", 1.49012e-8)), float(fp.get("xtol", 1.49012e-8)),
                 float(fp.get("gtol", 0.0)), maxfev, float(fp.get("factor", 100.0)),
-                _lib.LM_MODE_FD if self.fd else _lib.LM_MODE_ANALYTIC,
+                self._lm_mode(),
                 _lib.ptr(lo) if lo is not None else None,
                 _lib.ptr(hi) if hi is not None else None, _stream()),
                 "ngmix_lm_init_batch")
+            self._record(ev_init, 1)
+        nsplit = self._nsplit_wanted()
         d_sobj = d_sband = d_start = None
         if trivial_map:
             # stamp i is object i in band 0: the kernels take NULL for the three
             # maps (as pieces on several streams they need the absolute indices)
-            if self._nsplit_wanted() > 1:
+            if nsplit > 1:
                 d_sobj = torch.arange(ns, dtype=torch.int32, device=dev)
                 d_sband = torch.zeros(ns, dtype=torch.int32, device=dev)
                 d_start = torch.arange(nobj + 1, dtype=torch.int64, device=dev)
@@ -365,7 +386,6 @@ class LMBatchFitter(object):
         # (every row is written by the first round's launch)
         d_sums = torch.empty((ns, nsum), dtype=torch.float64, device=dev)
         d_status = torch.empty(ns, dtype=torch.int32, device=dev)
-        d_nact = torch.zeros(1, dtype=torch.int32, device=dev)
         # the loglike statistics of set_fit_result ride with the analytic
         # kernel's sums (lnprob = -fnorm^2 / 2 has no prior term to add)
         loop_stats = not self.fd and self.prior is None and \
@@ -375,19 +395,11 @@ class LMBatchFitter(object):
         if loop_stats:
             d_sstats = torch.empty((ns, 2), dtype=torch.float64, device=dev)
             d_ostats = torch.zeros((nobj, 2), dtype=torch.float64, device=dev)
-        b = stamps._batch(1)
         modnum = get_model_num(self.model)
         if self.ngauss is not None:
             modnum += 256 * self.ngauss   # the count rides with the model id
             if nband != 1:
                 raise ValueError("coellip fits one band: guess needs %d columns" % self.nloc)
-        # float64 view of the state records: the columns a prior needs
-        fields = _lib.LM_STATE_DTYPE.fields
-        sview = d_states.view(torch.float64)
-
-        def col(name):
-            a = fields[name][1] // 8
-            return sview[:, a:a + npars]
         d_osums = None
         prior_desc = None
         if self.prior is not None and self.device_prior and \
@@ -401,15 +413,248 @@ class LMBatchFitter(object):
                                   dtype=torch.float64, device=dev)
         self.prior_path = ("kernel" if prior_desc is not None else
                            "torch" if self.prior is not None else None)
+        if self.prior is not None and prior_desc is None:
+            nsplit = 1
+        nsplit = max(1, min(int(nsplit), nobj))
+
+        job.__dict__.update(
+            stamps=stamps, psf=psf, nobj=nobj, npars=npars, nband=nband, ns=ns, npsf=npsf,
+            sobj=sobj, sband=sband, obj_start=obj_start, trivial_map=trivial_map,
+            maxfev=maxfev, d_states=d_states, d_guess=d_guess, d_sobj=d_sobj,
+            d_sband=d_sband, d_start=d_start, d_sums=d_sums, d_status=d_status,
+            d_sstats=d_sstats, d_ostats=d_ostats, d_osums=d_osums, modnum=modnum,
+            prior_desc=prior_desc, loop_stats=loop_stats, nsplit=nsplit, nsum=nsum,
+            streaming=streaming, check_every=check_every, ev_init=ev_init,
+            batch=stamps._batch(1), chunks=[], useful_rounds=None, ev_post=None,
+            legacy_ev=None, loop_ms_host=0.0)
+        # the host-free loop serves one piece with no prior or the kernel prior;
+        # a torch-evaluated prior sits between the two launches of a round and
+        # pieces on several streams are interleaved by the host: the host-driven
+        # loop (NGMIX_LM_HOST_LOOP selects it for A/B)
+        job.host_loop = (nsplit > 1 or (self.prior is not None and prior_desc is None)
+                         or bool(os.environ.get("NGMIX_LM_HOST_LOOP"))
+                         or bool(getattr(self, "host_loop", False)))
+        self._mark(job, "setup")
+        if job.host_loop:
+            self._rounds_host_loop(job)
+            self._queue_results(job)
+            return job
+        # ---- the whole fit, queued blind: R rounds sized by the last batch's
+        # count, then finalize / pack / downloads.  _collect() finds out
+        # whether R was enough (the rare miss: more rounds, results re-made).
+        hint = getattr(self, "_rounds_hint", None)
+        first = 4 if hint is None else max(1, min(int(hint), 16))
+        self._queue_rounds(job, first)
+        self._mark(job, "loop")
+        self._queue_results(job)
+        return job
+
+    def _lm_mode(self):
+        """ngmix_lm_state.mode of this fitter's fits: lmdif, or lmder with the
+        jacobian left out of the trials that are predicted to end the fit
+        (fitter.lazy_jacobian = False or NGMIX_LM_EAGER_JAC: the jacobian with
+        every evaluation; the iterates are the same to the bit either way)"""
+        if self.fd:
+            return _lib.LM_MODE_FD
+        lazy = getattr(self, "lazy_jacobian", True) and \
+            not os.environ.get("NGMIX_LM_EAGER_JAC") and \
+            not os.environ.get("NGMIX_LM_JBASIS")
+        return _lib.LM_MODE_ANALYTIC_LAZY if lazy else _lib.LM_MODE_ANALYTIC
+
+    def _problem(self, job):
+        """the ngmix_lm_problem record of a job (kept alive with it)"""
+        P = _lib.LMProblem()
+        P.batch = ctypes.pointer(job.batch)
+        P.states = job.d_states.data_ptr()
+        P.nobj = job.nobj
+        opt = lambda t: t.data_ptr() if t is not None else None
+        P.stamp_obj = opt(job.d_sobj)
+        P.stamp_band = opt(job.d_sband)
+        P.obj_start = opt(job.d_start)
+        P.psf = job.psf.data.data_ptr() if job.psf is not None else None
+        P.sums = job.d_sums.data_ptr()
+        P.status = job.d_status.data_ptr()
+        P.stamp_stats = opt(job.d_sstats)
+        P.obj_stats = opt(job.d_ostats)
+        if job.prior_desc is not None:
+            P.prior = job.prior_desc.ctypes.data
+            P.obj_sums = job.d_osums.data_ptr()
+        P.prior_step = STEP_PRIOR
+        P.model = job.modnum
+        P.fd = int(self.fd)
+        P.npsf = job.npsf
+        P.nloc_npars = self.nloc + 256 * job.npars
+        return P
+
+    def _timing_events(self, n):
+        """n hipEvent_t handles when fitter.time_kernels is set (bench.py), else
+        None; released with the fitter"""
+        if not getattr(self, "time_kernels", False):
+            return None
+        pool = self.__dict__.setdefault("_event_pool", _EventPool())
+        return pool.take(n)
+
+    def _record(self, events, i):
+        if events is not None:
+            _lib.check(_lib.lib().ngmix_event_record(events[i], _stream()),
+                       "ngmix_event_record")
+
+    def _queue_rounds(self, job, nrounds):
+        """nrounds lock-step rounds by one call into the library
+        (ngmix_lm_rounds_batch): no host between the launches"""
+        torch = _torch()
+        L = _lib.lib()
+        if not hasattr(job, "problem"):
+            job.problem = self._problem(job)
+        d_counts = torch.empty(nrounds, dtype=torch.int32, device=job.dev)
+        h_counts = torch.empty(nrounds, dtype=torch.int32, pin_memory=True)
+        ev = self._timing_events(3 * nrounds)
+        span = _HipEvents(2)
+        with torch.cuda.device(job.dev):
+            span.record(0)
+            _lib.check(L.ngmix_lm_rounds_batch(
+                ctypes.byref(job.problem), nrounds, _dptr(d_counts),
+                ctypes.c_void_p(h_counts.data_ptr()), ev, _stream()),
+                "ngmix_lm_rounds_batch")
+            span.record(1)
+        job.chunks.append((nrounds, d_counts, h_counts, ev, span))
+
+    def _rounds_done(self, job):
+        """after the last queued chunk has run: the count of fits still running"""
+        return int(job.chunks[-1][2][-1])
+
+    def _collect(self, job):
+        """the host's half: wait for the downloads, make sure the rounds queued
+        blind were enough (else run more and re-make the results), package"""
+        torch = _torch()
+        job.copied.synchronize()
+        if not job.host_loop:
+            grow = 2
+            total = sum(c[0] for c in job.chunks)
+            redo = False
+            while self._rounds_done(job) != 0:
+                if total > 2 * job.maxfev + 5:
+                    raise RuntimeError("batched LM did not terminate")
+                redo = True
+                with torch.cuda.device(job.dev):
+                    self._queue_rounds(job, grow)
+                    done = torch.cuda.Event()
+                    done.record()
+                done.synchronize()
+                total += grow
+                grow = min(2 * grow, 32)
+            if redo:
+                self._queue_results(job)
+                job.copied.synchronize()
+            # counts after each round -> the rounds that had fits to advance
+            counts = np.concatenate([c[2].numpy() for c in job.chunks])
+            before = np.concatenate([[job.nobj], counts[:-1]])
+            job.useful_rounds = int((before > 0).sum())
+            self.rounds_launched = int(counts.size)
+            self._rounds_hint = job.useful_rounds + 1
+            # the device time of the rounds (events around every chunk)
+            self.loop_seconds = sum(c[4].elapsed_ms(0, 1) for c in job.chunks) * 1e-3
+            if job.chunks[0][3] is not None:
+                self._kernel_times(job, before)
+        else:
+            self.loop_seconds = job.loop_ms_host * 1e-3
+            self.rounds_launched = job.useful_rounds
+            if job.legacy_ev is not None:
+                self._kernel_times_host_loop(job)
+        self.rounds = job.useful_rounds
+        self.nsplit_used = job.nsplit
+        self._d_states = job.d_states
+        # (fitter.gmix belongs to the batch whose result is being returned)
+        self._fit_ctx = job.fit_ctx
+        self._gmix = None
+        self._mark(job, "download")
+        res = self._package(job)
+        self._mark(job, "package")
+        return res
+
+    def _kernel_times(self, job, before):
+        """HIP-event times of every launch of the rounds (time_kernels)"""
+        L = _lib.lib()
+        ms = ctypes.c_float()
+
+        def elapsed(a, b):
+            _lib.check(L.ngmix_event_elapsed_ms(a, b, ctypes.byref(ms)), "elapsed")
+            return float(ms.value)
+        ev_ms, adv_ms = [], []
+        for nr, _, _, ev, _ in job.chunks:
+            for r in range(nr):
+                ev_ms.append(elapsed(ev[3 * r], ev[3 * r + 1]))
+                adv_ms.append(elapsed(ev[3 * r + 1], ev[3 * r + 2]))
+        nstamp_obj = job.ns / float(job.nobj)
+        w = before.astype("f8") * nstamp_obj
+        # (the launches that found every fit finished are left out of the mean)
+        live = before > 0
+        self.eval_ms = float(np.mean(np.asarray(ev_ms)[live]))
+        self.eval_ms_total = float(np.sum(ev_ms))
+        self.eval_stamps_total = float(np.sum(w))
+        self.eval_launches = [(float(t), float(x)) for t, x in zip(ev_ms, w)]
+        self.eval_launch_count = int(live.sum())
+        self.advance_ms_total = float(np.sum(adv_ms))
+        self.kernel_ms = {
+            "lm_eval": float(np.sum(ev_ms)), "lm_advance": float(np.sum(adv_ms)),
+            "lm_init": elapsed(job.ev_init[0], job.ev_init[1]),
+            "lm_finalize": elapsed(job.ev_post[0], job.ev_post[1]),
+            "lm_pack": elapsed(job.ev_post[1], job.ev_post[2]),
+        }
+        pool = self.__dict__.get("_event_pool")
+        if pool is not None:
+            pool.give(job.ev_init)
+            pool.give(job.ev_post)
+            for c in job.chunks:
+                pool.give(c[3])
+
+    def _kernel_times_host_loop(self, job):
+        ev = job.legacy_ev
+        # per-launch mean, and the whole fit: stamps evaluated / time spent
+        # (a launch whose count was never read -- check_every > 1 -- keeps
+        # the last count known before it)
+        last = 0.0
+        for rec_ in ev:
+            if rec_[2] is None:
+                rec_[2] = last
+            last = rec_[2]
+        ms = [a.elapsed_time(b) for a, b, _ in ev]
+        self.eval_ms = float(np.mean(ms))
+        self.eval_ms_total = float(np.sum(ms))
+        self.eval_stamps_total = float(np.sum([w for _, _, w in ev]))
+        self.eval_launches = [(float(t), float(w)) for t, (_, _, w) in zip(ms, ev)]
+        self.eval_launch_count = len(ms)
+
+    def _rounds_host_loop(self, job):
+        """the lock-step loop driven from the host, one round at a time (a prior
+        evaluated by torch ops between the two launches of a round; pieces of
+        the batch on several streams, fitter.nsplit).  One round is kept in
+        flight ahead of the count being read."""
+        import time
+        torch = _torch()
+        L = _lib.lib()
+        dev = job.dev
+        nobj, npars, ns, npsf = job.nobj, job.npars, job.ns, job.npsf
+        psf, obj_start = job.psf, job.obj_start
+        d_states, d_sums, d_status = job.d_states, job.d_sums, job.d_status
+        d_sobj, d_sband, d_start = job.d_sobj, job.d_sband, job.d_start
+        d_sstats, d_ostats, d_osums = job.d_sstats, job.d_ostats, job.d_osums
+        prior_desc, loop_stats, nsum = job.prior_desc, job.loop_stats, job.nsum
+        modnum, maxfev, check_every = job.modnum, job.maxfev, job.check_every
+        b = job.batch
+        # float64 view of the state records: the columns a prior needs
+        fields = _lib.LM_STATE_DTYPE.fields
+        sview = d_states.view(torch.float64)
+
+        def col(name):
+            a = fields[name][1] // 8
+            return sview[:, a:a + npars]
         # Pieces of the batch on separate streams (fitter.nsplit = k, or the
         # NGMIX_LM_NSPLIT environment knob): one piece's lm_advance -- one thread
         # per fit, latency bound -- runs under another piece's pixel pass.
         # Measured on 100k fits: 6.65 against 6.70 ms for the loop once lm_advance
         # runs from registers (DESIGN 3.7), so the default is one piece.
-        nsplit = self._nsplit_wanted()
-        if self.prior is not None and prior_desc is None:
-            nsplit = 1
-        nsplit = max(1, min(int(nsplit), nobj))
+        nsplit = job.nsplit
         isz = _lib.LM_STATE_DTYPE.itemsize
         wosum = npars * (npars + 1) // 2 + npars + 1
 
@@ -434,10 +679,7 @@ class LMBatchFitter(object):
                 "pend": [], "launched": 0, "ev_idx": [],
             })
         rounds = 0
-        import time
-        mark("setup")
-        yield "ready"
-        if not streaming:
+        if not job.streaming:
             torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         # time_kernels: HIP events around every pixel-pass launch (bench.py),
@@ -530,27 +772,43 @@ class LMBatchFitter(object):
                 rounds += 1
                 if rounds > 2 * maxfev + 5:
                     raise RuntimeError("batched LM did not terminate")
-                yield "round"
             # rounds that had fits to advance (not the one in flight at the end)
             rounds = max(sub["launched"] - len(sub["pend"]) for sub in subs)
             if nsplit > 1:
                 for sub in subs:
                     main.wait_stream(sub["stream"])
-        if not streaming:
+        if not job.streaming:
             torch.cuda.synchronize(dev)
         # seconds in the lock-step loop (kernels + one 4-byte readback per round)
-        self.loop_seconds = time.perf_counter() - t0
-        mark("loop")
-        self.nsplit_used = nsplit
-        self._d_states = d_states
-        self.rounds = rounds
-        # run_leastsq's packaging, one thread per fit (ngmix_lm_finalize_batch)
-        n = npars
-        if trivial_map:
-            npix_obj = stamps.npix_kept.astype(np.int64)
-        else:
-            npix_obj = np.add.reduceat(stamps.npix_kept.astype(np.int64), obj_start[:-1])
-        d_npix = torch.from_numpy(npix_obj).to(dev)
+        job.loop_ms_host = (time.perf_counter() - t0) * 1e3
+        job.useful_rounds = rounds
+        job.legacy_ev = ev
+        self._mark(job, "loop")
+
+    def _queue_results(self, job):
+        """run_leastsq's packaging, one thread per fit (ngmix_lm_finalize_batch),
+        the statistics / packing kernel and the downloads, all queued"""
+        torch = _torch()
+        L = _lib.lib()
+        dev = job.dev
+        stamps, psf = job.stamps, job.psf
+        nobj, n = job.nobj, job.npars
+        obj_start, sband, sobj = job.obj_start, job.sband, job.sobj
+        d_states = job.d_states
+        fields = _lib.LM_STATE_DTYPE.fields
+        sview = d_states.view(torch.float64)
+
+        def col(name):
+            a = fields[name][1] // 8
+            return sview[:, a:a + n]
+        if not hasattr(job, "d_npix"):
+            if job.trivial_map:
+                job.npix_obj = stamps.npix_kept.astype(np.int64)
+            else:
+                job.npix_obj = np.add.reduceat(stamps.npix_kept.astype(np.int64),
+                                               obj_start[:-1])
+            job.d_npix = torch.from_numpy(job.npix_obj).to(dev)
+        d_npix = job.d_npix
         width = 4 + 2 * n + 2 * n * n
         d_rec = torch.empty((nobj, width), dtype=torch.float64, device=dev)
         d_ffx = None
@@ -564,35 +822,40 @@ class LMBatchFitter(object):
             d_ffx = torch.where(bad, torch.zeros_like(rows[:, 0]),
                                 (rows * rows).sum(dim=1))
             d_ffx = torch.where(torch.isfinite(d_ffx), d_ffx, torch.zeros_like(d_ffx))
-            nskip = get_lm_n_prior_pars(self.model, nband) - rows.shape[1]
+            nskip = get_lm_n_prior_pars(self.model, job.nband) - rows.shape[1]
             if nskip > 0:
                 d_ffx = d_ffx + self._first_pixels_fdiff2(
                     stamps, psf, col("x"), obj_start, sband, nskip)
             d_ffx = d_ffx.contiguous()
+        ev_post = self._timing_events(3)
         with torch.cuda.device(dev):
+            self._record(ev_post, 0)
             _lib.check(L.ngmix_lm_finalize_batch(
                 _dptr(d_states), nobj, _dptr(d_npix),
                 _dptr(d_ffx) if d_ffx is not None else None, float(PDEF), float(CDEF),
                 _dptr(d_rec), _stream()), "ngmix_lm_finalize_batch")
-        mark("finalize")
+            self._record(ev_post, 1)
+        self._mark(job, "finalize")
         # Two downloads through pinned memory on a side stream (PyTorch's
         # caching host allocator: no hipHostMalloc after the first call):
         #   * the head -- pars, pars_err, flags / nfev / ier / dof / njev and
         #     the seven statistics columns, 2 n + 12 doubles per fit -- which
         #     go() waits for;
-        #   * pars_cov (n^2 per fit, three quarters of the bytes), which keeps
-        #     flowing after go() has returned and is waited for when it is
+        #   * the upper triangle of pars_cov (n (n + 1) / 2 per fit: the matrix
+        #     is symmetric to the bit), which keeps flowing after go() has
+        #     returned and is waited for -- and mirrored -- when pars_cov is
         #     first read (LMBatchResult lazy key; so are the blocks cut from it).
         # pars_cov0 stays on the device until it is asked for.
         c0, c1 = 4 + 2 * n, 4 + 2 * n + n * n
-        d_cov0 = d_rec[:, c0:c1]
-        d_cov = d_rec[:, c1:].contiguous()
+        job.d_cov0 = d_rec[:, c0:c1]
+        ntri = n * (n + 1) // 2
+        d_tri = torch.empty((nobj, ntri), dtype=torch.float64, device=dev)
         side = self._side_stream(dev)
         d_ok = d_rec[:, 0] == 0.0
-        self._fit_ctx = (stamps, psf, sobj, sband, d_rec, d_ok, n)
+        job.fit_ctx = self._fit_ctx = (stamps, psf, sobj, sband, d_rec, d_ok, n)
         self._gmix = None
         tot = None
-        if not loop_stats:
+        if not job.loop_stats:
             tot = self._loglike_at_solutions(stamps, psf, sobj, sband,
                                              obj_start).contiguous()
         # pars | pars_err rows, then twelve contiguous columns (integers and
@@ -601,14 +864,17 @@ class LMBatchFitter(object):
         d_flat = torch.empty(nobj * (2 * n + ncols), dtype=torch.float64, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.ngmix_lm_pack_batch(
-                _dptr(d_states), nobj, n, _dptr(d_rec), _dptr(d_ostats) if loop_stats else None,
+                _dptr(d_states), nobj, n, _dptr(d_rec),
+                _dptr(job.d_ostats) if job.loop_stats else None,
                 _dptr(tot), _dptr(d_npix), _dptr(d_flat),
-                ctypes.c_void_p(d_flat.data_ptr() + 8 * nobj * 2 * n), _stream()),
+                ctypes.c_void_p(d_flat.data_ptr() + 8 * nobj * 2 * n), _dptr(d_tri),
+                _stream()),
                 "ngmix_lm_pack_batch")
-        mark("pack")
+            self._record(ev_post, 2)
+        self._mark(job, "pack")
         h_flat = torch.empty(d_flat.shape, dtype=torch.float64, pin_memory=True)
-        h_cov = torch.empty((nobj, n * n), dtype=torch.float64, pin_memory=True)
-        mark("pinned_alloc")
+        h_tri = torch.empty((nobj, ntri), dtype=torch.float64, pin_memory=True)
+        self._mark(job, "pinned_alloc")
         ready = torch.cuda.Event()
         ready.record()
         with torch.cuda.stream(side):
@@ -616,30 +882,24 @@ class LMBatchFitter(object):
             h_flat.copy_(d_flat, non_blocking=True)
             copied = torch.cuda.Event()
             copied.record()
-            h_cov.copy_(d_cov, non_blocking=True)
+            h_tri.copy_(d_tri, non_blocking=True)
             cov_copied = torch.cuda.Event()
             cov_copied.record()
         d_flat.record_stream(side)
-        d_cov.record_stream(side)
-        mark("enqueue_copy")
-        yield "copies"
-        copied.synchronize()
-        if ev is not None:
-            # per-launch mean, and the whole fit: stamps evaluated / time spent
-            # (a launch whose count was never read -- check_every > 1 -- keeps
-            # the last count known before it)
-            last = 0.0
-            for rec_ in ev:
-                if rec_[2] is None:
-                    rec_[2] = last
-                last = rec_[2]
-            ms = [a.elapsed_time(b) for a, b, _ in ev]
-            self.eval_ms = float(np.mean(ms))
-            self.eval_ms_total = float(np.sum(ms))
-            self.eval_stamps_total = float(np.sum([w for _, _, w in ev]))
-            self.eval_launches = [(float(t), float(w)) for t, (_, _, w) in zip(ms, ev)]
-        mark("download")
-        flat = h_flat.numpy()
+        d_tri.record_stream(side)
+        pool = self.__dict__.get("_event_pool")
+        if pool is not None and job.ev_post is not None:
+            pool.give(job.ev_post)   # (results re-made after a miss)
+        job.ev_post = ev_post
+        job.h_flat, job.h_tri = h_flat, h_tri
+        job.copied, job.cov_copied = copied, cov_copied
+        self._mark(job, "enqueue_copy")
+
+    def _package(self, job):
+        """the result dict over the downloaded block (views, no copies)"""
+        nobj, n = job.nobj, job.npars
+        ncols = _lib.LM_NCOLS
+        flat = job.h_flat.numpy()
         rec = flat[:nobj * 2 * n].reshape(nobj, 2 * n)
         cols = flat[nobj * 2 * n:].reshape(ncols, nobj)
         res = LMBatchResult({
@@ -651,19 +911,23 @@ class LMBatchFitter(object):
             # views of the downloaded block (no copies)
             "pars": rec[:, 0:n],
             "pars_err": rec[:, n:2 * n],
-            "npix": npix_obj,
+            "npix": job.npix_obj,
             "dof": cols[3].astype(np.int64),
         })
+        h_tri, cov_copied, d_cov0 = job.h_tri, job.cov_copied, job.d_cov0
 
         def fetch_cov(_):
             cov_copied.synchronize()
-            a = h_cov.numpy().reshape(nobj, n, n)
+            iu = np.triu_indices(n)
+            a = np.empty((nobj, n, n))
+            tri = h_tri.numpy()
+            a[:, iu[0], iu[1]] = tri
+            a[:, iu[1], iu[0]] = tri
             a.flags.writeable = False
             return a
         res.set_lazy("pars_cov", fetch_cov)
         res.set_lazy("pars_cov0", lambda _: d_cov0.cpu().numpy().reshape(nobj, n, n))
-        self._add_stats(res, cols[5:], nband)
-        mark("package")
+        self._add_stats(res, cols[5:], job.nband)
         return res
 
     @property

@@ -77,6 +77,8 @@ def test_binding_record_sizes_match_the_library():
         "ngmix_stamp": _lib.STAMP_DTYPE.itemsize,
         "ngmix_batch": ctypes.sizeof(_lib.Batch),
         "ngmix_lm_state": _lib.LM_STATE_DTYPE.itemsize,
+        "ngmix_simple_sep_prior": _lib.SIMPLE_SEP_PRIOR_DTYPE.itemsize,
+        "ngmix_lm_problem": ctypes.sizeof(_lib.LMProblem),
     }
     for name, size in sizes.items():
         assert L.ngmix_abi_sizeof(name.encode()) == size, name

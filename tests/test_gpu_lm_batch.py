@@ -855,3 +855,89 @@ def test_go_stream_pipeline_equals_go():
     r2 = list(fd.go_stream(items[1:2]))[0]
     np.testing.assert_array_equal(r1["pars"], r2["pars"])
     np.testing.assert_array_equal(r1["lnprob"], r2["lnprob"])
+
+
+def _same_fit(a, b, keys=("flags", "nfev", "njev", "ier", "pars", "pars_err", "pars_cov",
+                          "pars_cov0", "lnprob", "chi2per", "s2n", "s2n_numer", "s2n_denom",
+                          "npix", "dof")):
+    for key in keys:
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+
+
+@pytest.mark.parametrize("model", ["exp", "gauss", "dev"])
+def test_lazy_jacobian_is_the_eager_fit_to_the_bit(model):
+    """mode ANALYTIC_LAZY (the default): the trials predicted to end a fit are
+    evaluated for |f|^2 alone by the lean pixel pass of lm_eval_kernel; a failed
+    prediction gets its jacobian one round later.  The result -- nfev, njev,
+    ier, parameters, covariance, statistics -- is the eager fit's, bit for bit,
+    on single stamps, on multi-epoch two-band objects, masked pixels, poor
+    guesses (rejected steps) and with the kernel prior."""
+    from ngmix_amd import prior_batch as pb
+    rng = np.random.RandomState({"exp": 41, "gauss": 42, "dev": 43}[model])
+    n = 200
+    pars, guess, images, weights, jac, sb, psf = _make_objects(n, model, rng)
+    weights[::7, 3:9, 4:11] = 0.0            # masked stamps
+    sb = StampBatch.from_images(images, weights, jac)
+    guess[::5] = pars[::5] * rng.uniform(0.5, 1.8, size=(pars[::5].shape))   # poor guesses
+    guess[::5, 2:4] = rng.uniform(-0.3, 0.3, size=guess[::5, 2:4].shape)
+    lazy = LMBatchFitter(model)
+    eager = LMBatchFitter(model)
+    eager.lazy_jacobian = False
+    r_lazy = lazy.go(sb, guess, psf=psf)
+    st = lazy.states()
+    assert np.all(st["mode"] == _lib.LM_MODE_ANALYTIC_LAZY)
+    r_eager = eager.go(sb, guess, psf=psf)
+    assert np.all(eager.states()["mode"] == _lib.LM_MODE_ANALYTIC)
+    _same_fit(r_lazy, r_eager)
+    assert np.all(r_lazy["flags"][np.arange(n) % 5 != 0] == 0)
+
+    # two bands x two epochs per object
+    nobj = n // 4
+    sobj = np.repeat(np.arange(nobj), 4).astype(np.int32)
+    sband = np.tile([0, 0, 1, 1], nobj).astype(np.int32)
+    g2 = np.concatenate([guess[::4][:, :5], guess[::4][:, 5:6], guess[2::4][:, 5:6]], axis=1)
+    _same_fit(lazy.go(sb, g2, psf=psf, stamp_obj=sobj, stamp_band=sband),
+              eager.go(sb, g2, psf=psf, stamp_obj=sobj, stamp_band=sband))
+
+    # the kernel prior (rows added by ngmix_lm_prior_sums_batch every round)
+    prior = pb.PriorSimpleSepBatch(pb.GaussianCen(0.0, 0.0, 0.3, 0.3), pb.GPriorBA(0.3),
+                                   pb.TwoSidedErf(-1.0, 0.1, 1.0e3, 1.0),
+                                   [pb.TwoSidedErf(-1.0e3, 1.0, 1.0e5, 10.0)])
+    lp = LMBatchFitter(model, prior=prior)
+    ep = LMBatchFitter(model, prior=prior)
+    ep.lazy_jacobian = False
+    keys = ("flags", "nfev", "njev", "ier", "pars", "pars_cov", "lnprob", "chi2per")
+    _same_fit(lp.go(sb, guess, psf=psf), ep.go(sb, guess, psf=psf), keys)
+    assert lp.prior_path == "kernel"
+
+
+def test_host_free_rounds_equal_the_host_driven_loop():
+    """ngmix_lm_rounds_batch (rounds queued blind by one call, results queued
+    behind them, the count checked afterwards) against the loop that reads the
+    count of running fits every round: the same fit, and the launch census
+    shows the rounds went through the one-call path"""
+    rng = np.random.RandomState(77)
+    pars, guess, images, weights, jac, sb, psf = _make_objects(300, "exp", rng)
+    guess[::3] = pars[::3] * rng.uniform(0.4, 2.0, size=pars[::3].shape)  # a long tail
+    fast = LMBatchFitter("exp")
+    slow = LMBatchFitter("exp")
+    slow.host_loop = True
+    a = fast.go(sb, guess, psf=psf)
+    b = slow.go(sb, guess, psf=psf)
+    _same_fit(a, b)
+    assert fast.rounds == slow.rounds
+    assert fast.rounds_launched >= fast.rounds
+    # the second call sizes its blind chunk by the first (one spare round)
+    _lib.launch_census(reset=True)
+    c = fast.go(sb, guess, psf=psf)
+    seen = _lib.launch_census(reset=True)
+    _same_fit(a, c)
+    assert seen.get("lm_eval_kernel<true, true>") == fast.rounds_launched
+    assert fast.rounds_launched == min(fast.rounds + 1, 16) or fast.rounds > 15
+    # timing events through the C ABI
+    fast.time_kernels = True
+    d = fast.go(sb, guess, psf=psf)
+    _same_fit(a, d)
+    assert set(fast.kernel_ms) == {"lm_eval", "lm_advance", "lm_init", "lm_finalize", "lm_pack"}
+    assert all(v > 0.0 for v in fast.kernel_ms.values())
+    assert len(fast.eval_launches) == fast.rounds_launched

@@ -404,7 +404,7 @@ def test_batch_prior_equals_the_reference_prior(golden, tag):
 
 
 @pytest.mark.parametrize("n", [6, 7, 8, 9, 10])
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("bounded", [False, True])
 def test_register_form_equals_generic_form_bit_for_bit(n, mode, bounded, monkeypatch):
     """lm_core_reg.hpp (compile-time parameter count, arrays in registers: what
@@ -472,6 +472,10 @@ def test_register_form_equals_generic_form_bit_for_bit(n, mode, bounded, monkeyp
                     ff[i] = np.inf                 # an out-of-range trial
                 g[i, :n] = J.T @ f
                 A[i, :n, :n] = J.T @ J
+                if mode == 2 and st["fonly"][i] and st["phase"][i] == 1:
+                    # an |f|^2-only trial: the step must not read the jacobian
+                    g[i] = np.nan
+                    A[i] = np.nan
             L.ngmix_lm_advance_host(_lib.ptr(st), nfit, _lib.ptr(ff), _lib.ptr(g),
                                     _lib.ptr(A))
             history.append(st.copy().tobytes())
@@ -482,3 +486,61 @@ def test_register_form_equals_generic_form_bit_for_bit(n, mode, bounded, monkeyp
         assert a == b, "state records differ after step %d" % r
     # the fits did something: several steps, several outcomes
     assert len(states["generic"]) > 4
+
+
+def run_lm_lazy(func, jac, x0, mode, **kw):
+    """run_lm in mode 0 (the jacobian with every evaluation) or 2 (left out of
+    the trials predicted to end the fit): returns the final state and the
+    number of jacobians / of |f|^2-only evaluations the driver was asked for"""
+    L = _lib.lib()
+    x0 = np.ascontiguousarray(x0, dtype="f8").reshape(1, -1)
+    n = x0.shape[1]
+    st = np.zeros(1, dtype=_lib.LM_STATE_DTYPE)
+    assert L.ngmix_lm_init(_lib.ptr(st), 1, n, _lib.ptr(x0), kw.get("ftol", 1e-5),
+                           kw.get("xtol", 1e-5), 0.0, 4000, 100.0, mode, None, None) == 0
+    njac = nfonly = rounds = 0
+    while st["phase"][0] != _lib.LM_PHASE_DONE:
+        xt = st["xt"][0, :n].copy()
+        f = func(xt)
+        ff = np.array([np.dot(f, f)])
+        g = np.full((1, NP), np.nan)
+        A = np.full((1, NP, NP), np.nan)
+        if st["fonly"][0] and st["phase"][0] == 1:
+            nfonly += 1
+        else:
+            J = jac(xt)
+            njac += 1
+            g[0] = 0.0
+            A[0] = 0.0
+            g[0, :n] = J.T @ f
+            A[0, :n, :n] = J.T @ J
+        L.ngmix_lm_advance_host(_lib.ptr(st), 1, _lib.ptr(ff), _lib.ptr(g), _lib.ptr(A))
+        rounds += 1
+        assert rounds < 10000
+    return st[0], njac, nfonly
+
+
+@pytest.mark.parametrize("tol", [1e-5, 1e-8])
+def test_lazy_jacobian_mode_is_lmder_to_the_bit(tol):
+    """NGMIX_LM_MODE_ANALYTIC_LAZY: a trial predicted to end the fit is
+    evaluated for |f|^2 alone -- lmder itself never forms the jacobian at its
+    last point; a failed prediction asks for the jacobian one round later
+    (phase JAC).  Either way the fit is the one mode ANALYTIC runs: the same
+    x, nfev, njev, info, factor R -- every byte of the state but the phase
+    bookkeeping -- with fewer jacobians asked of the evaluator."""
+    saved = 0
+    for name, func, jac, x0 in problems():
+        eager, njac0, nf0 = run_lm_lazy(func, jac, x0, 0, ftol=tol, xtol=tol)
+        lazy, njac2, nf2 = run_lm_lazy(func, jac, x0, 2, ftol=tol, xtol=tol)
+        assert nf0 == 0
+        for key in _lib.LM_STATE_DTYPE.names:
+            if key in ("mode", "fonly"):
+                continue
+            assert np.array_equal(eager[key], lazy[key], equal_nan=True), (name, key)
+        # what lmder reports is the same; the evaluator was asked for no more
+        # jacobians than lmder itself forms (njev) where every prediction held
+        assert lazy["nfev"] == eager["nfev"] and lazy["njev"] == eager["njev"]
+        assert njac2 <= njac0
+        assert njac2 >= lazy["njev"]
+        saved += njac0 - njac2
+    assert saved > 0
