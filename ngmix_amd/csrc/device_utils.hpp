@@ -442,4 +442,51 @@ __device__ __forceinline__ int kept_rank(const unsigned long long *cmask,
     return cpre[p >> 6] + __popcll(below);
 }
 
+// a wave-uniform double moved to SGPRs (a VOP3 instruction reads one SGPR pair
+// for free; as a VGPR pair it would cost two registers across the tile loop)
+__device__ __forceinline__ double uniform_f64(double x)
+{
+    // asm with "=s" results: the builtin readfirstlane of a value the compiler
+    // already knows to be uniform folds away and leaves it in VGPRs.  The
+    // s_nop covers the wait states gfx950 wants between a VALU write of a VGPR
+    // and a v_readfirstlane of it: the hazard recognizer does not look inside
+    // inline asm (without it the constants were stale now and then).
+    int lo, hi;
+    asm volatile("s_nop 4\n\tv_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3"
+                 : "=&s"(lo), "=s"(hi)
+                 : "v"(__double2loint(x)), "v"(__double2hiint(x)));
+    return __hiloint2double(hi, lo);
+}
+
+// a * b + c and a * b with the wave-uniform a read from its SGPR pair (left to
+// itself the compiler copies such constants into VGPRs outside the tile loop)
+__device__ __forceinline__ double fma_sgpr(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "s"(a), "v"(b), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ double mul_sgpr(double a, double b)
+{
+    double r;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b));
+    return r;
+}
+
+// b - a and a - b with the wave-uniform a in its SGPR pair
+__device__ __forceinline__ double sub_sgpr_from(double a, double b)
+{
+    double r;
+    asm("v_add_f64 %0, -%1, %2" : "=v"(r) : "s"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ double sgpr_minus(double a, double b)
+{
+    double r;
+    asm("v_add_f64 %0, %1, -%2" : "=v"(r) : "s"(a), "v"(b));
+    return r;
+}
+
 }  // namespace ngmix

@@ -62,7 +62,7 @@ struct EmWaveShared {
     double red[NV * (NT + 2)];
     double part[NV * 16];
     double tot[NV];
-    double sky, frac_diff, elogL_last, p_last;
+    double sky, frac_diff, elogL_last, p_last, npix;
     double psf_irr, psf_irc, psf_icc, psf_row, psf_col, psf_ipsum;
     int numiter, stop, status, pad;
 };
@@ -161,6 +161,16 @@ __device__ __forceinline__ void em_wave_body(
     }
     const double area = src.area;
     double cnt[1] = {(double)__popcll(kept)};
+    // every slot of every lane holds a listed pixel (a 32 x 32 stamp fills a
+    // wave's 16 slots exactly; config 4, most psf stamps): the one-gaussian
+    // one-wave kernels then run a pixel pass without per-slot EXEC masks --
+    // left in, the compiler keeps one 64-bit mask per slot in SGPRs across the
+    // iteration loop, 32 of the wave's 102, and spills what no longer fits to
+    // VGPR lanes (v_writelane / v_readlane in the VALU stream)
+    constexpr bool kFullForm = NT == WAVE && NPSF == 1 && NG == 1 && PPT < 64;
+    bool full = false;
+    if constexpr (kFullForm)
+        full = __ballot(kept == ((1ull << PPT) - 1ull)) == ~0ull && n == PPT * NT;
 
     if (lane < 16) {
         sh.tab[lane] = c_exp_table_e[lane];
@@ -172,7 +182,9 @@ __device__ __forceinline__ void em_wave_body(
         for (int k = 0; k < 6 * NG + 2; k++) pad[k] = k == 0 ? cnt[0] : 0.0;
         em_group_reduce<NT, 6 * NG + 2>(pad, sh.red, sh.part, sh.tot);
     }
-    const double npix = sh.tot[0];
+    // (kept in LDS: lane 0 reads it once per iteration, a register pair held
+    // across the iteration loop for that is one the pixel pass cannot have)
+    if (lane == 0) sh.npix = sh.tot[0];
     __syncthreads();
     for (int i = lane; i < ngauss; i += NT) gmix[i] = gmix_io[i];
     for (int i = lane; i < npsf; i += NT) psf[i] = psf_io[i];
@@ -264,9 +276,14 @@ __device__ __forceinline__ void em_wave_body(
         // fill_zero_weight_pixels overwrites val of the zero-weight pixels
         // with sky + model, as the reference does in its pixel copy
         if (fill_zero_weight && zw != 0ull) {
+            // (opaque to the optimiser: sixteen loop-invariant EXEC masks would
+            // otherwise live in SGPRs across the whole iteration loop)
+            unsigned zlo = (unsigned)zw, zhi = (unsigned)(zw >> 32);
+            asm volatile("" : "+v"(zlo), "+v"(zhi));
+            const unsigned long long zwl = ((unsigned long long)zhi << 32) | zlo;
 #pragma unroll
             for (int k = 0; k < PPT; k++)
-                if (zw & (1ull << k))
+                if (zwl & (1ull << k))
                     pval[k] = em_fill_value(conv, nconv, pv[k], pu[k], area, sky, sh.tab);
         }
 
@@ -283,9 +300,14 @@ __device__ __forceinline__ void em_wave_body(
         // register budget.
         auto pixel_pass = [&](auto with_logl) {
             constexpr bool LOGL = decltype(with_logl)::value;
+            // (kernels with the full-wave form: the slot masks of this general
+            // form are made per pass, not kept in SGPRs across the iterations)
+            unsigned klo = (unsigned)kept, khi = (unsigned)(kept >> 32);
+            if constexpr (kFullForm) asm volatile("" : "+v"(klo), "+v"(khi));
+            const unsigned long long keptl = ((unsigned long long)khi << 32) | klo;
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
-            if (!(kept & (1ull << k))) continue;
+            if (!(keptl & (1ull << k))) continue;
             const double v = pv[k], u = pu[k];
             const double val_pix = pval[k];
             if constexpr (NPSF1) {
@@ -408,9 +430,75 @@ __device__ __forceinline__ void em_wave_body(
         }
 
         };
+        // The same arithmetic for a full wave with ONE component in all: no
+        // per-slot masks, and the component's seven numbers and the sky in
+        // SGPRs (a VALU instruction reads one scalar operand for free) instead
+        // of four LDS reads and their wait at the head of every pixel.
+        auto pixel_pass_full1 = [&](auto with_logl) {
+            constexpr bool LOGL = decltype(with_logl)::value;
+            const EmConvF c0 = ce[0];
+            const double crow = uniform_f64(c0.row), ccol = uniform_f64(c0.col);
+            const double ca = uniform_f64(c0.a), cb = uniform_f64(c0.b);
+            const double cc = uniform_f64(c0.c), cpa = uniform_f64(c0.pa);
+            const double cK = LOGL ? uniform_f64(c0.K) : 0.0;
+            const double ssky = uniform_f64(sky);
+#pragma unroll
+            for (int k = 0; k < PPT; k++) {
+                const double v = pv[k], u = pu[k];
+                const double vdiff = sub_sgpr_from(crow, v);
+                const double udiff = sub_sgpr_from(ccol, u);
+                const double u2 = udiff * udiff;
+                const double v2 = vdiff * vdiff;
+                const double uv = udiff * vdiff;
+                const double y = fma_sgpr(ca, v2, fma_sgpr(cb, u2, mul_sgpr(cc, uv)));
+                double val = 0.0, logL = 0.0;
+                // hard cut 0 <= chi2 < 25 (em_nb.py:222-227) as one unsigned
+                // compare on the high word of y = chi2 / 2: negative, nan and
+                // inf fail it as they fail the reference's two compares
+                if ((unsigned)__double2hiint(y) < 0x40290000u) {
+                    val = mul_sgpr(cpa, fexp_neg_fused(y, sh.tabr, K));
+                    if (LOGL) logL = val != 0.0 ? sgpr_minus(cK, y) : 0.0;
+                }
+                double gtot;
+                asm("v_add_f64 %0, %1, %2" : "=v"(gtot) : "s"(ssky), "v"(val));
+                if (gtot == 0.0) {
+                    bad = true;  // GMixRangeError('gtot == 0')
+                    continue;
+                }
+                const double factor = pval[k] * fast_rcp(gtot);
+                if (LOGL) acc[6] += logL;
+                acc[7] = fma_sgpr(ssky, factor, acc[7]);
+                const double w = val * factor;
+                acc[0] += w;
+                if (use_cen) {
+                    acc[2] = fma(u, w, acc[2]);
+                    acc[1] = fma(v, w, acc[1]);
+                }
+                if (use_cov) {
+                    acc[3] = fma(u2, w, acc[3]);
+                    acc[4] = fma(uv, w, acc[4]);
+                    acc[5] = fma(v2, w, acc[5]);
+                }
+                // (ends the pixel here: without the branches that used to sit
+                // between the slots the scheduler runs several pixels side by
+                // side and the kernel leaves its three-waves-per-SIMD band)
+                asm volatile("" : "+v"(acc[0]), "+v"(acc[7]));
+            }
+        };
         constexpr bool kTwoForms = NT == WAVE && use_logl && NG <= 3 && (NPSF1 || NPSF == 3);
-        if (kTwoForms && !need_logl) pixel_pass(std::integral_constant<bool, false>{});
-        else pixel_pass(std::integral_constant<bool, use_logl>{});
+        if constexpr (kFullForm) {
+            if (full) {
+                if (use_logl && need_logl) pixel_pass_full1(std::true_type{});
+                else pixel_pass_full1(std::false_type{});
+            } else if (kTwoForms && !need_logl) {
+                pixel_pass(std::integral_constant<bool, false>{});
+            } else {
+                pixel_pass(std::integral_constant<bool, use_logl>{});
+            }
+        } else {
+            if (kTwoForms && !need_logl) pixel_pass(std::integral_constant<bool, false>{});
+            else pixel_pass(std::integral_constant<bool, use_logl>{});
+        }
 
         const bool anybad = __syncthreads_or(bad ? 1 : 0) != 0;
         em_group_reduce<NT, NV>(acc, sh.red, sh.part, sh.tot);
@@ -432,7 +520,7 @@ __device__ __forceinline__ void em_wave_body(
                     sh.status = st;
                     sh.stop = 1;
                 } else {
-                    if (conf.vary_sky) sh.sky = skysum / npix;
+                    if (conf.vary_sky) sh.sky = skysum / sh.npix;
                     sh.numiter = it + 1;
                     if (kind == NGMIX_EM_FLUXONLY) {
                         double psum = 0.0;
@@ -482,8 +570,12 @@ __device__ __forceinline__ void em_wave_body(
 
 static __constant__ double c_fexp_coef_e[9] = NGMIX_FEXP_COEF;
 
+// (the one-gaussian one-wave kernels are held to the three waves per SIMD
+// they were tuned at: 168 registers; every other form takes what it needs)
 template <int NT, int PPT, int KIND, int NG, int NPSF>
-__global__ __launch_bounds__(NT) void em_wave_kernel(
+__global__ __launch_bounds__(NT)
+__attribute__((amdgpu_waves_per_eu((NT == WAVE && NPSF == 1 && NG == 1) ? 3 : 1)))
+void em_wave_kernel(
     ngmix_em_conf conf, const ngmix_stamp *stamps, const double *val,
     const double *ierr, const ngmix_jacobian *jacs, ngmix_gauss2d *gmix,
     ngmix_gauss2d *gmix_psf, int npsf, ngmix_gauss2d *gmix_conv,

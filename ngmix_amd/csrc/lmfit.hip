@@ -75,22 +75,6 @@ struct LmEvalShared {
     double hc[6][3];       // the rows of the raw -> parameter map, 3 terms each
 };
 
-// a wave-uniform double moved to SGPRs (a VOP3 instruction reads one SGPR pair
-// for free; as a VGPR pair it would cost two registers across the tile loop)
-__device__ __forceinline__ double uniform_f64(double x)
-{
-    // asm with "=s" results: the builtin readfirstlane of a value the compiler
-    // already knows to be uniform folds away and leaves it in VGPRs.  The
-    // s_nop covers the wait states gfx950 wants between a VALU write of a VGPR
-    // and a v_readfirstlane of it: the hazard recognizer does not look inside
-    // inline asm (without it the constants were stale now and then).
-    int lo, hi;
-    asm volatile("s_nop 4\n\tv_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3"
-                 : "=&s"(lo), "=s"(hi)
-                 : "v"(__double2loint(x)), "v"(__double2hiint(x)));
-    return __hiloint2double(hi, lo);
-}
-
 // fexp(-chi2/2) for 0 <= chi2 < 25 (fastexp_nb.py:223-262) straight from chi2:
 // 0.5 * chi2 is exact, so n and f are those of fexp_neg_fused(chi2 / 2)
 __device__ __forceinline__ double fexp_neg_half(double chi2, const double *tabr,
@@ -108,22 +92,6 @@ __device__ __forceinline__ double fexp_neg_half(double chi2, const double *tabr,
     p = fma(f, p, k.c1);
     p = fma(f, p, k.c0);
     return tv * p;
-}
-
-// a * b + c and a * b with the wave-uniform a read from its SGPR pair (left to
-// itself the compiler copies such constants into VGPRs outside the tile loop)
-__device__ __forceinline__ double fma_sgpr(double a, double b, double c)
-{
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "s"(a), "v"(b), "v"(c));
-    return r;
-}
-
-__device__ __forceinline__ double mul_sgpr(double a, double b)
-{
-    double r;
-    asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b));
-    return r;
 }
 
 // LDS_TILES: the tile records of the stamp are staged in LDS (every batch whose
