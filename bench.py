@@ -1297,30 +1297,42 @@ def main():
         line["rccl_ranks"] = dist.get_world_size() if world > 1 else 1
         line["backend"] = backend or "none (single process)"
         line["per_rank_ms_per_step"] = list(PER_RANK_MS)
-        if args.config == "C2" and world == 1 and not args.no_other_configs:
-            import torch
-            torch.cuda.empty_cache()
-            other = {}
-            # (short legs, but long enough for the clock governor: each runs its
-            # own settle + warm-up steps, ~0.1 s of load, before the timed ones)
-            for name, fn, kw in (("C3", run_c3, dict(nstamps=100000, steps=30)),
-                                 ("C4", run_c4, dict(nstamps=125000, steps=16)),
-                                 ("C5", run_c5, dict(nobj=20000, steps=60))):
-                try:
-                    o = fn(args, rank, world, device, backend, **kw)
+    other = {}
+    if args.config == "C2" and not args.no_other_configs:
+        # a default run carries a short leg of every other config, so that ONE
+        # driver record holds C2-C5 -- at N > 1 too: every rank runs the legs
+        # (each shards its config as its own --config run does and gathers its
+        # records), rank 0 keeps the lines with every rank's own ms per step
+        import torch
+        torch.cuda.empty_cache()
+        # (short legs, but long enough for the clock governor: each runs its
+        # own settle + warm-up steps, ~0.45 s of load, before the timed ones)
+        # (--nstamps, a testing knob, caps the legs' sizes too)
+        cap = args.nstamps or (1 << 30)
+        for name, fn, kw in (("C3", run_c3, dict(nstamps=min(100000, cap), steps=30)),
+                             ("C4", run_c4, dict(nstamps=min(125000, cap), steps=16)),
+                             ("C5", run_c5, dict(nobj=min(20000, max(cap // 10, 8)), steps=60))):
+            try:
+                o = fn(args, rank, world, device, backend, **kw)
+                if rank == 0:
                     other[name] = {k: o[k] for k in (
                         "metric", "value", "unit", "config", "roofline", "kernels_ms",
                         "bad_status") if k in o}
                     for k in ("rooflines", "mean_numiter", "device_loop_ms", "rounds",
                               "fits_per_s_device_loop", "mean_nfev", "ms_per_step",
                               "kernels_ms_sum", "rounds_launched", "pipelined", "steps",
-                              "settle_steps"):
+                              "settle_steps", "n_gpus"):
                         if k in o:
                             other[name][k] = o[k]
-                except Exception as e:   # never lose the headline line
-                    other[name] = {"error": repr(e)}
-                torch.cuda.empty_cache()
-            if not args.no_cpu_baseline:
+                    other[name]["per_rank_ms_per_step"] = list(PER_RANK_MS)
+            except Exception as e:   # never lose the headline line
+                if world > 1:
+                    raise              # (a rank that stops would hang the others)
+                other[name] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+    if rank == 0:
+        if other:
+            if world == 1 and not args.no_cpu_baseline:
                 # the C port on this box's host cores next to
                 # the GPU figures, bounded to ~2 s per leg
                 try:

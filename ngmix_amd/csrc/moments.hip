@@ -1149,6 +1149,14 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
             }
         }
     }
+    // slots (of this wave) that hold a non-finite value somewhere: the reference
+    // forms weight * val for every pixel, so a NaN / inf outside the weight's
+    // cut is 0 * NaN = NaN in its sums (and flags the object) -- such a slot is
+    // never skipped by the all-lanes-outside-the-cut test below
+    unsigned long long nf_slots = 0ull;
+#pragma unroll
+    for (int k = 0; k < PPT; k++)
+        if (__ballot(!(fabs(pval[k]) < INFINITY)) != 0ull) nf_slots |= 1ull << k;
     if (tid < 16) sh.tab[tid] = c_exp_table_m[15 - tid];  // exp(-n)
     const FexpCoef K = load_fexp_coef(c_fexp_coef_m);
     const int last_pos = group_max_int<NT>(my_last, sh.iscratch);
@@ -1196,7 +1204,8 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
                     fma(dcc * vd, vd, fma(drr * ud, ud, (mdrc2 * vd) * ud));
                 // a slot no lane of which is inside the weight's cut adds exact
                 // zeros to every sum: skipped whole (the rows beyond 5 sigma)
-                if (__ballot(chi2 < MAX_CHI2 && chi2 >= 0.0) == 0ull) continue;
+                if (__ballot(chi2 < MAX_CHI2 && chi2 >= 0.0) == 0ull && !((nf_slots >> k) & 1ull))
+                    continue;
                 const double wdata = weight_fused(chi2, pa, sh.tab, K) * pval[k];
                 a[0] = fma(wdata, pv[k], a[0]);
                 a[1] = fma(wdata, pu[k], a[1]);
@@ -1242,7 +1251,8 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
                 const double vd = pv[k] - row, ud = pu[k] - col;
                 const double vv = vd * vd, uu = ud * ud, vu = vd * ud;
                 const double chi2 = fma(dcc, vv, fma(drr, uu, mdrc2 * vu));
-                if (__ballot(chi2 < MAX_CHI2 && chi2 >= 0.0) == 0ull) continue;
+                if (__ballot(chi2 < MAX_CHI2 && chi2 >= 0.0) == 0ull && !((nf_slots >> k) & 1ull))
+                    continue;
                 const double weight = weight_fused(chi2, pa, sh.tab, K);
                 const double wdata = weight * pval[k];
                 a[0] = fma(wdata, pv[k], a[0]);

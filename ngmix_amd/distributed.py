@@ -222,3 +222,88 @@ def gather_object_results(compute_shard, n_objects, record_shape, dtype=None,
         local = torch.empty((0,) + tuple(record_shape),
                             dtype=dtype or torch.float64, device=device)
     return allgather_records(local, n_objects=n_objects, group=group)
+
+
+def allgather_columns(columns, n_objects=None, group=None):
+    """
+    ONE all-gather for several per-object arrays of a pipeline (the psf, guess
+    and fit records of bootstrap_batch, say) instead of one collective per
+    stage: on the point-to-point xGMI mesh a collective costs its launch and
+    ring set-up whatever its size, and these records are small.
+
+    columns: dict name -> (n_local, ...) array or tensor of this rank's block
+    of objects (shard_bounds); integer and boolean arrays ride as float64
+    (exact below 2^53) and come back in their own dtype.  Returns a dict of
+    (n_objects, ...) numpy arrays, the same on every rank.  Without a process
+    group: the columns themselves, as numpy.
+    """
+    import torch
+    import torch.distributed as dist
+    names = sorted(columns)
+    arrs, metas = [], []
+    for k in names:
+        a = columns[k]
+        a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+        if a.dtype.kind not in "fiub" or a.dtype.itemsize > 8:
+            raise TypeError("allgather_columns: %s has dtype %s" % (k, a.dtype))
+        if a.dtype.kind in "iu" and a.size and np.abs(a).max() >= 2 ** 53:
+            raise ValueError("allgather_columns: %s does not fit a float64" % k)
+        metas.append((k, a.dtype, a.shape[1:]))
+        width = int(np.prod(a.shape[1:], dtype=np.int64))
+        arrs.append(a.reshape(a.shape[0], width).astype(np.float64))
+    if not names:
+        return {}
+    nloc = arrs[0].shape[0]
+    if any(a.shape[0] != nloc for a in arrs):
+        raise ValueError("allgather_columns: the columns have different lengths")
+    if not (dist.is_available() and dist.is_initialized()):
+        return {k: np.asarray(a.reshape((nloc,) + tuple(sh)), dtype=dt)
+                for a, (k, dt, sh) in zip(arrs, metas)}
+    packed = torch.from_numpy(np.concatenate(arrs, axis=1))
+    if dist.get_backend(group) == "nccl":
+        packed = packed.to(torch.device("cuda", torch.cuda.current_device()))
+    full = allgather_records(packed, n_objects=n_objects, group=group).cpu().numpy()
+    out, c = {}, 0
+    for a, (k, dt, sh) in zip(arrs, metas):
+        w = a.shape[1]
+        out[k] = full[:, c:c + w].reshape((full.shape[0],) + tuple(sh)).astype(dt)
+        c += w
+    return out
+
+
+def bootstrap_sharded(make_shard, n_objects, keys=None, group=None, **boot_kw):
+    """
+    pipeline.bootstrap_batch over this rank's block of objects, its per-object
+    results gathered to every rank by ONE collective (allgather_columns).
+
+    make_shard(lo, hi) -> (stamps, psf_stamps, kwargs): the StampBatch pair of
+    objects lo..hi-1 and keyword arguments for bootstrap_batch (stamp_obj /
+    stamp_band relative to lo, ...).  keys: the result arrays to gather
+    (default: the per-object records -- flags, nfev, pars, pars_err, psf_T,
+    psf_g, psf_flags, guess, guess_flags, s2n, chi2per, lnprob).
+    """
+    import torch.distributed as dist
+    from .pipeline import bootstrap_batch
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(n_objects, rank, world)
+    if keys is None:
+        keys = ("flags", "nfev", "pars", "pars_err", "psf_T", "psf_g", "psf_flags",
+                "guess", "guess_flags", "s2n", "chi2per", "lnprob")
+    if hi > lo:
+        stamps, psf_stamps, kw = make_shard(lo, hi)
+        kw = dict(kw or {})
+        kw.update(boot_kw)
+        res = bootstrap_batch(stamps, psf_stamps, **kw)
+        cols = {k: np.asarray(res[k]) for k in keys if k in res}
+        shapes = {k: (v.dtype, v.shape[1:]) for k, v in cols.items()}
+    else:
+        cols, shapes = None, None
+    if world > 1:
+        # an empty shard learns the record layout from its neighbours
+        layouts = [None] * world
+        dist.all_gather_object(layouts, shapes, group=group)
+        known = next(s for s in layouts if s is not None)
+        if cols is None:
+            cols = {k: np.zeros((0,) + tuple(sh), dtype=dt) for k, (dt, sh) in known.items()}
+    return allgather_columns(cols, n_objects=n_objects, group=group)

@@ -15,7 +15,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_HERE, "libngmix_oracle.so")
+# NGMIX_ORACLE_LIB selects another build (the sanitizer build: make -C oracle asan)
+_LIBPATH = os.environ.get("NGMIX_ORACLE_LIB", os.path.join(_HERE, "libngmix_oracle.so"))
 
 # status codes (ngmix_oracle.h)
 OK = 0

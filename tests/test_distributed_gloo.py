@@ -177,3 +177,47 @@ def test_bench_gpus_flag_is_honoured_or_refused():
     assert p.returncode != 0
     assert "GPU" in p.stderr and "2 ranks asked for" in p.stderr
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def _columns_worker(rank, world, port, n_objects, outdir):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ngmix_amd.distributed import allgather_columns, shard_bounds
+        lo, hi = shard_bounds(n_objects, rank, world)
+        idx = np.arange(lo, hi)
+        cols = {"pars": np.stack([idx * 1.5, -idx * 1.0, idx ** 2 * 1.0], axis=1),
+                "flags": (idx % 3).astype(np.int64),
+                "ok": (idx % 2 == 0),
+                "cov": (idx[:, None, None] * np.ones((1, 2, 2))).astype("f8")}
+        full = allgather_columns(cols, n_objects=n_objects)
+        np.savez(os.path.join(outdir, "cols_%d.npz" % rank), **full)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_objects,world", [(11, 2), (5, 3), (1, 2)])
+def test_allgather_columns_is_one_collective_for_many_records(tmp_path, n_objects, world):
+    """distributed.allgather_columns: several per-object arrays of different
+    widths and dtypes (the psf / guess / fit records of a pipeline) packed into
+    ONE all-gather, uneven and empty shards included, dtypes restored"""
+    import torch.multiprocessing as mp
+    mp.spawn(_columns_worker, args=(world, _free_port(), n_objects, str(tmp_path)),
+             nprocs=world, join=True)
+    idx = np.arange(n_objects)
+    for r in range(world):
+        got = np.load(tmp_path / ("cols_%d.npz" % r))
+        np.testing.assert_array_equal(got["pars"], np.stack([idx * 1.5, -idx * 1.0,
+                                                             idx ** 2 * 1.0], axis=1))
+        assert got["flags"].dtype == np.int64 and got["ok"].dtype == np.bool_
+        np.testing.assert_array_equal(got["flags"], idx % 3)
+        np.testing.assert_array_equal(got["ok"], idx % 2 == 0)
+        assert got["cov"].shape == (n_objects, 2, 2)
+        np.testing.assert_array_equal(got["cov"][:, 1, 0], idx * 1.0)
+    # without a process group: the columns themselves
+    from ngmix_amd.distributed import allgather_columns
+    one = allgather_columns({"a": np.arange(3), "b": np.ones((3, 2))})
+    assert one["a"].dtype == np.arange(3).dtype and one["b"].shape == (3, 2)

@@ -758,3 +758,45 @@ def test_admom_and_em_ragged_shapes_vs_oracle():
         for f in ("p", "row", "col", "irr", "irc", "icc"):
             np.testing.assert_allclose(gm_out[i][f], g[f], rtol=1e-9, atol=1e-12,
                                        err_msg="%s %s" % (shapes[i], f))
+
+
+@pytest.mark.parametrize("shape", [(32, 32), (48, 48)])
+@pytest.mark.parametrize("bad", [np.nan, np.inf])
+def test_admom_nonfinite_pixel_outside_the_weight(shape, bad):
+    """a NaN / inf pixel far outside the weight's 5-sigma cut: the reference
+    forms weight * val for EVERY pixel (admom_nb.py:111-175), so 0 * NaN = NaN
+    poisons its sums whatever the pixel's distance.  The kernel skips slots no
+    lane of which is inside the cut -- but never a slot that holds a non-finite
+    value: the record (flags, numiter, the NaN pattern) is the oracle's"""
+    import ngmix_amd as ngmix
+    from ngmix_amd.batch import StampBatch, GMixBatch, records_to_numpy
+    from oracle import oracle as ora
+    nrow, ncol = shape
+    rng = np.random.RandomState(5)
+    jac = ngmix.DiagonalJacobian(row=(nrow - 1) / 2.0, col=(ncol - 1) / 2.0, scale=0.263)
+    gm = ngmix.GMixModel([0.0, 0.0, 0.05, -0.03, 0.35, 40.0], "gauss")   # small object
+    obs, pix_all = [], []
+    for corner in ((0, 0), (nrow - 1, ncol - 1), (0, ncol // 2)):
+        im = gm.make_image((nrow, ncol), jacobian=jac) + 0.003 * rng.normal(size=shape)
+        im[corner] = bad
+        obs.append(ngmix.Observation(im, weight=np.full(shape, 1.0 / 0.003 ** 2), jacobian=jac))
+    sb = StampBatch.from_observations(obs)
+    guess = np.tile([0.0, 0.0, 0.0, 0.0, 0.4, 1.0], (len(obs), 1))
+    wt, _ = GMixBatch.from_pars(guess, "gauss")
+    wt_in = wt.to_numpy()
+    res, status = sb.admom(wt)
+    res = records_to_numpy(res, _lib.ADMOM_RESULT_DTYPE)
+    conf = np.zeros(1, dtype=ora.ADMOM_CONF_DTYPE)
+    conf["maxiter"], conf["shiftmax"], conf["etol"], conf["Ttol"] = 200, 5.0, 1e-5, 1e-3
+    j = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+    j[0] = tuple(jac.get_data().view(np.float64).reshape(8))
+    for i, o in enumerate(obs):
+        pix = ora.make_pixels(o.image, o.weight, j, True)
+        w = conv_rec(wt_in[i], ora.GAUSS2D_DTYPE)
+        r = np.zeros(1, dtype=ora.ADMOM_RESULT_DTYPE)
+        st = ora.admom(conf, w, pix, r)
+        assert int(status[i]) == st
+        assert res["flags"][i] == r["flags"][0], (i, res["flags"][i], r["flags"][0])
+        assert res["numiter"][i] == r["numiter"][0]
+        for f in ("sums", "pars"):
+            np.testing.assert_array_equal(np.isfinite(res[f][i]), np.isfinite(r[f][0]), err_msg=f)

@@ -38,6 +38,15 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    # a default (C2) run carries a leg of every other config at N > 1 too, each
+    # with every rank's own time per step; no CPU legs beside them
+    oc = d["other_configs"]
+    for name in ("C3", "C4", "C5"):
+        assert "error" not in oc[name], oc[name]
+        assert oc[name]["n_gpus"] == 2 and oc[name]["value"] > 0
+        assert len(oc[name]["per_rank_ms_per_step"]) == 2
+        assert "cpu_baseline" not in oc[name]
+    assert oc["C3"]["bad_status"] == 0 and oc["C3"]["kernels_ms"]["lm_eval"] > 0
     assert d["rccl_ranks"] == 2 and d["backend"] == "gloo"
     assert d["bad_status"] == 0 and d["value"] > 0
     # which of render / loglike is "dominant" at 3,000 stamps x 3 steps is
