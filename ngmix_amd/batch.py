@@ -177,7 +177,8 @@ class StampBatch(object):
     pixel with weight > 0 in row-major order (pixels_nb.py:33-38).
     """
 
-    def __init__(self, val, ierr, jac, nrow, ncol, pix_off, ignore_zero_weight):
+    def __init__(self, val, ierr, jac, nrow, ncol, pix_off, ignore_zero_weight,
+                 npix_kept=None):
         torch = _torch()
         self.val = val
         self.ierr = ierr
@@ -197,7 +198,10 @@ class StampBatch(object):
         self._stamp_tables = {}
         # count kept pixels once (device) so masked stamps are known
         self.npix_kept = self.npix.astype(np.int32).copy()
-        if ierr is not None and self.n:
+        if npix_kept is not None:
+            # (counted by the caller from the host weights: no kernel, no read-back)
+            self.npix_kept = np.ascontiguousarray(npix_kept, dtype=np.int32)
+        elif ierr is not None and self.n:
             tab = self._make_table(self.npix_kept, 0, 0)
             with torch.cuda.device(self.device):
                 st = _lib.lib().ngmix_count_kept_batch(
@@ -254,18 +258,33 @@ class StampBatch(object):
         ncol = np.array([im.shape[1] for im in imgs], dtype=np.int32)
         npix = nrow.astype(np.int64) * ncol
         off = np.concatenate([[0], np.cumsum(npix)[:-1]]).astype(np.int64)
-        val = np.concatenate([np.asarray(im, dtype="f8").ravel() for im in imgs])
-        wt = np.concatenate([np.asarray(o._weight, dtype="f8").ravel() for o in obs_list])
-        jac = np.stack([o._jacobian._data.view(np.float64).reshape(8) for o in obs_list])
         izw = np.array([o._ignore_zero_weight for o in obs_list], dtype=bool)
-        dval = _as_device_f64(val, dev)
-        dw = _as_device_f64(wt, dev)
+        # ONE upload: [val | weight | jacobian records] (a host-to-device copy
+        # costs ~30 us whatever its size: three of them were a third of a
+        # one-object fit's set-up), and the listed pixels are counted here
+        # from the host weights instead of by a kernel and a read-back
+        tot = int(npix.sum())
+        n = len(obs_list)
+        host = np.empty(2 * tot + 8 * n)
+        kept = np.empty(n, dtype=np.int32)
+        for i, o in enumerate(obs_list):
+            a, b = int(off[i]), int(off[i] + npix[i])
+            host[a:b] = np.asarray(imgs[i], dtype="f8").ravel()
+            w = np.asarray(o._weight, dtype="f8").ravel()
+            host[tot + a:tot + b] = w
+            kept[i] = np.count_nonzero(w > 0.0) if izw[i] else npix[i]
+            host[2 * tot + 8 * i:2 * tot + 8 * i + 8] = \
+                o._jacobian._data.view(np.float64).reshape(8)
+        dev_all = torch.from_numpy(host).to(dev)
+        dval = dev_all[:tot]
+        dw = dev_all[tot:2 * tot]
+        djac = dev_all[2 * tot:].reshape(n, 8)
         ierr = torch.empty_like(dw)
         with torch.cuda.device(dev):
             st = _lib.lib().ngmix_weight_to_ierr_batch(
                 _dptr(dw), _dptr(ierr), dw.numel(), _stream())
         _lib.check(st, "ngmix_weight_to_ierr_batch")
-        return cls(dval, ierr, _as_device_f64(jac, dev), nrow, ncol, off, izw)
+        return cls(dval, ierr, djac, nrow, ncol, off, izw, npix_kept=kept)
 
     @classmethod
     def from_observations_geometry(cls, obs_list, device=None):

@@ -19,6 +19,8 @@ convolution / norms per evaluation go through the C ABI's host entry points.
 import copy
 import logging
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -378,14 +380,22 @@ class FitModel(dict):
         self._kept = self._batch.npix_kept.astype(np.int64)
         self.totpix = int(self._kept.sum())
         self._pix_start = np.concatenate([[0], np.cumsum(self._kept)[:-1]]).astype(np.int64)
-        # sqrt(weight) of each listed pixel, in residual order (host copy)
-        ierr = []
-        for o in self._flat_obs:
-            w = np.asarray(o.weight, dtype="f8").ravel()
-            if o.ignore_zero_weight:
-                w = w[w > 0.0]
-            ierr.append(np.sqrt(np.where(w > 0.0, w, 0.0)))
-        self._ierr_host = np.concatenate(ierr) if ierr else np.zeros(0)
+        self._ierr_cache = None
+
+    @property
+    def _ierr_host(self):
+        """sqrt(weight) of each listed pixel, in residual order (host copy: the
+        MINPACK route's calc_jacobian scales its rows by it; made when first
+        asked for -- the batched route never does)"""
+        if self._ierr_cache is None:
+            ierr = []
+            for o in self._flat_obs:
+                w = np.asarray(o.weight, dtype="f8").ravel()
+                if o.ignore_zero_weight:
+                    w = w[w > 0.0]
+                ierr.append(np.sqrt(np.where(w > 0.0, w, 0.0)))
+            self._ierr_cache = np.concatenate(ierr) if ierr else np.zeros(0)
+        return self._ierr_cache
 
     def _setup_fit(self, guess):
         guess = np.array(guess, dtype="f8")
@@ -689,7 +699,7 @@ class Fitter(object):
     """
 
     def __init__(self, model, prior=None, fit_pars=None, use_noise_image=False,
-                 analytic_jacobian=True):
+                 analytic_jacobian=True, batched=None):
         self.prior = prior
         self.model = gmix_mod.get_model_num(model)
         self.model_name = gmix_mod.get_model_name(self.model)
@@ -697,10 +707,24 @@ class Fitter(object):
         self.analytic_jacobian = analytic_jacobian
         self.fit_pars = (fit_pars.copy() if fit_pars is not None
                          else DEFAULT_LM_PARS.copy())
+        # batched: run the fit as a one-object batch of the lock-step driver
+        # (lm_batch.LMBatchFitter: the whole lmder iteration on the device, ~15
+        # launches and two small downloads) instead of MINPACK on the host
+        # calling back into one kernel per evaluation (~100 launch + PCIe round
+        # trips for an 'exp' fit).  Same algorithm, same nfev / ier; iterates
+        # agree to the rounding of the normal-equation factorisation.  None:
+        # NGMIX_FITTER_BATCHED (default on); False: the MINPACK path -- what
+        # the tests use as the independent check of the batched driver.
+        if batched is None:
+            batched = os.environ.get("NGMIX_FITTER_BATCHED", "1") not in ("0", "")
+        self.batched = bool(batched)
+        self._batch_fitter = None
 
     def go(self, obs, guess):
         guess = np.asarray(guess, dtype="f8")
         fit_model = self._make_fit_model(obs=obs, guess=guess)
+        if self.batched and self._go_batched(fit_model, guess):
+            return fit_model
         if self.analytic_jacobian and self.model_name in SIMPLE_ANALYTIC_MODELS:
             dfun = fit_model.calc_jacobian
         else:
@@ -715,6 +739,55 @@ class Fitter(object):
         fit_model.set_fit_result(result)
         return fit_model
 
+    def _batched_model(self):
+        """(model name, ngauss) for LMBatchFitter, or None when this fit is not
+        one it runs"""
+        return (self.model_name, None) if self.model_name in (
+            "gauss", "exp", "dev", "turb", "bdf", "bd") else None
+
+    def _go_batched(self, fm, guess):
+        """the fit as a one-object batch (every epoch / band of the object a
+        stamp); fills fm as set_fit_result would and returns True, or returns
+        False when the fit is outside what the lock-step driver runs (a prior
+        object of the per-object interface, the noise-image covariance, psf
+        mixtures of different sizes, more parameters than its state holds)"""
+        from .lm_batch import LMBatchFitter
+        from .batch import GMixBatch
+        spec = self._batched_model()
+        if spec is None or self.prior is not None or self.use_noise_image or \
+                fm.npars > _lib.LM_NPMAX or guess.size != fm.npars:
+            return False
+        psf = None
+        if fm.dopsf:
+            if len({len(p) for p in fm._psf_list}) != 1:
+                return False
+            psf = GMixBatch.from_numpy(np.stack([p._data for p in fm._psf_list]))
+        if self._batch_fitter is None:
+            self._batch_fitter = LMBatchFitter(
+                spec[0], fit_pars=self.fit_pars, ngauss=spec[1],
+                analytic_jacobian=self.analytic_jacobian)
+        res = self._batch_fitter.go(
+            fm._batch, guess[None, :], psf=psf,
+            stamp_obj=np.zeros(fm.nimage, dtype=np.int32),
+            stamp_band=np.asarray(fm._band_of, dtype=np.int32))
+        flags = int(res["flags"][0])
+        ier = int(res["ier"][0])
+        fm.update(flags=flags, nfev=int(res["nfev"][0]), ier=ier,
+                  errmsg="" if flags == 0 else "lmder/lmdif ier %d, flags %d" % (ier, flags),
+                  pars=res["pars"][0].copy(), pars_err=res["pars_err"][0].copy(),
+                  pars_cov0=res["pars_cov0"][0].copy(), pars_cov=res["pars_cov"][0].copy())
+        if flags != 0:
+            return True
+        pars, cov, err = fm["pars"], fm["pars_cov"], fm["pars_err"]
+        fm.update(lnprob=float(res["lnprob"][0]), s2n_numer=float(res["s2n_numer"][0]),
+                  s2n_denom=float(res["s2n_denom"][0]), npix=int(res["npix"][0]),
+                  chi2per=float(res["chi2per"][0]), dof=int(res["npix"][0]) - fm.npars,
+                  s2n_w=float(res["s2n_w"][0]), s2n=float(res["s2n"][0]),
+                  g=pars[2:4].copy(), g_cov=cov[2:4, 2:4].copy(), g_err=err[2:4].copy(),
+                  T=pars[4], T_err=np.sqrt(cov[4, 4]))
+        fm._set_flux()
+        return True
+
     def _make_fit_model(self, obs, guess):
         return FitModel(obs=obs, model=self.model, guess=guess, prior=self.prior)
 
@@ -722,9 +795,12 @@ class Fitter(object):
 class CoellipFitter(Fitter):
     """LM fit of ngauss co-elliptical gaussians"""
 
-    def __init__(self, ngauss, prior=None, fit_pars=None):
+    def __init__(self, ngauss, prior=None, fit_pars=None, batched=None):
         self._ngauss = ngauss
-        super().__init__(model="coellip", prior=prior, fit_pars=fit_pars)
+        super().__init__(model="coellip", prior=prior, fit_pars=fit_pars, batched=batched)
+
+    def _batched_model(self):
+        return ("coellip", self._ngauss) if 4 + 2 * self._ngauss <= _lib.LM_NPMAX else None
 
     def _make_fit_model(self, obs, guess):
         return CoellipFitModel(obs=obs, ngauss=self._ngauss, guess=guess,

@@ -150,8 +150,8 @@ class _HipEvents(object):
         self.handles = (ctypes.c_void_p * n)()
         _lib.check(_lib.lib().ngmix_events_create(n, self.handles), "ngmix_events_create")
 
-    def record(self, i):
-        _lib.check(_lib.lib().ngmix_event_record(self.handles[i], _stream()),
+    def record(self, i, stream=None):
+        _lib.check(_lib.lib().ngmix_event_record(self.handles[i], stream or _stream()),
                    "ngmix_event_record")
 
     def elapsed_ms(self, i, j):
@@ -308,6 +308,20 @@ class LMBatchFitter(object):
         dev = stamps.device
         job = _Job()
         job.dev = dev
+        # (the device context and the stream handle are looked up once per fit:
+        # each torch.cuda.device(...) / current_stream() costs ~10 us of host
+        # time, a tenth of a one-object fit when done per launch)
+        with torch.cuda.device(dev):
+            job.stream = _stream()
+            return self._enqueue_on(job, stamps, guess, psf, stamp_obj, stamp_band,
+                                    check_every, streaming)
+
+    def _enqueue_on(self, job, stamps, guess, psf, stamp_obj, stamp_band, check_every,
+                    streaming):
+        import time
+        torch = _torch()
+        L = _lib.lib()
+        dev = job.dev
         job.phases = {} if getattr(self, "time_phases", False) else None
         job.tmark = time.perf_counter()
         self.phase_ms = job.phases
@@ -357,31 +371,53 @@ class LMBatchFitter(object):
         ev_init = self._timing_events(2)
         d_states = torch.empty((nobj, _lib.LM_STATE_DTYPE.itemsize), dtype=torch.uint8,
                                device=dev)
-        d_guess = torch.from_numpy(guess).to(dev)
-        with torch.cuda.device(dev):
-            self._record(ev_init, 0)
+        nsplit = self._nsplit_wanted()
+        if trivial_map:
+            npix_obj = stamps.npix_kept.astype(np.int64)
+        else:
+            npix_obj = np.add.reduceat(stamps.npix_kept.astype(np.int64), obj_start[:-1])
+        # ONE upload for the guess, the stamp -> object / band maps, the object
+        # offsets and the pixel counts (a host-to-device copy costs ~30 us
+        # whatever its size; a one-object fit made five): 8-byte aligned pieces
+        # of one buffer, viewed in their own types on the device
+        need_maps = not trivial_map
+        ns_pad = (ns + 1) // 2 * 2
+        pieces = [("guess", guess.view(np.uint8).reshape(-1)),
+                  ("npix", npix_obj.view(np.uint8).reshape(-1))]
+        if need_maps:
+            pad32 = lambda a: np.concatenate([a, np.zeros(ns_pad - ns, dtype=np.int32)])
+            pieces += [("start", obj_start.view(np.uint8).reshape(-1)),
+                       ("sobj", pad32(sobj).view(np.uint8).reshape(-1)),
+                       ("sband", pad32(sband).view(np.uint8).reshape(-1))]
+        d_all = torch.from_numpy(np.concatenate([a for _, a in pieces])).to(dev)
+        view, at = {}, 0
+        for name, a in pieces:
+            view[name] = d_all[at:at + a.size]
+            at += a.size
+        d_guess = view["guess"].view(torch.float64).reshape(nobj, npars)
+        d_npix = view["npix"].view(torch.int64)
+        d_sobj = d_sband = d_start = None
+        if need_maps:
+            d_start = view["start"].view(torch.int64)
+            d_sobj = view["sobj"].view(torch.int32)[:ns]
+            d_sband = view["sband"].view(torch.int32)[:ns]
+        elif nsplit > 1:
+            # stamp i is object i in band 0: the kernels take NULL for the three
+            # maps (as pieces on several streams they need the absolute indices)
+            d_sobj = torch.arange(ns, dtype=torch.int32, device=dev)
+            d_sband = torch.zeros(ns, dtype=torch.int32, device=dev)
+            d_start = torch.arange(nobj + 1, dtype=torch.int64, device=dev)
+        if True:
+            self._record(ev_init, 0, job.stream)
             _lib.check(L.ngmix_lm_init_batch(
                 _dptr(d_states), nobj, npars, _dptr(d_guess),
                 float(fp.get("ftol", 1.49012e-8)), float(fp.get("xtol", 1.49012e-8)),
                 float(fp.get("gtol", 0.0)), maxfev, float(fp.get("factor", 100.0)),
                 self._lm_mode(),
                 _lib.ptr(lo) if lo is not None else None,
-                _lib.ptr(hi) if hi is not None else None, _stream()),
+                _lib.ptr(hi) if hi is not None else None, job.stream),
                 "ngmix_lm_init_batch")
-            self._record(ev_init, 1)
-        nsplit = self._nsplit_wanted()
-        d_sobj = d_sband = d_start = None
-        if trivial_map:
-            # stamp i is object i in band 0: the kernels take NULL for the three
-            # maps (as pieces on several streams they need the absolute indices)
-            if nsplit > 1:
-                d_sobj = torch.arange(ns, dtype=torch.int32, device=dev)
-                d_sband = torch.zeros(ns, dtype=torch.int32, device=dev)
-                d_start = torch.arange(nobj + 1, dtype=torch.int64, device=dev)
-        else:
-            d_sobj = torch.from_numpy(sobj).to(dev)
-            d_sband = torch.from_numpy(sband).to(dev)
-            d_start = torch.from_numpy(obj_start).to(dev)
+            self._record(ev_init, 1, job.stream)
         nsum = self.nloc * (self.nloc + 1) // 2 + self.nloc + 1
         # (every row is written by the first round's launch)
         d_sums = torch.empty((ns, nsum), dtype=torch.float64, device=dev)
@@ -425,6 +461,7 @@ class LMBatchFitter(object):
             d_sstats=d_sstats, d_ostats=d_ostats, d_osums=d_osums, modnum=modnum,
             prior_desc=prior_desc, loop_stats=loop_stats, nsplit=nsplit, nsum=nsum,
             streaming=streaming, check_every=check_every, ev_init=ev_init,
+            npix_obj=npix_obj, d_npix=d_npix, d_all=d_all,
             batch=stamps._batch(1), chunks=[], useful_rounds=None, ev_post=None,
             legacy_ev=None, loop_ms_host=0.0)
         # the host-free loop serves one piece with no prior or the kernel prior;
@@ -494,9 +531,9 @@ class LMBatchFitter(object):
         pool = self.__dict__.setdefault("_event_pool", _EventPool())
         return pool.take(n)
 
-    def _record(self, events, i):
+    def _record(self, events, i, stream=None):
         if events is not None:
-            _lib.check(_lib.lib().ngmix_event_record(events[i], _stream()),
+            _lib.check(_lib.lib().ngmix_event_record(events[i], stream or _stream()),
                        "ngmix_event_record")
 
     def _queue_rounds(self, job, nrounds):
@@ -510,13 +547,14 @@ class LMBatchFitter(object):
         h_counts = torch.empty(nrounds, dtype=torch.int32, pin_memory=True)
         ev = self._timing_events(3 * nrounds)
         span = _HipEvents(2)
-        with torch.cuda.device(job.dev):
-            span.record(0)
-            _lib.check(L.ngmix_lm_rounds_batch(
-                ctypes.byref(job.problem), nrounds, _dptr(d_counts),
-                ctypes.c_void_p(h_counts.data_ptr()), ev, _stream()),
-                "ngmix_lm_rounds_batch")
-            span.record(1)
+        # (the caller holds the device context; the copy of the counts is
+        # queued by the library on the same stream)
+        span.record(0, job.stream)
+        _lib.check(L.ngmix_lm_rounds_batch(
+            ctypes.byref(job.problem), nrounds, _dptr(d_counts),
+            ctypes.c_void_p(h_counts.data_ptr()), ev, job.stream),
+            "ngmix_lm_rounds_batch")
+        span.record(1, job.stream)
         job.chunks.append((nrounds, d_counts, h_counts, ev, span))
 
     def _rounds_done(self, job):
@@ -544,7 +582,8 @@ class LMBatchFitter(object):
                 total += grow
                 grow = min(2 * grow, 32)
             if redo:
-                self._queue_results(job)
+                with torch.cuda.device(job.dev):
+                    self._queue_results(job)
                 job.copied.synchronize()
             # counts after each round -> the rounds that had fits to advance
             counts = np.concatenate([c[2].numpy() for c in job.chunks])
@@ -801,13 +840,6 @@ class LMBatchFitter(object):
         def col(name):
             a = fields[name][1] // 8
             return sview[:, a:a + n]
-        if not hasattr(job, "d_npix"):
-            if job.trivial_map:
-                job.npix_obj = stamps.npix_kept.astype(np.int64)
-            else:
-                job.npix_obj = np.add.reduceat(stamps.npix_kept.astype(np.int64),
-                                               obj_start[:-1])
-            job.d_npix = torch.from_numpy(job.npix_obj).to(dev)
         d_npix = job.d_npix
         width = 4 + 2 * n + 2 * n * n
         d_rec = torch.empty((nobj, width), dtype=torch.float64, device=dev)
@@ -828,13 +860,13 @@ class LMBatchFitter(object):
                     stamps, psf, col("x"), obj_start, sband, nskip)
             d_ffx = d_ffx.contiguous()
         ev_post = self._timing_events(3)
-        with torch.cuda.device(dev):
-            self._record(ev_post, 0)
+        if True:
+            self._record(ev_post, 0, job.stream)
             _lib.check(L.ngmix_lm_finalize_batch(
                 _dptr(d_states), nobj, _dptr(d_npix),
                 _dptr(d_ffx) if d_ffx is not None else None, float(PDEF), float(CDEF),
-                _dptr(d_rec), _stream()), "ngmix_lm_finalize_batch")
-            self._record(ev_post, 1)
+                _dptr(d_rec), job.stream), "ngmix_lm_finalize_batch")
+            self._record(ev_post, 1, job.stream)
         self._mark(job, "finalize")
         # Two downloads through pinned memory on a side stream (PyTorch's
         # caching host allocator: no hipHostMalloc after the first call):
@@ -862,15 +894,15 @@ class LMBatchFitter(object):
         # statistics): one kernel, one download, contiguous host views
         ncols = _lib.LM_NCOLS
         d_flat = torch.empty(nobj * (2 * n + ncols), dtype=torch.float64, device=dev)
-        with torch.cuda.device(dev):
+        if True:
             _lib.check(L.ngmix_lm_pack_batch(
                 _dptr(d_states), nobj, n, _dptr(d_rec),
                 _dptr(job.d_ostats) if job.loop_stats else None,
                 _dptr(tot), _dptr(d_npix), _dptr(d_flat),
                 ctypes.c_void_p(d_flat.data_ptr() + 8 * nobj * 2 * n), _dptr(d_tri),
-                _stream()),
+                job.stream),
                 "ngmix_lm_pack_batch")
-            self._record(ev_post, 2)
+            self._record(ev_post, 2, job.stream)
         self._mark(job, "pack")
         h_flat = torch.empty(d_flat.shape, dtype=torch.float64, pin_memory=True)
         h_tri = torch.empty((nobj, ntri), dtype=torch.float64, pin_memory=True)
@@ -883,6 +915,12 @@ class LMBatchFitter(object):
             copied = torch.cuda.Event()
             copied.record()
             h_tri.copy_(d_tri, non_blocking=True)
+            h_cov0 = None
+            if nobj <= 4096:
+                # (a small batch: pars_cov0 rides along instead of costing its
+                # first reader a synchronous download of its own)
+                h_cov0 = torch.empty((nobj, n * n), dtype=torch.float64, pin_memory=True)
+                h_cov0.copy_(job.d_cov0, non_blocking=True)
             cov_copied = torch.cuda.Event()
             cov_copied.record()
         d_flat.record_stream(side)
@@ -891,7 +929,7 @@ class LMBatchFitter(object):
         if pool is not None and job.ev_post is not None:
             pool.give(job.ev_post)   # (results re-made after a miss)
         job.ev_post = ev_post
-        job.h_flat, job.h_tri = h_flat, h_tri
+        job.h_flat, job.h_tri, job.h_cov0 = h_flat, h_tri, h_cov0
         job.copied, job.cov_copied = copied, cov_copied
         self._mark(job, "enqueue_copy")
 
@@ -926,7 +964,14 @@ class LMBatchFitter(object):
             a.flags.writeable = False
             return a
         res.set_lazy("pars_cov", fetch_cov)
-        res.set_lazy("pars_cov0", lambda _: d_cov0.cpu().numpy().reshape(nobj, n, n))
+        h_cov0 = job.h_cov0
+
+        def fetch_cov0(_):
+            if h_cov0 is None:
+                return d_cov0.cpu().numpy().reshape(nobj, n, n)
+            cov_copied.synchronize()
+            return h_cov0.numpy().reshape(nobj, n, n)
+        res.set_lazy("pars_cov0", fetch_cov0)
         self._add_stats(res, cols[5:], job.nband)
         return res
 

@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The per-object Fitter of the tests is MINPACK on the host calling the seam
+# kernels once per evaluation -- the INDEPENDENT check of the batched
+# lock-step driver (and of the reference goldens' exact nfev).  Outside the
+# tests Fitter.go defaults to the one-object batch of that driver; the tests of
+# that route ask for it explicitly (batched=True).
+os.environ.setdefault("NGMIX_FITTER_BATCHED", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line(

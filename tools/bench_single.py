@@ -35,4 +35,7 @@ t("GaussMom(1.2).go(obs)", lambda: ngmix.GaussMom(fwhm=1.2).go(obs))
 t("run_admom(obs, 0.6)", lambda: ngmix.admom.run_admom(obs, 0.6, rng=rng), n=100)
 t("run_em(psf obs, 1 gaussian)", lambda: ngmix.em.run_em(pobs, ngmix.GMixModel([0.0, 0.0, 0.0, 0.0, 0.3, 1.0], "gauss")), n=50)
 guess = np.array([0.1, -0.05, 0.1, 0.05, 0.6, 100.0]) * 1.03
-t("Fitter('exp').go(obs, guess)", lambda: ngmix.fitting.Fitter(model="exp").go(obs=obs, guess=guess), n=50)
+fb = ngmix.fitting.Fitter(model="exp", batched=True)
+t("Fitter('exp', batched=True).go(obs, guess)", lambda: fb.go(obs=obs, guess=guess), n=200)
+t("  (a new Fitter per call)", lambda: ngmix.fitting.Fitter(model="exp", batched=True).go(obs=obs, guess=guess), n=100)
+t("Fitter('exp', batched=False).go(obs, guess)", lambda: ngmix.fitting.Fitter(model="exp", batched=False).go(obs=obs, guess=guess), n=50)
