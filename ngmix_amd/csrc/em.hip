@@ -391,11 +391,11 @@ int launch_em_grid(int kind, const ngmix_em_conf *conf, const ngmix_batch *b,
     int nt = 0;
     if (const char *e = getenv("NGMIX_EM_NT")) nt = atoi(e);
     const int np = b->max_npix;
-    // the fused kernels: <= 3 object gaussians up to 64 x 64 pixels, 4 .. 6 up
-    // to 2304 pixels (one or two waves per stamp)
+    // the fused kernels: <= 6 object gaussians up to 64 x 64 pixels (one, two or
+    // four waves per stamp), 7 and 8 up to 2304 pixels (one or two waves)
     // (two waves hold 16 pixels per lane, 18 in the full run only)
     const int np_hi = kind == NGMIX_EM_FULL ? 18 * 2 * WAVE : 16 * 2 * WAVE;
-    const bool fused = (np <= 16 * BLOCK && ngauss <= 3) || (np <= np_hi && ngauss <= 6);
+    const bool fused = (np <= 16 * BLOCK && ngauss <= 6) || (np <= np_hi && ngauss <= 8);
     if (nt == 0) nt = fused ? WAVE : BLOCK;
     if (nt == WAVE && fused)
         return launch_em_wave(kind, conf, b, gmix, ngauss, psf, npsf, conv, sky_in, fzw,

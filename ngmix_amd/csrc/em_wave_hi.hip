@@ -3,8 +3,9 @@
 // (em_nb.py:160-246,284-354), and psf / galaxy fits with four to six free
 // gaussians used to fall to the generic 256-thread kernel of em.hip, six
 // times slower per gaussian than the one-wave form (tools/bench_em_ng.py).
-// One or two waves per stamp (<= 2304 pixels); a translation unit of its own
-// so that it compiles beside em_wave.hip.
+// One, two or four waves per stamp (<= 64 x 64 pixels); a translation unit of
+// its own so that it compiles beside em_wave.hip.  Seven and eight gaussians:
+// em_wave_8.hip.
 #include "em_wave_impl.hpp"
 
 namespace ngmix {
@@ -28,10 +29,11 @@ int launch_em_wave_hi(int kind, const ngmix_em_conf *conf, const ngmix_batch *b,
                       ngmix_gauss2d *conv, const double *sky_in, int fzw, double *out,
                       int32_t *status, hipStream_t s)
 {
-    const int np_max = kind == NGMIX_EM_FULL ? 18 * 2 * WAVE : 16 * 2 * WAVE;
-    if (ngauss < 4 || ngauss > 6 || b->max_npix > np_max) {
-        set_last_error_msg("launch_em_wave_hi: 4..6 gaussians on stamps of <= 2048 pixels "
-                           "(2304 for the full run)");
+    if (ngauss > 6)
+        return launch_em_wave_8(kind, conf, b, gmix, ngauss, psf, npsf, conv, sky_in, fzw,
+                                out, status, s);
+    if (ngauss < 4 || b->max_npix > 16 * BLOCK) {
+        set_last_error_msg("launch_em_wave_hi: 4..6 gaussians on stamps of <= 4096 pixels");
         return NGMIX_ERR_BAD_ARG;
     }
     switch (kind) {

@@ -55,12 +55,27 @@ __device__ __forceinline__ double fast_rcp(double x)
     return r;
 }
 
+// values reduced per pass of em_group_reduce: the transposed tile of a several-
+// wave group is NVC x (NT + 2) doubles and must fit the 64 kB of static LDS
+// next to the rest (a 256-thread group with the 38 sums of six gaussians would
+// need 78 kB: two passes of 19)
+template <int NT, int NV>
+constexpr int em_reduce_chunk()
+{
+    constexpr int cap = 40960 / (8 * (NT + 2));
+    if (NT == WAVE || NV <= cap) return NV;
+    // equal chunks
+    constexpr int passes = (NV + cap - 1) / cap;
+    return (NV + passes - 1) / passes;
+}
+
 template <int NT, int NV>
 struct EmWaveShared {
+    static constexpr int NVC = em_reduce_chunk<NT, NV>();
     double tab[16];    // exp(i), i = -15..0  (zero-weight fill, apodised evaluator)
     double tabr[16];   // exp(-n), n = 0..15  (fused evaluator)
-    double red[NV * (NT + 2)];
-    double part[NV * 16];
+    double red[NVC * (NT + 2)];
+    double part[NVC * 16];
     double tot[NV];
     double sky, frac_diff, elogL_last, p_last, npix;
     double psf_irr, psf_irc, psf_icc, psf_row, psf_col, psf_ipsum;
@@ -82,14 +97,12 @@ static __device__ __noinline__ double em_fill_value(const ngmix_gauss2d *conv, i
 // The sum of each of NV per-thread values over an NT-thread work-group (NT = 64,
 // 128, 256), left in tot[k]: the values go through a transposed LDS tile, NV*S
 // threads each add one segment of one row, NV threads fold the S partials.
-// Fixed order.  One wave: wave_reduce_lds (no barriers).
+// Fixed order.  One wave: wave_reduce_lds (no barriers).  Several waves and
+// many values: em_reduce_chunk() values per pass through the same tile.
 template <int NT, int NV>
-__device__ __forceinline__ void em_group_reduce(const double (&acc)[NV], double *red,
-                                                double *part, double *tot)
+__device__ __forceinline__ void em_group_reduce_pass(const double (&acc)[NV], double *red,
+                                                     double *part, double *tot)
 {
-    if constexpr (NT == WAVE) {
-        wave_reduce_lds<NV>(acc, red, tot);
-    } else {
     constexpr int STRIDE = NT + 2;
     // segments per value: the largest power of two with NV*S <= NT, at most 16
     constexpr int Q = NT / NV;
@@ -117,6 +130,56 @@ __device__ __forceinline__ void em_group_reduce(const double (&acc)[NV], double 
         tot[tid] = s;
     }
     __syncthreads();
+}
+
+template <int NT, int NV>
+__device__ __forceinline__ void em_group_reduce(const double (&acc)[NV], double *red,
+                                                double *part, double *tot)
+{
+    if constexpr (NT == WAVE) {
+        wave_reduce_lds<NV>(acc, red, tot);
+    } else {
+        constexpr int NVC = em_reduce_chunk<NT, NV>();
+        if constexpr (NVC == NV) {
+            em_group_reduce_pass<NT, NV>(acc, red, part, tot);
+        } else {
+#pragma unroll
+            for (int c0 = 0; c0 < NV; c0 += NVC) {
+                // (the last pass is padded with zeros: one instantiation)
+                double sub[NVC];
+#pragma unroll
+                for (int k = 0; k < NVC; k++) sub[k] = c0 + k < NV ? acc[c0 + k] : 0.0;
+                double *dst = tot + c0;
+                // tot[] has NV entries: the padded tail of the last pass lands
+                // in part[] only
+                constexpr int STRIDE = NT + 2;
+                constexpr int Q = NT / NVC;
+                constexpr int S = Q >= 16 ? 16 : Q >= 8 ? 8 : Q >= 4 ? 4 : 2;
+                static_assert(NVC * S <= NT && NT % S == 0, "em_group_reduce sizing");
+                constexpr int SEGLEN = NT / S;
+                const int tid = threadIdx.x;
+#pragma unroll
+                for (int k = 0; k < NVC; k++) red[k * STRIDE + tid] = sub[k];
+                __syncthreads();
+                if (tid < NVC * S) {
+                    const int k = tid / S, j = tid - k * S;
+                    const double *row = red + k * STRIDE + j * SEGLEN;
+                    double s = 0.0;
+#pragma unroll 8
+                    for (int i = 0; i < SEGLEN; i++) s += row[i];
+                    part[k * 16 + j] = s;
+                }
+                __syncthreads();
+                if (tid < NVC && c0 + tid < NV) {
+                    const double *r = part + tid * 16;
+                    double s = 0.0;
+#pragma unroll
+                    for (int j = 0; j < S; j++) s += r[j];
+                    dst[tid] = s;
+                }
+                __syncthreads();
+            }
+        }
     }
 }
 
@@ -656,12 +719,13 @@ static void em_wave_launch(const ngmix_em_conf *conf, const ngmix_batch *b,
     else if (np <= 16 * 2 * WAVE)
         em_wave_launch_nt<2 * WAVE, 16, KIND, NG>(conf, b, gmix, psf, npsf, conv, sky_in,
                                                   fzw, out, status, s);
-    else if constexpr (NG <= 3)
+    else if constexpr (NG <= 6)
+        // (four to six object gaussians: the 26 .. 38 sums go through the
+        // reduction tile in two passes, em_reduce_chunk)
         em_wave_launch_nt<BLOCK, 16, KIND, NG>(conf, b, gmix, psf, npsf, conv, sky_in,
                                                fzw, out, status, s);
-    // (four and more object gaussians: the reduction tile of a 256-thread group
-    // would not fit the 64 kB of static LDS -- em.hip sends such stamps, beyond
-    // 2048 pixels (2304 in the full run), to the generic kernel)
+    // (seven and eight object gaussians: one or two waves, em_wave_8.hip; em.hip
+    // sends larger stamps to the generic kernel)
 }
 
 }  // namespace ngmix

@@ -40,6 +40,10 @@ int launch_em_wave_hi(int kind, const ngmix_em_conf *conf, const ngmix_batch *b,
                    ngmix_gauss2d *gmix, int ngauss, ngmix_gauss2d *psf, int npsf,
                    ngmix_gauss2d *conv, const double *sky_in, int fzw, double *out,
                    int32_t *status, hipStream_t s);
+int launch_em_wave_8(int kind, const ngmix_em_conf *conf, const ngmix_batch *b,
+                   ngmix_gauss2d *gmix, int ngauss, ngmix_gauss2d *psf, int npsf,
+                   ngmix_gauss2d *conv, const double *sky_in, int fzw, double *out,
+                   int32_t *status, hipStream_t s);
 
 // derivs.hip
 int launch_deriv_list(const double *gpars, const double *dcov, int ng,

@@ -549,16 +549,21 @@ def test_em_kernel_variants_vs_oracle(shape, ngauss):
                                        err_msg="%s stamp %d %s" % (shape, i, f))
 
 
-@pytest.mark.parametrize("shape", [(25, 25), (32, 32), (45, 47), (48, 48), (56, 60)])
+@pytest.mark.parametrize("shape", [(25, 25), (32, 32), (45, 47), (48, 48), (56, 60), (64, 64),
+                                   (70, 66)])
 @pytest.mark.parametrize("ngauss,npsf,kind", [(3, 1, 0), (4, 1, 0), (5, 1, 0), (6, 1, 0),
                                               (4, 3, 0), (6, 3, 0), (4, 1, 1), (5, 1, 2),
-                                              (6, 1, 3), (1, 3, 0), (2, 3, 1)])
+                                              (6, 1, 3), (1, 3, 0), (2, 3, 1), (7, 1, 0),
+                                              (8, 1, 0), (8, 3, 0), (7, 1, 2), (8, 1, 3),
+                                              (9, 1, 0)])
 def test_em_many_gaussians_vs_oracle(shape, ngauss, npsf, kind):
     """em_run is general in the gaussian counts (em_nb.py:160-246, 284-354): the
-    fused kernels for four to six object gaussians (em_wave_hi.hip: one wave up
-    to 32x32, two up to 48x48; the 56x60 stamps run the generic kernel), with
-    one- and three-gaussian psfs and every run kind, against the oracle --
-    exact numiter, mixtures to 1e-9"""
+    fused kernels for up to six object gaussians (em_wave.hip / em_wave_hi.hip:
+    one wave up to 32x32, two up to 48x48, four up to 64x64) and for seven and
+    eight on one or two waves (em_wave_8.hip), with one- and three-gaussian psfs
+    and every run kind, against the oracle -- exact numiter, mixtures to 1e-9;
+    the census says which kernel served each case (the generic one only for
+    nine gaussians, seven / eight beyond 48x48, and stamps beyond 64x64)"""
     import ngmix_amd as ngmix
     from ngmix_amd.batch import StampBatch, GMixBatch
     from oracle import oracle as ora
@@ -605,7 +610,7 @@ def test_em_many_gaussians_vs_oracle(shape, ngauss, npsf, kind):
     # (2304 in the full run, 4096 for <= 3 object gaussians) with the psf count
     # compile-time for 1 and (one wave, <= 3 gaussians) 3; the generic beyond
     npix = nrow * ncol
-    fused = npix <= (4096 if ngauss <= 3 else (2304 if kind == 0 else 2048))
+    fused = ngauss <= 8 and npix <= (4096 if ngauss <= 6 else (2304 if kind == 0 else 2048))
     assert len(seen) == 1, seen
     name = list(seen)[0]
     if fused:
