@@ -353,6 +353,8 @@ def run_c2(args, rank, world, device, backend):
             "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": dom_bytes,
             "avg_launch_ms": dom_ms,
+            **load_issue("pixpass_wave_kernel7<0, false, 8>" if dominant == "loglike"
+                         else "pixpass_wave_kernel<2, false, 16>"),
         },
         "kernels_ms": {"render": render_ms, "loglike": loglike_ms},
         "loglike_stamp_evals_per_s_per_gpu": n / (loglike_ms * 1e-3),
@@ -497,6 +499,7 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
             "algorithmic_bytes_per_launch": eval_bytes * stamps_per_launch,
             "avg_launch_ms": eval_ms, "stamps_per_launch": stamps_per_launch,
             "launches_per_fit": nl / K, "pieces": state.get("nsplit", 1),
+            **load_issue("lm_eval_kernel<true, true>"),
             "note": "the kernel evaluates value + 5 derivative images per pixel-gaussian "
                     "pair and is VALU-issue bound (profiles/*_pmc_summary.txt), not HBM "
                     "bound; bytes and time are summed over the launches of whole fits, "
@@ -635,6 +638,8 @@ def run_c4(args, rank, world, device, backend, nstamps=None, steps=None, quiet=F
 
     r_admom = roof(admom_ms, fl_admom, "admom", 16 * npx + 64 + 48 + 584)
     r_em = roof(em_ms, fl_em, "em", 16 * npx + 64 + 6 * 8 * 2 + 24)
+    r_admom.update(load_issue("admom_grid_kernel<64, 16>", fl_admom / n))
+    r_em.update(load_issue("em_wave_kernel<64, 16, 0, 1, 1>", fl_em / n))
     dom = r_em if em_ms >= admom_ms else r_admom
     line = {
         "metric": "objects/sec (admom + em_run), 32x32 stamps, 1/2/4/8 GPU",
@@ -772,6 +777,8 @@ def run_c5(args, rank, world, device, backend, nobj=None, steps=None):
             "frac": achieved / HBM_PEAK_GBS, "traffic": c5_traffic[0],
             "traffic_source": c5_traffic[1],
             "algorithmic_bytes_per_launch": epoch_bytes * ns, "avg_launch_ms": ll_ms,
+            # (on this shape the kernel is instruction-issue bound, not HBM bound)
+            **load_issue("pixpass_wave_kernel7<0, false, 8>", c5=True),
         },
         "kernels_ms": {"loglike": ll_ms, "epoch_reduce": red_ms},
         "pixel_gaussian_evals_per_s": world * ns * dim * dim * 16 * K / elapsed,
@@ -1243,6 +1250,36 @@ def load_traffic(kernel, nstamps, key="nstamps"):
     if v is None:
         return None, None
     return v, "profiles/pmc_traffic.json (%s)" % t.get("source", "rocprofv3 --pmc pass")
+
+
+def load_issue(kernel_fragment, flop_per_stamp=None, c5=False):
+    """instruction-issue figures of a VALU-bound kernel from the committed
+    rocprofv3 PMC pass (profiles/pmc_valu.json, written by
+    tools/make_profiles.py): the fraction of the SIMDs' issue slots the kernel
+    fills (valu_busy), its VALU wave-instructions per stamp, and -- with a flop
+    model -- the flops one lane-instruction carries.  A bare roofline fraction
+    of 0.26 reads differently next to '87 % of the issue slots, 0.6 flop per
+    slot'.  {} when the file or the kernel is missing."""
+    path = os.path.join(ROOT, "profiles", "pmc_valu.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return {}
+    for name, fig in table.items():
+        if not isinstance(fig, dict) or kernel_fragment not in name:
+            continue
+        if c5 != name.startswith("c5:"):
+            continue
+        out = {"valu_busy": fig["valu_busy"],
+               "valu_insts_per_stamp": fig["valu_insts_per_stamp"],
+               "issue_source": table.get("source")}
+        if "salu_insts_per_stamp" in fig:
+            out["salu_insts_per_stamp"] = fig["salu_insts_per_stamp"]
+        if flop_per_stamp:
+            out["flop_per_lane_inst"] = flop_per_stamp / (fig["valu_insts_per_stamp"] * 64.0)
+        return out
+    return {}
 
 
 def main():

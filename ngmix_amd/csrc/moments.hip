@@ -1075,13 +1075,22 @@ __device__ __forceinline__ int group_sum_int(int x, int *scratch)
 }
 
 // gauss2d_eval_pixel_fast with FMAs on a precomputed chi2; pa = pnorm*area
+// 0 <= chi2 < 25 (admom_nb.py:117-118, 141-142) as ONE unsigned compare on the
+// high word: negative, nan and inf fail it as they fail the reference's two
+// compares (chi2 is a positive-definite form here: never -0.0)
+__device__ __forceinline__ bool chi2_in_cut(double chi2)
+{
+    return (unsigned)__double2hiint(chi2) < 0x40390000u;   // 25.0
+}
+
 __device__ __forceinline__ double weight_fused(double chi2, double pa,
                                                const double *tabr, const FexpCoef &K)
 {
     double w = 0.0;
-    if (chi2 < MAX_CHI2 && chi2 >= 0.0) {
+    if (chi2_in_cut(chi2)) {
         double e = fexp_neg_fused(0.5 * chi2, tabr, K);
-        if (chi2 > APOD_CHI2) {
+        // (>= 20.0: the window is exactly 1 at chi2 == 20)
+        if ((unsigned)__double2hiint(chi2) >= 0x40340000u) {
             const double au = (MAX_CHI2 - chi2) * APOD_IWIDTH;
             const double aq = fma(au, fma(au, 6.0, -15.0), 10.0);
             e *= (au * au) * (au * aq);
@@ -1204,7 +1213,7 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
                     fma(dcc * vd, vd, fma(drr * ud, ud, (mdrc2 * vd) * ud));
                 // a slot no lane of which is inside the weight's cut adds exact
                 // zeros to every sum: skipped whole (the rows beyond 5 sigma)
-                if (__ballot(chi2 < MAX_CHI2 && chi2 >= 0.0) == 0ull && !((nf_slots >> k) & 1ull))
+                if (__ballot(chi2_in_cut(chi2)) == 0ull && !((nf_slots >> k) & 1ull))
                     continue;
                 const double wdata = weight_fused(chi2, pa, sh.tab, K) * pval[k];
                 a[0] = fma(wdata, pv[k], a[0]);
@@ -1251,7 +1260,7 @@ __device__ __forceinline__ void admom_fused_body(const GridSrc &src,
                 const double vd = pv[k] - row, ud = pu[k] - col;
                 const double vv = vd * vd, uu = ud * ud, vu = vd * ud;
                 const double chi2 = fma(dcc, vv, fma(drr, uu, mdrc2 * vu));
-                if (__ballot(chi2 < MAX_CHI2 && chi2 >= 0.0) == 0ull && !((nf_slots >> k) & 1ull))
+                if (__ballot(chi2_in_cut(chi2)) == 0ull && !((nf_slots >> k) & 1ull))
                     continue;
                 const double weight = weight_fused(chi2, pa, sh.tab, K);
                 const double wdata = weight * pval[k];

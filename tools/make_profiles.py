@@ -109,6 +109,42 @@ for logname in ("iter.log", "lm.log"):
                if l.startswith(("admom", "em_run", "batched LM", "   mean"))]
         lines.append("# %s" % logname)
         lines.extend(txt)
+# ---- instruction-issue figures of the VALU-bound kernels, read by bench.py
+# next to each roofline block (as pmc_traffic.json is for the HBM bytes):
+#   valu_busy            = SQ_ACTIVE_INST_VALU x 4 cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)
+#   valu_insts_per_stamp = SQ_INSTS_VALU (wave instructions) of a launch with
+#                          every stamp running / the stamps of that launch
+def issue_figures(cs, n, busiest=False):
+    if not all(k in cs for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE")):
+        return None
+    mean = lambda v: sum(v) / len(v)
+    insts = max(cs["SQ_INSTS_VALU"]) if busiest else mean(cs["SQ_INSTS_VALU"])
+    fig = {"valu_busy": mean(cs["SQ_ACTIVE_INST_VALU"]) * 4.0 /
+                        (mean(cs["GRBM_GUI_ACTIVE"]) / 8.0 * 1024.0),
+           "valu_insts_per_stamp": insts / n, "stamps_per_launch": n,
+           "launches": len(cs["SQ_INSTS_VALU"])}
+    if "SQ_INSTS_SALU" in cs:
+        fig["salu_insts_per_stamp"] = (max(cs["SQ_INSTS_SALU"]) if busiest
+                                       else mean(cs["SQ_INSTS_SALU"])) / n
+    if "SQ_WAIT_INST_ANY" in cs and "SQ_WAVE_CYCLES" in cs:
+        fig["wait_inst_frac_of_wave_cycles"] = mean(cs["SQ_WAIT_INST_ANY"]) / \
+            mean(cs["SQ_WAVE_CYCLES"])
+    return fig
+
+
+valu = {"source": "profiles/%s_pmc_summary.txt" % tag,
+        "method": "valu_busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024); "
+                  "valu_insts_per_stamp = SQ_INSTS_VALU / stamps per launch (lm_eval: the "
+                  "launch with every fit running and the full pass); rocprofv3 --pmc "
+                  "passes of tools/run_prof.sh / run_prof_all.sh"}
+for k, cs in sorted(acc.items()):
+    fig = issue_figures(cs, nstamps, busiest=k.startswith("lm_eval"))
+    if fig:
+        valu[k] = fig
+fig = issue_figures(c5acc, 200000)
+if fig:
+    valu["c5:pixpass_wave_kernel7<0, false, 8>"] = fig
+json.dump(valu, open(os.path.join(out, "pmc_valu.json"), "w"), indent=1)
 open(os.path.join(out, "%s_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print("\n".join(lines[:60]))
