@@ -612,7 +612,7 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
 // each per-parameter array and the leading n x n block of R.  The record is
 // sized for NGMIX_LM_NPMAX = 14 parameters (2.9 kB); a six-parameter fit uses a
 // fifth of it, and lm_advance_kernel moves every record in and out once per
-// round.  (Entries beyond n keep the zeros lm_init wrote.)
+// round.  (Entries beyond n are never read: lm_init_kernel leaves them as allocated.)
 template <int ND, int NS, class D, class S>
 __device__ __forceinline__ void lm_state_copy_live(D &d, const S &g)
 {
@@ -1375,10 +1375,13 @@ struct LmInitPars {
     int n, maxfev, mode, has_bounds;
 };
 
-// lmcore::lm_init onto a ZERO-FILLED record (the launcher's hipMemsetAsync):
-// only what lm_init sets to something other than zero is written, straight to
-// the record -- a 2.9 kB private copy per thread, stored whole, cost three times
-// the traffic and 0.29 ms per 100k fits.
+// lmcore::lm_init, the LIVE part of the record only: the scalars, the first n
+// entries of every per-parameter array and the leading n x n block of R --
+// what a fit of n parameters ever reads.  The record is sized for
+// NGMIX_LM_NPMAX = 14 parameters (2.9 kB); zero-filling all of it first (round
+// 3: a 290 MB hipMemsetAsync per 100k fits, 0.33 ms of HBM time per batch, 5 %
+// of a config-3 step) wrote 2 kB per six-parameter fit that nothing reads.
+// The dead part keeps whatever the allocation held.
 __global__ __launch_bounds__(WAVE) void lm_init_kernel(lm_state *states, int64_t nobj,
                                                        const double *__restrict__ x0,
                                                        LmInitPars P)
@@ -1404,13 +1407,23 @@ __global__ __launch_bounds__(WAVE) void lm_init_kernel(lm_state *states, int64_t
         s.xti[j] = xi;
         s.xt[j] = xt;
         s.x[j] = xt;
+        double h = 0.0, xs = 0.0;
         if (P.mode == NGMIX_LM_MODE_FD) {
-            double h = EPS * fabs(xi);
+            h = EPS * fabs(xi);
             if (h == 0.0) h = EPS;
-            s.hstep[j] = h;
-            s.xstep[j] = bounded ? lmcore::i2e(xi + h, P.lo[j], P.hi[j]) : xi + h;
+            xs = bounded ? lmcore::i2e(xi + h, P.lo[j], P.hi[j]) : xi + h;
         }
+        s.hstep[j] = h;
+        s.xstep[j] = xs;
+        s.diag[j] = 0.0;
+        s.qtf[j] = 0.0;
+        s.step[j] = 0.0;
+        for (int k = 0; k < n; k++) s.R[j * LM_NPMAX + k] = 0.0;
     }
+    s.fnorm = s.xnorm = s.delta = s.par = s.gnorm = s.pnorm = 0.0;
+    s.nfev = s.njev = s.info = 0;
+    s.phase = LM_PHASE_INIT;
+    s.fonly = 0;
     s.ftol = P.ftol;
     s.xtol = P.xtol;
     s.gtol = P.gtol;
@@ -1420,7 +1433,6 @@ __global__ __launch_bounds__(WAVE) void lm_init_kernel(lm_state *states, int64_t
     s.bounded = bounded;
     s.maxfev = P.maxfev;
     s.iter = 1;
-    static_assert(LM_PHASE_INIT == 0, "the zero fill is the INIT phase");
 }
 
 int launch_lm_init(lm_state *states, int64_t nobj, int npars, const double *x0,
@@ -1442,7 +1454,6 @@ int launch_lm_init(lm_state *states, int64_t nobj, int npars, const double *x0,
         P.lo[j] = (lo && j < npars) ? lo[j] : -INFINITY;
         P.hi[j] = (hi && j < npars) ? hi[j] : INFINITY;
     }
-    NGMIX_HIP_CHECK(hipMemsetAsync(states, 0, (size_t)nobj * sizeof(lm_state), s));
     hipLaunchKernelGGL(lm_init_kernel, dim3((unsigned)((nobj + WAVE - 1) / WAVE)),
                        dim3(WAVE), 0, s, states, nobj, x0, P);
     NGMIX_HIP_CHECK(hipGetLastError());
