@@ -444,6 +444,8 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
             state["launched"] += fitter.rounds_launched
             for k, v in getattr(fitter, "kernel_ms", {}).items():
                 state["kernels"][k] = state["kernels"].get(k, 0.0) + v
+            for k, v in (fitter.host_ms or {}).items():
+                state.setdefault("host", {})[k] = state.setdefault("host", {}).get(k, 0.0) + v
             state["nsplit"] = fitter.nsplit_used
             state["rounds"] = fitter.rounds
             state["bad"] = int((res["flags"] != 0).sum())
@@ -509,6 +511,9 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
         # timed steps): what ms_per_step is to be read against
         "kernels_ms": {k: v / K for k, v in sorted(state["kernels"].items())},
         "kernels_ms_sum": sum(state["kernels"].values()) / K,
+        # what the host did per step: queueing, blocked on the downloads (> 0: the
+        # GPU is the bottleneck), packaging
+        "host_ms_per_step": {k: v / K for k, v in sorted(state.get("host", {}).items())},
         "rounds_launched": state["launched"] / float(K),
         "device_loop_ms": loop_ms, "rounds": rounds, "pipelined": pipelined,
         "fits_per_s_device_loop": n / (loop_ms * 1e-3) if loop_ms > 0 else None,
@@ -1357,7 +1362,8 @@ def main():
                         "bad_status") if k in o}
                     for k in ("rooflines", "mean_numiter", "device_loop_ms", "rounds",
                               "fits_per_s_device_loop", "mean_nfev", "ms_per_step",
-                              "kernels_ms_sum", "rounds_launched", "pipelined", "steps",
+                              "kernels_ms_sum", "host_ms_per_step", "rounds_launched",
+                              "pipelined", "steps",
                               "settle_steps", "n_gpus"):
                         if k in o:
                             other[name][k] = o[k]

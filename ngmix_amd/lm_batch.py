@@ -253,6 +253,13 @@ class LMBatchFitter(object):
         job = self._enqueue(stamps, guess, psf, stamp_obj, stamp_band, check_every, False)
         return self._collect(job)
 
+    # host time of the last batch, by what the host was doing (milliseconds):
+    # "enqueue" (set-up and queueing, _enqueue), "wait" (blocked on the batch's
+    # downloads: the GPU is the bottleneck while this is > 0), "package"
+    # (_collect after the wait) -- a pipeline keeps up as long as enqueue +
+    # package stays below the GPU's time per batch
+    host_ms = None
+
     def go_stream(self, batches, check_every=1):
         """
         Fit a SEQUENCE of batches as a software pipeline: a generator of result
@@ -311,10 +318,13 @@ class LMBatchFitter(object):
         # (the device context and the stream handle are looked up once per fit:
         # each torch.cuda.device(...) / current_stream() costs ~10 us of host
         # time, a tenth of a one-object fit when done per launch)
+        t0 = time.perf_counter()
         with torch.cuda.device(dev):
             job.stream = _stream()
-            return self._enqueue_on(job, stamps, guess, psf, stamp_obj, stamp_band,
-                                    check_every, streaming)
+            self._enqueue_on(job, stamps, guess, psf, stamp_obj, stamp_band,
+                             check_every, streaming)
+        job.host_enqueue_ms = (time.perf_counter() - t0) * 1e3
+        return job
 
     def _enqueue_on(self, job, stamps, guess, psf, stamp_obj, stamp_band, check_every,
                     streaming):
@@ -389,7 +399,14 @@ class LMBatchFitter(object):
             pieces += [("start", obj_start.view(np.uint8).reshape(-1)),
                        ("sobj", pad32(sobj).view(np.uint8).reshape(-1)),
                        ("sband", pad32(sband).view(np.uint8).reshape(-1))]
-        d_all = torch.from_numpy(np.concatenate([a for _, a in pieces])).to(dev)
+        # (through pinned memory, asynchronously: a copy from pageable memory
+        # makes torch synchronise the stream -- the host would wait there for
+        # everything queued before, i.e. for the previous batch of a pipeline,
+        # and the GPU would idle while the rest of this batch is being queued)
+        nbytes = sum(a.size for _, a in pieces)
+        h_all = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        np.concatenate([a for _, a in pieces], out=h_all.numpy())
+        d_all = h_all.to(dev, non_blocking=True)
         view, at = {}, 0
         for name, a in pieces:
             view[name] = d_all[at:at + a.size]
@@ -461,7 +478,7 @@ class LMBatchFitter(object):
             d_sstats=d_sstats, d_ostats=d_ostats, d_osums=d_osums, modnum=modnum,
             prior_desc=prior_desc, loop_stats=loop_stats, nsplit=nsplit, nsum=nsum,
             streaming=streaming, check_every=check_every, ev_init=ev_init,
-            npix_obj=npix_obj, d_npix=d_npix, d_all=d_all,
+            npix_obj=npix_obj, d_npix=d_npix, d_all=d_all, h_all=h_all,
             batch=stamps._batch(1), chunks=[], useful_rounds=None, ev_post=None,
             legacy_ev=None, loop_ms_host=0.0)
         # the host-free loop serves one piece with no prior or the kernel prior;
@@ -564,8 +581,11 @@ class LMBatchFitter(object):
     def _collect(self, job):
         """the host's half: wait for the downloads, make sure the rounds queued
         blind were enough (else run more and re-make the results), package"""
+        import time
         torch = _torch()
+        t0 = time.perf_counter()
         job.copied.synchronize()
+        t1 = time.perf_counter()
         if not job.host_loop:
             grow = 2
             total = sum(c[0] for c in job.chunks)
@@ -609,6 +629,8 @@ class LMBatchFitter(object):
         self._mark(job, "download")
         res = self._package(job)
         self._mark(job, "package")
+        self.host_ms = {"enqueue": job.host_enqueue_ms, "wait": (t1 - t0) * 1e3,
+                        "package": (time.perf_counter() - t1) * 1e3}
         return res
 
     def _kernel_times(self, job, before):
