@@ -90,7 +90,7 @@ for sub, name in (("bench_stats", "bench"), ("c3_stats", "c3"), ("c4_stats", "c4
         csv.writer(fo, quoting=csv.QUOTE_ALL).writerows(keep)
     lines.append("# rocprofv3 --kernel-trace --stats -- %s (ngmix kernels): calls, average ns"
                  % {"bench": "python3 bench.py --no-cpu-baseline --no-other-configs",
-                    "c3": "python3 bench.py --config C3 --steps 10 --warmup 2",
+                    "c3": "python3 bench.py --config C3 --steps 20 --warmup 2 --no-cpu-baseline",
                     "c4": "python3 bench.py --config C4 --steps 20 --warmup 5",
                     "c5": "python3 bench.py --config C5 --steps 50 --warmup 10",
                     "iter": "python3 tools/bench_iter.py 200000 3",

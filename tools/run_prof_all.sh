@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 # same kernel symbol as C2's and would mix into its average)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -o run -- python3 $ROOT/bench.py --no-cpu-baseline --no-other-configs > $OUT/bench_under_rocprof.json 2> $OUT/bench_stats.log
 # 2b. configs 3, 4 and 5 through the same bench.py, each with its own kernel stats
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_stats -o run -- python3 $ROOT/bench.py --config C3 --steps 10 --warmup 2 > $OUT/bench_c3_under_rocprof.json 2> $OUT/c3_stats.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_stats -o run -- python3 $ROOT/bench.py --config C3 --steps 20 --warmup 2 --no-cpu-baseline > $OUT/bench_c3_under_rocprof.json 2> $OUT/c3_stats.log
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_stats -o run -- python3 $ROOT/bench.py --config C4 --steps 20 --warmup 5 > $OUT/bench_c4_under_rocprof.json 2> $OUT/c4_stats.log
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_stats -o run -- python3 $ROOT/bench.py --config C5 --steps 50 --warmup 10 > $OUT/bench_c5_under_rocprof.json 2> $OUT/c5_stats.log
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_c5fetch -o run -- python3 $ROOT/bench.py --config C5 --steps 3 --warmup 1 --settle-steps 0 > /dev/null 2> $OUT/pmc_c5fetch.log
@@ -29,7 +29,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_lm -o run -- python3 $ROOT/tools/bench_lm.py 100000 0 > $OUT/pmc_lm.log 2>&1
 cd $ROOT
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-python bench.py --config C3 --steps 20 > $OUT/bench_c3.json 2>> $OUT/bench.err
+python bench.py --config C3 --steps 60 > $OUT/bench_c3.json 2>> $OUT/bench.err
 python bench.py --config C4 > $OUT/bench_c4.json 2>> $OUT/bench.err
 python bench.py --config C5 > $OUT/bench_c5.json 2>> $OUT/bench.err
 ls $OUT
