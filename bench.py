@@ -303,6 +303,19 @@ def run_c2(args, rank, world, device, backend):
     bad = int((status != 0).sum().item())
     render_ms = _mean_ms(ev_r0, ev_r1)
     loglike_ms = _mean_ms(ev_l0, ev_l1)
+    # outside the timed region: the write-only form of the render (what
+    # GMix.make_image / StampBatch.render(image=None) run: the model is stored
+    # without the image being read -- NGMIX_BATCH_RENDER_OVERWRITE), 20 launches
+    fe0, fe1 = _events(20), _events(20)
+    for k in range(25):
+        if k >= 5:
+            fe0[k - 5].record()
+        fresh, _ = sb.render(gm, image=None, fast_exp=True, status=status, exact=args.exact)
+        if k >= 5:
+            fe1[k - 5].record()
+    torch.cuda.synchronize()
+    fresh_ms = _mean_ms(fe0, fe1)
+    del fresh
     if rank != 0:
         return None
 
@@ -357,6 +370,10 @@ def run_c2(args, rank, world, device, backend):
                          else "pixpass_wave_kernel<2, false, 16>"),
         },
         "kernels_ms": {"render": render_ms, "loglike": loglike_ms},
+        # the fresh (write-only) render, not part of `value`: 18,432 B written per stamp
+        "fresh_render": {"ms": fresh_ms, "stamp_renders_per_s_per_gpu": n / (fresh_ms * 1e-3),
+                         "hbm_frac": (RENDER_BYTES / 2) * n / (fresh_ms * 1e-3) / 1e9 /
+                         HBM_PEAK_GBS},
         "loglike_stamp_evals_per_s_per_gpu": n / (loglike_ms * 1e-3),
         "render_stamp_evals_per_s_per_gpu": n / (render_ms * 1e-3),
         "loglike_hbm_frac": LOGLIKE_BYTES * n / (loglike_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -728,16 +728,20 @@ def _writeback_gm(gm_data, gmb):
     gm_data[:] = gmb.to_numpy()[0]
 
 
-def render_single(gm_data, image, jac_record, fast_exp, exact=False):
-    """ADD the mixture into a host image (GMix._fill_image)"""
+def render_single(gm_data, image, jac_record, fast_exp, exact=False, fresh=False):
+    """ADD the mixture into a host image (GMix._fill_image); fresh: the image
+    is known to be zeros (GMix.make_image, gmix.py:561-562) -- nothing is
+    uploaded and the kernel writes the model without reading the buffer
+    (NGMIX_BATCH_RENDER_OVERWRITE: bit-identical to zeros + accumulate)"""
     torch = _torch()
     dev = _require_cuda(None)
     nrow, ncol = image.shape
     jac = np.ascontiguousarray(jac_record).view(np.float64).reshape(1, 8)
     sb = StampBatch(None, None, _as_device_f64(jac, dev), [nrow], [ncol], [0], True)
     gmb = _gm_batch(gm_data, dev)
-    dimg = torch.from_numpy(np.ascontiguousarray(image, dtype="f8").ravel()).to(dev)
-    _, status = sb.render(gmb, image=dimg, fast_exp=fast_exp, exact=exact)
+    dimg = None if fresh else \
+        torch.from_numpy(np.ascontiguousarray(image, dtype="f8").ravel()).to(dev)
+    dimg, status = sb.render(gmb, image=dimg, fast_exp=fast_exp, exact=exact)
     _raise_status(status, "render")
     _writeback_gm(gm_data, gmb)
     image[:, :] = dimg.cpu().numpy().reshape(nrow, ncol)

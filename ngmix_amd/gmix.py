@@ -388,10 +388,12 @@ class GMix(object):
         if dims.size != 2:
             raise ValueError("images must have two dimensions, got %s" % str(dims))
         image = _np.zeros(dims, dtype="f8")
-        self._fill_image(image, jacobian=jacobian, fast_exp=fast_exp)
+        # (a fresh image: the overwriting form of the render kernel -- no upload
+        # of the zeros, no read of the buffer; bit-identical to zeros + add)
+        self._fill_image(image, jacobian=jacobian, fast_exp=fast_exp, fresh=True)
         return image
 
-    def _fill_image(self, image, jacobian=None, fast_exp=False):
+    def _fill_image(self, image, jacobian=None, fast_exp=False, fresh=False):
         """ADD the rendered mixture into image (render_nb.py:9-36)"""
         from .jacobian import Jacobian, UnitJacobian
         from .batch import render_single
@@ -401,7 +403,7 @@ class GMix(object):
         else:
             assert isinstance(jacobian, Jacobian)
         self.set_norms_if_needed()
-        render_single(self._data, image, jacobian._data, fast_exp, exact=_EXACT)
+        render_single(self._data, image, jacobian._data, fast_exp, exact=_EXACT, fresh=fresh)
 
     def get_loglike(self, obs, more=False):
         self.set_norms_if_needed()
