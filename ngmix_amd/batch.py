@@ -24,8 +24,38 @@ def _torch():
 
 
 def _stream():
+    """the current stream of the current device as a hipStream_t (the raw
+    handle straight from torch's C layer: torch.cuda.current_stream() builds a
+    Stream object per call, ~9 us -- a tenth of a one-object fit's host time
+    when every launch asks for it)"""
     torch = _torch()
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        return ctypes.c_void_p(raw(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _on_device(object):
+    """torch.cuda.device(dev) only when dev is not already the current device
+    (entering and leaving that context costs ~12 us; nearly every call here is
+    made on the current device)"""
+
+    def __init__(self, dev):
+        torch = _torch()
+        idx = dev.index if hasattr(dev, "index") else int(dev)
+        self._ctx = None
+        if idx is not None and idx != torch.cuda.current_device():
+            self._ctx = torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            return self._ctx.__exit__(*exc)
+        return False
 
 
 def _dptr(t):
@@ -115,7 +145,7 @@ class GMixBatch(object):
         extra = None
         if cm_extra is not None:
             extra = _as_device_f64(cm_extra, dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             st = _lib.lib().ngmix_fill_model_batch(
                 _dptr(out.data), n, ngauss, modnum, _dptr(pars), npars,
                 _dptr(extra), _dptr(status), _stream())
@@ -129,7 +159,7 @@ class GMixBatch(object):
         assert psf.n == self.n
         out = GMixBatch.empty(self.n, self.ngauss * psf.ngauss, self.device)
         status = torch.zeros(self.n, dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             st = _lib.lib().ngmix_convolve_fill_batch(
                 _dptr(out.data), _dptr(self.data), self.ngauss, _dptr(psf.data),
                 psf.ngauss, self.n, _dptr(status), _stream())
@@ -140,7 +170,7 @@ class GMixBatch(object):
         """gmix_set_norms per stamp (gmix_nb.py:176-218); returns status"""
         torch = _torch()
         status = torch.zeros(self.n, dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             st = _lib.lib().ngmix_set_norms_batch(
                 _dptr(self.data), self.ngauss, self.n, _dptr(status), _stream())
         _lib.check(st, "ngmix_set_norms_batch")
@@ -203,7 +233,7 @@ class StampBatch(object):
             self.npix_kept = np.ascontiguousarray(npix_kept, dtype=np.int32)
         elif ierr is not None and self.n:
             tab = self._make_table(self.npix_kept, 0, 0)
-            with torch.cuda.device(self.device):
+            with _on_device(self.device):
                 st = _lib.lib().ngmix_count_kept_batch(
                     _dptr(tab), self.n, _dptr(self.ierr), _stream())
             _lib.check(st, "ngmix_count_kept_batch")
@@ -235,7 +265,7 @@ class StampBatch(object):
                 w = w[None]
             assert w.shape == val.shape, "image and weight must match"
             ierr = torch.empty_like(w)
-            with torch.cuda.device(dev):
+            with _on_device(dev):
                 st = _lib.lib().ngmix_weight_to_ierr_batch(
                     _dptr(w), _dptr(ierr), w.numel(), _stream())
             _lib.check(st, "ngmix_weight_to_ierr_batch")
@@ -265,7 +295,7 @@ class StampBatch(object):
         # from the host weights instead of by a kernel and a read-back
         tot = int(npix.sum())
         n = len(obs_list)
-        host = np.empty(2 * tot + 8 * n)
+        host = np.empty(2 * tot + 8 * n + 4 * n)      # ... | stamp table (32 B records)
         kept = np.empty(n, dtype=np.int32)
         for i, o in enumerate(obs_list):
             a, b = int(off[i]), int(off[i] + npix[i])
@@ -275,16 +305,28 @@ class StampBatch(object):
             kept[i] = np.count_nonzero(w > 0.0) if izw[i] else npix[i]
             host[2 * tot + 8 * i:2 * tot + 8 * i + 8] = \
                 o._jacobian._data.view(np.float64).reshape(8)
+        # (the stamp table of one-gaussian-per-stamp mixtures -- what the lock-step
+        # fits and the moments kernels ask for -- rides along: one upload less)
+        tab = np.zeros(n, dtype=_lib.STAMP_DTYPE)
+        tab["pix_off"], tab["nrow"], tab["ncol"] = off, nrow, ncol
+        tab["gm_off"] = np.arange(n, dtype=np.int32)
+        tab["ngauss"] = 1
+        tab["flags"] = np.where(izw, _lib.STAMP_IGNORE_ZERO_WEIGHT, 0)
+        tab["npix_kept"] = kept
+        host[2 * tot + 8 * n:] = tab.view(np.float64)
         dev_all = torch.from_numpy(host).to(dev)
         dval = dev_all[:tot]
         dw = dev_all[tot:2 * tot]
-        djac = dev_all[2 * tot:].reshape(n, 8)
+        djac = dev_all[2 * tot:2 * tot + 8 * n].reshape(n, 8)
+        dtab = dev_all[2 * tot + 8 * n:].view(torch.int32).reshape(n, 8)
         ierr = torch.empty_like(dw)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             st = _lib.lib().ngmix_weight_to_ierr_batch(
                 _dptr(dw), _dptr(ierr), dw.numel(), _stream())
         _lib.check(st, "ngmix_weight_to_ierr_batch")
-        return cls(dval, ierr, djac, nrow, ncol, off, izw, npix_kept=kept)
+        sb = cls(dval, ierr, djac, nrow, ncol, off, izw, npix_kept=kept)
+        sb._stamp_tables[1] = dtab
+        return sb
 
     @classmethod
     def from_observations_geometry(cls, obs_list, device=None):
@@ -412,7 +454,7 @@ class StampBatch(object):
         if status is None:
             status = torch.empty(self.n, dtype=torch.int32, device=self.device)
         b = self._batch(gm.ngauss, no_skip, exact)
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             st = _lib.lib().ngmix_loglike_batch(
                 ctypes.byref(b), _dptr(gm.data), _dptr(out), _dptr(status),
                 _stream())
@@ -464,7 +506,7 @@ class StampBatch(object):
         if status is None:
             status = torch.empty(self.n, dtype=torch.int32, device=self.device)
         b = self._batch(gm.ngauss, no_skip, exact)
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             st = _lib.lib().ngmix_fill_fdiff_batch(
                 ctypes.byref(b), _dptr(gm.data), _dptr(fdiff),
                 _dptr(fdiff_start), _dptr(status), _stream())
@@ -497,7 +539,7 @@ class StampBatch(object):
         b = self._batch(gm.ngauss, no_skip, exact)
         if overwrite:
             b.flags |= _lib.BATCH_RENDER_OVERWRITE
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             st = _lib.lib().ngmix_render_batch(
                 ctypes.byref(b), _dptr(gm.data), _dptr(image), int(fast_exp),
                 _dptr(status), _stream())
@@ -513,7 +555,7 @@ class StampBatch(object):
         if status is None:
             status = torch.empty(self.n, dtype=torch.int32, device=self.device)
         b = self._batch(gm.ngauss, False, exact)
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             st = _lib.lib().ngmix_model_s2n_sum_batch(
                 ctypes.byref(b), _dptr(gm.data), _dptr(out), _dptr(status),
                 _stream())
@@ -544,7 +586,7 @@ class StampBatch(object):
                                                 (self.n,)).copy(), self.device) \
             if not isinstance(maxrad, torch.Tensor) else maxrad
         b = self._batch(wt.ngauss, False, exact)
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             st = _lib.lib().ngmix_weighted_sums_batch(
                 ctypes.byref(b), _dptr(wt.data), _dptr(res), nmom, _dptr(maxrad),
                 _dptr(status), _stream())
@@ -575,7 +617,7 @@ class StampBatch(object):
         if status is None:
             status = torch.empty(self.n, dtype=torch.int32, device=self.device)
         b = self._batch(1)
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             st = _lib.lib().ngmix_admom_batch(
                 _lib.ptr(conf), ctypes.byref(b), _dptr(wt.data), _dptr(res),
                 _dptr(status), _stream())
@@ -609,7 +651,7 @@ class StampBatch(object):
         if status is None:
             status = torch.empty(self.n, dtype=torch.int32, device=self.device)
         b = self._batch(conv.ngauss)
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             st = _lib.lib().ngmix_em_batch(
                 int(kind), _lib.ptr(conf), ctypes.byref(b), _dptr(gm.data),
                 gm.ngauss, _dptr(psf.data), psf.ngauss, _dptr(conv.data),
@@ -683,7 +725,7 @@ class StampBatch(object):
         gpars = _as_device_f64(gpars, self.device)
         dcov = _as_device_f64(dcov, self.device)
         b = self._batch(ngauss)
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             st = _lib.lib().ngmix_deriv_images_batch(
                 ctypes.byref(b), _dptr(gpars), _dptr(dcov), _dptr(out),
                 _dptr(out_start), _stream())

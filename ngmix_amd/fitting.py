@@ -761,7 +761,8 @@ class Fitter(object):
         if fm.dopsf:
             if len({len(p) for p in fm._psf_list}) != 1:
                 return False
-            psf = GMixBatch.from_numpy(np.stack([p._data for p in fm._psf_list]))
+            # (host records: they ride in the driver's one upload per fit)
+            psf = np.stack([p._data for p in fm._psf_list])
         if self._batch_fitter is None:
             self._batch_fitter = LMBatchFitter(
                 spec[0], fit_pars=self.fit_pars, ngauss=spec[1],

@@ -36,7 +36,7 @@ import os
 import numpy as np
 
 from . import _lib
-from .batch import GMixBatch, _dptr, _stream, _torch
+from .batch import GMixBatch, _dptr, _stream, _torch, _on_device
 from .defaults import PDEF, CDEF, DEFAULT_LM_PARS
 from .gmix import get_model_num
 from .fitting import get_lm_n_prior_pars, STEP_PRIOR
@@ -319,7 +319,7 @@ class LMBatchFitter(object):
         # each torch.cuda.device(...) / current_stream() costs ~10 us of host
         # time, a tenth of a one-object fit when done per launch)
         t0 = time.perf_counter()
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             job.stream = _stream()
             self._enqueue_on(job, stamps, guess, psf, stamp_obj, stamp_band,
                              check_every, streaming)
@@ -367,7 +367,13 @@ class LMBatchFitter(object):
         if np.any(np.diff(obj_start) == 0):
             raise ValueError("every object needs at least one stamp")
         npsf = 0
-        if psf is not None:
+        psf_host = None
+        if psf is not None and isinstance(psf, np.ndarray):
+            # host gauss2d records (nstamps, npsf): uploaded with the batch's
+            # other small arrays (Fitter.go's one-object batches)
+            psf_host = np.ascontiguousarray(psf, dtype=_lib.GAUSS2D_DTYPE).reshape(ns, -1)
+            npsf = psf_host.shape[1]
+        elif psf is not None:
             assert psf.n == ns, "one psf mixture per stamp"
             npsf = psf.ngauss
 
@@ -394,6 +400,8 @@ class LMBatchFitter(object):
         ns_pad = (ns + 1) // 2 * 2
         pieces = [("guess", guess.view(np.uint8).reshape(-1)),
                   ("npix", npix_obj.view(np.uint8).reshape(-1))]
+        if psf_host is not None:
+            pieces.append(("psf", psf_host.view(np.uint8).reshape(-1)))
         if need_maps:
             pad32 = lambda a: np.concatenate([a, np.zeros(ns_pad - ns, dtype=np.int32)])
             pieces += [("start", obj_start.view(np.uint8).reshape(-1)),
@@ -413,6 +421,8 @@ class LMBatchFitter(object):
             at += a.size
         d_guess = view["guess"].view(torch.float64).reshape(nobj, npars)
         d_npix = view["npix"].view(torch.int64)
+        if psf_host is not None:
+            psf = GMixBatch(view["psf"].view(torch.float64).reshape(-1, 13), ns, npsf)
         d_sobj = d_sband = d_start = None
         if need_maps:
             d_start = view["start"].view(torch.int64)
