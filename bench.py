@@ -472,7 +472,13 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
                                   res["nfev"][:, None].astype("f8"), res["pars"],
                                   res["pars_err"]], axis=1)
             gat.wait_consumed()
-            gat.gather("lm", torch.from_numpy(rec).to(device))
+            # (through pinned memory, asynchronously: a copy from pageable memory
+            # synchronises the stream, i.e. would make this rank's host wait for
+            # the batch it has just queued)
+            pin = state.setdefault("pin", torch.empty(rec.shape, dtype=torch.float64,
+                                                      pin_memory=True))
+            pin.numpy()[:] = rec
+            gat.gather("lm", pin.to(device, non_blocking=True))
 
     # what one synchronous call spends in its lock-step loop (kernels + the
     # counter read-backs), measured before the pipeline starts
