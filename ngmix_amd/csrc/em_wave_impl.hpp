@@ -233,7 +233,10 @@ __device__ __forceinline__ void em_wave_body(
     constexpr bool kFullForm = NT == WAVE && NPSF == 1 && NG == 1 && PPT < 64;
     bool full = false;
     if constexpr (kFullForm)
-        full = __ballot(kept == ((1ull << PPT) - 1ull)) == ~0ull && n == PPT * NT;
+        // (bit 1 of fill_zero_weight: the launcher's A/B and test knob
+        // NGMIX_EM_NO_FULL -- the general form on full waves too)
+        full = __ballot(kept == ((1ull << PPT) - 1ull)) == ~0ull && n == PPT * NT &&
+               !(fill_zero_weight & 2);
 
     if (lane < 16) {
         sh.tab[lane] = c_exp_table_e[lane];
@@ -338,7 +341,7 @@ __device__ __forceinline__ void em_wave_body(
 
         // fill_zero_weight_pixels overwrites val of the zero-weight pixels
         // with sky + model, as the reference does in its pixel copy
-        if (fill_zero_weight && zw != 0ull) {
+        if ((fill_zero_weight & 1) && zw != 0ull) {
             // (opaque to the optimiser: sixteen loop-invariant EXEC masks would
             // otherwise live in SGPRs across the whole iteration loop)
             unsigned zlo = (unsigned)zw, zhi = (unsigned)(zw >> 32);
@@ -677,6 +680,8 @@ static void em_wave_launch_nt(const ngmix_em_conf *conf, const ngmix_batch *b,
                  npsf == 1 ? 1 : (npsf == 3 && NG <= 3 && NT == WAVE) ? 3 : 0);
         census(name);
     }
+    static const bool no_full = getenv("NGMIX_EM_NO_FULL") != nullptr;
+    if (no_full) fzw |= 2;
     if (npsf == 1)
         hipLaunchKernelGGL((em_wave_kernel<NT, PPT, KIND, NG, 1>),
                            dim3((unsigned)b->nstamps), dim3(NT), lds, s, *conf,

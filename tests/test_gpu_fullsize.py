@@ -218,6 +218,14 @@ def test_c3_full_size(bench):
     assert np.array_equal(r2["nfev"], res["nfev"][sub])
     assert np.array_equal(r2["pars"], res["pars"][sub])
     assert np.array_equal(r2["pars_cov"], res["pars_cov"][sub])
+    # the default mode leaves the jacobian out of the trials predicted to end a
+    # fit (here: the fourth pixel pass of nearly every fit); with the jacobian
+    # at every evaluation the fits are the same, to the bit
+    eager = LMBatchFitter("exp")
+    eager.lazy_jacobian = False
+    r3 = eager.go(sb.select(sub), guess[sub], psf=psf.select(sub))
+    for key in ("nfev", "njev", "ier", "flags", "pars", "pars_cov", "lnprob", "s2n"):
+        assert np.array_equal(r3[key], r2[key], equal_nan=True), key
 
     # a sample against the per-object Fitter: scipy's MINPACK calling the exact
     # (reference-order) fdiff / jacobian kernels once per function evaluation

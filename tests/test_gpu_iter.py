@@ -805,3 +805,46 @@ def test_admom_nonfinite_pixel_outside_the_weight(shape, bad):
         assert res["numiter"][i] == r["numiter"][0]
         for f in ("sums", "pars"):
             np.testing.assert_array_equal(np.isfinite(res[f][i]), np.isfinite(r[f][0]), err_msg=f)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_em_full_wave_form_is_the_general_form_to_the_bit(kind, monkeypatch):
+    """the one-gaussian one-wave kernels run a pixel pass without per-slot masks,
+    the component and the sky in SGPRs, when every slot of every lane holds a
+    listed pixel (32x32 stamps): the same expressions as the general form --
+    numiter, frac_diff, sky and the mixtures are the same BYTES
+    (NGMIX_EM_NO_FULL sends full waves through the general form; a second
+    process, since the knob is read once)"""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import ngmix_amd as ngmix
+from ngmix_amd.batch import StampBatch, GMixBatch
+rng = np.random.RandomState(17)
+n, dim, scale, sky = 64, 32, 0.263, 0.01
+obs = []
+for k in range(n):
+    jac = ngmix.DiagonalJacobian(row=15.5 + rng.uniform(-0.4, 0.4), col=15.5 + rng.uniform(-0.4, 0.4), scale=scale)
+    gm = ngmix.GMixModel([rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), rng.uniform(-0.1, 0.1),
+                          rng.uniform(-0.1, 0.1), rng.uniform(0.4, 0.9), 30.0], "gauss")
+    im = gm.make_image((dim, dim), jacobian=jac) + sky + 0.001 * rng.normal(size=(dim, dim))
+    obs.append(ngmix.Observation(im, weight=np.full((dim, dim), 1.0e6), jacobian=jac))
+sb = StampBatch.from_observations(obs)
+g = np.zeros((n, 6)); g[:, 4] = rng.uniform(0.3, 0.6, size=n); g[:, 5] = 30.0 * scale ** 2
+gm0, _ = GMixBatch.from_pars(g, "gauss")
+psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.05, 1.0], (n, 1)), "gauss")
+out, status, conv = sb.em(gm0, psf, sky=sky, kind=%d, miniter=20 if %d != 3 else 5, maxiter=60, tol=1e-6)
+assert int(status.abs().sum()) == 0
+sys.stdout.buffer.write(out.cpu().numpy().tobytes() + gm0.to_numpy().tobytes() + conv.to_numpy().tobytes())
+""" % (root, kind, kind)
+    env = {k: v for k, v in os.environ.items() if k != "NGMIX_EM_NO_FULL"}
+    a = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=280)
+    assert a.returncode == 0, a.stderr[-2000:]
+    b = subprocess.run([sys.executable, "-c", code], env=dict(env, NGMIX_EM_NO_FULL="1"),
+                       capture_output=True, timeout=280)
+    assert b.returncode == 0, b.stderr[-2000:]
+    assert len(a.stdout) > 64 * 3 * 8 and a.stdout == b.stdout
