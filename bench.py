@@ -1394,8 +1394,8 @@ def main():
                             other[name][k] = o[k]
                     other[name]["per_rank_ms_per_step"] = list(PER_RANK_MS)
             except Exception as e:   # never lose the headline line
-                if world > 1:
-                    raise              # (a rank that stops would hang the others)
+                # (at N > 1 a failure in the leg's own code is the same on every
+                # rank: all of them record it and go on to the next leg)
                 other[name] = {"error": repr(e)}
             torch.cuda.empty_cache()
     if rank == 0:
