@@ -42,21 +42,56 @@ struct lm_state_n {
 
 #define LMREG_UNROLL _Pragma("unroll")
 
+// On the device every element goes through an empty asm before the select
+// chain: left as plain loads, LLVM folds "select of loads" into ONE load from a
+// selected address -- a run-time index into the array after all, which pins
+// the array (for a member: the whole state) in private memory.  (Found in
+// round 4 in the IR of lm_advance_kernel<6, true>: 59 dynamically indexed
+// accesses, 912 B of scratch holding the state the "register form" was meant
+// to keep in registers.)  Only up to six parameters: from seven on the state
+// no longer fits 512 registers and the allocator's spills cost more than the
+// indexed private array did (tools/lm_advance_sweep.py, per launch at 50k
+// fits: n=6 0.054 -> 0.047 ms, n=8 0.095 -> 0.109 ms).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LMREG_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define LMREG_OPAQUE(x) ((void)0)
+#endif
+
 // a[idx] / a[idx] = v for a run-time idx in [0, N) without indexing memory
 template <int N, class T>
 NGMIX_HD T dget(const T (&a)[N], int idx)
 {
     T r = a[0];
-    LMREG_UNROLL
-    for (int k = 1; k < N; k++) r = (idx == k) ? a[k] : r;
+    if constexpr (N <= 6) {
+        LMREG_OPAQUE(r);
+        LMREG_UNROLL
+        for (int k = 1; k < N; k++) {
+            T ak = a[k];
+            LMREG_OPAQUE(ak);
+            r = (idx == k) ? ak : r;
+        }
+    } else {
+        LMREG_UNROLL
+        for (int k = 1; k < N; k++) r = (idx == k) ? a[k] : r;
+    }
     return r;
 }
 
 template <int N, class T>
 NGMIX_HD void dset(T (&a)[N], int idx, T v)
 {
-    LMREG_UNROLL
-    for (int k = 0; k < N; k++) a[k] = (idx == k) ? v : a[k];
+    if constexpr (N <= 6) {
+        LMREG_UNROLL
+        for (int k = 0; k < N; k++) {
+            T ak = a[k];
+            LMREG_OPAQUE(ak);
+            a[k] = (idx == k) ? v : ak;
+        }
+    } else {
+        LMREG_UNROLL
+        for (int k = 0; k < N; k++) a[k] = (idx == k) ? v : a[k];
+    }
 }
 
 template <int N>

@@ -1,0 +1,36 @@
+"""lm_advance_kernel<N> per launch for N = 6..10 (an "exp" fit over 1..5
+bands): HIP-event time of the advance launches and of the whole fit.
+usage: python tools/lm_advance_sweep.py [nobj]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402
+from ngmix_amd.batch import GMixBatch  # noqa: E402
+from ngmix_amd.lm_batch import LMBatchFitter  # noqa: E402
+
+nobj = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
+for nband in (1, 2, 3, 4, 5):
+    ns = nobj * nband
+    sb, _, pars = bench.make_workload(ns, 1000, "cuda")
+    rng = np.random.RandomState(7)
+    # every band of an object shows the object's first stamp's galaxy: keep
+    # the shape of stamp i*nband, one flux per band
+    shape = pars[::nband, :5]
+    guess = np.concatenate([shape, pars[:, 5].reshape(nobj, nband)], axis=1)
+    guess = guess * rng.uniform(0.95, 1.05, size=guess.shape)
+    psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (ns, 1)), "gauss")
+    sobj = np.repeat(np.arange(nobj), nband)
+    sband = np.tile(np.arange(nband), nobj)
+    f = LMBatchFitter("exp")
+    f.time_kernels = True
+    for _ in range(3):
+        res = f.go(sb, guess, psf=psf, stamp_obj=sobj, stamp_band=sband)
+    torch.cuda.synchronize()
+    k = f.kernel_ms
+    print("n=%2d  rounds %2d  lm_advance %.3f ms/launch  (total %.2f ms; lm_eval %.2f ms)  flags==0: %.3f"
+          % (5 + nband, f.rounds_launched, k["lm_advance"] / f.rounds_launched, k["lm_advance"],
+             k["lm_eval"], float(np.mean(res["flags"] == 0))))
