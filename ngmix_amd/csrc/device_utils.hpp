@@ -36,15 +36,16 @@ __device__ __forceinline__ double wave_sum(double x)
 
 // ---- the fused fexp evaluator (pixpass.hip, moments.hip, em.hip, lmfit.hip) ------------------------
 // exp5_smooth coefficients c0..c5 (fastexp_nb.py:252-258) followed by the
-// apodisation constants 10, -15, 6: read with scalar loads so that they live
+// apodisation constants 10, -15, 6 and (the window in b = 0.8 u, pixpass.hip)
+// -0.32, 1/15, 9.375/0.512: read with scalar loads so that they live
 // in SGPRs and every Horner step is a single v_fma_f64 v, v, v, s
 #define NGMIX_FEXP_COEF                                                      \
     {1.0000011318561302,  0.999993601071577,    0.49992478810274166,        \
      0.16674612720799442, 0.042330947141114836, 0.008197933236258961,       \
-     10.0, -15.0, 6.0}
+     10.0, -15.0, 6.0, -0.32, 1.0 / 15.0, 9.375 / 0.512}
 
 struct FexpCoef {
-    double c0, c1, c2, c3, c4, c5, w10, wm15, w6;
+    double c0, c1, c2, c3, c4, c5, w10, wm15, w6, wb, wq, wk;
     int c5lo, c5hi, w6lo, w6hi;
 };
 
@@ -57,6 +58,7 @@ __device__ __forceinline__ FexpCoef load_fexp_coef(const double *coef)
     FexpCoef k;
     k.c0 = c[0]; k.c1 = c[1]; k.c2 = c[2]; k.c3 = c[3]; k.c4 = c[4]; k.c5 = c[5];
     k.w10 = c[6]; k.wm15 = c[7]; k.w6 = c[8];
+    k.wb = c[9]; k.wq = c[10]; k.wk = c[11];
     // a VOP3 instruction reads at most one SGPR pair: the multiplicands of the
     // two-constant steps live in VGPRs (opaque moves, so they stay there)
     asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"

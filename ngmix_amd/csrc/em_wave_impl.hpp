@@ -634,7 +634,7 @@ __device__ __forceinline__ void em_wave_body(
     }
 }
 
-static __constant__ double c_fexp_coef_e[9] = NGMIX_FEXP_COEF;
+static __constant__ double c_fexp_coef_e[12] = NGMIX_FEXP_COEF;
 
 // (the one-gaussian one-wave kernels are held to the three waves per SIMD
 // they were tuned at: 168 registers; every other form takes what it needs)

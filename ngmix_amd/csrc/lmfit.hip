@@ -31,7 +31,7 @@ namespace ngmix {
 
 __constant__ ModelTables c_tables_lm = NGMIX_MODEL_TABLES;
 __constant__ double c_exp_table_lm[16] = NGMIX_EXP_TABLE;
-__constant__ double c_fexp_coef_lm[9] = NGMIX_FEXP_COEF;
+__constant__ double c_fexp_coef_lm[12] = NGMIX_FEXP_COEF;
 
 constexpr int LM_NSUM = NGMIX_LM_NSUM;  // 21 + 6 + 1
 

@@ -17,7 +17,7 @@
 namespace ngmix {
 
 __constant__ double c_exp_table_m[16] = NGMIX_EXP_TABLE;
-__constant__ double c_fexp_coef_m[9] = NGMIX_FEXP_COEF;
+__constant__ double c_fexp_coef_m[12] = NGMIX_FEXP_COEF;
 
 // ===========================================================================
 // weighted sums

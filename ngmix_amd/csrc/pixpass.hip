@@ -27,7 +27,7 @@ __constant__ double c_exp_table[16] = NGMIX_EXP_TABLE;
 // exp5_smooth coefficients c0..c5 (fastexp_nb.py:252-258) followed by the
 // apodisation constants 10, -15, 6: read with scalar loads so that they live
 // in SGPRs and every Horner step is a single v_fma_f64 v, v, v, s
-__constant__ double c_fexp_coef[9] = NGMIX_FEXP_COEF;
+__constant__ double c_fexp_coef[12] = NGMIX_FEXP_COEF;
 
 enum PassOp { OP_LOGLIKE = 0, OP_FDIFF = 1, OP_RENDER_FAST = 2,
               OP_RENDER_EXACT = 3, OP_S2N = 4 };
@@ -312,12 +312,27 @@ __global__ __launch_bounds__(BLOCK) void pixpass_grid_kernel(
 // are the reference's; only the rounding of individual operations differs.
 // ===========================================================================
 
+// The chi2 < 25 box of a gaussian as the tile test reads it: a tile whose first
+// pixel is (r0, c0) reaches the box when r0 is in [rmin - (TH-1), rmax], i.e.
+// (unsigned)(r0 - r_lo) <= r_span -- one subtraction and one compare per axis.
+struct TileBox {
+    int r_lo;
+    unsigned r_span;
+    int c_lo;
+    unsigned c_span;
+};
+
+// In the 64 B per gaussian of the LDS layout: 48-byte records first, then the
+// boxes, 16 B apart -- the box test reads lane g's box, and inside 64-byte
+// records those reads fell on two banks (8-way conflicts on a 16-gaussian
+// stamp: a quarter of the LDS cycles of config 5, rocprofv3
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, round 4).
 struct GaussFused {
     double a, b, c, pa;  // y = chi2/2 = a dv^2 + b du^2 + c dv du ; pa = pnorm*area
     double row, col;
-    PixBox box;
 };
-static_assert(sizeof(GaussFused) == 64, "GaussFused");
+static_assert(sizeof(GaussFused) == 48, "GaussFused");
+static_assert(sizeof(GaussFused) + sizeof(TileBox) == sizeof(GaussLds), "LDS budget");
 
 constexpr int FUSED_PF = 4;         // register sets: tiles requested ahead
 constexpr int FUSED_SENTINELS = 8;  // look-ahead past the last tile
@@ -406,7 +421,8 @@ __device__ __forceinline__ void wait_vm_all(double &a, double &b, double &c, dou
 // definite and shares one centre.
 template <int OP, bool MASKED, bool FAST, bool FULL, int TW>
 __device__ __forceinline__ void wave_tiles(
-    const LdsLayout &L, const GaussFused *gf, const TileEnt *te, int ng,
+    const LdsLayout &L, const GaussFused *gf, const TileBox *gbox, const TileEnt *te,
+    int ng,
     const ngmix_stamp &st, const double *__restrict__ sval,
     const double *__restrict__ sierr, bool masked, double *out, int64_t out_base,
     const ngmix_jacobian &jac, double (&pv)[FUSED_PF], double (&pe)[FUSED_PF],
@@ -452,12 +468,13 @@ __device__ __forceinline__ void wave_tiles(
     const unsigned ngmask = chunked ? (unsigned)((1ull << ng) - 1ull) : 0u;
     int k_l = 0;
     bool lane_valid = false;
-    const PixBox *mybox_p = &gf[0].box;   // re-read at every ballot: 4 registers less
+    const TileBox *mybox_p = &gbox[0];   // re-read at every ballot: 4 registers less
     if (chunked) {
         k_l = lane / ng;
         lane_valid = k_l < CH;
-        mybox_p = &gf[lane - k_l * ng].box;
+        mybox_p = &gbox[lane - k_l * ng];
     }
+    const unsigned long long valid_mask = __builtin_amdgcn_ballot_w64(lane_valid);
     unsigned long long allmask = 0ull;
     int kc = 0;
     const FexpCoef K = load_fexp_coef(c_fexp_coef);
@@ -510,11 +527,16 @@ __device__ __forceinline__ void wave_tiles(
                     asm volatile("v_add_u32 %0, %1, %2" : "=v"(Tk) : "s"(Tc), "v"(k_l));
                     if (Tk > ntiles) Tk = ntiles;  // a sentinel
                     const int r0k = te[Tk].r0, c0k = te[Tk].c0;
-                    const PixBox mybox = *mybox_p;
-                    const bool hit = lane_valid & (r0k <= mybox.rmax) &
-                                     (r0k >= mybox.rmin - (TH - 1)) & (c0k <= mybox.cmax) &
-                                     (c0k >= mybox.cmin - (TW - 1));
-                    allmask = __ballot(hit);
+                    const TileBox mybox = *mybox_p;
+                    // the two compares write their lane masks straight into
+                    // scalar registers (a ballot of a combined bool costs a
+                    // v_cndmask + v_cmp on top); EXEC is the whole wave here
+                    unsigned long long mr, mc;
+                    asm("v_cmp_le_u32 %0, %1, %2"
+                        : "=s"(mr) : "v"((unsigned)(r0k - mybox.r_lo)), "v"(mybox.r_span));
+                    asm("v_cmp_le_u32 %0, %1, %2"
+                        : "=s"(mc) : "v"((unsigned)(c0k - mybox.c_lo)), "v"(mybox.c_span));
+                    allmask = mr & mc & valid_mask;
                 }
                 gmask = (unsigned)allmask & ngmask;
                 allmask >>= ng;
@@ -523,11 +545,11 @@ __device__ __forceinline__ void wave_tiles(
                 // lane g tests gaussian g0+g's box against this tile
                 const int r0 = te[Tc].r0, c0 = te[Tc].c0;
                 const int gi = (lane < 32 && g0 + lane < ng) ? g0 + lane : g0;
-                const PixBox box = gf[gi].box;
-                const bool hit = (lane < 32) & (g0 + lane < ng) & (r0 <= box.rmax) &
-                                 (r0 >= box.rmin - (TH - 1)) & (c0 <= box.cmax) &
-                                 (c0 >= box.cmin - (TW - 1));
-                gmask = (unsigned)__ballot(hit);
+                const TileBox box = gbox[gi];
+                const bool hit = (lane < 32) & (g0 + lane < ng) &
+                                 ((unsigned)(r0 - box.r_lo) <= box.r_span) &
+                                 ((unsigned)(c0 - box.c_lo) <= box.c_span);
+                gmask = (unsigned)__builtin_amdgcn_ballot_w64(hit);
             }
             while (gmask) {
                 const int g = g0 + __builtin_ctz(gmask);
@@ -550,17 +572,18 @@ __device__ __forceinline__ void wave_tiles(
                     const bool band = FAST ? ((unsigned)__double2hiint(y) >= 0x40240000u)
                                            : (y > 10.0);
                     if (band) {
-                        // apod_window with FMAs (fastexp_nb.py:97-117);
-                        // W(chi2 == 20) == 1 exactly
-                        const double au = (12.5 - y) * 0.4;
-                        // (6.0 materialised here, in the rare band path: two
-                        // registers less across the tile loop)
-                        int w6l, w6h;
-                        asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0x40180000"
-                                     : "=v"(w6l), "=v"(w6h));
-                        const double w6v = __hiloint2double(w6h, w6l);
-                        const double aq = fma(au, fma(au, w6v, K.wm15), K.w10);
-                        e *= (au * au) * (au * aq);
+                        // apod_window (fastexp_nb.py:97-117): W = u^3 (10 - 15 u
+                        // + 6 u^2), u = (12.5 - y) * 0.4, written in b = 0.8 u:
+                        //   W = kappa b^3 ((b - 1)^2 + 1/15), kappa = 9.375 / 0.512
+                        // -- b is ONE fma (4.0 and 1.0 are inline constants), and no
+                        // step reads two SGPR constants, so none has to be moved to
+                        // a VGPR first: 8 instructions against 10 for the textbook
+                        // form.  W(chi2 == 20) = 1 to 1 ulp.
+                        const double bb = fma(y, K.wb, 4.0);
+                        const double bm = bb - 1.0;
+                        const double bq = fma(bm, bm, K.wq);
+                        e *= (bb * bb) * (bb * bq);
+                        e *= K.wk;
                     }
                     model = fma(gpa, e, model);
                 }
@@ -656,6 +679,7 @@ __device__ __forceinline__ void pixpass_wave_body(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LdsLayout L = carve(smem, max_ngauss, nchunks_cap, tile_cap);
     GaussFused *gf = (GaussFused *)L.gl;
+    TileBox *gbox = (TileBox *)(gf + max_ngauss);
     TileEnt *te = (TileEnt *)L.tb;
 
     const int s = blockIdx.x;
@@ -751,7 +775,17 @@ __device__ __forceinline__ void pixpass_wave_body(
         r.pa = t.pnorm * area;
         r.row = t.row;
         r.col = t.col;
-        r.box = (no_skip & 1) ? full_box() : gauss_pixel_box(t, jac);
+        const PixBox pb = (no_skip & 1) ? full_box() : gauss_pixel_box(t, jac);
+        // (|rmin|, |rmax| <= 2^30: the spans fit an unsigned; an inverted box
+        // would wrap to a huge span, so it is stored as one no tile reaches)
+        TileBox tb;
+        tb.r_lo = pb.rmin - (TH - 1);
+        tb.c_lo = pb.cmin - (TW - 1);
+        const bool none = pb.rmax < tb.r_lo || pb.cmax < tb.c_lo;
+        tb.r_span = none ? 0u : (unsigned)pb.rmax - (unsigned)tb.r_lo;
+        tb.c_span = none ? 0u : (unsigned)pb.cmax - (unsigned)tb.c_lo;
+        if (none) tb.r_lo = 1 << 30;
+        gbox[g] = tb;
         gf[g] = r;
         if (!(t.row == row0 && t.col == col0)) L.ctl[2] = 0;
         const double detq = t.dcc * t.drr - t.drc * t.drc;
@@ -771,19 +805,19 @@ __device__ __forceinline__ void pixpass_wave_body(
     double acc_ll = 0.0, acc_sn = 0.0, acc_sd = 0.0;
     if (ng > 0) {
         if (fast && full)
-            wave_tiles<OP, MASKED, true, true, TW>(L, gf, te, ng, st, sval, sierr, masked,
+            wave_tiles<OP, MASKED, true, true, TW>(L, gf, gbox, te, ng, st, sval, sierr, masked,
                                                out, out_base, jac, pv, pe, acc_ll,
                                                acc_sn, acc_sd, keep);
         else if (fast)
-            wave_tiles<OP, MASKED, true, false, TW>(L, gf, te, ng, st, sval, sierr, masked,
+            wave_tiles<OP, MASKED, true, false, TW>(L, gf, gbox, te, ng, st, sval, sierr, masked,
                                                 out, out_base, jac, pv, pe, acc_ll,
                                                 acc_sn, acc_sd, keep);
         else if (full)
-            wave_tiles<OP, MASKED, false, true, TW>(L, gf, te, ng, st, sval, sierr, masked,
+            wave_tiles<OP, MASKED, false, true, TW>(L, gf, gbox, te, ng, st, sval, sierr, masked,
                                                 out, out_base, jac, pv, pe, acc_ll,
                                                 acc_sn, acc_sd, keep);
         else
-            wave_tiles<OP, MASKED, false, false, TW>(L, gf, te, ng, st, sval, sierr,
+            wave_tiles<OP, MASKED, false, false, TW>(L, gf, gbox, te, ng, st, sval, sierr,
                                                  masked, out, out_base, jac, pv, pe,
                                                  acc_ll, acc_sn, acc_sd, keep);
     } else if (OP != OP_RENDER_FAST) {
@@ -844,7 +878,7 @@ __global__ __launch_bounds__(WAVE) void pixpass_wave_kernel(
 }
 
 // get_loglike at seven waves per SIMD: its body fits 72 VGPRs without spilling
-// (the boxes re-read at each ballot, 6.0 materialised in the band path), and
+// (the boxes re-read at each ballot, the window in the form that needs no VGPR constant), and
 // with instruction issue and memory both ~80 % busy one more resident wave per
 // SIMD is what overlaps them better
 template <int OP, bool MASKED, int TW>
