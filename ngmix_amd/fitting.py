@@ -376,7 +376,11 @@ class FitModel(dict):
     def _setup_device(self):
         """one StampBatch for every observation of the object"""
         from .batch import StampBatch
-        self._batch = StampBatch.from_observations(self._flat_obs)
+        if len(self._flat_obs) == 1:
+            # (kept on the Observation: see Observation._device_batch)
+            self._batch = self._flat_obs[0]._device_batch()
+        else:
+            self._batch = StampBatch.from_observations(self._flat_obs)
         self._kept = self._batch.npix_kept.astype(np.int64)
         self.totpix = int(self._kept.sum())
         self._pix_start = np.concatenate([[0], np.cumsum(self._kept)[:-1]]).astype(np.int64)

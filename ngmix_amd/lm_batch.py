@@ -192,6 +192,32 @@ class _EventPool(object):
             self.free.extend(arr[i] for i in range(len(arr)))
 
 
+# A small batch (the per-object interface's one-object fits above all) is host
+# bound: ~0.4 ms of Python per fit against 0.26 ms of kernels, and every
+# torch.empty / copy_ / event is 2-8 us of it.  Its device buffers are therefore
+# views of ONE allocation, its outputs (packed block | covariance triangle |
+# finalize records) contiguous at the end of it so that they come back in ONE
+# download, and the zeros of the statistics accumulator ride in the upload.
+SMALL_BATCH = 64
+
+
+def _carve(torch, dev, pieces, pin=False):
+    """one uint8 allocation cut into named views: pieces = [(name, shape,
+    torch dtype)], each 16-byte aligned; returns (buffer, views, offsets)"""
+    offs, at = {}, 0
+    for name, shape, dt in pieces:
+        nbytes = int(np.prod(shape)) * dt.itemsize
+        offs[name] = (at, nbytes)
+        at += (nbytes + 15) // 16 * 16
+    buf = (torch.empty(at, dtype=torch.uint8, pin_memory=True) if pin
+           else torch.empty(at, dtype=torch.uint8, device=dev))
+    views = {}
+    for name, shape, dt in pieces:
+        a, nb = offs[name]
+        views[name] = buf[a:a + nb].view(dt).reshape(shape)
+    return buf, views, offs
+
+
 class LMBatchFitter(object):
     """
     fitter = LMBatchFitter(model='exp')
@@ -349,10 +375,17 @@ class LMBatchFitter(object):
             sobj = np.arange(ns, dtype=np.int32)
         else:
             sobj = np.ascontiguousarray(stamp_obj, dtype=np.int32)
-            if sobj.shape != (ns,) or np.any(np.diff(sobj) < 0):
+            if sobj.shape != (ns,):
                 raise ValueError("stamp_obj must be (nstamps,) and non-decreasing")
-            if sobj.min() < 0 or sobj.max() >= nobj:
-                raise ValueError("stamp_obj out of range")
+            if nobj == 1:
+                # (a one-object fit: the per-object interface's batches)
+                if sobj.any():
+                    raise ValueError("stamp_obj out of range")
+            else:
+                if np.any(np.diff(sobj) < 0):
+                    raise ValueError("stamp_obj must be (nstamps,) and non-decreasing")
+                if sobj.min() < 0 or sobj.max() >= nobj:
+                    raise ValueError("stamp_obj out of range")
         if stamp_band is None:
             sband = np.zeros(ns, dtype=np.int32)
         else:
@@ -362,9 +395,11 @@ class LMBatchFitter(object):
         trivial_map = stamp_obj is None and stamp_band is None   # stamp i = object i
         if trivial_map:
             obj_start = np.arange(nobj + 1, dtype=np.int64)
+        elif nobj == 1:
+            obj_start = np.array([0, ns], dtype=np.int64)
         else:
             obj_start = np.searchsorted(sobj, np.arange(nobj + 1)).astype(np.int64)
-        if np.any(np.diff(obj_start) == 0):
+        if ns < nobj or (nobj > 1 and np.any(np.diff(obj_start) == 0)) or ns == 0:
             raise ValueError("every object needs at least one stamp")
         npsf = 0
         psf_host = None
@@ -385,11 +420,37 @@ class LMBatchFitter(object):
         # calls with an analytic jacobian, 200 (n + 1) in forward-difference mode
         maxfev = int(fp.get("maxfev", 0)) or (200 if self.fd else 100) * (npars + 1)
         ev_init = self._timing_events(2)
-        d_states = torch.empty((nobj, _lib.LM_STATE_DTYPE.itemsize), dtype=torch.uint8,
-                               device=dev)
         nsplit = self._nsplit_wanted()
+        nsum = self.nloc * (self.nloc + 1) // 2 + self.nloc + 1
+        # the loglike statistics of set_fit_result ride with the analytic
+        # kernel's sums (lnprob = -fnorm^2 / 2 has no prior term to add)
+        loop_stats = not self.fd and self.prior is None and \
+            not getattr(self, "stats_pass", False) and \
+            not os.environ.get("NGMIX_LM_JBASIS")
+        # (see SMALL_BATCH: every device buffer of the fit out of one allocation)
+        arena = None
+        if nobj <= SMALL_BATCH and ns <= 16 * SMALL_BATCH and nsplit <= 1 and \
+                not os.environ.get("NGMIX_LM_NO_ARENA"):
+            ntri = npars * (npars + 1) // 2
+            abuf, arena, arena_off = _carve(torch, dev, [
+                ("states", (nobj, _lib.LM_STATE_DTYPE.itemsize), torch.uint8),
+                ("sums", (ns, nsum), torch.float64),
+                ("status", (ns,), torch.int32),
+                ("sstats", (ns, 2), torch.float64),
+                # the three outputs, contiguous: one download
+                ("flat", (nobj * (2 * npars + _lib.LM_NCOLS),), torch.float64),
+                ("tri", (nobj, ntri), torch.float64),
+                ("rec", (nobj, 4 + 2 * npars + 2 * npars * npars), torch.float64)])
+            arena["out"] = abuf[arena_off["flat"][0]:
+                                arena_off["rec"][0] + arena_off["rec"][1]]
+            arena["out_off"] = {k: arena_off[k][0] - arena_off["flat"][0]
+                                for k in ("flat", "tri", "rec")}
+        d_states = arena["states"] if arena is not None else torch.empty(
+            (nobj, _lib.LM_STATE_DTYPE.itemsize), dtype=torch.uint8, device=dev)
         if trivial_map:
             npix_obj = stamps.npix_kept.astype(np.int64)
+        elif nobj == 1:
+            npix_obj = np.array([stamps.npix_kept.sum()], dtype=np.int64)
         else:
             npix_obj = np.add.reduceat(stamps.npix_kept.astype(np.int64), obj_start[:-1])
         # ONE upload for the guess, the stamp -> object / band maps, the object
@@ -400,6 +461,8 @@ class LMBatchFitter(object):
         ns_pad = (ns + 1) // 2 * 2
         pieces = [("guess", guess.view(np.uint8).reshape(-1)),
                   ("npix", npix_obj.view(np.uint8).reshape(-1))]
+        if arena is not None and loop_stats:
+            pieces.append(("ostats", np.zeros(16 * nobj, dtype=np.uint8)))
         if psf_host is not None:
             pieces.append(("psf", psf_host.view(np.uint8).reshape(-1)))
         if need_maps:
@@ -445,19 +508,19 @@ class LMBatchFitter(object):
                 _lib.ptr(hi) if hi is not None else None, job.stream),
                 "ngmix_lm_init_batch")
             self._record(ev_init, 1, job.stream)
-        nsum = self.nloc * (self.nloc + 1) // 2 + self.nloc + 1
-        # (every row is written by the first round's launch)
-        d_sums = torch.empty((ns, nsum), dtype=torch.float64, device=dev)
-        d_status = torch.empty(ns, dtype=torch.int32, device=dev)
-        # the loglike statistics of set_fit_result ride with the analytic
-        # kernel's sums (lnprob = -fnorm^2 / 2 has no prior term to add)
-        loop_stats = not self.fd and self.prior is None and \
-            not getattr(self, "stats_pass", False) and \
-            not os.environ.get("NGMIX_LM_JBASIS")
         d_sstats = d_ostats = None
-        if loop_stats:
-            d_sstats = torch.empty((ns, 2), dtype=torch.float64, device=dev)
-            d_ostats = torch.zeros((nobj, 2), dtype=torch.float64, device=dev)
+        if arena is not None:
+            d_sums, d_status = arena["sums"], arena["status"]
+            if loop_stats:
+                d_sstats = arena["sstats"]
+                d_ostats = view["ostats"].view(torch.float64).reshape(nobj, 2)
+        else:
+            # (every row is written by the first round's launch)
+            d_sums = torch.empty((ns, nsum), dtype=torch.float64, device=dev)
+            d_status = torch.empty(ns, dtype=torch.int32, device=dev)
+            if loop_stats:
+                d_sstats = torch.empty((ns, 2), dtype=torch.float64, device=dev)
+                d_ostats = torch.zeros((nobj, 2), dtype=torch.float64, device=dev)
         modnum = get_model_num(self.model)
         if self.ngauss is not None:
             modnum += 256 * self.ngauss   # the count rides with the model id
@@ -488,7 +551,7 @@ class LMBatchFitter(object):
             d_sstats=d_sstats, d_ostats=d_ostats, d_osums=d_osums, modnum=modnum,
             prior_desc=prior_desc, loop_stats=loop_stats, nsplit=nsplit, nsum=nsum,
             streaming=streaming, check_every=check_every, ev_init=ev_init,
-            npix_obj=npix_obj, d_npix=d_npix, d_all=d_all, h_all=h_all,
+            npix_obj=npix_obj, d_npix=d_npix, d_all=d_all, h_all=h_all, arena=arena,
             batch=stamps._batch(1), chunks=[], useful_rounds=None, ev_post=None,
             legacy_ev=None, loop_ms_host=0.0)
         # the host-free loop serves one piece with no prior or the kernel prior;
@@ -874,7 +937,9 @@ class LMBatchFitter(object):
             return sview[:, a:a + n]
         d_npix = job.d_npix
         width = 4 + 2 * n + 2 * n * n
-        d_rec = torch.empty((nobj, width), dtype=torch.float64, device=dev)
+        arena = job.arena
+        d_rec = arena["rec"] if arena is not None else \
+            torch.empty((nobj, width), dtype=torch.float64, device=dev)
         d_ffx = None
         if self.prior is not None:
             # chi2/dof is over fdiff[n_prior_pars:] (leastsqbound.py:97): the
@@ -913,7 +978,8 @@ class LMBatchFitter(object):
         c0, c1 = 4 + 2 * n, 4 + 2 * n + n * n
         job.d_cov0 = d_rec[:, c0:c1]
         ntri = n * (n + 1) // 2
-        d_tri = torch.empty((nobj, ntri), dtype=torch.float64, device=dev)
+        d_tri = arena["tri"] if arena is not None else \
+            torch.empty((nobj, ntri), dtype=torch.float64, device=dev)
         side = self._side_stream(dev)
         d_ok = d_rec[:, 0] == 0.0
         job.fit_ctx = self._fit_ctx = (stamps, psf, sobj, sband, d_rec, d_ok, n)
@@ -925,7 +991,8 @@ class LMBatchFitter(object):
         # pars | pars_err rows, then twelve contiguous columns (integers and
         # statistics): one kernel, one download, contiguous host views
         ncols = _lib.LM_NCOLS
-        d_flat = torch.empty(nobj * (2 * n + ncols), dtype=torch.float64, device=dev)
+        d_flat = arena["flat"] if arena is not None else \
+            torch.empty(nobj * (2 * n + ncols), dtype=torch.float64, device=dev)
         if True:
             _lib.check(L.ngmix_lm_pack_batch(
                 _dptr(d_states), nobj, n, _dptr(d_rec),
@@ -936,27 +1003,44 @@ class LMBatchFitter(object):
                 "ngmix_lm_pack_batch")
             self._record(ev_post, 2, job.stream)
         self._mark(job, "pack")
-        h_flat = torch.empty(d_flat.shape, dtype=torch.float64, pin_memory=True)
-        h_tri = torch.empty((nobj, ntri), dtype=torch.float64, pin_memory=True)
-        self._mark(job, "pinned_alloc")
-        ready = torch.cuda.Event()
-        ready.record()
-        with torch.cuda.stream(side):
-            side.wait_event(ready)
-            h_flat.copy_(d_flat, non_blocking=True)
-            copied = torch.cuda.Event()
+        if arena is not None:
+            # one download of the three outputs, on the fit's own stream (a
+            # side stream buys nothing when the host waits for all of it)
+            d_out = arena["out"]
+            h_out = torch.empty(d_out.shape, dtype=torch.uint8, pin_memory=True)
+            h_out.copy_(d_out, non_blocking=True)
+            copied = cov_copied = torch.cuda.Event()
             copied.record()
-            h_tri.copy_(d_tri, non_blocking=True)
-            h_cov0 = None
-            if nobj <= 4096:
-                # (a small batch: pars_cov0 rides along instead of costing its
-                # first reader a synchronous download of its own)
-                h_cov0 = torch.empty((nobj, n * n), dtype=torch.float64, pin_memory=True)
-                h_cov0.copy_(job.d_cov0, non_blocking=True)
-            cov_copied = torch.cuda.Event()
-            cov_copied.record()
-        d_flat.record_stream(side)
-        d_tri.record_stream(side)
+            oo = arena["out_off"]
+
+            def hview(name, like):
+                nb = like.numel() * 8
+                return h_out[oo[name]:oo[name] + nb].view(torch.float64).reshape(like.shape)
+            h_flat, h_tri = hview("flat", d_flat), hview("tri", d_tri)
+            h_cov0 = hview("rec", d_rec)[:, c0:c1]
+        else:
+            h_flat = torch.empty(d_flat.shape, dtype=torch.float64, pin_memory=True)
+            h_tri = torch.empty((nobj, ntri), dtype=torch.float64, pin_memory=True)
+            self._mark(job, "pinned_alloc")
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                h_flat.copy_(d_flat, non_blocking=True)
+                copied = torch.cuda.Event()
+                copied.record()
+                h_tri.copy_(d_tri, non_blocking=True)
+                h_cov0 = None
+                if nobj <= 4096:
+                    # (a small batch: pars_cov0 rides along instead of costing its
+                    # first reader a synchronous download of its own)
+                    h_cov0 = torch.empty((nobj, n * n), dtype=torch.float64,
+                                         pin_memory=True)
+                    h_cov0.copy_(job.d_cov0, non_blocking=True)
+                cov_copied = torch.cuda.Event()
+                cov_copied.record()
+            d_flat.record_stream(side)
+            d_tri.record_stream(side)
         pool = self.__dict__.get("_event_pool")
         if pool is not None and job.ev_post is not None:
             pool.give(job.ev_post)   # (results re-made after a miss)

@@ -63,7 +63,7 @@ class Observation(MetadataMixin):
         self._writeable = False
         self._ignore_zero_weight = ignore_zero_weight
         self._store_pixels = store_pixels
-        self._pixels = self._stamp = None
+        self._pixels = self._stamp = self._stamp_batch = None
         # image, weight and jacobian define the pixel list: set all three, then
         # derive it once; the rest are plain attributes
         for setter, value in ((self.set_image, image), (self.set_weight, weight),
@@ -98,6 +98,7 @@ class Observation(MetadataMixin):
         """invalidate the derived pixel data (AoS list and device copy)"""
         self._pixels = None
         self._stamp = None
+        self._stamp_batch = None
         if not self._store_pixels:
             return
         if self._ignore_zero_weight and not np.any(self._weight > 0.0):
@@ -116,6 +117,15 @@ class Observation(MetadataMixin):
             self._pixels = pixels
         return self._pixels
 
+
+    def _device_batch(self):
+        """this observation as a one-stamp StampBatch, made once (what the
+        fitters read: a second fit of the same observation -- another model,
+        another guess -- uploads nothing); update_pixels() drops it"""
+        if self._stamp_batch is None:
+            from .batch import StampBatch
+            self._stamp_batch = StampBatch.from_observations([self])
+        return self._stamp_batch
 
     def _device_stamp(self):
         """the compact device-resident copy the kernels read"""

@@ -37,5 +37,14 @@ t("run_em(psf obs, 1 gaussian)", lambda: ngmix.em.run_em(pobs, ngmix.GMixModel([
 guess = np.array([0.1, -0.05, 0.1, 0.05, 0.6, 100.0]) * 1.03
 fb = ngmix.fitting.Fitter(model="exp", batched=True)
 t("Fitter('exp', batched=True).go(obs, guess)", lambda: fb.go(obs=obs, guess=guess), n=200)
+
+
+def first_fit():
+    # an Observation the device has not seen: its pixels are uploaded by the fit
+    o = ngmix.Observation(im, weight=wt, jacobian=jac, psf=pobs)
+    fb.go(obs=o, guess=guess)
+
+
+t("  (first fit of a new Observation)", first_fit, n=200)
 t("  (a new Fitter per call)", lambda: ngmix.fitting.Fitter(model="exp", batched=True).go(obs=obs, guess=guess), n=100)
 t("Fitter('exp', batched=False).go(obs, guess)", lambda: ngmix.fitting.Fitter(model="exp", batched=False).go(obs=obs, guess=guess), n=50)

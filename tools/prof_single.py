@@ -18,3 +18,12 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(200): fb.go(obs=obs, guess=guess)
 pr.disable()
 pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+bf = fb._batch_fitter
+print("host_ms", bf.host_ms, "rounds_launched", bf.rounds_launched, "useful", getattr(bf, "useful_rounds", None))
+bf.time_kernels = True
+for _ in range(5): fb.go(obs=obs, guess=guess)
+print("kernel_ms", bf.kernel_ms, "loop_seconds", getattr(bf, "loop_seconds", None))
+bf.time_kernels = False
+t0 = time.perf_counter()
+for _ in range(500): fb.go(obs=obs, guess=guess)
+print("Fitter.go: %.1f us" % ((time.perf_counter() - t0) / 500 * 1e6))
