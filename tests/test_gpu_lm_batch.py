@@ -953,3 +953,36 @@ def test_host_free_rounds_equal_the_host_driven_loop():
     assert set(fast.kernel_ms) == {"lm_eval", "lm_advance", "lm_init", "lm_finalize", "lm_pack"}
     assert all(v > 0.0 for v in fast.kernel_ms.values())
     assert len(fast.eval_launches) == fast.rounds_launched
+
+
+@pytest.mark.gpu
+def test_small_batch_arena_equals_separate_buffers(monkeypatch):
+    """a small batch's buffers out of one allocation and one download
+    (lm_batch.SMALL_BATCH) against the separate-buffer path of the large
+    batches: every key of the result to the bit, several stamps per object"""
+    import torch
+    import bench
+    from ngmix_amd.batch import GMixBatch
+    from ngmix_amd.lm_batch import LMBatchFitter, SMALL_BATCH
+    nobj, nband = 5, 2
+    ns = nobj * nband
+    assert nobj <= SMALL_BATCH
+    sb, _, pars = bench.make_workload(ns, 1000, "cuda")
+    rng = np.random.RandomState(3)
+    guess = np.concatenate([pars[::nband, :5], pars[:, 5].reshape(nobj, nband)], axis=1)
+    guess = guess * rng.uniform(0.97, 1.03, size=guess.shape)
+    psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (ns, 1)), "gauss")
+    sobj = np.repeat(np.arange(nobj), nband)
+    sband = np.tile(np.arange(nband), nobj)
+
+    def run():
+        f = LMBatchFitter("exp")
+        r = f.go(sb, guess, psf=psf, stamp_obj=sobj, stamp_band=sband)
+        return {k: np.array(r[k]) for k in r.keys() if k != "model"}
+    a = run()
+    monkeypatch.setenv("NGMIX_LM_NO_ARENA", "1")
+    b = run()
+    assert set(a) == set(b)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert np.all(a["flags"] == 0)

@@ -467,3 +467,33 @@ def test_lm_batch_result_lazy_keys_are_ordinary_keys():
         assert w() is None
     finally:
         gc.enable()
+
+
+def test_lm_small_batch_arena_layout():
+    """lm_batch._carve: the views of a small batch's one allocation are
+    16-byte aligned, disjoint, of the requested shapes and types, and the three
+    outputs are contiguous in the order the single download assumes"""
+    import torch
+    from ngmix_amd.lm_batch import _carve
+    pieces = [("states", (3, 1000), torch.uint8), ("sums", (5, 28), torch.float64),
+              ("status", (5,), torch.int32), ("sstats", (5, 2), torch.float64),
+              ("flat", (3 * 24,), torch.float64), ("tri", (3, 21), torch.float64),
+              ("rec", (3, 88), torch.float64)]
+    buf, views, offs = _carve(torch, "cpu", pieces)
+    base = buf.data_ptr()
+    spans = []
+    for name, shape, dt in pieces:
+        v = views[name]
+        assert tuple(v.shape) == tuple(shape) and v.dtype == dt and v.is_contiguous()
+        a, nb = offs[name]
+        assert v.data_ptr() == base + a and a % 16 == 0
+        assert nb == v.numel() * v.element_size()
+        spans.append((a, a + nb))
+    assert all(e0 <= s1 for (_, e0), (s1, _) in zip(spans, spans[1:]))
+    assert spans[-1][1] <= buf.numel()
+    # writes through one view never show in another
+    for name, _, _ in pieces:
+        views[name].zero_()
+    views["tri"].fill_(7.0)
+    assert float(views["flat"].sum()) == 0.0 and float(views["rec"].sum()) == 0.0
+    assert offs["flat"][0] < offs["tri"][0] < offs["rec"][0]
