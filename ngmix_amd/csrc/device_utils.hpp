@@ -410,6 +410,43 @@ __device__ __forceinline__ PixBox gauss_pixel_box(const ngmix_gauss2d &g,
     return box;
 }
 
+// The chi2 < 25 box of a gaussian as a tile test reads it: a TH x TW tile whose
+// first pixel is (r0, c0) reaches the box when r0 is in [rmin - (TH-1), rmax],
+// i.e. (unsigned)(r0 - r_lo) <= r_span -- one subtraction and one compare per
+// axis (the four signed compares of the plain form came out of the compiler as
+// 16-bit mask arithmetic: 20 instructions).
+struct TileBox {
+    int r_lo;
+    unsigned r_span;
+    int c_lo;
+    unsigned c_span;
+};
+
+__device__ __forceinline__ TileBox tile_box(const PixBox &pb, int th, int tw)
+{
+    // (|rmin|, |rmax| <= 2^30: the spans fit an unsigned; an inverted box
+    // would wrap to a huge span, so it is stored as one no tile reaches)
+    TileBox tb;
+    tb.r_lo = pb.rmin - (th - 1);
+    tb.c_lo = pb.cmin - (tw - 1);
+    const bool none = pb.rmax < tb.r_lo || pb.cmax < tb.c_lo;
+    tb.r_span = none ? 0u : (unsigned)pb.rmax - (unsigned)tb.r_lo;
+    tb.c_span = none ? 0u : (unsigned)pb.cmax - (unsigned)tb.c_lo;
+    if (none) tb.r_lo = 1 << 30;
+    return tb;
+}
+
+// lanes whose box is reached by the tile starting at (r0, c0): the two compares
+// write their lane masks straight into scalar registers (a ballot of a combined
+// bool costs a v_cndmask + v_cmp on top).  EXEC must be the whole wave.
+__device__ __forceinline__ unsigned long long tile_hits(const TileBox &b, int r0, int c0)
+{
+    unsigned long long mr, mc;
+    asm("v_cmp_le_u32 %0, %1, %2" : "=s"(mr) : "v"((unsigned)(r0 - b.r_lo)), "v"(b.r_span));
+    asm("v_cmp_le_u32 %0, %1, %2" : "=s"(mc) : "v"((unsigned)(c0 - b.c_lo)), "v"(b.c_span));
+    return mr & mc;
+}
+
 // Row-major rank of position p among the kept pixels of a masked stamp
 // (the index into the reference's pixel list): per-64-pixel keep masks and
 // their exclusive prefix counts live in LDS (cmask/cpre, one entry per chunk).

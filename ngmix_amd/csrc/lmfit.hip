@@ -52,7 +52,7 @@ struct DerivGauss {
     double pa;             // norm * area
     double tk;             // irr + icc of the object's gaussian before the psf
     double pad_;
-    PixBox box;
+    TileBox box;           // device_utils.hpp: the chi2 < 25 box as the tile test reads it
 };
 static_assert(sizeof(DerivGauss) == 80, "DerivGauss");
 
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
             r.pa = gc.p * (rs * 0.15915494309189535) * area;   // p / (2 pi sqrt(det))
             r.tk = g0.irr + g0.icc;
             r.pad_ = 0.0;
-            r.box = no_skip ? full_box() : gauss_pixel_box(gc, jac);
+            r.box = tile_box(no_skip ? full_box() : gauss_pixel_box(gc, jac), TILE_H, TILE_W);
             dg[i] = r;
         }
     }
@@ -305,12 +305,13 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
     const unsigned ngmask = chunked ? (unsigned)((1ull << G) - 1ull) : 0u;
     int k_l = 0;
     bool lane_valid = false;
-    PixBox mybox = dg[0].box;
+    TileBox mybox = dg[0].box;
     if (chunked) {
         k_l = lane / G;
         lane_valid = k_l < CH;
         mybox = dg[lane - k_l * G].box;
     }
+    const unsigned long long valid_mask = __builtin_amdgcn_ballot_w64(lane_valid);
     // mode ANALYTIC_LAZY: a trial whose acceptance is predicted to end the fit
     // asks for |f|^2 alone (ngmix_hip.h): the same per-pixel model value -- the
     // same expressions in the same order, so f is what the full pass computes,
@@ -336,11 +337,7 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
                     int Tk = Tc + k_l;
                     if (Tk > ntiles) Tk = ntiles;  // the sentinel
                     const LmTile tk = tile(Tk);
-                    const bool hit = lane_valid & (tk.r0 <= mybox.rmax) &
-                                     (tk.r0 >= mybox.rmin - (TILE_H - 1)) &
-                                     (tk.c0 <= mybox.cmax) &
-                                     (tk.c0 >= mybox.cmin - (TILE_W - 1));
-                    allmask = __ballot(hit);
+                    allmask = tile_hits(mybox, tk.r0, tk.c0) & valid_mask;
                 }
                 gmask = (unsigned)allmask & ngmask;
                 allmask >>= G;
@@ -348,11 +345,9 @@ __global__ __launch_bounds__(WAVE) void lm_eval_kernel(
             } else {
                 // lane g tests gaussian gb+g's chi2<25 box against this tile
                 const int gi = gb + lane < G ? gb + lane : gb;
-                const PixBox box = dg[gi].box;
-                const bool hit = (gb + lane < G) & (tc.r0 <= box.rmax) &
-                                 (tc.r0 + TILE_H - 1 >= box.rmin) & (tc.c0 <= box.cmax) &
-                                 (tc.c0 + TILE_W - 1 >= box.cmin);
-                gmask = __ballot(hit);
+                const TileBox box = dg[gi].box;
+                gmask = tile_hits(box, tc.r0, tc.c0) &
+                        __builtin_amdgcn_ballot_w64(gb + lane < G);
             }
             while (gmask) {
                 const int g = gb + __builtin_ctzll(gmask);
@@ -899,7 +894,7 @@ void lm_eval_fd_kernel(
     const int npsf1 = npsf > 0 ? npsf : 1;
     const int G = ng0 * npsf1;
     FdGauss *ev = (FdGauss *)dyn;                    // [NSETS][G]
-    PixBox *boxes = (PixBox *)(ev + NSETS * G);      // [G], from the base set
+    TileBox *boxes = (TileBox *)(ev + NSETS * G);    // [G], from the base set
 
     // local parameters and the fdjac2 points the state prepared (xstep /
     // hstep: the step is taken in leastsqbound's internal parameters)
@@ -962,7 +957,9 @@ void lm_eval_fd_kernel(
         r.c = -gc.drc;
         r.pa = gc.pnorm * area;
         ev[k * G + i] = r;
-        if (k == 0) boxes[i] = no_skip ? full_box() : gauss_pixel_box(gc, jac);
+        if (k == 0)
+            boxes[i] = tile_box(no_skip ? full_box() : gauss_pixel_box(gc, jac),
+                                TILE_H, TILE_W);
     }
     if (__ballot(bad != 0) != 0ull) {
         // out of range at (or one step from) the trial point: LOWVAL residuals
@@ -1063,11 +1060,9 @@ void lm_eval_fd_kernel(
 
             for (int gb = 0; gb < G; gb += WAVE) {
                 const int gi = gb + lane < G ? gb + lane : gb;
-                const PixBox box = boxes[gi];
-                const bool hit = (gb + lane < G) & (r0 <= box.rmax) &
-                                 (r0 + TILE_H - 1 >= box.rmin) & (c0 <= box.cmax) &
-                                 (c0 + TILE_W - 1 >= box.cmin);
-                unsigned long long gmask = __ballot(hit);
+                const TileBox box = boxes[gi];
+                unsigned long long gmask = tile_hits(box, r0, c0) &
+                                           __builtin_amdgcn_ballot_w64(gb + lane < G);
                 while (gmask) {
                     const int g = gb + __builtin_ctzll(gmask);
                     gmask &= gmask - 1ull;
@@ -1095,9 +1090,13 @@ void lm_eval_fd_kernel(
                             const bool band = (unsigned)__double2hiint(y) >= 0x40240000u;
                             if (__ballot(band) != 0ull) {
                                 if (band) {
-                                    const double au = (12.5 - y) * 0.4;
-                                    const double aq = fma(au, fma(au, K.w6, K.wm15), K.w10);
-                                    e *= (au * au) * (au * aq);
+                                    // the window in b = 0.8 u (pixpass.hip): no
+                                    // step reads two SGPR constants
+                                    const double bb = fma(y, K.wb, 4.0);
+                                    const double bm = bb - 1.0;
+                                    const double bq = fma(bm, bm, K.wq);
+                                    e *= (bb * bb) * (bb * bq);
+                                    e *= K.wk;
                                 }
                             }
                             m[k] = fma(E.pa, e, m[k]);
@@ -1635,7 +1634,7 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *stat
                            "kernel only (stamp_stats must be NULL in forward-difference mode)");
         return NGMIX_ERR_BAD_ARG;
     }
-    const size_t lds = (size_t)(nloc + 1) * G * sizeof(FdGauss) + (size_t)G * sizeof(PixBox);
+    const size_t lds = (size_t)(nloc + 1) * G * sizeof(FdGauss) + (size_t)G * sizeof(TileBox);
     if (lds > 128 * 1024) {
         set_last_error_msg("lm_eval: too many composed gaussians for LDS");
         return NGMIX_ERR_BAD_ARG;

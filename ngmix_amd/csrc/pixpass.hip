@@ -312,16 +312,6 @@ __global__ __launch_bounds__(BLOCK) void pixpass_grid_kernel(
 // are the reference's; only the rounding of individual operations differs.
 // ===========================================================================
 
-// The chi2 < 25 box of a gaussian as the tile test reads it: a tile whose first
-// pixel is (r0, c0) reaches the box when r0 is in [rmin - (TH-1), rmax], i.e.
-// (unsigned)(r0 - r_lo) <= r_span -- one subtraction and one compare per axis.
-struct TileBox {
-    int r_lo;
-    unsigned r_span;
-    int c_lo;
-    unsigned c_span;
-};
-
 // In the 64 B per gaussian of the LDS layout: 48-byte records first, then the
 // boxes, 16 B apart -- the box test reads lane g's box, and inside 64-byte
 // records those reads fell on two banks (8-way conflicts on a 16-gaussian
@@ -528,15 +518,7 @@ __device__ __forceinline__ void wave_tiles(
                     if (Tk > ntiles) Tk = ntiles;  // a sentinel
                     const int r0k = te[Tk].r0, c0k = te[Tk].c0;
                     const TileBox mybox = *mybox_p;
-                    // the two compares write their lane masks straight into
-                    // scalar registers (a ballot of a combined bool costs a
-                    // v_cndmask + v_cmp on top); EXEC is the whole wave here
-                    unsigned long long mr, mc;
-                    asm("v_cmp_le_u32 %0, %1, %2"
-                        : "=s"(mr) : "v"((unsigned)(r0k - mybox.r_lo)), "v"(mybox.r_span));
-                    asm("v_cmp_le_u32 %0, %1, %2"
-                        : "=s"(mc) : "v"((unsigned)(c0k - mybox.c_lo)), "v"(mybox.c_span));
-                    allmask = mr & mc & valid_mask;
+                    allmask = tile_hits(mybox, r0k, c0k) & valid_mask;
                 }
                 gmask = (unsigned)allmask & ngmask;
                 allmask >>= ng;
@@ -546,10 +528,8 @@ __device__ __forceinline__ void wave_tiles(
                 const int r0 = te[Tc].r0, c0 = te[Tc].c0;
                 const int gi = (lane < 32 && g0 + lane < ng) ? g0 + lane : g0;
                 const TileBox box = gbox[gi];
-                const bool hit = (lane < 32) & (g0 + lane < ng) &
-                                 ((unsigned)(r0 - box.r_lo) <= box.r_span) &
-                                 ((unsigned)(c0 - box.c_lo) <= box.c_span);
-                gmask = (unsigned)__builtin_amdgcn_ballot_w64(hit);
+                gmask = (unsigned)(tile_hits(box, r0, c0) &
+                                   __builtin_amdgcn_ballot_w64((lane < 32) & (g0 + lane < ng)));
             }
             while (gmask) {
                 const int g = g0 + __builtin_ctz(gmask);
@@ -776,15 +756,7 @@ __device__ __forceinline__ void pixpass_wave_body(
         r.row = t.row;
         r.col = t.col;
         const PixBox pb = (no_skip & 1) ? full_box() : gauss_pixel_box(t, jac);
-        // (|rmin|, |rmax| <= 2^30: the spans fit an unsigned; an inverted box
-        // would wrap to a huge span, so it is stored as one no tile reaches)
-        TileBox tb;
-        tb.r_lo = pb.rmin - (TH - 1);
-        tb.c_lo = pb.cmin - (TW - 1);
-        const bool none = pb.rmax < tb.r_lo || pb.cmax < tb.c_lo;
-        tb.r_span = none ? 0u : (unsigned)pb.rmax - (unsigned)tb.r_lo;
-        tb.c_span = none ? 0u : (unsigned)pb.cmax - (unsigned)tb.c_lo;
-        if (none) tb.r_lo = 1 << 30;
+        const TileBox tb = tile_box(pb, TH, TW);
         gbox[g] = tb;
         gf[g] = r;
         if (!(t.row == row0 && t.col == col0)) L.ctl[2] = 0;
