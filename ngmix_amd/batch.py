@@ -758,16 +758,43 @@ def _gm_batch(gm_data, device):
     return GMixBatch.from_numpy(np.ascontiguousarray(gm_data), device=device)
 
 
-def _raise_status(status, context):
-    st = int(status.cpu()[0])
+_NP_OF = {}
+
+
+def _fetch(*tensors):
+    """several small device tensors in ONE download (a device-to-host copy is
+    20-40 us of host time whatever its size, and the per-object calls made
+    three to five): the tensors are concatenated as bytes on the device and come
+    back as host arrays of their own shapes and types.  8-byte types first."""
+    torch = _torch()
+    if not _NP_OF:
+        _NP_OF.update({torch.float64: np.float64, torch.int32: np.int32,
+                       torch.int64: np.int64, torch.uint8: np.uint8})
+    flat = [t.detach().contiguous().reshape(-1).view(torch.uint8) for t in tensors]
+    host = torch.cat(flat).cpu().numpy()
+    out, at = [], 0
+    for t, f in zip(tensors, flat):
+        n = f.numel()
+        out.append(host[at:at + n].view(_NP_OF[t.dtype]).reshape(tuple(t.shape)))
+        at += n
+    return out
+
+
+def _gm_records(flat, gmb):
+    """the host copy of a GMixBatch's tensor as the reference's record array"""
+    return flat.reshape(-1).view(_lib.GAUSS2D_DTYPE).reshape(gmb.n, gmb.ngauss)
+
+
+def _finish(gm_data, gmb, status, context, *results):
+    """the common tail of the per-object calls in one download: raise on the
+    status, mirror the (possibly mutated) mixture onto the caller's records,
+    return the host copies of `results`"""
+    got = _fetch(*results, gmb.data, status)
+    st = int(got[-1][0])
     if st != 0:
         _lib.check(st, context)
-
-
-def _writeback_gm(gm_data, gmb):
-    """mirror in-kernel mutation of the mixture (norms, admom/em updates)
-    onto the caller's host record array, as the reference mutates it"""
-    gm_data[:] = gmb.to_numpy()[0]
+    gm_data[:] = _gm_records(got[-2], gmb)[0]
+    return got[:-2]
 
 
 def render_single(gm_data, image, jac_record, fast_exp, exact=False, fresh=False):
@@ -784,9 +811,8 @@ def render_single(gm_data, image, jac_record, fast_exp, exact=False, fresh=False
     dimg = None if fresh else \
         torch.from_numpy(np.ascontiguousarray(image, dtype="f8").ravel()).to(dev)
     dimg, status = sb.render(gmb, image=dimg, fast_exp=fast_exp, exact=exact)
-    _raise_status(status, "render")
-    _writeback_gm(gm_data, gmb)
-    image[:, :] = dimg.cpu().numpy().reshape(nrow, ncol)
+    (himg,) = _finish(gm_data, gmb, status, "render", dimg)
+    image[:, :] = himg.reshape(nrow, ncol)
 
 
 class SingleStamp(object):
@@ -806,9 +832,8 @@ class SingleStamp(object):
     def loglike_single(self, gm_data, exact=False):
         gmb = _gm_batch(gm_data, self.device)
         out, status = self.sb.loglike(gmb, exact=exact)
-        _raise_status(status, "get_loglike")
-        _writeback_gm(gm_data, gmb)
-        o = out.cpu().numpy()[0]
+        (o,) = _finish(gm_data, gmb, status, "get_loglike", out)
+        o = o[0]
         return float(o[0]), float(o[1]), float(o[2]), int(o[3])
 
     def fdiff_single(self, gm_data, fdiff, start, exact=False):
@@ -818,16 +843,14 @@ class SingleStamp(object):
         d = torch.empty(nk, dtype=torch.float64, device=self.device)
         _, status = self.sb.fill_fdiff(gmb, fdiff=d, fdiff_start=np.zeros(1, "i8"),
                                        exact=exact)
-        _raise_status(status, "fill_fdiff")
-        _writeback_gm(gm_data, gmb)
-        fdiff[start:start + nk] = d.cpu().numpy()
+        (hd,) = _finish(gm_data, gmb, status, "fill_fdiff", d)
+        fdiff[start:start + nk] = hd
 
     def s2n_single(self, gm_data, exact=False):
         gmb = _gm_batch(gm_data, self.device)
         out, status = self.sb.model_s2n_sum(gmb, exact=exact)
-        _raise_status(status, "get_model_s2n_sum")
-        _writeback_gm(gm_data, gmb)
-        return float(out.cpu()[0])
+        (o,) = _finish(gm_data, gmb, status, "get_model_s2n_sum", out)
+        return float(o.reshape(-1)[0])
 
     def wsums_single(self, gm_data, res, nmom, maxrad):
         """res: numpy record (void scalar) accumulated into"""
@@ -839,8 +862,10 @@ class SingleStamp(object):
             host[n] = res[n]
         dres = torch.from_numpy(host.view(np.float64).reshape(1, -1).copy()).to(self.device)
         _, status = self.sb.weighted_sums(gmb, maxrad, nmom=nmom, res=dres)
-        _raise_status(status, "get_weighted_sums")
-        back = records_to_numpy(dres, dt)
+        hres, hst = _fetch(dres, status)
+        if int(hst[0]) != 0:
+            _lib.check(int(hst[0]), "get_weighted_sums")
+        back = hres.reshape(-1).view(dt)
         for n in dt.names:
             res[n] = back[n][0]
 
@@ -857,9 +882,10 @@ class SingleStamp(object):
             wtb, maxiter=int(c["maxiter"]), shiftmax=float(c["shiftmax"]),
             etol=float(c["etol"]), Ttol=float(c["Ttol"]), cenonly=bool(c["cenonly"]),
             res=dres)
-        res[:] = records_to_numpy(dres, _lib.ADMOM_RESULT_DTYPE)
-        _writeback_gm(wt_data, wtb)
-        return int(status.cpu()[0])
+        hres, hwt, hst = _fetch(dres, wtb.data, status)
+        res[:] = hres.reshape(-1).view(_lib.ADMOM_RESULT_DTYPE)
+        wt_data[:] = _gm_records(hwt, wtb)[0]
+        return int(hst[0])
 
     def em_single(self, kind, conf, gm_data, psf_data, conv_data, fill_zero_weight):
         """returns (status, numiter, frac_diff, sky); mixtures updated in place"""
@@ -871,7 +897,8 @@ class SingleStamp(object):
             miniter=int(conf["miniter"]), maxiter=int(conf["maxiter"]),
             tol=float(conf["tol"]), vary_sky=bool(conf["vary_sky"]),
             fill_zero_weight=fill_zero_weight)
-        o = out.cpu().numpy()[0]
-        _writeback_gm(gm_data, gmb)
-        _writeback_gm(conv_data, convb)
-        return int(status.cpu()[0]), int(o[0]), float(o[1]), float(o[2])
+        ho, hgm, hconv, hst = _fetch(out, gmb.data, convb.data, status)
+        o = ho[0]
+        gm_data[:] = _gm_records(hgm, gmb)[0]
+        conv_data[:] = _gm_records(hconv, convb)[0]
+        return int(hst[0]), int(o[0]), float(o[1]), float(o[2])
