@@ -278,33 +278,41 @@ class StampBatch(object):
     @classmethod
     def from_observations(cls, obs_list, device=None):
         """ragged batch from Observation objects (any mix of shapes)"""
-        torch = _torch()
-        dev = _require_cuda(device)
         # the Observations' own arrays (their public properties hand out
         # read-only views and a COPY of the jacobian: 10 us per object, more than
         # the packing itself)
-        imgs = [o._image for o in obs_list]
+        return cls.from_arrays([o._image for o in obs_list],
+                               [o._weight for o in obs_list],
+                               [o._jacobian._data for o in obs_list],
+                               [o._ignore_zero_weight for o in obs_list], device=device)
+
+    @classmethod
+    def from_arrays(cls, imgs, weights, jac_records, ignore_zero_weight, device=None):
+        """ragged batch from host arrays: 2-d images and weight maps, jacobian
+        records (the reference dtype, or 8 doubles), one flag per stamp"""
+        torch = _torch()
+        dev = _require_cuda(device)
         nrow = np.array([im.shape[0] for im in imgs], dtype=np.int32)
         ncol = np.array([im.shape[1] for im in imgs], dtype=np.int32)
         npix = nrow.astype(np.int64) * ncol
         off = np.concatenate([[0], np.cumsum(npix)[:-1]]).astype(np.int64)
-        izw = np.array([o._ignore_zero_weight for o in obs_list], dtype=bool)
+        izw = np.array(ignore_zero_weight, dtype=bool)
         # ONE upload: [val | weight | jacobian records] (a host-to-device copy
         # costs ~30 us whatever its size: three of them were a third of a
         # one-object fit's set-up), and the listed pixels are counted here
         # from the host weights instead of by a kernel and a read-back
         tot = int(npix.sum())
-        n = len(obs_list)
+        n = len(imgs)
         host = np.empty(2 * tot + 8 * n + 4 * n)      # ... | stamp table (32 B records)
         kept = np.empty(n, dtype=np.int32)
-        for i, o in enumerate(obs_list):
+        for i in range(n):
             a, b = int(off[i]), int(off[i] + npix[i])
             host[a:b] = np.asarray(imgs[i], dtype="f8").ravel()
-            w = np.asarray(o._weight, dtype="f8").ravel()
+            w = np.asarray(weights[i], dtype="f8").ravel()
             host[tot + a:tot + b] = w
             kept[i] = np.count_nonzero(w > 0.0) if izw[i] else npix[i]
             host[2 * tot + 8 * i:2 * tot + 8 * i + 8] = \
-                o._jacobian._data.view(np.float64).reshape(8)
+                np.ascontiguousarray(jac_records[i]).view(np.float64).reshape(8)
         # (the stamp table of one-gaussian-per-stamp mixtures -- what the lock-step
         # fits and the moments kernels ask for -- rides along: one upload less)
         tab = np.zeros(n, dtype=_lib.STAMP_DTYPE)
@@ -780,6 +788,24 @@ def _fetch(*tensors):
     return out
 
 
+def _upload(device, *arrays):
+    """several small host arrays of doubles (or gauss2d records) in ONE upload;
+    returns float64 device views of their element counts, in order"""
+    torch = _torch()
+    flats = [np.ascontiguousarray(a).reshape(-1).view(np.float64) for a in arrays]
+    dev_all = torch.from_numpy(np.concatenate(flats)).to(device)
+    out, at = [], 0
+    for f in flats:
+        out.append(dev_all[at:at + f.size])
+        at += f.size
+    return out
+
+
+def _gm_view(flat, gm_data):
+    """a GMixBatch over an uploaded view of one mixture's records"""
+    return GMixBatch(flat.reshape(-1, 13), 1, int(np.asarray(gm_data).size))
+
+
 def _gm_records(flat, gmb):
     """the host copy of a GMixBatch's tensor as the reference's record array"""
     return flat.reshape(-1).view(_lib.GAUSS2D_DTYPE).reshape(gmb.n, gmb.ngauss)
@@ -819,10 +845,10 @@ class SingleStamp(object):
     """an Observation's pixels resident on the device (1-stamp StampBatch)"""
 
     def __init__(self, image, weight, jac_record, ignore_zero_weight, device=None):
-        self.sb = StampBatch.from_images(
-            np.asarray(image, dtype="f8")[None], np.asarray(weight, dtype="f8")[None],
-            np.ascontiguousarray(jac_record).view(np.float64).reshape(1, 8),
-            ignore_zero_weight=ignore_zero_weight, device=device)
+        # (one upload, the listed pixels counted on the host: from_arrays)
+        self.sb = StampBatch.from_arrays([np.asarray(image)], [np.asarray(weight)],
+                                         [jac_record], [bool(ignore_zero_weight)],
+                                         device=device)
         self.device = self.sb.device
 
     @property
@@ -855,12 +881,14 @@ class SingleStamp(object):
     def wsums_single(self, gm_data, res, nmom, maxrad):
         """res: numpy record (void scalar) accumulated into"""
         torch = _torch()
-        gmb = _gm_batch(gm_data, self.device)
         dt = _lib.moments_result_dtype(nmom)
         host = np.zeros(1, dtype=dt)
         for n in dt.names:
             host[n] = res[n]
-        dres = torch.from_numpy(host.view(np.float64).reshape(1, -1).copy()).to(self.device)
+        dgm, dres = _upload(self.device, np.ascontiguousarray(gm_data, dtype=_lib.GAUSS2D_DTYPE),
+                            host)
+        gmb = _gm_view(dgm, gm_data)
+        dres = dres.reshape(1, -1)
         _, status = self.sb.weighted_sums(gmb, maxrad, nmom=nmom, res=dres)
         hres, hst = _fetch(dres, status)
         if int(hst[0]) != 0:
@@ -873,10 +901,10 @@ class SingleStamp(object):
         """conf / res: 1-element record arrays (reference dtypes); wt and res
         are updated in place.  Returns the C-ABI status."""
         torch = _torch()
-        wtb = _gm_batch(wt_data, self.device)
-        dres = torch.from_numpy(
-            np.ascontiguousarray(res).view(np.float64).reshape(1, -1).copy()
-        ).to(self.device)
+        dwt, dres = _upload(self.device, np.ascontiguousarray(wt_data, dtype=_lib.GAUSS2D_DTYPE),
+                            np.ascontiguousarray(res))
+        wtb = _gm_view(dwt, wt_data)
+        dres = dres.reshape(1, -1)
         c = conf[0] if conf.ndim else conf
         _, status = self.sb.admom(
             wtb, maxiter=int(c["maxiter"]), shiftmax=float(c["shiftmax"]),
@@ -889,11 +917,15 @@ class SingleStamp(object):
 
     def em_single(self, kind, conf, gm_data, psf_data, conv_data, fill_zero_weight):
         """returns (status, numiter, frac_diff, sky); mixtures updated in place"""
-        gmb = _gm_batch(gm_data, self.device)
-        psfb = _gm_batch(psf_data, self.device)
-        convb = _gm_batch(conv_data, self.device)
+        G = _lib.GAUSS2D_DTYPE
+        dgm, dpsf, dconv, dsky = _upload(
+            self.device, np.ascontiguousarray(gm_data, dtype=G),
+            np.ascontiguousarray(psf_data, dtype=G), np.ascontiguousarray(conv_data, dtype=G),
+            np.array([float(conf["sky"])]))
+        gmb, psfb, convb = _gm_view(dgm, gm_data), _gm_view(dpsf, psf_data), \
+            _gm_view(dconv, conv_data)
         out, status, _ = self.sb.em(
-            gmb, psfb, convb, sky=float(conf["sky"]), kind=kind,
+            gmb, psfb, convb, sky=dsky, kind=kind,
             miniter=int(conf["miniter"]), maxiter=int(conf["maxiter"]),
             tol=float(conf["tol"]), vary_sky=bool(conf["vary_sky"]),
             fill_zero_weight=fill_zero_weight)
