@@ -1,11 +1,15 @@
 #!/bin/bash
-# config 3 under runtime knobs that could change how device-to-host copies share the GPU with kernels
-# usage (GPU box): bash tools/env_ab.sh
+# one bench config under a list of environment settings, alternating, twice
+# usage (GPU box): bash tools/env_ab.sh <config> "A=1" "B=1" ...   ("NONE=1" = the default build)
+CFG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
-for e in "NGMIX_NOOP=1" "GPU_MAX_HW_QUEUES=8" "GPU_MAX_HW_QUEUES=2" "HSA_ENABLE_SDMA=0" "DEBUG_CLR_LIMIT_BLIT_WG=16" "HIP_FORCE_DEV_KERNARG=0"; do
-  env $e python bench.py --config C3 --steps 60 --no-cpu-baseline 2>/dev/null | E="$e" python -c '
+for rep in 1 2; do
+for e in "$@"; do
+  env $e python bench.py --config $CFG --no-cpu-baseline 2>/dev/null | tail -1 | E="$e" python -c '
 import json, os, sys
 d = json.loads(sys.stdin.read())
-print(os.environ["E"].ljust(30), "%.4g fits/s" % d["value"], "ms/step %.3f" % d["ms_per_step"], "kernel sum %.3f" % d["kernels_ms_sum"])'
+r = d["roofline"]
+print(os.environ["E"].ljust(28), "%.4g" % d["value"], "ms/step %.4f" % d["ms_per_step"], r.get("kernel", "")[:40], "frac %.4f" % r["frac"], "launch %.4f ms" % r.get("avg_launch_ms", 0))'
+done
 done
