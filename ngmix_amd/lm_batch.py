@@ -201,7 +201,7 @@ class _EventPool(object):
 SMALL_BATCH = 64
 
 
-def _carve(torch, dev, pieces, pin=False):
+def _carve(torch, dev, pieces):
     """one uint8 allocation cut into named views: pieces = [(name, shape,
     torch dtype)], each 16-byte aligned; returns (buffer, views, offsets)"""
     offs, at = {}, 0
@@ -209,8 +209,7 @@ def _carve(torch, dev, pieces, pin=False):
         nbytes = int(np.prod(shape)) * dt.itemsize
         offs[name] = (at, nbytes)
         at += (nbytes + 15) // 16 * 16
-    buf = (torch.empty(at, dtype=torch.uint8, pin_memory=True) if pin
-           else torch.empty(at, dtype=torch.uint8, device=dev))
+    buf = torch.empty(at, dtype=torch.uint8, device=dev)
     views = {}
     for name, shape, dt in pieces:
         a, nb = offs[name]
