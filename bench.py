@@ -1066,33 +1066,29 @@ def cpu_baseline_c4(budget=1.5, usable=None, teams=None, verbose=False):
     return out
 
 
-def _c3_cpu_fits(budget, seed, nstamps=16):
-    """Complete 'exp' (x) gaussian-psf LM fits of 48x48 stamps on THIS core
-    for `budget` seconds, the reference's algorithm: scipy's MINPACK lmder
-    (what run_leastsq calls with Dfun = FitModel.calc_jacobian,
-    fitters.py:93-104) at DEFAULT_LM_PARS (ftol = xtol = 1e-5, maxfev 4000:
-    defaults.py:17) around the C port of fill_fdiff and of deriv_images
-    (results.py:439-570, derivs_nb.py:40-127).  Returns (fits, seconds, sum of
-    nfev, fits that ended with ier 1..4)."""
+def c3_lmder_fit(ora, pix, psf, guess, work=None):
+    """ONE complete 'exp' (x) psf LM fit of a stamp's pixel list on this core,
+    the reference's algorithm: scipy's MINPACK lmder (what run_leastsq calls
+    with Dfun = FitModel.calc_jacobian, fitters.py:93-104) at DEFAULT_LM_PARS
+    (ftol = xtol = 1e-5, maxfev 4000: defaults.py:17) around the C port of
+    fill_fdiff and of deriv_images (results.py:439-570, derivs_nb.py:40-127).
+    Returns leastsq's full output.  (tests/test_oracle_lm.py holds it to the
+    reference's own fits, nfev for nfev.)"""
     from scipy.optimize import leastsq
-    w = _CpuWorkloads(seed)
-    ora = w.ora
-    _, pix, _, pars = w.stamps(nstamps, 48, "exp")
-    psf = np.zeros(1, dtype=ora.GAUSS2D_DTYPE)
-    ora.gmix_fill(psf, np.array([0.0, 0.0, 0.0, 0.0, 0.27, 1.0]), "gauss")
-    rng = np.random.RandomState(33 + seed)
-    npix = pix.shape[1]
-    vv = [np.ascontiguousarray(pix[i]["v"]) for i in range(nstamps)]
-    uu = [np.ascontiguousarray(pix[i]["u"]) for i in range(nstamps)]
-    area = [np.ascontiguousarray(pix[i]["area"]) for i in range(nstamps)]
-    ierr = [np.ascontiguousarray(pix[i]["ierr"]) for i in range(nstamps)]
+    npix = pix.shape[0]
+    ng = 6 * psf.size
+    if work is None:
+        work = {}
+    if work.get("npix") != npix or work.get("ng") != ng:
+        work.update(npix=npix, ng=ng, gm0=np.zeros(6, dtype=ora.GAUSS2D_DTYPE),
+                    gm=np.zeros(ng, dtype=ora.GAUSS2D_DTYPE), fd=np.zeros(npix),
+                    dimg=np.zeros((6, npix)), jac=np.zeros((npix, 6)))
+    gm0, gm, fd, dimg, jac = (work[k] for k in ("gm0", "gm", "fd", "dimg", "jac"))
+    vv = np.ascontiguousarray(pix["v"])
+    uu = np.ascontiguousarray(pix["u"])
+    area = np.ascontiguousarray(pix["area"])
+    ierr = np.ascontiguousarray(pix["ierr"])
     dcov_de = np.array([[-1.0, 0.0, 1.0], [0.0, 1.0, 0.0]])
-    gm0 = np.zeros(6, dtype=ora.GAUSS2D_DTYPE)
-    gm = np.zeros(6, dtype=ora.GAUSS2D_DTYPE)
-    fd = np.zeros(npix)
-    dimg = np.zeros((6, npix))
-    jac = np.zeros((npix, 6))
-    stat = {"nfev": 0, "ok": 0}
 
     def fill(p):
         # out of range -> GMixRangeError in the reference
@@ -1103,40 +1099,57 @@ def _c3_cpu_fits(budget, seed, nstamps=16):
         ora.gmix_set_norms(gm)
         return True
 
-    def fit(i):
-        def resid(p):
-            if not fill(p):
-                return np.full(npix, -9.999e9)      # LOWVAL (results.py:461-463)
-            ora.fill_fdiff(gm, pix[i], fd, 0)
-            return fd.copy()
+    def resid(p):
+        if not fill(p):
+            return np.full(npix, -9.999e9)      # LOWVAL (results.py:461-463)
+        ora.fill_fdiff(gm, pix, fd, 0)
+        return fd.copy()
 
-        def dfun(p):
-            # FitModel.calc_jacobian: composed gaussians + d cov / d(g1, g2, T)
-            # (results.py:955-1010), deriv_images, rows scaled by ierr
-            if not fill(p):
-                return np.zeros((npix, 6))
-            g1, g2, T, flux = p[2:6]
-            gpars = np.stack([gm[k] for k in ("p", "row", "col", "irr", "irc", "icc")], axis=1)
-            mcov = np.stack([gm0[k] for k in ("irr", "irc", "icc")], axis=1)
-            half_tk = 0.5 * (mcov[:, 0] + mcov[:, 2])
-            gsq = g1 * g1 + g2 * g2
-            f = 2.0 / (1.0 + gsq)
-            g = np.array([g1, g2])
-            jac_e = f * np.eye(2) + (2.0 * g[:, None] * g[None, :]) * (-f / (1.0 + gsq))
-            dcov = np.empty((6, 3, 3))
-            dcov[:, 0:2, :] = half_tk[:, None, None] * (jac_e @ dcov_de)[None, :, :]
-            dcov[:, 2, :] = mcov / T
-            dimg[:] = 0.0       # deriv_images accumulates (derivs_nb.py:107-125)
-            ora.deriv_images(gpars, dcov, vv[i], uu[i], area[i], dimg)
-            for k in range(5):
-                jac[:, k] = dimg[1 + k] * ierr[i]
-            jac[:, 5] = dimg[0] * (ierr[i] / flux)
-            return jac
+    def dfun(p):
+        # FitModel.calc_jacobian: composed gaussians + d cov / d(g1, g2, T)
+        # (results.py:955-1010), deriv_images, rows scaled by ierr
+        if not fill(p):
+            return np.zeros((npix, 6))
+        g1, g2, T, flux = p[2:6]
+        gpars = np.stack([gm[k] for k in ("p", "row", "col", "irr", "irc", "icc")], axis=1)
+        mcov = np.repeat(np.stack([gm0[k] for k in ("irr", "irc", "icc")], axis=1),
+                         psf.size, axis=0)
+        half_tk = 0.5 * (mcov[:, 0] + mcov[:, 2])
+        gsq = g1 * g1 + g2 * g2
+        f = 2.0 / (1.0 + gsq)
+        g = np.array([g1, g2])
+        jac_e = f * np.eye(2) + (2.0 * g[:, None] * g[None, :]) * (-f / (1.0 + gsq))
+        dcov = np.empty((ng, 3, 3))
+        dcov[:, 0:2, :] = half_tk[:, None, None] * (jac_e @ dcov_de)[None, :, :]
+        dcov[:, 2, :] = mcov / T
+        dimg[:] = 0.0       # deriv_images accumulates (derivs_nb.py:107-125)
+        ora.deriv_images(gpars, dcov, vv, uu, area, dimg)
+        for k in range(5):
+            jac[:, k] = dimg[1 + k] * ierr
+        jac[:, 5] = dimg[0] * (ierr / flux)
+        return jac
+    return leastsq(resid, guess, Dfun=dfun, full_output=1, ftol=1.0e-5, xtol=1.0e-5,
+                   maxfev=4000)
+
+
+def _c3_cpu_fits(budget, seed, nstamps=16):
+    """Complete 'exp' (x) gaussian-psf LM fits of 48x48 stamps on THIS core
+    for `budget` seconds (c3_lmder_fit: the reference's algorithm).  Returns
+    (fits, seconds, sum of nfev, fits that ended with ier 1..4)."""
+    w = _CpuWorkloads(seed)
+    ora = w.ora
+    _, pix, _, pars = w.stamps(nstamps, 48, "exp")
+    psf = np.zeros(1, dtype=ora.GAUSS2D_DTYPE)
+    ora.gmix_fill(psf, np.array([0.0, 0.0, 0.0, 0.0, 0.27, 1.0]), "gauss")
+    rng = np.random.RandomState(33 + seed)
+    stat = {"nfev": 0, "ok": 0}
+    work = {}
+
+    def fit(i):
         guess = pars[i] * rng.uniform(0.9, 1.1, size=6)
         guess[0:2] = pars[i][0:2] + rng.uniform(-0.05, 0.05, size=2)
         guess[2:4] = pars[i][2:4] + rng.uniform(-0.03, 0.03, size=2)
-        out = leastsq(resid, guess, Dfun=dfun, full_output=1, ftol=1.0e-5, xtol=1.0e-5,
-                      maxfev=4000)
+        out = c3_lmder_fit(ora, pix[i], psf, guess, work)
         stat["nfev"] += out[2]["nfev"]
         stat["ok"] += int(1 <= out[4] <= 4)
 

@@ -986,3 +986,34 @@ def test_small_batch_arena_equals_separate_buffers(monkeypatch):
     for k in a:
         assert np.array_equal(a[k], b[k], equal_nan=True), k
     assert np.all(a["flags"] == 0)
+
+
+def test_c3_shaped_batch_against_the_reference_fit_by_fit(golden):
+    """forty independent 48x48 'exp' (x) gaussian-psf objects (config 3's shape
+    and guess; off-grid centres, some sheared jacobians, s/n 85-400) fitted by
+    the REFERENCE's Fitter (MINPACK lmder, DEFAULT_LM_PARS: oracle/gen_golden_c3.py)
+    against ONE lock-step batch of the driver: the same nfev and ier for every
+    object, pars / pars_cov / statistics to the tolerances the single golden
+    object is held to (test_gpu_api.py) -- the direct link the round-3 review
+    asked for, not through this package's own per-object Fitter"""
+    g = golden("lm_c3")
+    n = g["images"].shape[0]
+    weights = np.broadcast_to((1.0 / g["sigma"] ** 2)[:, None, None], g["images"].shape).copy()
+    sb = StampBatch.from_images(g["images"], weights, g["jac"])
+    psf = GMixBatch.from_numpy(np.tile(
+        ngmix.GMix(pars=g["psf_pars"])._data[None, :], (n, 1)).reshape(n, -1))
+    for lazy in (True, False):
+        f = LMBatchFitter("exp")
+        f.lazy_jacobian = lazy
+        res = f.go(sb, g["guess"], psf=psf)
+        assert np.all(res["flags"] == g["flags"]) and np.all(g["flags"] == 0)
+        assert np.array_equal(res["nfev"], g["nfev"])
+        assert np.array_equal(res["ier"], g["ier"])
+        np.testing.assert_allclose(res["pars"], g["pars"], rtol=1e-6, atol=1e-8)
+        sig = np.sqrt(np.einsum("ijj->ij", g["pars_cov"]))
+        tol = 1e-4 * np.abs(g["pars_cov"]) + 1e-7 * sig[:, :, None] * sig[:, None, :]
+        assert np.all(np.abs(res["pars_cov"] - g["pars_cov"]) <= tol)
+        np.testing.assert_allclose(res["pars_err"], g["pars_err"], rtol=1e-4)
+        for k in ("lnprob", "chi2per", "s2n"):
+            np.testing.assert_allclose(res[k], g[k], rtol=1e-5)
+        assert np.array_equal(res["dof"], g["dof"]) and np.array_equal(res["npix"], g["npix"])

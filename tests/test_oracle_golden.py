@@ -353,3 +353,29 @@ def test_deriv_images(golden):
         ora.deriv_images(g[name + "_gpars"], g[name + "_dcov"], g["v"], g["u"],
                          g["area"], out)
         np.testing.assert_array_equal(out, g[name + "_out"], err_msg=name)
+
+
+def test_cpu_lm_leg_is_the_reference_fit(golden):
+    """bench.py's config-3 cpu_baseline leg (bench.c3_lmder_fit: scipy's MINPACK
+    lmder around the C port of fill_fdiff / deriv_images at DEFAULT_LM_PARS)
+    against the REFERENCE's own Fitter on the forty objects of
+    tests/golden/lm_c3.npz: the same nfev and ier fit by fit, the same
+    solution -- the CPU figure printed beside the GPU's is the reference's
+    algorithm, not a look-alike"""
+    import bench
+    g = golden("lm_c3")
+    psf = np.zeros(1, dtype=ora.GAUSS2D_DTYPE)
+    ora.gmix_fill(psf, np.array([0.0, 0.0, 0.0, 0.0, 0.27, 1.0]), "gauss")
+    work = {}
+    for i in range(g["images"].shape[0]):
+        jac = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+        for n in ora.JACOBIAN_DTYPE.names:
+            jac[n] = g["jac"][i][n]
+        wt = np.full(g["images"][i].shape, 1.0 / g["sigma"][i] ** 2)
+        pix = ora.make_pixels(g["images"][i], wt, jac, True)
+        out = bench.c3_lmder_fit(ora, pix, psf, g["guess"][i].copy(), work)
+        assert out[2]["nfev"] == int(g["nfev"][i]), i
+        assert out[4] == int(g["ier"][i]), i
+        np.testing.assert_allclose(out[0], g["pars"][i], rtol=1e-8, atol=1e-10)
+        # leastsq's cov_x is the reference's pars_cov0
+        np.testing.assert_allclose(out[1], g["pars_cov0"][i], rtol=1e-6)
