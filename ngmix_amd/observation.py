@@ -127,6 +127,14 @@ class Observation(MetadataMixin):
             self._stamp_batch = StampBatch.from_observations([self])
         return self._stamp_batch
 
+    def __getstate__(self):
+        """pickling (worker pools, checkpoints) carries the host arrays only:
+        the device-resident copies are made again where they are needed"""
+        state = self.__dict__.copy()
+        state["_stamp"] = None
+        state["_stamp_batch"] = None
+        return state
+
     def _device_stamp(self):
         """the compact device-resident copy the kernels read"""
         if self._stamp is None:

@@ -497,3 +497,21 @@ def test_lm_small_batch_arena_layout():
     views["tri"].fill_(7.0)
     assert float(views["flat"].sum()) == 0.0 and float(views["rec"].sum()) == 0.0
     assert offs["flat"][0] < offs["tri"][0] < offs["rec"][0]
+
+
+def test_observation_pickles_without_its_device_copies():
+    """an Observation sent to a worker process (pickle) carries its host arrays;
+    the device-resident stamp and batch are dropped and made again on use"""
+    import pickle
+    import ngmix_amd as ngmix
+    rng = np.random.RandomState(5)
+    obs = ngmix.Observation(rng.normal(size=(7, 9)), weight=np.full((7, 9), 4.0),
+                            jacobian=ngmix.DiagonalJacobian(row=3.0, col=4.0, scale=0.2),
+                            meta={"id": 3})
+    obs._stamp = object.__new__(type("DeviceThing", (), {"__reduce__": lambda s: 1 / 0}))
+    obs._stamp_batch = obs._stamp
+    back = pickle.loads(pickle.dumps(obs))
+    assert back._stamp is None and back._stamp_batch is None
+    assert obs._stamp is not None                       # the original keeps its copies
+    assert np.array_equal(back.image, obs.image) and np.array_equal(back.weight, obs.weight)
+    assert back.meta["id"] == 3 and back.jacobian.get_scale() == obs.jacobian.get_scale()
