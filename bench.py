@@ -113,23 +113,102 @@ def init_rank(args):
     return rank, world, torch.device("cuda", local_rank), backend
 
 
-def timed_steps(step, args, distributed, device):
+class PeerFailure(RuntimeError):
+    """another rank failed in this leg (every rank records it and moves on)"""
+
+
+# One leg of a run at N > 1.  A failure that is local to one rank (an
+# allocation that fails on one shard) must neither leave the other ranks
+# blocked in the leg's collectives nor cost the headline line: the ranks agree
+# on an ok flag when they enter the steps and again after the leg, and a rank
+# that fails INSIDE its steps keeps the leg's collectives matched with empty
+# records until the leg is over (Gather.drain).
+LEG = {"entered": False, "error": None}
+
+
+def agree(failed, device):
+    """MAX over the ranks of a failure flag (one small all-reduce)"""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1 if failed else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
+
+
+def inject_failure(where):
+    """testing knob NGMIX_BENCH_FAIL = "<config>:<rank>:<setup|stepN>" """
+    spec = os.environ.get("NGMIX_BENCH_FAIL")
+    if spec:
+        cfg, rk, at = spec.split(":")
+        if (cfg, int(rk), at) == (LEG.get("config"), int(os.environ.get("RANK", "0")), where):
+            raise RuntimeError("injected failure (%s)" % spec)
+
+
+def run_leg(name, fn, world, device, *a, **kw):
+    """fn(*a, **kw) as one leg; returns (result, error).  At N > 1 the error is
+    the same kind on every rank: the failing rank's own, PeerFailure elsewhere."""
+    LEG.update(entered=False, error=None, config=name)
+    out = err = None
+    try:
+        out = fn(*a, **kw)
+    except Exception as e:
+        err = e
+    if world > 1:
+        if not LEG["entered"]:
+            # failed before its steps: the others are at the entry agreement
+            agree(True, device)
+        elif not isinstance(err, PeerFailure):
+            if agree(err is not None, device) and err is None:
+                out, err = None, PeerFailure("a peer rank failed in leg %s" % name)
+    return out, err
+
+
+def timed_steps(step, args, distributed, device, gat=None):
     """settle + W warm-up steps untimed, then exactly K steps between barrier +
     synchronize on both sides; returns the max over ranks of the elapsed time"""
     import torch
     import torch.distributed as dist
+    if distributed:
+        LEG["entered"] = True
+        try:
+            inject_failure("setup")
+            mine = None
+        except Exception as e:
+            mine = e
+        if agree(mine is not None, device):
+            raise mine or PeerFailure("a peer rank failed while setting leg %s up"
+                                      % LEG.get("config"))
+    count = [0]
+
+    def run(i):
+        done = 0
+        if LEG["error"] is None:
+            before = gat.calls if gat is not None else 0
+            try:
+                inject_failure("step%d" % count[0])
+                count[0] += 1
+                step(i)
+                return
+            except Exception as e:
+                if not distributed:
+                    raise
+                LEG["error"] = e
+                done = (gat.calls - before) if gat is not None else 0
+        if gat is not None:
+            gat.drain(done)
+
     for _ in range(max(args.settle_steps, 0)):
-        step(None)
+        run(None)
     torch.cuda.synchronize()
     for _ in range(args.warmup):
-        step(None)
+        run(None)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        run(i)
     torch.cuda.synchronize()
     own = time.perf_counter() - t0          # this rank's K steps, before the barrier
     if distributed:
@@ -146,6 +225,8 @@ def timed_steps(step, args, distributed, device):
         every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(every, mine)
         PER_RANK_MS[:] = [float(v.item()) for v in every]
+    if LEG["error"] is not None:
+        raise LEG["error"]
     return elapsed
 
 
@@ -155,15 +236,30 @@ PER_RANK_MS = []
 
 class Gather:
     """north_star's all-gather of per-object result records, on a side stream
-    so that it overlaps the next step's first kernel"""
+    so that it overlaps the next step's first kernel.  pattern: the gathers of
+    one step in order, [(key, shape, dtype)] -- what drain() replays with empty
+    records for a rank whose step failed."""
 
-    def __init__(self, world, device):
+    def __init__(self, world, device, pattern=()):
         import torch
         self.world = world
+        self.device = device
         self.on = world > 1
         self.side = torch.cuda.Stream(device=device) if self.on else None
         self.pending = None
         self.bufs = {}
+        self.pattern = list(pattern)
+        self.calls = 0
+
+    def drain(self, done):
+        """the gathers a failed step still owes its peers (all but the first
+        `done` of the pattern), with zero records"""
+        import torch
+        if not self.on:
+            return
+        for key, shape, dtype in self.pattern[done:]:
+            self.wait_consumed()
+            self.gather(key, torch.zeros(shape, dtype=dtype, device=self.device))
 
     def wait_consumed(self):
         """the previous gather must have read its source before the kernel
@@ -176,6 +272,7 @@ class Gather:
     def gather(self, key, records):
         import torch
         from ngmix_amd import distributed as nd
+        self.calls += 1
         if not self.on:
             return records
         n = records.shape[0]
@@ -281,7 +378,7 @@ def run_c2(args, rank, world, device, backend):
     image = torch.zeros(sb.total_pix, dtype=torch.float64, device=device)
     out = torch.empty((n, 4), dtype=torch.float64, device=device)
     status = torch.empty(n, dtype=torch.int32, device=device)
-    gat = Gather(world, device)
+    gat = Gather(world, device, [("loglike", (n, 4), torch.float64)])
     ev_r0, ev_r1 = _events(args.steps), _events(args.steps)
     ev_l0, ev_l1 = _events(args.steps), _events(args.steps)
 
@@ -299,7 +396,7 @@ def run_c2(args, rank, world, device, backend):
             ev_l1[i].record()
         gat.gather("loglike", out)
 
-    elapsed = timed_steps(step, args, distributed, device)
+    elapsed = timed_steps(step, args, distributed, device, gat)
     bad = int((status != 0).sum().item())
     render_ms = _mean_ms(ev_r0, ev_r1)
     loglike_ms = _mean_ms(ev_l0, ev_l1)
@@ -422,7 +519,7 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
         a2.settle_steps = min(max(args.settle_steps, 0), 200)
     fitter = LMBatchFitter("exp")
     fitter.time_kernels = True     # HIP events around every lm_eval launch
-    gat = Gather(world, device)
+    gat = Gather(world, device, [("lm", (n, 14), torch.float64)])
     K = steps or args.steps
     state = {"loop": 0.0, "rounds": 0, "bad": 0, "nfev": 0.0, "eval_ms": 0.0,
              "eval_stamps": 0.0, "launches": 0, "kernels": {}, "launched": 0}
@@ -475,17 +572,30 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
             # (through pinned memory, asynchronously: a copy from pageable memory
             # synchronises the stream, i.e. would make this rank's host wait for
             # the batch it has just queued)
-            pin = state.setdefault("pin", torch.empty(rec.shape, dtype=torch.float64,
-                                                      pin_memory=True))
-            pin.numpy()[:] = rec
-            gat.gather("lm", pin.to(device, non_blocking=True))
+            # Two pinned buffers alternate; a buffer is rewritten only after the
+            # event behind its last upload has completed on the HOST (the upload
+            # is queued behind a whole batch of kernels: ordering the stream
+            # alone would let this write overtake it).
+            if "pins" not in state:
+                state["pins"] = [[torch.empty(rec.shape, dtype=torch.float64,
+                                              pin_memory=True), None] for _ in range(2)]
+                state["pin_turn"] = 0
+            slot = state["pins"][state["pin_turn"]]
+            state["pin_turn"] ^= 1
+            if slot[1] is not None:
+                slot[1].synchronize()
+            slot[0].numpy()[:] = rec
+            up = slot[0].to(device, non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
+            gat.gather("lm", up)
 
     # what one synchronous call spends in its lock-step loop (kernels + the
     # counter read-backs), measured before the pipeline starts
     fitter.go(sb, guess, psf=psf)
     fitter.go(sb, guess, psf=psf)
     sync_loop_ms = fitter.loop_seconds * 1e3
-    elapsed = timed_steps(step, a2, distributed, device)
+    elapsed = timed_steps(step, a2, distributed, device, gat)
     if rank != 0:
         return None
     # (inside the pipeline a batch's loop time is host time and spans the
@@ -599,7 +709,8 @@ def run_c4(args, rank, world, device, backend, nstamps=None, steps=None, quiet=F
     sb, sb_em, dim = w["sb"], w["sb_em"], w["dim"]
     npx = dim * dim
     distributed = world > 1
-    gat = Gather(world, device)
+    gat = Gather(world, device, [("admom", (n, 73), torch.float64),
+                                 ("em", (n, 9), torch.float64)])
     wt = w["wt0"].clone()
     gm = w["gm0"].clone()
     conv, _ = gm.convolve(w["psf"])
@@ -639,7 +750,7 @@ def run_c4(args, rank, world, device, backend, nstamps=None, steps=None, quiet=F
     a2.steps = K
     if steps is not None:       # the short leg of a C2 run
         a2.warmup, a2.settle_steps = 2, 30   # ~0.45 s of load before the clock starts
-    elapsed = timed_steps(step, a2, distributed, device)
+    elapsed = timed_steps(step, a2, distributed, device, gat)
     admom_ms = _mean_ms(ev[0], ev[1])
     em_ms = _mean_ms(ev[2], ev[3])
     # iteration counts of the last pass: the flop model's multiplier
@@ -750,7 +861,7 @@ def run_c5(args, rank, world, device, backend, nobj=None, steps=None):
     out = torch.empty((ns, 4), dtype=torch.float64, device=device)
     status = torch.empty(ns, dtype=torch.int32, device=device)
     distributed = world > 1
-    gat = Gather(world, device)
+    gat = Gather(world, device, [("c5", (nobj, 4), torch.float64)])
     K = steps or args.steps
     ev0, ev1, ev2 = _events(K), _events(K), _events(K)
     holder = {}
@@ -773,7 +884,7 @@ def run_c5(args, rank, world, device, backend, nobj=None, steps=None):
     a2.steps = K
     if steps is not None:
         a2.warmup, a2.settle_steps = 5, 160   # ~0.45 s of load before the clock starts
-    elapsed = timed_steps(step, a2, distributed, device)
+    elapsed = timed_steps(step, a2, distributed, device, gat)
     ll_ms = _mean_ms(ev0, ev1)
     red_ms = _mean_ms(ev1, ev2)
     bad = int((status != 0).sum().item())
@@ -1372,7 +1483,9 @@ def main():
     import torch.distributed as dist
     rank, world, device, backend = init_rank(args)
     run = {"C2": run_c2, "C3": run_c3, "C4": run_c4, "C5": run_c5}[args.config]
-    line = run(args, rank, world, device, backend)
+    line, err = run_leg(args.config, run, world, device, args, rank, world, device, backend)
+    if err is not None:
+        raise err
     if rank == 0:
         line["rccl_ranks"] = dist.get_world_size() if world > 1 else 1
         line["backend"] = backend or "none (single process)"
@@ -1392,24 +1505,23 @@ def main():
         for name, fn, kw in (("C3", run_c3, dict(nstamps=min(100000, cap), steps=30)),
                              ("C4", run_c4, dict(nstamps=min(125000, cap), steps=16)),
                              ("C5", run_c5, dict(nobj=min(20000, max(cap // 10, 8)), steps=60))):
-            try:
-                o = fn(args, rank, world, device, backend, **kw)
-                if rank == 0:
-                    other[name] = {k: o[k] for k in (
-                        "metric", "value", "unit", "config", "roofline", "kernels_ms",
-                        "bad_status") if k in o}
-                    for k in ("rooflines", "mean_numiter", "device_loop_ms", "rounds",
-                              "fits_per_s_device_loop", "mean_nfev", "ms_per_step",
-                              "kernels_ms_sum", "host_ms_per_step", "rounds_launched",
-                              "pipelined", "steps",
-                              "settle_steps", "n_gpus"):
-                        if k in o:
-                            other[name][k] = o[k]
-                    other[name]["per_rank_ms_per_step"] = list(PER_RANK_MS)
-            except Exception as e:   # never lose the headline line
-                # (at N > 1 a failure in the leg's own code is the same on every
-                # rank: all of them record it and go on to the next leg)
-                other[name] = {"error": repr(e)}
+            # (a failure local to one rank is agreed on by all of them, run_leg:
+            # every rank records it and goes on to the next leg)
+            o, err = run_leg(name, fn, world, device, args, rank, world, device, backend, **kw)
+            if err is not None:   # never lose the headline line
+                other[name] = {"error": repr(err)}
+            elif rank == 0:
+                other[name] = {k: o[k] for k in (
+                    "metric", "value", "unit", "config", "roofline", "kernels_ms",
+                    "bad_status") if k in o}
+                for k in ("rooflines", "mean_numiter", "device_loop_ms", "rounds",
+                          "fits_per_s_device_loop", "mean_nfev", "ms_per_step",
+                          "kernels_ms_sum", "host_ms_per_step", "rounds_launched",
+                          "pipelined", "steps",
+                          "settle_steps", "n_gpus"):
+                    if k in o:
+                        other[name][k] = o[k]
+                other[name]["per_rank_ms_per_step"] = list(PER_RANK_MS)
             torch.cuda.empty_cache()
     if rank == 0:
         if other:

@@ -336,7 +336,8 @@ int ngmix_batch_upload(ngmix_batch *b, const double *images, const double *weigh
 int ngmix_batch_npix_kept(const ngmix_batch *b, int32_t *npix_kept);
 int ngmix_batch_free(ngmix_batch *b);
 
-/* ierr = sqrt(max(weight,0)) elementwise (pixels_nb.py:49-52) */
+/* ierr = sqrt(max(weight,0)) elementwise (pixels_nb.py:49-52); ierr == weight
+ * (in place) is allowed; weight == NULL fills unit ierr */
 int ngmix_weight_to_ierr_batch(const double *weight, double *ierr, int64_t n,
                                void *stream);
 /* count kept pixels per stamp into stamps[i].npix_kept (pixels.py:33-37);

@@ -327,12 +327,14 @@ class StampBatch(object):
         dw = dev_all[tot:2 * tot]
         djac = dev_all[2 * tot:2 * tot + 8 * n].reshape(n, 8)
         dtab = dev_all[2 * tot + 8 * n:].view(torch.int32).reshape(n, 8)
-        ierr = torch.empty_like(dw)
+        # in place (the kernel is element-wise, as in ngmix_batch_upload): the
+        # weight slice of the one allocation BECOMES ierr, so a batch holds two
+        # doubles per pixel, not three
         with _on_device(dev):
             st = _lib.lib().ngmix_weight_to_ierr_batch(
-                _dptr(dw), _dptr(ierr), dw.numel(), _stream())
+                _dptr(dw), _dptr(dw), dw.numel(), _stream())
         _lib.check(st, "ngmix_weight_to_ierr_batch")
-        sb = cls(dval, ierr, djac, nrow, ncol, off, izw, npix_kept=kept)
+        sb = cls(dval, dw, djac, nrow, ncol, off, izw, npix_kept=kept)
         sb._stamp_tables[1] = dtab
         return sb
 

@@ -1,0 +1,586 @@
+// lm_core_team.hpp -- lm_core.hpp's lmder step for a TEAM of 16 lanes per fit.
+//
+// One thread per fit (lm_core.hpp's generic form in the device kernel) keeps a
+// fit's work arrays -- two n x n matrices and a dozen vectors, indexed at run
+// time by MINPACK's pivot order -- in private memory: a step is a serial chain
+// of ~2,000 dependent scratch accesses, 0.5-2.3 ms per launch for fits of
+// 11-14 parameters however few fits there are (multi-band fits, co-elliptical
+// psf fits with 4 / 5 gaussians).  The register form (lm_core_reg.hpp) removes
+// the memory latency for up to 10 parameters and does not fit beyond.
+//
+// Here a fit belongs to 16 lanes and its arrays live in LDS:
+//
+//   * every lane runs lmder's SCALAR logic -- pivot searches, Givens
+//     coefficients, the sums whose order of addition matters (enorm, the
+//     triangular solves), every branch -- redundantly on the same LDS values:
+//     all lanes of a team hold the same scalars to the bit and take the same
+//     branches, with no broadcast step;
+//   * the loops over independent elements (a rotation applied to the rows
+//     below the pivot, the rank-1 update of the factorisation, row / column
+//     swaps, the element-wise vector updates, the fold of the stamps' sums)
+//     run one element per lane;
+//   * the vectors that are only ever touched element-wise (x, xt, xi, xti, lo,
+//     hi, xstep, hstep) are one register per lane.
+//
+// The operations on every element and the order of every sum are lm_core.hpp's,
+// statement for statement (and the build has no FMA contraction), so a state
+// record after a step is BYTE-IDENTICAL to the generic form's:
+// tests/test_gpu_lm_team.py compares the records of the two forms after every
+// round; nfev / ier parity with MINPACK and the reference is therefore untouched.
+//
+// A team's lanes communicate through LDS only.  LDS instructions of one wave
+// execute in order, so a phase boundary needs no hardware barrier: tsync() is a
+// compiler fence (no memory operation may move across it) and a wave barrier.
+// Within a phase no lane reads an element another lane writes.
+#pragma once
+
+#include "lm_core.hpp"
+
+namespace lmteam {
+
+constexpr int TEAM = 16;
+
+__device__ __forceinline__ void tsync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
+// the scalars of a fit: one copy per lane, identical across the team
+struct Scal {
+    double fnorm, xnorm, delta, par, gnorm, pnorm;
+    double ftol, xtol, gtol, factor;
+    int32_t n, iter, nfev, njev, info, phase, maxfev, mode, bounded, fonly;
+};
+
+// a team's view of its fit
+struct Fit {
+    int lane;       // 0 .. 15; lane j owns element j of every vector
+    int ld;         // stride of the matrices (odd: 16 lanes walking a column hit 16 banks)
+    // LDS
+    double *R;      // the pivoted factor (state)
+    double *M;      // A = J^T J on entry, S inside factor_normal, r inside lmpar
+    double *diag, *qtf, *step, *g, *acnorm, *sdiag, *p, *wa1, *wa2, *wa3;
+    int32_t *ipvt;
+    // one element per lane (lane >= n: unused)
+    double x, xt, xi, xti, lo, hi, xstep, hstep;
+    Scal s;
+};
+
+// doubles of LDS per team for fits of up to np parameters
+__host__ __device__ inline int team_lds_doubles(int np)
+{
+    const int ld = np | 1;
+    return 2 * np * ld + 11 * np;
+}
+
+__device__ __forceinline__ void carve(Fit &f, double *base, int np)
+{
+    f.ld = np | 1;
+    f.R = base;
+    f.M = f.R + np * f.ld;
+    f.diag = f.M + np * f.ld;
+    f.qtf = f.diag + np;
+    f.step = f.qtf + np;
+    f.g = f.step + np;
+    f.acnorm = f.g + np;
+    f.sdiag = f.acnorm + np;
+    f.p = f.sdiag + np;
+    f.wa1 = f.p + np;
+    f.wa2 = f.wa1 + np;
+    f.wa3 = f.wa2 + np;
+    f.ipvt = (int32_t *)(f.wa3 + np);
+}
+
+// "for (int i = lo; i < hi; i++)" with one element per lane (hi - lo <= 16)
+#define TFOR(i, lo_, hi_) for (int i = (lo_) + f.lane, i##_once = 1; i##_once && i < (hi_); i##_once = 0)
+#define LEAD if (f.lane == 0)
+
+// lmcore::enorm on an LDS vector: every lane adds in index order
+__device__ __forceinline__ double enorm(int n, const double *x)
+{
+    double s = 0.0;
+    for (int i = 0; i < n; i++) s += x[i] * x[i];
+    return sqrt(s);
+}
+
+// lmcore::factor_normal.  M holds A on entry and is destroyed (the serial code's
+// copy S); R, ipvt, acnorm are written.
+__device__ __forceinline__ void factor_normal(Fit &f)
+{
+    const int n = f.s.n, ld = f.ld;
+    double *S = f.M, *R = f.R;
+    TFOR(j, 0, n) {
+        f.ipvt[j] = j;
+        const double d = S[j * ld + j];
+        f.acnorm[j] = d > 0.0 ? sqrt(d) : 0.0;
+        for (int k = 0; k < n; k++) R[j * ld + k] = 0.0;
+    }
+    tsync();
+    for (int k = 0; k < n; k++) {
+        int kmax = k;
+        for (int j = k + 1; j < n; j++)
+            if (S[j * ld + j] > S[kmax * ld + kmax]) kmax = j;
+        if (kmax != k) {
+            tsync();
+            TFOR(i, 0, n) {          // columns k <-> kmax of S; of R above row k
+                const double t = S[i * ld + k];
+                S[i * ld + k] = S[i * ld + kmax];
+                S[i * ld + kmax] = t;
+                if (i < k) {
+                    const double u = R[i * ld + k];
+                    R[i * ld + k] = R[i * ld + kmax];
+                    R[i * ld + kmax] = u;
+                }
+            }
+            tsync();
+            TFOR(j, 0, n) {          // rows k <-> kmax of S
+                const double t = S[k * ld + j];
+                S[k * ld + j] = S[kmax * ld + j];
+                S[kmax * ld + j] = t;
+            }
+            LEAD {
+                const int32_t ti = f.ipvt[k];
+                f.ipvt[k] = f.ipvt[kmax];
+                f.ipvt[kmax] = ti;
+            }
+            tsync();
+        }
+        const double d = S[k * ld + k];
+        if (!(d > 0.0)) {
+            tsync();
+            TFOR(kk, k, n)
+                for (int j = kk; j < n; j++) R[kk * ld + j] = 0.0;
+            tsync();
+            return;
+        }
+        const double rkk = sqrt(d);
+        tsync();
+        LEAD R[k * ld + k] = rkk;
+        TFOR(j, k + 1, n) R[k * ld + j] = S[k * ld + j] / rkk;
+        tsync();
+        TFOR(i, k + 1, n) {
+            const double rki = R[k * ld + i];
+            for (int j = i; j < n; j++) {
+                const double v = S[i * ld + j] - rki * R[k * ld + j];
+                S[i * ld + j] = v;
+                S[j * ld + i] = v;
+            }
+        }
+        tsync();
+    }
+}
+
+// lmcore::qtf_from_gradient
+__device__ __forceinline__ void qtf_from_gradient(Fit &f)
+{
+    const int n = f.s.n, ld = f.ld;
+    for (int j = 0; j < n; j++) {
+        double s = f.g[f.ipvt[j]];
+        for (int i = 0; i < j; i++) s -= f.R[i * ld + j] * f.qtf[i];
+        const double rjj = f.R[j * ld + j];
+        const double q = rjj != 0.0 ? s / rjj : 0.0;
+        tsync();
+        LEAD f.qtf[j] = q;
+        tsync();
+    }
+}
+
+// lmcore::qrsolv on r = f.M, with diag = dvec (an LDS vector), qtb = f.qtf,
+// x = f.p, sdiag = f.sdiag, wa = wa (an LDS vector)
+__device__ __forceinline__ void qrsolv(Fit &f, const double *dvec, double *wa)
+{
+    const int n = f.s.n, ld = f.ld;
+    double *r = f.M, *x = f.p, *sdiag = f.sdiag;
+    // (x doubles as the store of the diagonal of R until the end, as in MINPACK)
+    TFOR(j, 0, n) {
+        for (int i = j; i < n; i++) r[i * ld + j] = r[j * ld + i];
+        x[j] = r[j * ld + j];
+        wa[j] = f.qtf[j];
+    }
+    tsync();
+    for (int j = 0; j < n; j++) {
+        const int l = f.ipvt[j];
+        const double dl = dvec[l];
+        if (dl != 0.0) {
+            tsync();
+            TFOR(k, j, n) sdiag[k] = k == j ? dl : 0.0;
+            tsync();
+            double qtbpj = 0.0;
+            for (int k = j; k < n; k++) {
+                const double sk = sdiag[k];
+                if (sk == 0.0) continue;
+                double cs, sn;
+                const double rkk = r[k * ld + k];
+                if (fabs(rkk) < fabs(sk)) {
+                    const double cotan = rkk / sk;
+                    sn = 0.5 / sqrt(0.25 + 0.25 * (cotan * cotan));
+                    cs = sn * cotan;
+                } else {
+                    const double tn = sk / rkk;
+                    cs = 0.5 / sqrt(0.25 + 0.25 * (tn * tn));
+                    sn = cs * tn;
+                }
+                const double wak = wa[k];
+                const double temp = cs * wak + sn * qtbpj;
+                qtbpj = -sn * wak + cs * qtbpj;
+                tsync();
+                LEAD {
+                    r[k * ld + k] = cs * rkk + sn * sk;
+                    wa[k] = temp;
+                }
+                TFOR(i, k + 1, n) {
+                    const double rik = r[i * ld + k], si = sdiag[i];
+                    const double t = cs * rik + sn * si;
+                    sdiag[i] = -sn * rik + cs * si;
+                    r[i * ld + k] = t;
+                }
+                tsync();
+            }
+        }
+        const double rjj = r[j * ld + j], xj = x[j];
+        tsync();
+        LEAD {
+            sdiag[j] = rjj;
+            r[j * ld + j] = xj;
+        }
+        tsync();
+    }
+    int nsing = n;
+    for (int j = 0; j < n; j++)
+        if (sdiag[j] == 0.0 && nsing == n) nsing = j;
+    tsync();
+    TFOR(j, nsing, n) wa[j] = 0.0;
+    tsync();
+    for (int k = 0; k < nsing; k++) {
+        const int j = nsing - 1 - k;
+        double sum = 0.0;
+        for (int i = j + 1; i < nsing; i++) sum += r[i * ld + j] * wa[i];
+        const double w = (wa[j] - sum) / sdiag[j];
+        tsync();
+        LEAD wa[j] = w;
+        tsync();
+    }
+    TFOR(j, 0, n) x[f.ipvt[j]] = wa[j];
+    tsync();
+}
+
+// lmcore::lmpar on r = f.M (a copy of R made by the caller), diag = f.diag,
+// qtb = f.qtf, delta / par in f.s; x = f.p, sdiag = f.sdiag
+__device__ __forceinline__ void lmpar(Fit &f)
+{
+    const int n = f.s.n, ld = f.ld;
+    double *r = f.M, *x = f.p, *wa1 = f.wa1, *wa2 = f.wa2;
+    const double delta = f.s.delta;
+    // gauss-newton direction
+    int nsing = n;
+    for (int j = 0; j < n; j++)
+        if (r[j * ld + j] == 0.0 && nsing == n) nsing = j;
+    TFOR(j, 0, n) wa1[j] = j < nsing ? f.qtf[j] : 0.0;
+    tsync();
+    for (int k = 0; k < nsing; k++) {
+        const int j = nsing - 1 - k;
+        const double temp = wa1[j] / r[j * ld + j];
+        tsync();
+        LEAD wa1[j] = temp;
+        TFOR(i, 0, j) wa1[i] -= r[i * ld + j] * temp;
+        tsync();
+    }
+    TFOR(j, 0, n) x[f.ipvt[j]] = wa1[j];
+    tsync();
+
+    int iter = 0;
+    TFOR(j, 0, n) wa2[j] = f.diag[j] * x[j];
+    tsync();
+    double dxnorm = enorm(n, wa2);
+    double fp = dxnorm - delta;
+    if (fp <= 0.1 * delta) {
+        f.s.par = 0.0;
+        return;
+    }
+    // lower bound
+    double parl = 0.0;
+    if (nsing >= n) {
+        tsync();
+        TFOR(j, 0, n) {
+            const int l = f.ipvt[j];
+            wa1[j] = f.diag[l] * (wa2[l] / dxnorm);
+        }
+        tsync();
+        for (int j = 0; j < n; j++) {
+            double sum = 0.0;
+            for (int i = 0; i < j; i++) sum += r[i * ld + j] * wa1[i];
+            const double w = (wa1[j] - sum) / r[j * ld + j];
+            tsync();
+            LEAD wa1[j] = w;
+            tsync();
+        }
+        const double temp = enorm(n, wa1);
+        parl = ((fp / delta) / temp) / temp;
+    }
+    // upper bound
+    tsync();
+    TFOR(j, 0, n) {
+        double sum = 0.0;
+        for (int i = 0; i <= j; i++) sum += r[i * ld + j] * f.qtf[i];
+        wa1[j] = sum / f.diag[f.ipvt[j]];
+    }
+    tsync();
+    const double gnorm = enorm(n, wa1);
+    double paru = gnorm / delta;
+    if (paru == 0.0) paru = lmcore::DWARF / fmin(delta, 0.1);
+    double par = f.s.par;
+    par = fmax(par, parl);
+    par = fmin(par, paru);
+    if (par == 0.0) par = gnorm / dxnorm;
+
+    for (;;) {
+        iter++;
+        if (par == 0.0) par = fmax(lmcore::DWARF, 0.001 * paru);
+        double temp = sqrt(par);
+        tsync();
+        TFOR(j, 0, n) wa1[j] = temp * f.diag[j];
+        tsync();
+        qrsolv(f, wa1, wa2);
+        TFOR(j, 0, n) wa2[j] = f.diag[j] * x[j];
+        tsync();
+        dxnorm = enorm(n, wa2);
+        temp = fp;
+        fp = dxnorm - delta;
+        if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) ||
+            iter == 10)
+            break;
+        // newton correction
+        tsync();
+        TFOR(j, 0, n) {
+            const int l = f.ipvt[j];
+            wa1[j] = f.diag[l] * (wa2[l] / dxnorm);
+        }
+        tsync();
+        for (int j = 0; j < n; j++) {
+            const double t = wa1[j] / f.sdiag[j];
+            tsync();
+            LEAD wa1[j] = t;
+            TFOR(i, j + 1, n) wa1[i] -= r[i * ld + j] * t;
+            tsync();
+        }
+        temp = enorm(n, wa1);
+        const double parc = ((fp / delta) / temp) / temp;
+        if (fp > 0.0) parl = fmax(parl, par);
+        if (fp < 0.0) paru = fmin(paru, par);
+        par = fmax(parl, par + parc);
+    }
+    f.s.par = par;
+}
+
+// lmcore::set_trial: element j in lane j
+__device__ __forceinline__ void set_trial(Fit &f)
+{
+    constexpr double EPS = 1.4901161193847656e-08;  // sqrt(machine epsilon)
+    TFOR(j, 0, f.s.n) {
+        f.xt = f.s.bounded ? lmcore::i2e(f.xti, f.lo, f.hi) : f.xti;
+        if (f.s.mode == NGMIX_LM_MODE_FD) {
+            double h = EPS * fabs(f.xti);
+            if (h == 0.0) h = EPS;
+            f.hstep = h;
+            f.xstep = f.s.bounded ? lmcore::i2e(f.xti + h, f.lo, f.hi) : f.xti + h;
+        }
+    }
+}
+
+// wa3 = R (P^T step) as lmder forms it, then |wa3| / fnorm  (used twice)
+__device__ __forceinline__ double r_times_step_norm(Fit &f)
+{
+    const int n = f.s.n, ld = f.ld;
+    tsync();
+    TFOR(i, 0, n) {
+        double w = 0.0;
+        for (int j = i; j < n; j++) w += f.R[i * ld + j] * f.step[f.ipvt[j]];
+        f.wa3[i] = w;
+    }
+    tsync();
+    return enorm(n, f.wa3) / f.s.fnorm;
+}
+
+// lmcore::propose
+__device__ __forceinline__ void propose(Fit &f)
+{
+    const int n = f.s.n, ld = f.ld;
+    tsync();
+    TFOR(i, 0, n)
+        for (int j = 0; j < n; j++) f.M[i * ld + j] = f.R[i * ld + j];
+    tsync();
+    lmpar(f);
+    tsync();
+    TFOR(j, 0, n) {
+        const double st = -f.p[j];
+        f.step[j] = st;
+        f.xti = f.xi + st;
+        f.wa3[j] = f.diag[j] * st;
+    }
+    set_trial(f);
+    tsync();
+    f.s.pnorm = enorm(n, f.wa3);
+    if (f.s.iter == 1) f.s.delta = fmin(f.s.delta, f.s.pnorm);
+    f.s.fonly = 0;
+    if (f.s.mode == NGMIX_LM_MODE_ANALYTIC_LAZY) {
+        const double temp1 = r_times_step_norm(f);
+        const double temp2 = (sqrt(f.s.par) * f.s.pnorm) / f.s.fnorm;
+        const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+        if (prered <= f.s.ftol || f.s.pnorm / 0.5 <= f.s.xtol * f.s.xnorm) f.s.fonly = 1;
+    }
+}
+
+// lmcore::new_jacobian with A = f.M, g = f.g
+__device__ __forceinline__ bool new_jacobian(Fit &f)
+{
+    const int n = f.s.n, ld = f.ld;
+    f.s.njev++;
+    factor_normal(f);
+    if (f.s.iter == 1) {
+        TFOR(j, 0, n) {
+            double d = f.acnorm[j];
+            if (d == 0.0) d = 1.0;
+            f.diag[j] = d;
+            f.wa3[j] = d * f.xi;
+        }
+        tsync();
+        f.s.xnorm = enorm(n, f.wa3);
+        f.s.delta = f.s.factor * f.s.xnorm;
+        if (f.s.delta == 0.0) f.s.delta = f.s.factor;
+    }
+    qtf_from_gradient(f);
+    // norm of the scaled gradient
+    f.s.gnorm = 0.0;
+    if (f.s.fnorm != 0.0) {
+        for (int j = 0; j < n; j++) {
+            const int l = f.ipvt[j];
+            const double al = f.acnorm[l];
+            if (al == 0.0) continue;
+            double sum = 0.0;
+            for (int i = 0; i <= j; i++) sum += f.R[i * ld + j] * (f.qtf[i] / f.s.fnorm);
+            f.s.gnorm = fmax(f.s.gnorm, fabs(sum / al));
+        }
+    }
+    if (f.s.gnorm <= f.s.gtol) {
+        f.s.info = 4;
+        f.s.phase = LM_PHASE_DONE;
+        return true;
+    }
+    tsync();
+    TFOR(j, 0, n) f.diag[j] = fmax(f.diag[j], f.acnorm[j]);
+    tsync();
+    propose(f);
+    return false;
+}
+
+// lmcore::lm_advance with the evaluation folded into f.M (A), f.g (g), ff
+__device__ __forceinline__ void lm_advance(Fit &f, double ff)
+{
+    const int n = f.s.n, ld = f.ld;
+    if (f.s.phase == LM_PHASE_DONE) return;
+    if (f.s.bounded && f.s.mode != NGMIX_LM_MODE_FD) {
+        // the wrapped Dfun of leastsqbound.py:485-489: column j scaled by
+        // d xt_j / d xti_j
+        double sc = 1.0;
+        TFOR(j, 0, n) {
+            sc = lmcore::i2e_grad(f.xti, f.lo, f.hi);
+            f.wa1[j] = sc;
+        }
+        tsync();
+        TFOR(j, 0, n) {
+            f.g[j] = f.g[j] * sc;
+            for (int k = 0; k < n; k++) f.M[j * ld + k] = f.M[j * ld + k] * sc * f.wa1[k];
+        }
+        tsync();
+    }
+    if (f.s.phase == LM_PHASE_JAC) {
+        if (f.s.mode == NGMIX_LM_MODE_FD) f.s.nfev += n;
+        f.s.phase = LM_PHASE_TRIAL;
+        new_jacobian(f);
+        return;
+    }
+    if (f.s.phase == LM_PHASE_INIT) {
+        f.s.nfev = f.s.mode == NGMIX_LM_MODE_FD ? 1 + n : 1;
+        f.s.fnorm = sqrt(ff);
+        f.s.par = 0.0;
+        f.s.iter = 1;
+        if (!(f.s.fnorm < INFINITY)) {
+            f.s.njev = 1;
+            f.s.info = 4;
+            f.s.phase = LM_PHASE_DONE;
+            return;
+        }
+        f.s.phase = LM_PHASE_TRIAL;
+        new_jacobian(f);
+        return;
+    }
+
+    // ---- LM_PHASE_TRIAL: the rest of lmder's inner loop
+    f.s.nfev++;
+    const double fnorm1 = ff < INFINITY ? sqrt(ff) : NAN;
+    double actred = -1.0;
+    if (0.1 * fnorm1 < f.s.fnorm) {
+        const double t = fnorm1 / f.s.fnorm;
+        actred = 1.0 - t * t;
+    }
+    const double temp1 = r_times_step_norm(f);
+    const double temp2 = (sqrt(f.s.par) * f.s.pnorm) / f.s.fnorm;
+    const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+    const double dirder = -(temp1 * temp1 + temp2 * temp2);
+    double ratio = 0.0;
+    if (prered != 0.0) ratio = actred / prered;
+    if (ratio <= 0.25) {
+        double temp = 0.5;
+        if (actred < 0.0) temp = 0.5 * dirder / (dirder + 0.5 * actred);
+        if (0.1 * fnorm1 >= f.s.fnorm || temp < 0.1) temp = 0.1;
+        f.s.delta = temp * fmin(f.s.delta, f.s.pnorm / 0.1);
+        f.s.par = f.s.par / temp;
+    } else if (f.s.par == 0.0 || ratio >= 0.75) {
+        f.s.delta = f.s.pnorm / 0.5;
+        f.s.par = 0.5 * f.s.par;
+    }
+    const bool accepted = ratio >= 1.0e-4;
+    if (accepted) {
+        tsync();
+        TFOR(j, 0, n) {
+            f.x = f.xt;
+            f.xi = f.xti;
+            f.wa3[j] = f.diag[j] * f.xi;
+        }
+        tsync();
+        f.s.xnorm = enorm(n, f.wa3);
+        f.s.fnorm = fnorm1;
+        f.s.iter++;
+    }
+    int info = 0;
+    if (fabs(actred) <= f.s.ftol && prered <= f.s.ftol && 0.5 * ratio <= 1.0) info = 1;
+    if (f.s.delta <= f.s.xtol * f.s.xnorm) info = 2;
+    if (fabs(actred) <= f.s.ftol && prered <= f.s.ftol && 0.5 * ratio <= 1.0 && info == 2)
+        info = 3;
+    if (info == 0) {
+        if (f.s.nfev >= f.s.maxfev) info = 5;
+        if (fabs(actred) <= lmcore::EPSMCH && prered <= lmcore::EPSMCH && 0.5 * ratio <= 1.0)
+            info = 6;
+        if (f.s.delta <= lmcore::EPSMCH * f.s.xnorm) info = 7;
+        if (f.s.gnorm <= lmcore::EPSMCH) info = 8;
+    }
+    if (info != 0) {
+        f.s.info = info;
+        f.s.phase = LM_PHASE_DONE;
+        return;
+    }
+    if (!accepted) {
+        propose(f);
+    } else if (f.s.mode == NGMIX_LM_MODE_FD || f.s.fonly) {
+        f.xti = f.xi;
+        set_trial(f);
+        f.s.phase = LM_PHASE_JAC;
+        f.s.fonly = 0;
+    } else {
+        new_jacobian(f);
+    }
+}
+
+}  // namespace lmteam

@@ -199,6 +199,9 @@ class _EventPool(object):
 # finalize records) contiguous at the end of it so that they come back in ONE
 # download, and the zeros of the statistics accumulator ride in the upload.
 SMALL_BATCH = 64
+# the most lock-step rounds queued blind from the last batch's count (a round
+# that finds every fit finished costs two empty launches, ~20 us)
+ROUNDS_HINT_CAP = 64
 
 
 def _carve(torch, dev, pieces):
@@ -569,11 +572,21 @@ class LMBatchFitter(object):
         # count, then finalize / pack / downloads.  _collect() finds out
         # whether R was enough (the rare miss: more rounds, results re-made).
         hint = getattr(self, "_rounds_hint", None)
-        first = 4 if hint is None else max(1, min(int(hint), 16))
+        first = 4 if hint is None else max(1, min(int(hint), ROUNDS_HINT_CAP))
         self._queue_rounds(job, first)
         self._mark(job, "loop")
         self._queue_results(job)
         return job
+
+    @staticmethod
+    def _job_stream(job):
+        """the stream a job was queued on (job.stream, a raw handle) as a torch
+        stream, for the rare paths that queue torch work behind it again"""
+        torch = _torch()
+        handle = job.stream.value or 0
+        if handle == 0:
+            return torch.cuda.default_stream(job.dev)
+        return torch.cuda.ExternalStream(handle, device=job.dev)
 
     def _lm_mode(self):
         """ngmix_lm_state.mode of this fitter's fits: lmdif, or lmder with the
@@ -609,8 +622,16 @@ class LMBatchFitter(object):
         P.model = job.modnum
         P.fd = int(self.fd)
         P.npsf = job.npsf
-        P.nloc_npars = self.nloc + 256 * job.npars
+        P.nloc_npars = self._nloc_npars(job.npars)
         return P
+
+    def _nloc_npars(self, npars):
+        """the nloc argument of ngmix_lm_advance_batch carrying the fits'
+        parameter count (nloc + 256 npars), which selects the step's kernel: the
+        register form for 6-10 parameters, the team form for 11-14;
+        fitter.advance_hint = False leaves it out: the generic one-thread form
+        (what the tests compare the other two with, record by record)"""
+        return self.nloc + (256 * npars if getattr(self, "advance_hint", True) else 0)
 
     def _timing_events(self, n):
         """n hipEvent_t handles when fitter.time_kernels is set (bench.py), else
@@ -666,15 +687,17 @@ class LMBatchFitter(object):
                 if total > 2 * job.maxfev + 5:
                     raise RuntimeError("batched LM did not terminate")
                 redo = True
-                with torch.cuda.device(job.dev):
+                # (on the fit's OWN stream, whatever stream the consumer of
+                # go_stream() iterates under, and waited for through the event the
+                # chunk records there: the counts read next are this chunk's)
+                with torch.cuda.device(job.dev), torch.cuda.stream(self._job_stream(job)):
                     self._queue_rounds(job, grow)
-                    done = torch.cuda.Event()
-                    done.record()
-                done.synchronize()
+                _lib.check(_lib.lib().ngmix_event_synchronize(job.chunks[-1][4].handles[1]),
+                           "ngmix_event_synchronize")
                 total += grow
                 grow = min(2 * grow, 32)
             if redo:
-                with torch.cuda.device(job.dev):
+                with torch.cuda.device(job.dev), torch.cuda.stream(self._job_stream(job)):
                     self._queue_results(job)
                 job.copied.synchronize()
             # counts after each round -> the rounds that had fits to advance
@@ -853,13 +876,17 @@ class LMBatchFitter(object):
             # obj_start holds absolute stamp indices: sums / stamp_band stay whole
             _lib.check(L.ngmix_lm_advance_batch(
                 off(d_states, isz * o_lo), o_hi - o_lo, off(d_start, 8 * o_lo),
-                _dptr(d_sband), _dptr(d_sums), self.nloc + 256 * npars,
+                _dptr(d_sband), _dptr(d_sums), self._nloc_npars(npars),
                 off(osums, 8 * wosum * o_lo) if osums is not None else None,
                 _dptr(sub["nact"]), _dptr(d_sstats) if loop_stats else None,
                 off(d_ostats, 16 * o_lo), _stream()),
                 "ngmix_lm_advance_batch")
             # the count of fits still running, on its way to the host behind
             # the round that made it
+            hook = getattr(self, "round_hook", None)
+            if hook is not None:
+                # (tests: the state records after every round of the host loop)
+                hook(job, sub["launched"])
             h = sub["ring"][sub["launched"] % len(sub["ring"])]
             h.copy_(sub["nact"], non_blocking=True)
             done = torch.cuda.Event()

@@ -1,0 +1,221 @@
+"""
+The team form of the lmder step (csrc/lm_core_team.hpp: 16 lanes per fit, the
+fit's arrays in LDS -- what fits of 11-14 parameters run) against the generic
+one-thread form (csrc/lm_core.hpp, itself pinned to scipy's MINPACK on the CPU
+by tests/test_lm_core.py and to the reference's fits by test_gpu_lm_batch.py):
+the STATE RECORDS of the two forms are compared after every lock-step round,
+byte for byte over their live part -- analytic and forward-difference modes,
+multi-band objects, co-elliptical psf fits with their long lmpar iterations,
+bounds and prior rows, out-of-range starts, poor guesses (rejected steps), and
+one, two or four fits per wave.
+
+Reference semantics: ngmix/fitting/leastsqbound.py:289-552 (scipy's lmder /
+lmdif), results.py:439-570.
+"""
+import numpy as np
+import pytest
+import torch
+
+import ngmix_amd as ngmix
+from ngmix_amd import _lib
+from ngmix_amd.batch import StampBatch, GMixBatch
+from ngmix_amd.lm_batch import LMBatchFitter
+
+from test_gpu_lm_batch import _make_objects
+
+pytestmark = pytest.mark.gpu
+
+VECTORS = ("x", "xt", "diag", "qtf", "step", "xi", "xti", "lo", "hi", "xstep", "hstep", "ipvt")
+SCALARS = ("fnorm", "xnorm", "delta", "par", "gnorm", "pnorm", "ftol", "xtol", "gtol",
+           "factor", "n", "iter", "nfev", "njev", "info", "phase", "maxfev", "mode",
+           "bounded", "fonly")
+
+
+def _live(rec):
+    """the live part of the state records as bytes-comparable arrays"""
+    n = int(rec["n"][0])
+    assert np.all(rec["n"] == n)
+    out = {k: rec[k].copy() for k in SCALARS}
+    for k in VECTORS:
+        out[k] = rec[k][:, :n].copy()
+    nmax = _lib.LM_NPMAX
+    out["R"] = rec["R"].reshape(-1, nmax, nmax)[:, :n, :n].copy()
+    return out
+
+
+def _rounds(fitter, go, hint):
+    """run go() through the host-driven loop with the step's kernel selected
+    by the hint; returns (result, [live state after each round])"""
+    snaps = []
+
+    def hook(job, r):
+        torch.cuda.synchronize()
+        rec = job.d_states.cpu().numpy().view(_lib.LM_STATE_DTYPE).reshape(-1)
+        snaps.append(_live(rec))
+    fitter.host_loop = True
+    fitter.advance_hint = hint
+    fitter.round_hook = hook
+    res = go(fitter)
+    return res, snaps
+
+
+def _assert_same_rounds(a, b):
+    assert len(a) == len(b) and len(a) > 1
+    for r, (sa, sb) in enumerate(zip(a, b)):
+        for k in sa:
+            # bytes, not values: NaNs and signed zeros included
+            assert sa[k].tobytes() == sb[k].tobytes(), "round %d, field %s" % (r, k)
+
+
+def _census_has(seen, frag):
+    return any(frag in k for k in seen)
+
+
+def _multiband(nobj, nband, model, rng):
+    ns = nobj * nband
+    pars, guess, images, weights, jac, sb, psf = _make_objects(ns, model, rng)
+    sobj = np.repeat(np.arange(nobj), nband).astype(np.int32)
+    sband = np.tile(np.arange(nband), nobj).astype(np.int32)
+    shape = guess[::nband, :5]
+    g2 = np.concatenate([shape, guess[:, 5].reshape(nobj, nband)], axis=1)
+    return sb, psf, g2, sobj, sband
+
+
+@pytest.mark.parametrize("nband, lazy, teams", [(6, True, 4), (7, False, 2), (9, True, 1)])
+def test_team_step_equals_generic_step_multiband_lmder(nband, lazy, teams, monkeypatch):
+    """'exp' over 6 / 7 / 9 bands: 11 / 12 / 14 parameters, lmder (lazy and
+    eager jacobians)"""
+    monkeypatch.setenv("NGMIX_LM_TEAMS", str(teams))
+    rng = np.random.RandomState(100 + nband)
+    nobj = 37
+    sb, psf, guess, sobj, sband = _multiband(nobj, nband, "exp", rng)
+    guess[::4, 4:] *= 1.6                      # poor guesses: rejected steps, lmpar iterations
+    guess[::6, 2:4] = 0.4, -0.3
+
+    def go(f):
+        f.lazy_jacobian = lazy
+        return f.go(sb, guess, psf=psf, stamp_obj=sobj, stamp_band=sband)
+    _lib.launch_census(reset=True)
+    rt, st = _rounds(LMBatchFitter("exp"), go, True)
+    seen = _lib.launch_census(reset=True)
+    assert _census_has(seen, "lm_advance_team_kernel<%d>" % teams), seen
+    assert not _census_has(seen, "lm_advance_kernel<")
+    rg, sg = _rounds(LMBatchFitter("exp"), go, False)
+    seen = _lib.launch_census(reset=True)
+    assert _census_has(seen, "lm_advance_kernel<14, false>") and not _census_has(seen, "team")
+    _assert_same_rounds(st, sg)
+    for k in ("flags", "nfev", "njev", "ier", "pars", "pars_cov", "lnprob"):
+        np.testing.assert_array_equal(rt[k], rg[k], err_msg=k)
+    assert np.mean(rt["flags"] == 0) > 0.7
+    # and the host-free rounds (what go() runs by default) give the same fit
+    plain = LMBatchFitter("exp")
+    plain.lazy_jacobian = lazy
+    rp = plain.go(sb, guess, psf=psf, stamp_obj=sobj, stamp_band=sband)
+    for k in ("flags", "nfev", "ier", "pars", "pars_cov"):
+        np.testing.assert_array_equal(rp[k], rt[k], err_msg=k)
+
+
+@pytest.mark.parametrize("ngauss", [4, 5])
+def test_team_step_equals_generic_step_coellip(ngauss, monkeypatch):
+    """co-elliptical psf fits with 4 / 5 gaussians (12 / 14 parameters, lmdif):
+    nearly degenerate valleys -- many lmpar iterations with qrsolv, steps
+    against a singular factor"""
+    rng = np.random.RandomState(7 + ngauss)
+    dim, scale, n = 25, 0.263, 29
+    jac = ngmix.DiagonalJacobian(row=12.0, col=12.0, scale=scale)
+    gm = ngmix.GMixModel([0.0, 0.0, 0.02, -0.01, 0.3, 1.0], "turb")
+    im0 = gm.make_image((dim, dim), jacobian=jac)
+    images = im0[None] + 2.0e-4 * rng.normal(size=(n, dim, dim))
+    weights = np.full((n, dim, dim), 1.0 / 2.0e-4 ** 2)
+    sb = StampBatch.from_images(images, weights, jac)
+    T = 0.3 * np.array([0.3, 0.7, 1.5, 3.0, 6.0])[:ngauss]
+    F = np.array([0.25, 0.35, 0.25, 0.1, 0.05])[:ngauss]
+    g0 = np.concatenate([[0.0, 0.0, 0.02, -0.01], T, F / F.sum()])
+    guess = g0[None] * rng.uniform(0.9, 1.1, size=(n, g0.size))
+    guess[:, :2] = rng.uniform(-0.01, 0.01, size=(n, 2))
+    guess[3, 4:4 + ngauss] = guess[3, 4]       # identical components: a singular jacobian
+    pars = {"maxfev": 120, "ftol": 1e-5, "xtol": 1e-5}
+
+    def go(f):
+        return f.go(sb, guess)
+    rt, st = _rounds(LMBatchFitter("coellip", ngauss=ngauss, fit_pars=pars), go, True)
+    rg, sg = _rounds(LMBatchFitter("coellip", ngauss=ngauss, fit_pars=pars), go, False)
+    _assert_same_rounds(st, sg)
+    assert len(st) > 10
+    for k in ("flags", "nfev", "ier", "pars"):
+        np.testing.assert_array_equal(rt[k], rg[k], err_msg=k)
+
+
+def test_team_step_equals_generic_step_bdf_bands(monkeypatch):
+    """'bdf' over 5 bands: 11 parameters, lmdif with the MFMA normal equations"""
+    rng = np.random.RandomState(55)
+    nobj, nband = 21, 5
+    ns = nobj * nband
+    pars, guess, images, weights, jac, sb, psf = _make_objects(ns, "exp", rng)
+    sobj = np.repeat(np.arange(nobj), nband).astype(np.int32)
+    sband = np.tile(np.arange(nband), nobj).astype(np.int32)
+    g2 = np.concatenate([guess[::nband, :5], np.full((nobj, 1), 0.2),
+                         guess[:, 5].reshape(nobj, nband)], axis=1)
+    fp = {"maxfev": 150, "ftol": 1e-5, "xtol": 1e-5}
+
+    def go(f):
+        return f.go(sb, g2, psf=psf, stamp_obj=sobj, stamp_band=sband)
+    rt, st = _rounds(LMBatchFitter("bdf", fit_pars=fp), go, True)
+    rg, sg = _rounds(LMBatchFitter("bdf", fit_pars=fp), go, False)
+    _assert_same_rounds(st, sg)
+    for k in ("flags", "nfev", "ier", "pars", "pars_cov"):
+        np.testing.assert_array_equal(rt[k], rg[k], err_msg=k)
+
+
+@pytest.mark.parametrize("fd", [False, True])
+def test_team_step_with_bounds_prior_rows_and_bad_starts(fd, monkeypatch):
+    """the paths only small fits reach (the separable prior holds three bands):
+    NGMIX_LM_TEAM_MIN = 6 sends 6- to 8-parameter fits through the team form --
+    bounds (leastsqbound's transforms, the scaled analytic jacobian), prior
+    rows folded into the normal equations, a start out of range (g >= 1: the
+    fit ends at once, info 4), masked stamps"""
+    from ngmix_amd import prior_batch as pb
+    monkeypatch.setenv("NGMIX_LM_TEAM_MIN", "6")
+    rng = np.random.RandomState(91 + int(fd))
+    nobj, nband = 26, 2
+    sb, psf, guess, sobj, sband = _multiband(nobj, nband, "exp", rng)
+    guess[5, 2:4] = 0.9, 0.8                   # |g| >= 1 at the start
+    guess[::7, 4] *= 2.5
+    prior = pb.PriorSimpleSepBatch(
+        pb.GaussianCen(0.0, 0.0, 0.3, 0.3), pb.GPriorBA(0.3),
+        pb.Normal(0.6, 0.5, bounds=[0.05, 4.0]),
+        [pb.Normal(120.0, 200.0, bounds=[1.0, None]), pb.TwoSidedErf(-1.0e3, 1.0, 1.0e5, 10.0)])
+
+    def go(f):
+        return f.go(sb, guess, psf=psf, stamp_obj=sobj, stamp_band=sband)
+
+    def make():
+        return LMBatchFitter("exp", prior=prior, analytic_jacobian=not fd)
+    _lib.launch_census(reset=True)
+    rt, st = _rounds(make(), go, True)
+    seen = _lib.launch_census(reset=True)
+    assert _census_has(seen, "lm_advance_team_kernel<4>"), seen
+    rg, sg = _rounds(make(), go, False)
+    _assert_same_rounds(st, sg)
+    assert np.all(st[-1]["bounded"] == 1)
+    for k in ("flags", "nfev", "ier", "pars", "pars_cov", "lnprob"):
+        np.testing.assert_array_equal(rt[k], rg[k], err_msg=k)
+    assert rt["flags"][5] != 0
+    # the register form (the default for these sizes) is the same fit too
+    monkeypatch.delenv("NGMIX_LM_TEAM_MIN")
+    rr = make().go(sb, guess, psf=psf, stamp_obj=sobj, stamp_band=sband)
+    for k in ("flags", "nfev", "ier", "pars"):
+        np.testing.assert_array_equal(rr[k], rt[k], err_msg=k)
+
+
+def test_team_step_wrong_hint_ends_the_fit():
+    """a parameter-count hint smaller than a fit's n: the fit is ended as
+    MINPACK ends a call with improper input (info 0), not left un-advanced"""
+    rng = np.random.RandomState(3)
+    nobj, nband = 8, 7
+    sb, psf, guess, sobj, sband = _multiband(nobj, nband, "exp", rng)
+    f = LMBatchFitter("exp")
+    f._nloc_npars = lambda npars: f.nloc + 256 * 11     # says 11, the fits have 12
+    f.host_loop = True
+    res = f.go(sb, guess, psf=psf, stamp_obj=sobj, stamp_band=sband)
+    assert np.all(res["flags"] != 0) and f.rounds <= 2

@@ -92,6 +92,39 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert p.returncode != 0 and "refusing" in p.stderr
 
 
+@pytest.mark.parametrize("spec, leg", [("C4:1:step33", "C4"), ("C3:1:setup", "C3"),
+                                       ("C5:0:step1", "C5")])
+def test_bench_rank_local_failure_in_a_leg_keeps_the_headline(spec, leg):
+    """a failure on ONE rank inside an other_configs leg (injected: at the entry
+    of the steps, in a settle step, in a timed step; on rank 0 or rank 1): the
+    ranks agree on it (bench.run_leg), the failing rank keeps the leg's
+    all-gathers matched with empty records, nobody blocks, every other leg and
+    the headline line are intact"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NGMIX_DIST_BACKEND="gloo", NGMIX_BENCH_FAIL=spec)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--settle-steps", "1", "--nstamps", "2000"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["bad_status"] == 0
+    oc = d["other_configs"]
+    for name in ("C3", "C4", "C5"):
+        if name == leg:
+            assert "error" in oc[name], oc[name]
+            # rank 0 reports its own failure, or that a peer failed
+            assert ("injected failure" in oc[name]["error"]) == spec.startswith(leg + ":0:")
+            assert "PeerFailure" in oc[name]["error"] or "injected" in oc[name]["error"]
+        else:
+            assert "error" not in oc[name], oc[name]
+            assert oc[name]["value"] > 0 and oc[name]["n_gpus"] == 2
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     """RCCL needs one device per rank: bench.py --gpus 2 on this one-GPU box
     stops with a message instead of measuring one GPU"""
