@@ -268,7 +268,7 @@ LM_NCOLS = 12
 
 
 def _makefile_list(name):
-    """the file list `name = ...` of csrc/Makefile (SRCS, HDRS)"""
+    """the file list `name = ...` of csrc/Makefile (SRCS, HDRS, UNIT_HDRS)"""
     for line in open(os.path.join(_CSRC, "Makefile")):
         if line.startswith(name + " ="):
             return line.split("=", 1)[1].split()
@@ -280,7 +280,7 @@ def source_hash():
     same digest next to the library (libngmix_hip.so.srchash)"""
     import hashlib
     h = hashlib.sha256()
-    for name in _makefile_list("SRCS") + _makefile_list("HDRS"):
+    for name in _makefile_list("SRCS") + _makefile_list("HDRS") + _makefile_list("UNIT_HDRS"):
         with open(os.path.join(_CSRC, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()

@@ -49,6 +49,12 @@ int launch_lm_advance(ngmix_lm_state *states, int64_t nobj, const int64_t *obj_s
                       const int32_t *stamp_band, const double *sums, int nloc,
                       const double *obj_sums, int32_t *nactive, const double *stamp_stats,
                       double *obj_stats, hipStream_t s, bool zero_count = true);
+// lm_team.hip: the same step by 16 lanes per fit (teams = fits per wave: 1, 2, 4)
+int launch_lm_advance_team(ngmix_lm_state *states, int64_t nobj, const int64_t *obj_start,
+                           const int32_t *stamp_band, const double *sums, int nloc, int npars,
+                           const double *obj_sums, int32_t *nactive,
+                           const double *stamp_stats, double *obj_stats, int teams,
+                           hipStream_t s);
 int launch_lm_rounds(const ngmix_lm_problem *p, int nrounds, int32_t *counts,
                      int32_t *counts_host, void **events, hipStream_t s);
 

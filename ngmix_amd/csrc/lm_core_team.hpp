@@ -22,6 +22,14 @@
 //   * the vectors that are only ever touched element-wise (x, xt, xi, xti, lo,
 //     hi, xstep, hstep) are one register per lane.
 //
+// What a step costs is its number of DEPENDENT LDS round trips (~100 cycles
+// each), not its arithmetic.  A sum over a row, a column or a vector therefore
+// fetches all its operands with one batch of loads -- NP of them, NP the
+// compile-time bound of the parameter count, the elements outside the sum's
+// range replaced by +0.0 -- and adds in registers: a term (+0.0) * (+0.0) added
+// to (or subtracted from) a sum that started at +0.0 or at a finite value
+// changes no bit of it, so the sum is the serial loop's.
+//
 // The operations on every element and the order of every sum are lm_core.hpp's,
 // statement for statement (and the build has no FMA contraction), so a state
 // record after a step is BYTE-IDENTICAL to the generic form's:
@@ -97,490 +105,600 @@ __device__ __forceinline__ void carve(Fit &f, double *base, int np)
 #define TFOR(i, lo_, hi_) for (int i = (lo_) + f.lane, i##_once = 1; i##_once && i < (hi_); i##_once = 0)
 #define LEAD if (f.lane == 0)
 
-// lmcore::enorm on an LDS vector: every lane adds in index order
-__device__ __forceinline__ double enorm(int n, const double *x)
-{
-    double s = 0.0;
-    for (int i = 0; i < n; i++) s += x[i] * x[i];
-    return sqrt(s);
-}
+// The step for fits of up to NP parameters.  NP bounds the batches of loads
+// (and the registers that hold them), not the arithmetic: the loops run to n.
+template <int NP>
+struct Step {
+    // the stride of the matrices: a compile-time constant, so that every load of
+    // a batch is one ds_read with an immediate offset
+    static constexpr int LD = NP | 1;
 
-// lmcore::factor_normal.  M holds A on entry and is destroyed (the serial code's
-// copy S); R, ipvt, acnorm are written.
-__device__ __forceinline__ void factor_normal(Fit &f)
-{
-    const int n = f.s.n, ld = f.ld;
-    double *S = f.M, *R = f.R;
-    TFOR(j, 0, n) {
-        f.ipvt[j] = j;
-        const double d = S[j * ld + j];
-        f.acnorm[j] = d > 0.0 ? sqrt(d) : 0.0;
-        for (int k = 0; k < n; k++) R[j * ld + k] = 0.0;
+    // v[i] = p[i * st] for lo <= i < hi, +0.0 elsewhere: one batch of loads.
+    // The loads are unconditional (every index below NP is inside the team's
+    // block, which is sized for NP) and the selection is two v_cndmask: no
+    // branch per element.
+    static __device__ __forceinline__ void gather(double (&v)[NP], const double *p, int st,
+                                                  int lo, int hi)
+    {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const double t = p[i * st];
+            v[i] = (i >= lo && i < hi) ? t : 0.0;
+        }
     }
-    tsync();
-    for (int k = 0; k < n; k++) {
-        int kmax = k;
-        for (int j = k + 1; j < n; j++)
-            if (S[j * ld + j] > S[kmax * ld + kmax]) kmax = j;
-        if (kmax != k) {
-            tsync();
-            TFOR(i, 0, n) {          // columns k <-> kmax of S; of R above row k
-                const double t = S[i * ld + k];
-                S[i * ld + k] = S[i * ld + kmax];
-                S[i * ld + kmax] = t;
-                if (i < k) {
-                    const double u = R[i * ld + k];
-                    R[i * ld + k] = R[i * ld + kmax];
-                    R[i * ld + kmax] = u;
-                }
-            }
-            tsync();
-            TFOR(j, 0, n) {          // rows k <-> kmax of S
-                const double t = S[k * ld + j];
-                S[k * ld + j] = S[kmax * ld + j];
-                S[kmax * ld + j] = t;
-            }
-            LEAD {
-                const int32_t ti = f.ipvt[k];
-                f.ipvt[k] = f.ipvt[kmax];
-                f.ipvt[kmax] = ti;
-            }
-            tsync();
-        }
-        const double d = S[k * ld + k];
-        if (!(d > 0.0)) {
-            tsync();
-            TFOR(kk, k, n)
-                for (int j = kk; j < n; j++) R[kk * ld + j] = 0.0;
-            tsync();
-            return;
-        }
-        const double rkk = sqrt(d);
-        tsync();
-        LEAD R[k * ld + k] = rkk;
-        TFOR(j, k + 1, n) R[k * ld + j] = S[k * ld + j] / rkk;
-        tsync();
-        TFOR(i, k + 1, n) {
-            const double rki = R[k * ld + i];
-            for (int j = i; j < n; j++) {
-                const double v = S[i * ld + j] - rki * R[k * ld + j];
-                S[i * ld + j] = v;
-                S[j * ld + i] = v;
-            }
-        }
-        tsync();
-    }
-}
 
-// lmcore::qtf_from_gradient
-__device__ __forceinline__ void qtf_from_gradient(Fit &f)
-{
-    const int n = f.s.n, ld = f.ld;
-    for (int j = 0; j < n; j++) {
-        double s = f.g[f.ipvt[j]];
-        for (int i = 0; i < j; i++) s -= f.R[i * ld + j] * f.qtf[i];
-        const double rjj = f.R[j * ld + j];
-        const double q = rjj != 0.0 ? s / rjj : 0.0;
-        tsync();
-        LEAD f.qtf[j] = q;
-        tsync();
+    // sum_{lo <= i < hi} a[i * sa] * b[i * sb], added in index order from +0.0
+    static __device__ __forceinline__ double dot(const double *a, int sa, const double *b,
+                                                 int sb, int lo, int hi)
+    {
+        double av[NP], bv[NP];
+        gather(av, a, sa, lo, hi);
+        gather(bv, b, sb, lo, hi);
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NP; i++) s += av[i] * bv[i];
+        return s;
     }
-}
 
-// lmcore::qrsolv on r = f.M, with diag = dvec (an LDS vector), qtb = f.qtf,
-// x = f.p, sdiag = f.sdiag, wa = wa (an LDS vector)
-__device__ __forceinline__ void qrsolv(Fit &f, const double *dvec, double *wa)
-{
-    const int n = f.s.n, ld = f.ld;
-    double *r = f.M, *x = f.p, *sdiag = f.sdiag;
-    // (x doubles as the store of the diagonal of R until the end, as in MINPACK)
-    TFOR(j, 0, n) {
-        for (int i = j; i < n; i++) r[i * ld + j] = r[j * ld + i];
-        x[j] = r[j * ld + j];
-        wa[j] = f.qtf[j];
+    // s - sum_{lo <= i < hi} a[i * sa] * b[i * sb], subtracted in index order
+    static __device__ __forceinline__ double subdot(double s, const double *a, int sa,
+                                                    const double *b, int sb, int lo, int hi)
+    {
+        double av[NP], bv[NP];
+        gather(av, a, sa, lo, hi);
+        gather(bv, b, sb, lo, hi);
+#pragma unroll
+        for (int i = 0; i < NP; i++) s -= av[i] * bv[i];
+        return s;
     }
-    tsync();
-    for (int j = 0; j < n; j++) {
-        const int l = f.ipvt[j];
-        const double dl = dvec[l];
-        if (dl != 0.0) {
-            tsync();
-            TFOR(k, j, n) sdiag[k] = k == j ? dl : 0.0;
-            tsync();
-            double qtbpj = 0.0;
-            for (int k = j; k < n; k++) {
-                const double sk = sdiag[k];
-                if (sk == 0.0) continue;
-                double cs, sn;
-                const double rkk = r[k * ld + k];
-                if (fabs(rkk) < fabs(sk)) {
-                    const double cotan = rkk / sk;
-                    sn = 0.5 / sqrt(0.25 + 0.25 * (cotan * cotan));
-                    cs = sn * cotan;
-                } else {
-                    const double tn = sk / rkk;
-                    cs = 0.5 / sqrt(0.25 + 0.25 * (tn * tn));
-                    sn = cs * tn;
-                }
-                const double wak = wa[k];
-                const double temp = cs * wak + sn * qtbpj;
-                qtbpj = -sn * wak + cs * qtbpj;
-                tsync();
-                LEAD {
-                    r[k * ld + k] = cs * rkk + sn * sk;
-                    wa[k] = temp;
-                }
-                TFOR(i, k + 1, n) {
-                    const double rik = r[i * ld + k], si = sdiag[i];
-                    const double t = cs * rik + sn * si;
-                    sdiag[i] = -sn * rik + cs * si;
-                    r[i * ld + k] = t;
-                }
-                tsync();
-            }
-        }
-        const double rjj = r[j * ld + j], xj = x[j];
-        tsync();
-        LEAD {
-            sdiag[j] = rjj;
-            r[j * ld + j] = xj;
-        }
-        tsync();
-    }
-    int nsing = n;
-    for (int j = 0; j < n; j++)
-        if (sdiag[j] == 0.0 && nsing == n) nsing = j;
-    tsync();
-    TFOR(j, nsing, n) wa[j] = 0.0;
-    tsync();
-    for (int k = 0; k < nsing; k++) {
-        const int j = nsing - 1 - k;
-        double sum = 0.0;
-        for (int i = j + 1; i < nsing; i++) sum += r[i * ld + j] * wa[i];
-        const double w = (wa[j] - sum) / sdiag[j];
-        tsync();
-        LEAD wa[j] = w;
-        tsync();
-    }
-    TFOR(j, 0, n) x[f.ipvt[j]] = wa[j];
-    tsync();
-}
 
-// lmcore::lmpar on r = f.M (a copy of R made by the caller), diag = f.diag,
-// qtb = f.qtf, delta / par in f.s; x = f.p, sdiag = f.sdiag
-__device__ __forceinline__ void lmpar(Fit &f)
-{
-    const int n = f.s.n, ld = f.ld;
-    double *r = f.M, *x = f.p, *wa1 = f.wa1, *wa2 = f.wa2;
-    const double delta = f.s.delta;
-    // gauss-newton direction
-    int nsing = n;
-    for (int j = 0; j < n; j++)
-        if (r[j * ld + j] == 0.0 && nsing == n) nsing = j;
-    TFOR(j, 0, n) wa1[j] = j < nsing ? f.qtf[j] : 0.0;
-    tsync();
-    for (int k = 0; k < nsing; k++) {
-        const int j = nsing - 1 - k;
-        const double temp = wa1[j] / r[j * ld + j];
-        tsync();
-        LEAD wa1[j] = temp;
-        TFOR(i, 0, j) wa1[i] -= r[i * ld + j] * temp;
-        tsync();
+    // lmcore::enorm on an LDS vector: every lane adds in index order
+    static __device__ __forceinline__ double enorm(int n, const double *x)
+    {
+        return sqrt(dot(x, 1, x, 1, 0, n));
     }
-    TFOR(j, 0, n) x[f.ipvt[j]] = wa1[j];
-    tsync();
 
-    int iter = 0;
-    TFOR(j, 0, n) wa2[j] = f.diag[j] * x[j];
-    tsync();
-    double dxnorm = enorm(n, wa2);
-    double fp = dxnorm - delta;
-    if (fp <= 0.1 * delta) {
-        f.s.par = 0.0;
-        return;
-    }
-    // lower bound
-    double parl = 0.0;
-    if (nsing >= n) {
-        tsync();
+    // lmcore::factor_normal.  M holds A on entry and is destroyed (the serial
+    // code's copy S); R, ipvt, acnorm are written.
+    static __device__ __forceinline__ void factor_normal(Fit &f)
+    {
+        const int n = f.s.n;
+        constexpr int ld = LD;
+        double *S = f.M, *R = f.R;
         TFOR(j, 0, n) {
-            const int l = f.ipvt[j];
-            wa1[j] = f.diag[l] * (wa2[l] / dxnorm);
+            f.ipvt[j] = j;
+            const double d = S[j * ld + j];
+            f.acnorm[j] = d > 0.0 ? sqrt(d) : 0.0;
+#pragma unroll
+            for (int k = 0; k < NP; k++)
+                if (k < n) R[j * ld + k] = 0.0;
+        }
+        tsync();
+        for (int k = 0; k < n; k++) {
+            // the largest remaining diagonal element, first one on ties (qrfac's
+            // pivot rule): the diagonal in one batch, the scan in registers
+            double dg[NP];
+            gather(dg, S, ld + 1, k, n);
+            int kmax = k;
+            double d = 0.0;
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                if (j == k) {
+                    d = dg[j];
+                } else if (j > k && j < n && dg[j] > d) {
+                    d = dg[j];
+                    kmax = j;
+                }
+            }
+            if (kmax != k) {
+                tsync();
+                TFOR(i, 0, n) {          // columns k <-> kmax of S; of R above row k
+                    const double t = S[i * ld + k], u = S[i * ld + kmax];
+                    S[i * ld + k] = u;
+                    S[i * ld + kmax] = t;
+                    if (i < k) {
+                        const double a = R[i * ld + k], b = R[i * ld + kmax];
+                        R[i * ld + k] = b;
+                        R[i * ld + kmax] = a;
+                    }
+                }
+                tsync();
+                TFOR(j, 0, n) {          // rows k <-> kmax of S
+                    const double t = S[k * ld + j], u = S[kmax * ld + j];
+                    S[k * ld + j] = u;
+                    S[kmax * ld + j] = t;
+                }
+                LEAD {
+                    const int32_t ti = f.ipvt[k], tj = f.ipvt[kmax];
+                    f.ipvt[k] = tj;
+                    f.ipvt[kmax] = ti;
+                }
+                tsync();
+            }
+            // (d = S[k][k] after the swap: the element the search picked)
+            if (!(d > 0.0)) {
+                tsync();
+                TFOR(kk, k, n) {
+#pragma unroll
+                    for (int j = 0; j < NP; j++)
+                        if (j >= kk && j < n) R[kk * ld + j] = 0.0;
+                }
+                tsync();
+                return;
+            }
+            const double rkk = sqrt(d);
+            tsync();
+            LEAD R[k * ld + k] = rkk;
+            TFOR(j, k + 1, n) R[k * ld + j] = S[k * ld + j] / rkk;
+            tsync();
+            TFOR(i, k + 1, n) {
+                const double rki = R[k * ld + i];
+                double sr[NP], rk[NP];
+                gather(sr, S + i * ld, 1, i, n);
+                gather(rk, R + k * ld, 1, i, n);
+#pragma unroll
+                for (int j = 0; j < NP; j++) {
+                    if (j >= i && j < n) {
+                        const double v = sr[j] - rki * rk[j];
+                        S[i * ld + j] = v;
+                        S[j * ld + i] = v;
+                    }
+                }
+            }
+            tsync();
+        }
+    }
+
+    // lmcore::qtf_from_gradient
+    static __device__ __forceinline__ void qtf_from_gradient(Fit &f)
+    {
+        const int n = f.s.n;
+        constexpr int ld = LD;
+        // P^T g, once
+        TFOR(j, 0, n) f.wa1[j] = f.g[f.ipvt[j]];
+        tsync();
+        for (int j = 0; j < n; j++) {
+            const double s = subdot(f.wa1[j], f.R + j, ld, f.qtf, 1, 0, j);
+            const double rjj = f.R[j * ld + j];
+            const double q = rjj != 0.0 ? s / rjj : 0.0;
+            tsync();
+            LEAD f.qtf[j] = q;
+            tsync();
+        }
+    }
+
+    // lmcore::qrsolv on r = f.M, with diag = dvec (an LDS vector), qtb = f.qtf,
+    // x = f.p, sdiag = f.sdiag, wa = wa (an LDS vector)
+    static __device__ __forceinline__ void qrsolv(Fit &f, const double *dvec, double *wa)
+    {
+        const int n = f.s.n;
+        constexpr int ld = LD;
+        double *r = f.M, *x = f.p, *sdiag = f.sdiag;
+        // (x doubles as the store of the diagonal of R until the end, as in MINPACK)
+        TFOR(j, 0, n) {
+            double row[NP];
+            gather(row, r + j * ld, 1, j, n);
+#pragma unroll
+            for (int i = 0; i < NP; i++)
+                if (i >= j && i < n) r[i * ld + j] = row[i];
+            x[j] = r[j * ld + j];
+            wa[j] = f.qtf[j];
         }
         tsync();
         for (int j = 0; j < n; j++) {
-            double sum = 0.0;
-            for (int i = 0; i < j; i++) sum += r[i * ld + j] * wa1[i];
-            const double w = (wa1[j] - sum) / r[j * ld + j];
+            const int l = f.ipvt[j];
+            const double dl = dvec[l];
+            if (dl != 0.0) {
+                tsync();
+                TFOR(k, j, n) sdiag[k] = k == j ? dl : 0.0;
+                tsync();
+                double qtbpj = 0.0;
+                for (int k = j; k < n; k++) {
+                    const double sk = sdiag[k];
+                    const double rkk = r[k * ld + k];
+                    const double wak = wa[k];
+                    if (sk == 0.0) continue;
+                    double cs, sn;
+                    if (fabs(rkk) < fabs(sk)) {
+                        const double cotan = rkk / sk;
+                        sn = 0.5 / sqrt(0.25 + 0.25 * (cotan * cotan));
+                        cs = sn * cotan;
+                    } else {
+                        const double tn = sk / rkk;
+                        cs = 0.5 / sqrt(0.25 + 0.25 * (tn * tn));
+                        sn = cs * tn;
+                    }
+                    const double temp = cs * wak + sn * qtbpj;
+                    qtbpj = -sn * wak + cs * qtbpj;
+                    tsync();
+                    LEAD {
+                        r[k * ld + k] = cs * rkk + sn * sk;
+                        wa[k] = temp;
+                    }
+                    TFOR(i, k + 1, n) {
+                        const double rik = r[i * ld + k], si = sdiag[i];
+                        const double t = cs * rik + sn * si;
+                        sdiag[i] = -sn * rik + cs * si;
+                        r[i * ld + k] = t;
+                    }
+                    tsync();
+                }
+            }
+            const double rjj = r[j * ld + j], xj = x[j];
             tsync();
-            LEAD wa1[j] = w;
+            LEAD {
+                sdiag[j] = rjj;
+                r[j * ld + j] = xj;
+            }
             tsync();
         }
-        const double temp = enorm(n, wa1);
-        parl = ((fp / delta) / temp) / temp;
+        double sd[NP];
+        gather(sd, sdiag, 1, 0, n);
+        int nsing = n;
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+            if (j < n && sd[j] == 0.0 && nsing == n) nsing = j;
+        tsync();
+        TFOR(j, nsing, n) wa[j] = 0.0;
+        tsync();
+        for (int k = 0; k < nsing; k++) {
+            const int j = nsing - 1 - k;
+            const double sum = dot(r + j, ld, wa, 1, j + 1, nsing);
+            const double w = (wa[j] - sum) / sdiag[j];
+            tsync();
+            LEAD wa[j] = w;
+            tsync();
+        }
+        TFOR(j, 0, n) x[f.ipvt[j]] = wa[j];
+        tsync();
     }
-    // upper bound
-    tsync();
-    TFOR(j, 0, n) {
-        double sum = 0.0;
-        for (int i = 0; i <= j; i++) sum += r[i * ld + j] * f.qtf[i];
-        wa1[j] = sum / f.diag[f.ipvt[j]];
-    }
-    tsync();
-    const double gnorm = enorm(n, wa1);
-    double paru = gnorm / delta;
-    if (paru == 0.0) paru = lmcore::DWARF / fmin(delta, 0.1);
-    double par = f.s.par;
-    par = fmax(par, parl);
-    par = fmin(par, paru);
-    if (par == 0.0) par = gnorm / dxnorm;
 
-    for (;;) {
-        iter++;
-        if (par == 0.0) par = fmax(lmcore::DWARF, 0.001 * paru);
-        double temp = sqrt(par);
+    // lmcore::lmpar on r = f.M (a copy of R made by the caller), diag = f.diag,
+    // qtb = f.qtf, delta / par in f.s; x = f.p, sdiag = f.sdiag
+    static __device__ __forceinline__ void lmpar(Fit &f)
+    {
+        const int n = f.s.n;
+        constexpr int ld = LD;
+        double *r = f.M, *x = f.p, *wa1 = f.wa1, *wa2 = f.wa2;
+        const double delta = f.s.delta;
+        // gauss-newton direction
+        int nsing = n;
+        {
+            double dg[NP];
+            gather(dg, r, ld + 1, 0, n);
+#pragma unroll
+            for (int j = 0; j < NP; j++)
+                if (j < n && dg[j] == 0.0 && nsing == n) nsing = j;
+        }
+        TFOR(j, 0, n) wa1[j] = j < nsing ? f.qtf[j] : 0.0;
         tsync();
-        TFOR(j, 0, n) wa1[j] = temp * f.diag[j];
+        for (int k = 0; k < nsing; k++) {
+            const int j = nsing - 1 - k;
+            const double temp = wa1[j] / r[j * ld + j];
+            tsync();
+            LEAD wa1[j] = temp;
+            TFOR(i, 0, j) wa1[i] -= r[i * ld + j] * temp;
+            tsync();
+        }
+        TFOR(j, 0, n) x[f.ipvt[j]] = wa1[j];
         tsync();
-        qrsolv(f, wa1, wa2);
+
+        int iter = 0;
         TFOR(j, 0, n) wa2[j] = f.diag[j] * x[j];
         tsync();
-        dxnorm = enorm(n, wa2);
-        temp = fp;
-        fp = dxnorm - delta;
-        if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) ||
-            iter == 10)
-            break;
-        // newton correction
-        tsync();
-        TFOR(j, 0, n) {
-            const int l = f.ipvt[j];
-            wa1[j] = f.diag[l] * (wa2[l] / dxnorm);
-        }
-        tsync();
-        for (int j = 0; j < n; j++) {
-            const double t = wa1[j] / f.sdiag[j];
-            tsync();
-            LEAD wa1[j] = t;
-            TFOR(i, j + 1, n) wa1[i] -= r[i * ld + j] * t;
-            tsync();
-        }
-        temp = enorm(n, wa1);
-        const double parc = ((fp / delta) / temp) / temp;
-        if (fp > 0.0) parl = fmax(parl, par);
-        if (fp < 0.0) paru = fmin(paru, par);
-        par = fmax(parl, par + parc);
-    }
-    f.s.par = par;
-}
-
-// lmcore::set_trial: element j in lane j
-__device__ __forceinline__ void set_trial(Fit &f)
-{
-    constexpr double EPS = 1.4901161193847656e-08;  // sqrt(machine epsilon)
-    TFOR(j, 0, f.s.n) {
-        f.xt = f.s.bounded ? lmcore::i2e(f.xti, f.lo, f.hi) : f.xti;
-        if (f.s.mode == NGMIX_LM_MODE_FD) {
-            double h = EPS * fabs(f.xti);
-            if (h == 0.0) h = EPS;
-            f.hstep = h;
-            f.xstep = f.s.bounded ? lmcore::i2e(f.xti + h, f.lo, f.hi) : f.xti + h;
-        }
-    }
-}
-
-// wa3 = R (P^T step) as lmder forms it, then |wa3| / fnorm  (used twice)
-__device__ __forceinline__ double r_times_step_norm(Fit &f)
-{
-    const int n = f.s.n, ld = f.ld;
-    tsync();
-    TFOR(i, 0, n) {
-        double w = 0.0;
-        for (int j = i; j < n; j++) w += f.R[i * ld + j] * f.step[f.ipvt[j]];
-        f.wa3[i] = w;
-    }
-    tsync();
-    return enorm(n, f.wa3) / f.s.fnorm;
-}
-
-// lmcore::propose
-__device__ __forceinline__ void propose(Fit &f)
-{
-    const int n = f.s.n, ld = f.ld;
-    tsync();
-    TFOR(i, 0, n)
-        for (int j = 0; j < n; j++) f.M[i * ld + j] = f.R[i * ld + j];
-    tsync();
-    lmpar(f);
-    tsync();
-    TFOR(j, 0, n) {
-        const double st = -f.p[j];
-        f.step[j] = st;
-        f.xti = f.xi + st;
-        f.wa3[j] = f.diag[j] * st;
-    }
-    set_trial(f);
-    tsync();
-    f.s.pnorm = enorm(n, f.wa3);
-    if (f.s.iter == 1) f.s.delta = fmin(f.s.delta, f.s.pnorm);
-    f.s.fonly = 0;
-    if (f.s.mode == NGMIX_LM_MODE_ANALYTIC_LAZY) {
-        const double temp1 = r_times_step_norm(f);
-        const double temp2 = (sqrt(f.s.par) * f.s.pnorm) / f.s.fnorm;
-        const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
-        if (prered <= f.s.ftol || f.s.pnorm / 0.5 <= f.s.xtol * f.s.xnorm) f.s.fonly = 1;
-    }
-}
-
-// lmcore::new_jacobian with A = f.M, g = f.g
-__device__ __forceinline__ bool new_jacobian(Fit &f)
-{
-    const int n = f.s.n, ld = f.ld;
-    f.s.njev++;
-    factor_normal(f);
-    if (f.s.iter == 1) {
-        TFOR(j, 0, n) {
-            double d = f.acnorm[j];
-            if (d == 0.0) d = 1.0;
-            f.diag[j] = d;
-            f.wa3[j] = d * f.xi;
-        }
-        tsync();
-        f.s.xnorm = enorm(n, f.wa3);
-        f.s.delta = f.s.factor * f.s.xnorm;
-        if (f.s.delta == 0.0) f.s.delta = f.s.factor;
-    }
-    qtf_from_gradient(f);
-    // norm of the scaled gradient
-    f.s.gnorm = 0.0;
-    if (f.s.fnorm != 0.0) {
-        for (int j = 0; j < n; j++) {
-            const int l = f.ipvt[j];
-            const double al = f.acnorm[l];
-            if (al == 0.0) continue;
-            double sum = 0.0;
-            for (int i = 0; i <= j; i++) sum += f.R[i * ld + j] * (f.qtf[i] / f.s.fnorm);
-            f.s.gnorm = fmax(f.s.gnorm, fabs(sum / al));
-        }
-    }
-    if (f.s.gnorm <= f.s.gtol) {
-        f.s.info = 4;
-        f.s.phase = LM_PHASE_DONE;
-        return true;
-    }
-    tsync();
-    TFOR(j, 0, n) f.diag[j] = fmax(f.diag[j], f.acnorm[j]);
-    tsync();
-    propose(f);
-    return false;
-}
-
-// lmcore::lm_advance with the evaluation folded into f.M (A), f.g (g), ff
-__device__ __forceinline__ void lm_advance(Fit &f, double ff)
-{
-    const int n = f.s.n, ld = f.ld;
-    if (f.s.phase == LM_PHASE_DONE) return;
-    if (f.s.bounded && f.s.mode != NGMIX_LM_MODE_FD) {
-        // the wrapped Dfun of leastsqbound.py:485-489: column j scaled by
-        // d xt_j / d xti_j
-        double sc = 1.0;
-        TFOR(j, 0, n) {
-            sc = lmcore::i2e_grad(f.xti, f.lo, f.hi);
-            f.wa1[j] = sc;
-        }
-        tsync();
-        TFOR(j, 0, n) {
-            f.g[j] = f.g[j] * sc;
-            for (int k = 0; k < n; k++) f.M[j * ld + k] = f.M[j * ld + k] * sc * f.wa1[k];
-        }
-        tsync();
-    }
-    if (f.s.phase == LM_PHASE_JAC) {
-        if (f.s.mode == NGMIX_LM_MODE_FD) f.s.nfev += n;
-        f.s.phase = LM_PHASE_TRIAL;
-        new_jacobian(f);
-        return;
-    }
-    if (f.s.phase == LM_PHASE_INIT) {
-        f.s.nfev = f.s.mode == NGMIX_LM_MODE_FD ? 1 + n : 1;
-        f.s.fnorm = sqrt(ff);
-        f.s.par = 0.0;
-        f.s.iter = 1;
-        if (!(f.s.fnorm < INFINITY)) {
-            f.s.njev = 1;
-            f.s.info = 4;
-            f.s.phase = LM_PHASE_DONE;
+        double dxnorm = enorm(n, wa2);
+        double fp = dxnorm - delta;
+        if (fp <= 0.1 * delta) {
+            f.s.par = 0.0;
             return;
         }
-        f.s.phase = LM_PHASE_TRIAL;
-        new_jacobian(f);
-        return;
-    }
-
-    // ---- LM_PHASE_TRIAL: the rest of lmder's inner loop
-    f.s.nfev++;
-    const double fnorm1 = ff < INFINITY ? sqrt(ff) : NAN;
-    double actred = -1.0;
-    if (0.1 * fnorm1 < f.s.fnorm) {
-        const double t = fnorm1 / f.s.fnorm;
-        actred = 1.0 - t * t;
-    }
-    const double temp1 = r_times_step_norm(f);
-    const double temp2 = (sqrt(f.s.par) * f.s.pnorm) / f.s.fnorm;
-    const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
-    const double dirder = -(temp1 * temp1 + temp2 * temp2);
-    double ratio = 0.0;
-    if (prered != 0.0) ratio = actred / prered;
-    if (ratio <= 0.25) {
-        double temp = 0.5;
-        if (actred < 0.0) temp = 0.5 * dirder / (dirder + 0.5 * actred);
-        if (0.1 * fnorm1 >= f.s.fnorm || temp < 0.1) temp = 0.1;
-        f.s.delta = temp * fmin(f.s.delta, f.s.pnorm / 0.1);
-        f.s.par = f.s.par / temp;
-    } else if (f.s.par == 0.0 || ratio >= 0.75) {
-        f.s.delta = f.s.pnorm / 0.5;
-        f.s.par = 0.5 * f.s.par;
-    }
-    const bool accepted = ratio >= 1.0e-4;
-    if (accepted) {
+        // lower bound
+        double parl = 0.0;
+        if (nsing >= n) {
+            tsync();
+            TFOR(j, 0, n) {
+                const int l = f.ipvt[j];
+                wa1[j] = f.diag[l] * (wa2[l] / dxnorm);
+            }
+            tsync();
+            for (int j = 0; j < n; j++) {
+                const double sum = dot(r + j, ld, wa1, 1, 0, j);
+                const double w = (wa1[j] - sum) / r[j * ld + j];
+                tsync();
+                LEAD wa1[j] = w;
+                tsync();
+            }
+            const double temp = enorm(n, wa1);
+            parl = ((fp / delta) / temp) / temp;
+        }
+        // upper bound
         tsync();
         TFOR(j, 0, n) {
-            f.x = f.xt;
-            f.xi = f.xti;
-            f.wa3[j] = f.diag[j] * f.xi;
+            const double sum = dot(r + j, ld, f.qtf, 1, 0, j + 1);
+            wa1[j] = sum / f.diag[f.ipvt[j]];
         }
         tsync();
-        f.s.xnorm = enorm(n, f.wa3);
-        f.s.fnorm = fnorm1;
-        f.s.iter++;
+        const double gnorm = enorm(n, wa1);
+        double paru = gnorm / delta;
+        if (paru == 0.0) paru = lmcore::DWARF / fmin(delta, 0.1);
+        double par = f.s.par;
+        par = fmax(par, parl);
+        par = fmin(par, paru);
+        if (par == 0.0) par = gnorm / dxnorm;
+
+        for (;;) {
+            iter++;
+            if (par == 0.0) par = fmax(lmcore::DWARF, 0.001 * paru);
+            double temp = sqrt(par);
+            tsync();
+            TFOR(j, 0, n) wa1[j] = temp * f.diag[j];
+            tsync();
+            qrsolv(f, wa1, wa2);
+            TFOR(j, 0, n) wa2[j] = f.diag[j] * x[j];
+            tsync();
+            dxnorm = enorm(n, wa2);
+            temp = fp;
+            fp = dxnorm - delta;
+            if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) ||
+                iter == 10)
+                break;
+            // newton correction
+            tsync();
+            TFOR(j, 0, n) {
+                const int l = f.ipvt[j];
+                wa1[j] = f.diag[l] * (wa2[l] / dxnorm);
+            }
+            tsync();
+            for (int j = 0; j < n; j++) {
+                const double t = wa1[j] / f.sdiag[j];
+                tsync();
+                LEAD wa1[j] = t;
+                TFOR(i, j + 1, n) wa1[i] -= r[i * ld + j] * t;
+                tsync();
+            }
+            temp = enorm(n, wa1);
+            const double parc = ((fp / delta) / temp) / temp;
+            if (fp > 0.0) parl = fmax(parl, par);
+            if (fp < 0.0) paru = fmin(paru, par);
+            par = fmax(parl, par + parc);
+        }
+        f.s.par = par;
     }
-    int info = 0;
-    if (fabs(actred) <= f.s.ftol && prered <= f.s.ftol && 0.5 * ratio <= 1.0) info = 1;
-    if (f.s.delta <= f.s.xtol * f.s.xnorm) info = 2;
-    if (fabs(actred) <= f.s.ftol && prered <= f.s.ftol && 0.5 * ratio <= 1.0 && info == 2)
-        info = 3;
-    if (info == 0) {
-        if (f.s.nfev >= f.s.maxfev) info = 5;
-        if (fabs(actred) <= lmcore::EPSMCH && prered <= lmcore::EPSMCH && 0.5 * ratio <= 1.0)
-            info = 6;
-        if (f.s.delta <= lmcore::EPSMCH * f.s.xnorm) info = 7;
-        if (f.s.gnorm <= lmcore::EPSMCH) info = 8;
+
+    // lmcore::set_trial: element j in lane j
+    static __device__ __forceinline__ void set_trial(Fit &f)
+    {
+        constexpr double EPS = 1.4901161193847656e-08;  // sqrt(machine epsilon)
+        TFOR(j, 0, f.s.n) {
+            f.xt = f.s.bounded ? lmcore::i2e(f.xti, f.lo, f.hi) : f.xti;
+            if (f.s.mode == NGMIX_LM_MODE_FD) {
+                double h = EPS * fabs(f.xti);
+                if (h == 0.0) h = EPS;
+                f.hstep = h;
+                f.xstep = f.s.bounded ? lmcore::i2e(f.xti + h, f.lo, f.hi) : f.xti + h;
+            }
+        }
     }
-    if (info != 0) {
-        f.s.info = info;
-        f.s.phase = LM_PHASE_DONE;
-        return;
+
+    // wa3 = R (P^T step) as lmder forms it, then |wa3| / fnorm  (used twice)
+    static __device__ __forceinline__ double r_times_step_norm(Fit &f)
+    {
+        const int n = f.s.n;
+        constexpr int ld = LD;
+        tsync();
+        TFOR(j, 0, n) f.wa2[j] = f.step[f.ipvt[j]];
+        tsync();
+        TFOR(i, 0, n) f.wa3[i] = dot(f.R + i * ld, 1, f.wa2, 1, i, n);
+        tsync();
+        return enorm(n, f.wa3) / f.s.fnorm;
     }
-    if (!accepted) {
-        propose(f);
-    } else if (f.s.mode == NGMIX_LM_MODE_FD || f.s.fonly) {
-        f.xti = f.xi;
+
+    // lmcore::propose
+    static __device__ __forceinline__ void propose(Fit &f)
+    {
+        const int n = f.s.n;
+        constexpr int ld = LD;
+        tsync();
+        TFOR(i, 0, n) {
+            double row[NP];
+            gather(row, f.R + i * ld, 1, 0, n);
+#pragma unroll
+            for (int j = 0; j < NP; j++)
+                if (j < n) f.M[i * ld + j] = row[j];
+        }
+        tsync();
+        lmpar(f);
+        tsync();
+        TFOR(j, 0, n) {
+            const double st = -f.p[j];
+            f.step[j] = st;
+            f.xti = f.xi + st;
+            f.wa3[j] = f.diag[j] * st;
+        }
         set_trial(f);
-        f.s.phase = LM_PHASE_JAC;
+        tsync();
+        f.s.pnorm = enorm(n, f.wa3);
+        if (f.s.iter == 1) f.s.delta = fmin(f.s.delta, f.s.pnorm);
         f.s.fonly = 0;
-    } else {
-        new_jacobian(f);
+        if (f.s.mode == NGMIX_LM_MODE_ANALYTIC_LAZY) {
+            const double temp1 = r_times_step_norm(f);
+            const double temp2 = (sqrt(f.s.par) * f.s.pnorm) / f.s.fnorm;
+            const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+            if (prered <= f.s.ftol || f.s.pnorm / 0.5 <= f.s.xtol * f.s.xnorm) f.s.fonly = 1;
+        }
     }
-}
+
+    // lmcore::new_jacobian with A = f.M, g = f.g, up to its call of propose:
+    // returns true when the fit has terminated
+    static __device__ __forceinline__ bool new_jacobian(Fit &f)
+    {
+        const int n = f.s.n;
+        constexpr int ld = LD;
+        f.s.njev++;
+        factor_normal(f);
+        if (f.s.iter == 1) {
+            TFOR(j, 0, n) {
+                double d = f.acnorm[j];
+                if (d == 0.0) d = 1.0;
+                f.diag[j] = d;
+                f.wa3[j] = d * f.xi;
+            }
+            tsync();
+            f.s.xnorm = enorm(n, f.wa3);
+            f.s.delta = f.s.factor * f.s.xnorm;
+            if (f.s.delta == 0.0) f.s.delta = f.s.factor;
+        }
+        qtf_from_gradient(f);
+        // norm of the scaled gradient: sum_j = sum_{i <= j} R[i][j] (qtf[i] / fnorm)
+        // per column, one column per lane, then the maximum in column order
+        f.s.gnorm = 0.0;
+        if (f.s.fnorm != 0.0) {
+            const double fnorm = f.s.fnorm;
+            TFOR(i, 0, n) f.wa1[i] = f.qtf[i] / fnorm;
+            tsync();
+            TFOR(j, 0, n) {
+                const double al = f.acnorm[f.ipvt[j]];
+                const double sum = dot(f.R + j, ld, f.wa1, 1, 0, j + 1);
+                // (a column lmder skips: any value fmax(gnorm, .) ignores)
+                f.wa2[j] = al == 0.0 ? -1.0 : fabs(sum / al);
+            }
+            tsync();
+            double c[NP];
+            gather(c, f.wa2, 1, 0, n);
+            double gn = 0.0;
+#pragma unroll
+            for (int j = 0; j < NP; j++)
+                if (j < n) gn = fmax(gn, c[j]);
+            f.s.gnorm = gn;
+        }
+        if (f.s.gnorm <= f.s.gtol) {
+            f.s.info = 4;
+            f.s.phase = LM_PHASE_DONE;
+            return true;
+        }
+        tsync();
+        TFOR(j, 0, n) f.diag[j] = fmax(f.diag[j], f.acnorm[j]);
+        tsync();
+        return false;
+    }
+
+    // lmcore::lm_advance with the evaluation folded into f.M (A), f.g (g), ff.
+    // new_jacobian and propose have ONE call site each (the branches say what
+    // they want): the step is ~4k instructions instead of three times that.
+    static __device__ __forceinline__ void lm_advance(Fit &f, double ff)
+    {
+        const int n = f.s.n;
+        constexpr int ld = LD;
+        if (f.s.phase == LM_PHASE_DONE) return;
+        if (f.s.bounded && f.s.mode != NGMIX_LM_MODE_FD) {
+            // the wrapped Dfun of leastsqbound.py:485-489: column j scaled by
+            // d xt_j / d xti_j
+            double sc = 1.0;
+            TFOR(j, 0, n) {
+                sc = lmcore::i2e_grad(f.xti, f.lo, f.hi);
+                f.wa1[j] = sc;
+            }
+            tsync();
+            TFOR(j, 0, n) {
+                f.g[j] = f.g[j] * sc;
+                double row[NP], scv[NP];
+                gather(row, f.M + j * ld, 1, 0, n);
+                gather(scv, f.wa1, 1, 0, n);
+#pragma unroll
+                for (int k = 0; k < NP; k++)
+                    if (k < n) f.M[j * ld + k] = row[k] * sc * scv[k];
+            }
+            tsync();
+        }
+        bool want_jacobian = false, want_proposal = false;
+        if (f.s.phase == LM_PHASE_JAC) {
+            if (f.s.mode == NGMIX_LM_MODE_FD) f.s.nfev += n;
+            f.s.phase = LM_PHASE_TRIAL;
+            want_jacobian = true;
+        } else if (f.s.phase == LM_PHASE_INIT) {
+            f.s.nfev = f.s.mode == NGMIX_LM_MODE_FD ? 1 + n : 1;
+            f.s.fnorm = sqrt(ff);
+            f.s.par = 0.0;
+            f.s.iter = 1;
+            if (!(f.s.fnorm < INFINITY)) {
+                f.s.njev = 1;
+                f.s.info = 4;
+                f.s.phase = LM_PHASE_DONE;
+                return;
+            }
+            f.s.phase = LM_PHASE_TRIAL;
+            want_jacobian = true;
+        } else {
+            // ---- LM_PHASE_TRIAL: the rest of lmder's inner loop
+            f.s.nfev++;
+            const double fnorm1 = ff < INFINITY ? sqrt(ff) : NAN;
+            double actred = -1.0;
+            if (0.1 * fnorm1 < f.s.fnorm) {
+                const double t = fnorm1 / f.s.fnorm;
+                actred = 1.0 - t * t;
+            }
+            const double temp1 = r_times_step_norm(f);
+            const double temp2 = (sqrt(f.s.par) * f.s.pnorm) / f.s.fnorm;
+            const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+            const double dirder = -(temp1 * temp1 + temp2 * temp2);
+            double ratio = 0.0;
+            if (prered != 0.0) ratio = actred / prered;
+            if (ratio <= 0.25) {
+                double temp = 0.5;
+                if (actred < 0.0) temp = 0.5 * dirder / (dirder + 0.5 * actred);
+                if (0.1 * fnorm1 >= f.s.fnorm || temp < 0.1) temp = 0.1;
+                f.s.delta = temp * fmin(f.s.delta, f.s.pnorm / 0.1);
+                f.s.par = f.s.par / temp;
+            } else if (f.s.par == 0.0 || ratio >= 0.75) {
+                f.s.delta = f.s.pnorm / 0.5;
+                f.s.par = 0.5 * f.s.par;
+            }
+            const bool accepted = ratio >= 1.0e-4;
+            if (accepted) {
+                tsync();
+                TFOR(j, 0, n) {
+                    f.x = f.xt;
+                    f.xi = f.xti;
+                    f.wa3[j] = f.diag[j] * f.xi;
+                }
+                tsync();
+                f.s.xnorm = enorm(n, f.wa3);
+                f.s.fnorm = fnorm1;
+                f.s.iter++;
+            }
+            int info = 0;
+            if (fabs(actred) <= f.s.ftol && prered <= f.s.ftol && 0.5 * ratio <= 1.0) info = 1;
+            if (f.s.delta <= f.s.xtol * f.s.xnorm) info = 2;
+            if (fabs(actred) <= f.s.ftol && prered <= f.s.ftol && 0.5 * ratio <= 1.0 &&
+                info == 2)
+                info = 3;
+            if (info == 0) {
+                if (f.s.nfev >= f.s.maxfev) info = 5;
+                if (fabs(actred) <= lmcore::EPSMCH && prered <= lmcore::EPSMCH &&
+                    0.5 * ratio <= 1.0)
+                    info = 6;
+                if (f.s.delta <= lmcore::EPSMCH * f.s.xnorm) info = 7;
+                if (f.s.gnorm <= lmcore::EPSMCH) info = 8;
+            }
+            if (info != 0) {
+                f.s.info = info;
+                f.s.phase = LM_PHASE_DONE;
+                return;
+            }
+            if (!accepted) {
+                want_proposal = true;  // same factor, smaller region
+            } else if (f.s.mode == NGMIX_LM_MODE_FD || f.s.fonly) {
+                f.xti = f.xi;
+                set_trial(f);
+                f.s.phase = LM_PHASE_JAC;
+                f.s.fonly = 0;
+            } else {
+                want_jacobian = true;  // the trial point's jacobian is the new one
+            }
+        }
+        if (want_jacobian && !new_jacobian(f)) want_proposal = true;
+        if (want_proposal) propose(f);
+    }
+};
 
 }  // namespace lmteam

@@ -25,7 +25,6 @@
 #include "launch.hpp"
 #include "lm_core.hpp"
 #include "lm_core_reg.hpp"
-#include "lm_core_team.hpp"
 
 
 namespace ngmix {
@@ -832,208 +831,6 @@ __device__ __forceinline__ void lm_advance_dispatch(
                                nactive);
     } else {
         lm_advance_one<NP>(states, o, obj_start, stamp_band, sums, nloc, obj_sums, nactive);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// The same step by a TEAM of 16 lanes per fit with the fit's arrays in LDS
-// (lm_core_team.hpp): what fits of 11-14 parameters run, whose arrays fit no
-// register file and whose generic one-thread form is a chain of private-memory
-// round trips.  TEAMS fits per work-group (one wave of 16 * TEAMS lanes).
-// ---------------------------------------------------------------------------
-
-// A, g, ff from the stamps' sums: entry k of a stamp's record always lands in
-// the same element for a given band, so one lane per entry adds the stamps in
-// stamp order -- the order of the one-thread loop, element by element.
-__device__ __forceinline__ double lm_team_fold(
-    lmteam::Fit &f, const int64_t s0, const int64_t s1,
-    const int32_t *__restrict__ stamp_band, const double *__restrict__ sums, int nloc,
-    const double *__restrict__ obj_row)
-{
-    using lmteam::TEAM;
-    const int n = f.s.n, ld = f.ld;
-    const int ntri = nloc * (nloc + 1) / 2, nsum = ntri + nloc + 1;
-    TFOR(i, 0, n) {
-        for (int j = 0; j < n; j++) f.M[i * ld + j] = 0.0;
-        f.g[i] = 0.0;
-    }
-    lmteam::tsync();
-    // this lane's entries k = lane, lane + 16, ...: (a, b) of the triangle, or
-    // a gradient entry (b = -1)
-    constexpr int KMAX = (NGMIX_LM_NSUMS(LM_NPMAX) + TEAM - 1) / TEAM;
-    int ka[KMAX], kb[KMAX];
-#pragma unroll
-    for (int q = 0; q < KMAX; q++) {
-        const int k = f.lane + q * TEAM;
-        ka[q] = kb[q] = -1;
-        if (k < ntri) {
-            int a = 0, row = 0;
-            while (row + (nloc - a) <= k) {
-                row += nloc - a;
-                a++;
-            }
-            ka[q] = a;
-            kb[q] = a + (k - row);
-        } else if (k < ntri + nloc) {
-            ka[q] = k - ntri;
-        }
-    }
-    double ff = 0.0;
-    for (int64_t st = s0; st < s1; st++) {
-        const double *v = sums + st * nsum;
-        const int band = stamp_band ? stamp_band[st] : 0;
-#pragma unroll
-        for (int q = 0; q < KMAX; q++) {
-            const int a = ka[q], b = kb[q];
-            if (a < 0) continue;
-            const double t = v[f.lane + q * TEAM];
-            const int ga = a < nloc - 1 ? a : nloc - 1 + band;
-            if (b < 0) {
-                f.g[ga] += t;
-            } else {
-                const int gb = b < nloc - 1 ? b : nloc - 1 + band;
-                f.M[ga * ld + gb] += t;
-                if (ga != gb) f.M[gb * ld + ga] += t;
-            }
-        }
-        ff += v[ntri + nloc];
-    }
-    if (obj_row) {
-        // rows over the object's own n parameters (the prior rows)
-        lmteam::tsync();
-        const int nt = n * (n + 1) / 2;
-        for (int k = f.lane; k < nt + n; k += TEAM) {
-            const double t = obj_row[k];
-            if (k < nt) {
-                int a = 0, row = 0;
-                while (row + (n - a) <= k) {
-                    row += n - a;
-                    a++;
-                }
-                const int b = a + (k - row);
-                f.M[a * ld + b] += t;
-                if (a != b) f.M[b * ld + a] += t;
-            } else {
-                f.g[k - nt] += t;
-            }
-        }
-        ff += obj_row[nt + n];
-    }
-    lmteam::tsync();
-    return ff;
-}
-
-template <int TEAMS>
-__global__ __launch_bounds__(TEAMS * lmteam::TEAM) void lm_advance_team_kernel(
-    lm_state *states, int64_t nobj, const int64_t *__restrict__ obj_start,
-    const int32_t *__restrict__ stamp_band, const double *__restrict__ sums, int nloc,
-    const double *__restrict__ obj_sums, int32_t *nactive,
-    const double *__restrict__ stamp_stats, double *__restrict__ obj_stats, int np)
-{
-    using lmteam::TEAM;
-    extern __shared__ double team_lds[];
-    const int team = threadIdx.x / TEAM;
-    const int64_t o = blockIdx.x * (int64_t)TEAMS + team;
-    if (o >= nobj) return;
-    lm_state &G = states[o];
-    if (G.phase == LM_PHASE_DONE) return;
-    lmteam::Fit f;
-    f.lane = threadIdx.x % TEAM;
-    lmteam::carve(f, team_lds + (size_t)team * lmteam::team_lds_doubles(np), np);
-    const int n = G.n;
-    if (n > np || n < 1) {
-        // the caller's parameter-count hint was wrong for this fit: end it as
-        // MINPACK ends a call with improper input (see lm_advance_dispatch)
-        if (f.lane == 0) {
-            G.info = 0;
-            G.phase = LM_PHASE_DONE;
-        }
-        return;
-    }
-    // ---- the live part of the record: scalars to every lane, element j of the
-    // vectors to lane j (registers or LDS), row j of R to LDS
-    lmteam::Scal &s = f.s;
-    s.n = n;
-    s.iter = G.iter;
-    s.nfev = G.nfev;
-    s.njev = G.njev;
-    s.info = G.info;
-    s.phase = G.phase;
-    s.maxfev = G.maxfev;
-    s.mode = G.mode;
-    s.bounded = G.bounded;
-    s.fonly = G.fonly;
-    s.fnorm = G.fnorm;
-    s.xnorm = G.xnorm;
-    s.delta = G.delta;
-    s.par = G.par;
-    s.gnorm = G.gnorm;
-    s.pnorm = G.pnorm;
-    s.ftol = G.ftol;
-    s.xtol = G.xtol;
-    s.gtol = G.gtol;
-    s.factor = G.factor;
-    const int iter0 = s.iter, phase0 = s.phase;
-    f.x = f.xt = f.xi = f.xti = f.xstep = f.hstep = 0.0;
-    f.lo = -INFINITY;
-    f.hi = INFINITY;
-    TFOR(j, 0, n) {
-        f.x = G.x[j];
-        f.xt = G.xt[j];
-        f.xi = G.xi[j];
-        f.xti = G.xti[j];
-        f.lo = G.lo[j];
-        f.hi = G.hi[j];
-        f.xstep = G.xstep[j];
-        f.hstep = G.hstep[j];
-        f.diag[j] = G.diag[j];
-        f.qtf[j] = G.qtf[j];
-        f.step[j] = G.step[j];
-        f.ipvt[j] = G.ipvt[j];
-        for (int k = 0; k < n; k++) f.R[j * f.ld + k] = G.R[j * LM_NPMAX + k];
-    }
-    const int64_t s0 = obj_start ? obj_start[o] : o;
-    const int64_t s1 = obj_start ? obj_start[o + 1] : o + 1;
-    const double ff = lm_team_fold(
-        f, s0, s1, stamp_band, sums, nloc,
-        obj_sums ? obj_sums + o * (int64_t)(n * (n + 1) / 2 + n + 1) : nullptr);
-    lmteam::lm_advance(f, ff);
-    lmteam::tsync();
-    TFOR(j, 0, n) {
-        G.x[j] = f.x;
-        G.xt[j] = f.xt;
-        G.xi[j] = f.xi;
-        G.xti[j] = f.xti;
-        G.xstep[j] = f.xstep;
-        G.hstep[j] = f.hstep;
-        G.diag[j] = f.diag[j];
-        G.qtf[j] = f.qtf[j];
-        G.step[j] = f.step[j];
-        G.ipvt[j] = f.ipvt[j];
-        for (int k = 0; k < n; k++) G.R[j * LM_NPMAX + k] = f.R[j * f.ld + k];
-    }
-    if (f.lane != 0) return;
-    G.iter = s.iter;
-    G.nfev = s.nfev;
-    G.njev = s.njev;
-    G.info = s.info;
-    G.phase = s.phase;
-    G.fonly = s.fonly;
-    G.fnorm = s.fnorm;
-    G.xnorm = s.xnorm;
-    G.delta = s.delta;
-    G.par = s.par;
-    G.gnorm = s.gnorm;
-    G.pnorm = s.pnorm;
-    if (s.phase != LM_PHASE_DONE && nactive) atomicAdd(nactive, 1);
-    if (stamp_stats && obj_stats && (phase0 == LM_PHASE_INIT || s.iter != iter0)) {
-        double a = 0.0, b = 0.0;
-        for (int64_t st = s0; st < s1; st++) {
-            a += stamp_stats[2 * st];
-            b += stamp_stats[2 * st + 1];
-        }
-        obj_stats[2 * o] = a;
-        obj_stats[2 * o + 1] = b;
     }
 }
 
@@ -1885,31 +1682,21 @@ int launch_lm_advance(lm_state *states, int64_t nobj, const int64_t *obj_start,
         NGMIX_HIP_CHECK(hipMemsetAsync(nactive, 0, sizeof(int32_t), s));
     const dim3 grid((unsigned)((nobj + WAVE - 1) / WAVE)), block(WAVE);
     static const bool generic = getenv("NGMIX_LM_GENERIC") != nullptr;   // A/B knob
-    // The team form (16 lanes per fit, arrays in LDS) for the parameter counts
-    // the register form does not hold: 11-14.  A/B knobs: NGMIX_LM_TEAM_MIN = the
-    // smallest parameter count that goes to it (default 11; 6 = everything said),
-    // NGMIX_LM_TEAMS = fits per wave (1, 2, 4).
+    // The team form (16 lanes per fit, arrays in LDS: lm_team.hip) from 9
+    // parameters up: the register form holds 6-8 without spilling and is ahead
+    // there (one fit per lane: 16 times fewer wave instructions per fit); at 9 and
+    // 10 it spills and the team form is 2x ahead (tools/lm_advance_sweep.py), and
+    // beyond 10 the alternative is the private-memory code.  A/B knobs:
+    // NGMIX_LM_TEAM_MIN = the smallest parameter count that goes to the team form
+    // (6 = every count said), NGMIX_LM_TEAMS = fits per wave (1, 2, 4).
     // (read at every launch: the tests switch them between calls)
     const char *e_min = getenv("NGMIX_LM_TEAM_MIN"), *e_teams = getenv("NGMIX_LM_TEAMS");
-    const int team_min = e_min ? atoi(e_min) : 11;
+    const int team_min = e_min ? atoi(e_min) : 9;
     const int teams = e_teams ? atoi(e_teams) : 4;
-    if (npars >= team_min && !generic) {
-        char name[64];
-        snprintf(name, sizeof(name), "lm_advance_team_kernel<%d>", teams == 1 || teams == 2 ? teams : 4);
-        census(name);
-        const size_t per_team = (size_t)lmteam::team_lds_doubles(npars) * sizeof(double);
-#define NGMIX_TEAM_LAUNCH(T)                                                                   \
-        hipLaunchKernelGGL((lm_advance_team_kernel<T>), dim3((unsigned)((nobj + T - 1) / T)),    \
-                           dim3(T * lmteam::TEAM), T * per_team, s, states, nobj, obj_start,     \
-                           stamp_band, sums, nloc, obj_sums, nactive, stamp_stats, obj_stats,    \
-                           npars)
-        if (teams == 1) NGMIX_TEAM_LAUNCH(1);
-        else if (teams == 2) NGMIX_TEAM_LAUNCH(2);
-        else NGMIX_TEAM_LAUNCH(4);
-#undef NGMIX_TEAM_LAUNCH
-        NGMIX_HIP_CHECK(hipGetLastError());
-        return NGMIX_OK;
-    }
+    if (npars >= team_min && !generic)
+        return launch_lm_advance_team(states, nobj, obj_start, stamp_band, sums, nloc, npars,
+                                      obj_sums, nactive, stamp_stats, obj_stats,
+                                      teams == 1 || teams == 2 ? teams : 4, s);
     {
         char name[64];
         if (npars >= 6 && npars <= 10 && !generic)

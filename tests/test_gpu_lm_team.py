@@ -98,7 +98,7 @@ def test_team_step_equals_generic_step_multiband_lmder(nband, lazy, teams, monke
     _lib.launch_census(reset=True)
     rt, st = _rounds(LMBatchFitter("exp"), go, True)
     seen = _lib.launch_census(reset=True)
-    assert _census_has(seen, "lm_advance_team_kernel<%d>" % teams), seen
+    assert _census_has(seen, "lm_advance_team_kernel<%d," % teams), seen
     assert not _census_has(seen, "lm_advance_kernel<")
     rg, sg = _rounds(LMBatchFitter("exp"), go, False)
     seen = _lib.launch_census(reset=True)
@@ -194,7 +194,7 @@ def test_team_step_with_bounds_prior_rows_and_bad_starts(fd, monkeypatch):
     _lib.launch_census(reset=True)
     rt, st = _rounds(make(), go, True)
     seen = _lib.launch_census(reset=True)
-    assert _census_has(seen, "lm_advance_team_kernel<4>"), seen
+    assert _census_has(seen, "lm_advance_team_kernel<4,"), seen
     rg, sg = _rounds(make(), go, False)
     _assert_same_rounds(st, sg)
     assert np.all(st[-1]["bounded"] == 1)
@@ -208,14 +208,16 @@ def test_team_step_with_bounds_prior_rows_and_bad_starts(fd, monkeypatch):
         np.testing.assert_array_equal(rr[k], rt[k], err_msg=k)
 
 
-def test_team_step_wrong_hint_ends_the_fit():
-    """a parameter-count hint smaller than a fit's n: the fit is ended as
-    MINPACK ends a call with improper input (info 0), not left un-advanced"""
+def test_team_step_wrong_hint_ends_the_fit(monkeypatch):
+    """a parameter-count hint below a fit's n (the team kernel is built for the
+    hinted count rounded up to 8 / 10 / 12 / 14): the fit is ended as MINPACK
+    ends a call with improper input (info 0), not left un-advanced"""
+    monkeypatch.setenv("NGMIX_LM_TEAM_MIN", "6")
     rng = np.random.RandomState(3)
     nobj, nband = 8, 7
     sb, psf, guess, sobj, sband = _multiband(nobj, nband, "exp", rng)
     f = LMBatchFitter("exp")
-    f._nloc_npars = lambda npars: f.nloc + 256 * 11     # says 11, the fits have 12
+    f._nloc_npars = lambda npars: f.nloc + 256 * 10     # says 10, the fits have 12
     f.host_loop = True
     res = f.go(sb, guess, psf=psf, stamp_obj=sobj, stamp_band=sband)
     assert np.all(res["flags"] != 0) and f.rounds <= 2
