@@ -123,7 +123,7 @@ class PeerFailure(RuntimeError):
 # on an ok flag when they enter the steps and again after the leg, and a rank
 # that fails INSIDE its steps keeps the leg's collectives matched with empty
 # records until the leg is over (Gather.drain).
-LEG = {"entered": False, "error": None}
+LEG = {"entered": False, "settled": False, "error": None}
 
 
 def agree(failed, device):
@@ -136,7 +136,8 @@ def agree(failed, device):
 
 
 def inject_failure(where):
-    """testing knob NGMIX_BENCH_FAIL = "<config>:<rank>:<setup|stepN>" """
+    """testing knob NGMIX_BENCH_FAIL = "<config>:<rank>:<build|setup|stepN>"
+    (build: before the leg's workload exists; setup: at the entry of its steps) """
     spec = os.environ.get("NGMIX_BENCH_FAIL")
     if spec:
         cfg, rk, at = spec.split(":")
@@ -147,9 +148,10 @@ def inject_failure(where):
 def run_leg(name, fn, world, device, *a, **kw):
     """fn(*a, **kw) as one leg; returns (result, error).  At N > 1 the error is
     the same kind on every rank: the failing rank's own, PeerFailure elsewhere."""
-    LEG.update(entered=False, error=None, config=name)
+    LEG.update(entered=False, settled=False, error=None, config=name)
     out = err = None
     try:
+        inject_failure("build")
         out = fn(*a, **kw)
     except Exception as e:
         err = e
@@ -157,7 +159,7 @@ def run_leg(name, fn, world, device, *a, **kw):
         if not LEG["entered"]:
             # failed before its steps: the others are at the entry agreement
             agree(True, device)
-        elif not isinstance(err, PeerFailure):
+        elif not LEG["settled"]:
             if agree(err is not None, device) and err is None:
                 out, err = None, PeerFailure("a peer rank failed in leg %s" % name)
     return out, err
@@ -176,6 +178,8 @@ def timed_steps(step, args, distributed, device, gat=None):
         except Exception as e:
             mine = e
         if agree(mine is not None, device):
+            # (every rank knows: no second agreement after this leg)
+            LEG["settled"] = True
             raise mine or PeerFailure("a peer rank failed while setting leg %s up"
                                       % LEG.get("config"))
     count = [0]

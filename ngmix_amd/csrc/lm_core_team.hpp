@@ -285,50 +285,60 @@ struct Step {
             wa[j] = f.qtf[j];
         }
         tsync();
-        for (int j = 0; j < n; j++) {
-            const int l = f.ipvt[j];
-            const double dl = dvec[l];
-            if (dl != 0.0) {
-                tsync();
-                TFOR(k, j, n) sdiag[k] = k == j ? dl : 0.0;
-                tsync();
-                double qtbpj = 0.0;
-                for (int k = j; k < n; k++) {
-                    const double sk = sdiag[k];
+        // The sweeps.  MINPACK eliminates the diagonal element of sweep j with
+        // rotations (j, k), k = j .. n - 1, one sweep after the other: n^2 / 2
+        // rotations, each a divide - square root - divide chain.  Rotation (j, k)
+        // touches column k of r, wa[k] and sweep j's own work vector, and needs
+        // only (j - 1, k) and (j, k - 1) to have happened: sweep j runs in LANE j
+        // (its work vector and qtbpj in that lane's registers), rotation (j, k) at
+        // step t = j + k, all sweeps at once -- 2 n - 1 steps instead of n^2 / 2,
+        // the same operations on every element in an order its dependencies fix.
+        {
+            const int j = f.lane;
+            double dl = 0.0;
+            if (j < n) dl = dvec[f.ipvt[j]];
+            double sd[NP];
+#pragma unroll
+            for (int i = 0; i < NP; i++) sd[i] = i == j ? dl : 0.0;
+            double qtbpj = 0.0;
+            for (int t = 0; t < 2 * n - 1; t++) {
+                const int k = t - j;
+                if (j < n && k >= j && k < n && dl != 0.0) {
+                    double sk = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NP; i++) sk = i == k ? sd[i] : sk;
+                    // (the loads of the step in one batch: none depends on the chain)
                     const double rkk = r[k * ld + k];
                     const double wak = wa[k];
-                    if (sk == 0.0) continue;
-                    double cs, sn;
-                    if (fabs(rkk) < fabs(sk)) {
-                        const double cotan = rkk / sk;
-                        sn = 0.5 / sqrt(0.25 + 0.25 * (cotan * cotan));
-                        cs = sn * cotan;
-                    } else {
-                        const double tn = sk / rkk;
-                        cs = 0.5 / sqrt(0.25 + 0.25 * (tn * tn));
-                        sn = cs * tn;
-                    }
-                    const double temp = cs * wak + sn * qtbpj;
-                    qtbpj = -sn * wak + cs * qtbpj;
-                    tsync();
-                    LEAD {
+                    double col[NP];
+#pragma unroll
+                    for (int i = 0; i < NP; i++) col[i] = r[i * ld + k];
+                    if (sk != 0.0) {
+                        // cotan = rkk / sk or tan = sk / rkk: one chain for both cases
+                        const bool steep = fabs(rkk) < fabs(sk);
+                        const double ratio = steep ? rkk / sk : sk / rkk;
+                        const double q = 0.5 / sqrt(0.25 + 0.25 * (ratio * ratio));
+                        const double qr = q * ratio;
+                        const double sn = steep ? q : qr, cs = steep ? qr : q;
+                        const double temp = cs * wak + sn * qtbpj;
+                        qtbpj = -sn * wak + cs * qtbpj;
                         r[k * ld + k] = cs * rkk + sn * sk;
                         wa[k] = temp;
+#pragma unroll
+                        for (int i = 0; i < NP; i++) {
+                            if (i > k && i < n) {
+                                const double rik = col[i], si = sd[i];
+                                sd[i] = -sn * rik + cs * si;
+                                r[i * ld + k] = cs * rik + sn * si;
+                            }
+                        }
                     }
-                    TFOR(i, k + 1, n) {
-                        const double rik = r[i * ld + k], si = sdiag[i];
-                        const double t = cs * rik + sn * si;
-                        sdiag[i] = -sn * rik + cs * si;
-                        r[i * ld + k] = t;
-                    }
-                    tsync();
                 }
+                tsync();
             }
-            const double rjj = r[j * ld + j], xj = x[j];
-            tsync();
-            LEAD {
-                sdiag[j] = rjj;
-                r[j * ld + j] = xj;
+            TFOR(jj, 0, n) {
+                sdiag[jj] = r[jj * ld + jj];
+                r[jj * ld + jj] = x[jj];
             }
             tsync();
         }

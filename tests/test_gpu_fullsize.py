@@ -11,7 +11,8 @@ batch.
       (a stamp holding its own model has loglike == 0 exactly and
       s2n_numer == s2n_denom), exact linearity of the render, the checksum of
       the per-stamp sums, a sample against the oracle to 1e-10
-  C2+ 250,000 stamps: pixel planes beyond 2^32 bytes (64-bit offsets)
+  C2+ 250,000 stamps: pixel planes beyond 2^32 bytes (64-bit offsets);
+      960,000 stamps: pixel indices beyond 2^31, 17.7 GB planes
   C3  100,000 LM fits: all converge, pulls, order independence, a sample
       against the per-object Fitter (scipy MINPACK driving the exact kernels)
   C4  125,000 32x32 stamps (the per-GPU share of 1M / 8): admom and em_run,
@@ -166,6 +167,55 @@ def test_c2_planes_beyond_four_gigabytes(bench):
     n = 250000
     assert n * 2304 * 8 > 2 ** 32
     _c2_checks(bench, n, 6)
+
+
+def test_c2_pixel_indices_beyond_2_31(bench):
+    """960,000 48x48 stamps resident at once: 2.2e9 pixels per plane (pixel
+    INDICES beyond 2^31, planes of 17.7 GB -- the sizes a 288 GB device is
+    for), built on the device by tiling a 20,000-stamp batch.  Every block of
+    the big batch gives the small batch's results bit for bit: loglike,
+    fill_fdiff, both renders, model_s2n_sum; a ragged tail and a permuted
+    selection address across the 2^31 boundary too."""
+    import torch
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    base, reps = 20000, 48
+    n = base * reps
+    npix = 48 * 48
+    assert n * npix > 2 ** 31
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120 * 2 ** 30:
+        pytest.skip("needs 120 GB of free device memory")
+    sb0, gm0, _ = bench.make_workload(base, 7, "cuda")
+    sb = StampBatch(sb0.val.repeat(reps), sb0.ierr.repeat(reps), sb0.jac.repeat(reps, 1),
+                    np.full(n, 48), np.full(n, 48), np.arange(n, dtype=np.int64) * npix, True)
+    gm = GMixBatch(gm0.data.repeat(reps, 1), n, gm0.ngauss)
+    ref, st0 = sb0.loglike(gm0)
+    assert int(st0.abs().sum()) == 0
+    out, st = sb.loglike(gm)
+    assert int(st.abs().sum()) == 0
+    assert torch.equal(out.reshape(reps, base, 4), ref[None].expand(reps, base, 4))
+    s2n0, _ = sb0.model_s2n_sum(gm0)
+    s2n, _ = sb.model_s2n_sum(gm)
+    assert torch.equal(s2n.reshape(reps, base), s2n0.reshape(1, base).expand(reps, base))
+    del out, s2n
+    fd0, _ = sb0.fill_fdiff(gm0)
+    fd, _ = sb.fill_fdiff(gm)
+    for r in (0, reps // 2, reps - 2, reps - 1):        # (the last two lie beyond 2^31)
+        assert torch.equal(fd[r * base * npix:(r + 1) * base * npix], fd0), r
+    del fd
+    im0, _ = sb0.render(gm0)
+    im, _ = sb.render(gm)
+    for r in (0, reps // 2, reps - 2, reps - 1):
+        assert torch.equal(im[r * base * npix:(r + 1) * base * npix], im0), r
+    # accumulate-into form on the same planes: twice the model, exactly
+    sb.render(gm, image=im)
+    assert torch.equal(im[-base * npix:], 2.0 * im0)
+    del im
+    # a selection reaching across the boundary, in a scrambled order
+    pick = np.random.RandomState(3).choice(n, size=5000, replace=False)
+    sel = sb.select(pick)
+    o2, _ = sel.loglike(gm.select(pick))
+    assert torch.equal(o2, ref[torch.from_numpy(pick % base).cuda()])
 
 
 def test_c3_full_size(bench):

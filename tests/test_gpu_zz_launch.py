@@ -93,10 +93,11 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
 
 
 @pytest.mark.parametrize("spec, leg", [("C4:1:step33", "C4"), ("C3:1:setup", "C3"),
-                                       ("C5:0:step1", "C5")])
+                                       ("C5:0:step1", "C5"), ("C4:0:build", "C4")])
 def test_bench_rank_local_failure_in_a_leg_keeps_the_headline(spec, leg):
-    """a failure on ONE rank inside an other_configs leg (injected: at the entry
-    of the steps, in a settle step, in a timed step; on rank 0 or rank 1): the
+    """a failure on ONE rank inside an other_configs leg (injected: before the
+    leg's workload is built, at the entry of the steps, in a settle step, in a
+    timed step; on rank 0 or rank 1): the
     ranks agree on it (bench.run_leg), the failing rank keeps the leg's
     all-gathers matched with empty records, nobody blocks, every other leg and
     the headline line are intact"""
