@@ -29,7 +29,8 @@ from .jacobian import Jacobian, DiagonalJacobian, UnitJacobian  # noqa: F401
 from . import pixels  # noqa: F401
 from . import gmix  # noqa: F401
 from .gmix import (  # noqa: F401
-    GMix, GMixModel, GMixCM, GMixCoellip, make_gmix_model, gmix_concat,
+    GMix, GMixModel, GMixCM, GMixCoellip, GMixList, MultiBandGMixList, make_gmix_model,
+    gmix_concat,
     set_exact_kernels, get_exact_kernels,
 )
 from . import observation  # noqa: F401

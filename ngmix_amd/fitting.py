@@ -810,3 +810,8 @@ class CoellipFitter(Fitter):
     def _make_fit_model(self, obs, guess):
         return CoellipFitModel(obs=obs, ngauss=self._ngauss, guess=guess,
                                prior=self.prior)
+
+
+# the reference keeps the psf-flux (template amplitude) fitter in its fitting
+# package (ngmix/fitting/fitters.py:146-..., results.py:677-914)
+from .psfflux import PSFFluxFitter, PSFFluxFitModel  # noqa: E402,F401

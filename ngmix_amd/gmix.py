@@ -513,3 +513,34 @@ class GMixCoellip(GMixModel):
 
     def copy(self):
         return GMixCoellip(self._pars)
+
+
+class _TypedList(list):
+    """a list that only takes items of one type (append and item assignment)"""
+    _item_type = object
+    _what = "item"
+
+    def _check(self, item):
+        assert isinstance(item, self._item_type), "%s should be of type %s" % (
+            self._what, self._item_type.__name__)
+
+    def append(self, item):
+        self._check(item)
+        super().append(item)
+
+    def __setitem__(self, index, item):
+        self._check(item)
+        super().__setitem__(index, item)
+
+
+class GMixList(_TypedList):
+    """the mixtures of one band's observations, in order (reference:
+    ngmix/gmix/gmix_lists.py:6-27)"""
+    _item_type = GMix
+    _what = "gmix"
+
+
+class MultiBandGMixList(_TypedList):
+    """one GMixList per band (reference: ngmix/gmix/gmix_lists.py:30-57)"""
+    _item_type = GMixList
+    _what = "gmix_list"

@@ -216,6 +216,35 @@ def make_mom_result(sums, sums_cov, sums_norm=None):
     return res
 
 
+def regularize_mom_shapes(res, fwhm_reg):
+    """
+    Shapes from moment sums with the size regularised: e_{1,2} = M_{1,2} /
+    (T + T_reg), T_reg the T of a gaussian of FWHM fwhm_reg -- for gaussians,
+    the shape after smoothing with that round kernel.  res: a make_mom_result
+    dict; the flux, T and their flags are kept, the shapes and their errors
+    recomputed from the transformed sums (reference: ngmix/moments.py:578-640).
+    fwhm_reg <= 0 returns res itself.
+    """
+    if not fwhm_reg > 0:
+        return res
+    sums = np.array(res["sums"], dtype="f8")
+    cov = np.asarray(res["sums_cov"], dtype="f8")
+    # MT -> MT + T_reg * MF: a linear map of the six sums
+    amat = np.eye(6)
+    amat[4, 5] = fwhm_to_T(fwhm_reg)
+    # (pre-psf fitters leave the centroid sums NaN: they pass through untouched)
+    nan_cen = np.isnan(sums[:2])
+    sums[:2] = np.where(nan_cen, 0.0, sums[:2])
+    reg = amat @ sums
+    reg[:2] = np.where(nan_cen, np.nan, reg[:2])
+    out = make_mom_result(reg, amat @ (cov @ amat.T))
+    for key in ("T", "T_err", "T_flags", "T_flagstr"):
+        out[key] = res[key]
+    out["flags"] |= res["flags"]
+    out["flagstr"] = ngflags.get_flags_str(out["flags"])
+    return out
+
+
 def _ratio_error_arrays(a, b, var_a, var_b, cov_ab, where):
     """get_ratio_error over arrays, evaluated only where `where` (elsewhere nan);
     util.get_ratio_var's expression (equal to the scalar routine to the last

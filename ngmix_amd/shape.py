@@ -100,6 +100,38 @@ def eta1eta2_to_g1g2(eta1, eta2):
     return fac * eta1, fac * eta2
 
 
+def e1e2_to_eta1eta2(e1, e2):
+    """distortion (e1, e2) -> eta-space shape: |eta| = atanh(|e|), the same
+    position angle (reference: ngmix/shape.py:350-393); |e| >= 1 raises
+    GMixRangeError; scalars in, scalars out"""
+    scalar = not isinstance(e1, np.ndarray)
+    a1 = np.atleast_1d(np.asarray(e1, dtype="f8"))
+    a2 = np.atleast_1d(np.asarray(e2, dtype="f8"))
+    mag = np.sqrt(a1 * a1 + a2 * a2)
+    if np.any(mag >= 1.0):
+        raise GMixRangeError("some e were out of bounds")
+    eta1 = np.zeros(mag.size)
+    eta2 = np.zeros(mag.size)
+    w, = np.where(mag > 0.0)
+    if w.size > 0:
+        fac = np.arctanh(mag[w]) / mag[w]
+        eta1[w] = fac * a1[w]
+        eta2[w] = fac * a2[w]
+    if scalar:
+        return eta1[0], eta2[0]
+    return eta1, eta2
+
+
+def dgs_by_dgo_jacob(g1, g2, s1, s2):
+    """|d g_sheared / d g_observed| at fixed shear (s1, s2) for reduced-shear
+    shapes: (1 - |s|^2)^2 / (1 + 2 g.s + |g|^2 |s|^2)^2 (reference:
+    ngmix/shape.py:443-468)"""
+    ssq = s1 * s1 + s2 * s2
+    # (the reference's association: 1 + 2 g1 s1 + 2 g2 s2 + g1^2 ssq + g2^2 ssq)
+    root = 1 + 2 * g1 * s1 + 2 * g2 * s2 + g1 ** 2 * ssq + g2 ** 2 * ssq
+    return (ssq - 1) ** 2 / root ** 2
+
+
 def get_round_factor(g1, g2):
     """T_round = T * factor under the shear that rounds the shape"""
     gsq = g1 ** 2 + g2 ** 2

@@ -208,6 +208,83 @@ def test_team_step_with_bounds_prior_rows_and_bad_starts(fd, monkeypatch):
         np.testing.assert_array_equal(rr[k], rt[k], err_msg=k)
 
 
+@pytest.mark.parametrize("teams", [4, 2])
+def test_team_step_under_load_is_the_generic_fit_and_order_independent(teams, monkeypatch):
+    """thousands of fits in flight (several waves per SIMD, four fits per wave
+    each at its own point of lmder's control flow: guesses from good to bad,
+    some starts out of range): the complete fits of the team form are the
+    generic form's to the bit, run after run, and a fit's result does not depend
+    on which wave or team slot it sits in (a permuted batch gives the permuted
+    results) -- the checks a cross-lane hazard in the LDS protocol would fail"""
+    monkeypatch.setenv("NGMIX_LM_TEAMS", str(teams))
+    rng = np.random.RandomState(404 + teams)
+    nobj, nband = 3001, 6                       # (not a multiple of the fits per wave)
+    sb, psf, guess, sobj, sband = _multiband(nobj, nband, "exp", rng)
+    bad = rng.uniform(size=nobj)
+    guess[bad < 0.3, 4:] *= rng.uniform(0.4, 2.5, size=(int((bad < 0.3).sum()), guess.shape[1] - 4))
+    guess[bad < 0.1, 2:4] = rng.uniform(-0.6, 0.6, size=(int((bad < 0.1).sum()), 2))
+    guess[7, 2:4] = 0.95, 0.9                   # |g| >= 1
+    kw = dict(psf=psf, stamp_obj=sobj, stamp_band=sband)
+    keys = ("flags", "nfev", "njev", "ier", "pars", "pars_cov", "lnprob")
+    team = LMBatchFitter("exp")
+    _lib.launch_census(reset=True)
+    a = team.go(sb, guess, **kw)
+    seen = _lib.launch_census(reset=True)
+    assert _census_has(seen, "lm_advance_team_kernel<%d, 12>" % teams), seen
+    generic = LMBatchFitter("exp")
+    generic.advance_hint = False
+    b = generic.go(sb, guess, **kw)
+    for k in keys:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert team.rounds == generic.rounds and team.rounds > 8
+    assert 0.5 < np.mean(a["flags"] == 0) < 1.0 and a["flags"][7] != 0
+    # run-to-run
+    c = team.go(sb, guess, **kw)
+    for k in keys:
+        np.testing.assert_array_equal(a[k], c[k], err_msg=k)
+    # the objects in another order (their stamps moved along)
+    perm = rng.permutation(nobj)
+    sidx = (perm[:, None] * nband + np.arange(nband)[None, :]).reshape(-1)
+    d = team.go(sb.select(sidx), guess[perm], psf=psf.select(sidx), stamp_obj=sobj,
+                stamp_band=sband)
+    for k in keys:
+        np.testing.assert_array_equal(d[k], a[k][perm], err_msg=k)
+
+
+def test_team_step_coellip_under_load(monkeypatch):
+    """the same for two thousand 5-gaussian co-elliptical psf fits (14
+    parameters; lmpar's iterations with the wavefront form of qrsolv's sweeps
+    on most steps), and the launch census: no one-thread lm_advance kernel"""
+    rng = np.random.RandomState(77)
+    dim, scale, n, ngauss = 25, 0.263, 2003, 5
+    jac = ngmix.DiagonalJacobian(row=12.0, col=12.0, scale=scale)
+    gm = ngmix.GMixModel([0.0, 0.0, 0.02, -0.01, 0.3, 1.0], "turb")
+    im0 = gm.make_image((dim, dim), jacobian=jac)
+    images = im0[None] + 2.0e-4 * rng.normal(size=(n, dim, dim))
+    sb = StampBatch.from_images(images, np.full((n, dim, dim), 1.0 / 2.0e-4 ** 2), jac)
+    T = 0.3 * np.array([0.3, 0.7, 1.5, 3.0, 6.0])
+    F = np.array([0.25, 0.35, 0.25, 0.1, 0.05])
+    g0 = np.concatenate([[0.0, 0.0, 0.02, -0.01], T, F / F.sum()])
+    guess = g0[None] * rng.uniform(0.9, 1.1, size=(n, g0.size))
+    guess[:, :2] = rng.uniform(-0.01, 0.01, size=(n, 2))
+    pars = {"maxfev": 100, "ftol": 1e-5, "xtol": 1e-5}
+    team = LMBatchFitter("coellip", ngauss=ngauss, fit_pars=pars)
+    _lib.launch_census(reset=True)
+    a = team.go(sb, guess)
+    seen = _lib.launch_census(reset=True)
+    assert _census_has(seen, "lm_advance_team_kernel<4, 14>"), seen
+    assert not _census_has(seen, "lm_advance_kernel<"), seen
+    generic = LMBatchFitter("coellip", ngauss=ngauss, fit_pars=pars)
+    generic.advance_hint = False
+    b = generic.go(sb, guess)
+    for k in ("flags", "nfev", "ier", "pars", "pars_cov"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    perm = rng.permutation(n)
+    d = team.go(sb.select(perm), guess[perm])
+    for k in ("flags", "nfev", "ier", "pars"):
+        np.testing.assert_array_equal(d[k], a[k][perm], err_msg=k)
+
+
 def test_team_step_wrong_hint_ends_the_fit(monkeypatch):
     """a parameter-count hint below a fit's n (the team kernel is built for the
     hinted count rounded up to 8 / 10 / 12 / 14): the fit is ended as MINPACK

@@ -515,3 +515,57 @@ def test_observation_pickles_without_its_device_copies():
     assert obs._stamp is not None                       # the original keeps its copies
     assert np.array_equal(back.image, obs.image) and np.array_equal(back.weight, obs.weight)
     assert back.meta["id"] == 3 and back.jacobian.get_scale() == obs.jacobian.get_scale()
+
+
+def test_small_host_helpers_vs_reference(golden):
+    """moments.regularize_mom_shapes, shape.e1e2_to_eta1eta2 and
+    shape.dgs_by_dgo_jacob against the REFERENCE's own outputs
+    (tests/golden/host5.npz, oracle/gen_golden_r5.py), and the typed list
+    containers of ngmix/gmix/gmix_lists.py"""
+    from ngmix_amd import moments, shape
+    g = golden("host5")
+    numeric = ("flags", "flux", "flux_err", "flux_flags", "T", "T_err", "T_flags", "s2n",
+               "e1", "e2", "e", "e_err", "e_cov", "sums", "sums_cov", "pars")
+    for k in range(int(g["ncase"])):
+        res = moments.make_mom_result(g["reg%d_sums" % k].copy(), g["reg%d_cov" % k].copy())
+        for f, fwhm in enumerate(g["fwhm_reg"]):
+            reg = moments.regularize_mom_shapes(dict(res), float(fwhm))
+            if fwhm == 0:
+                assert set(reg) == set(res)
+            for key in numeric:
+                name = "reg%d_f%d_%s" % (k, f, key)
+                if name in g:
+                    np.testing.assert_allclose(np.asarray(reg[key], dtype="f8"), g[name],
+                                               rtol=1e-13, atol=0, equal_nan=True,
+                                               err_msg=name)
+                else:
+                    assert key not in reg, name
+            assert reg["flagstr"] == str(g["reg%d_f%d_flagstr" % (k, f)])
+            # the size and the flux are the unregularised ones
+            assert reg["T"] == res["T"] or (np.isnan(reg["T"]) and np.isnan(res["T"]))
+    e = g["e"]
+    eta1, eta2 = shape.e1e2_to_eta1eta2(e[:, 0].copy(), e[:, 1].copy())
+    np.testing.assert_allclose(np.stack([eta1, eta2], axis=1), g["eta"], rtol=1e-14, atol=0)
+    s1, s2 = shape.e1e2_to_eta1eta2(0.3, -0.4)
+    assert np.ndim(s1) == 0
+    np.testing.assert_allclose([s1, s2], g["eta_scalar"], rtol=1e-14)
+    with pytest.raises(ngmix.GMixRangeError):
+        shape.e1e2_to_eta1eta2(0.8, 0.7)
+    gg, ss = g["g"], g["s"]
+    np.testing.assert_array_equal(
+        shape.dgs_by_dgo_jacob(gg[:, 0], gg[:, 1], ss[:, 0], ss[:, 1]), g["jacob"])
+    # typed lists
+    gl = ngmix.GMixList()
+    gm = ngmix.GMix(pars=[1.0, 0.0, 0.0, 1.0, 0.0, 1.0])
+    gl.append(gm)
+    gl[0] = gm
+    with pytest.raises(AssertionError):
+        gl.append("not a gmix")
+    with pytest.raises(AssertionError):
+        gl[0] = 3
+    mb = ngmix.MultiBandGMixList()
+    mb.append(gl)
+    with pytest.raises(AssertionError):
+        mb.append([gm])
+    assert len(mb) == 1 and len(mb[0]) == 1
+    assert ngmix.fitting.PSFFluxFitter is ngmix.PSFFluxFitter
