@@ -849,11 +849,18 @@ struct FdGauss {
 };
 static_assert(sizeof(FdGauss) == 48, "FdGauss");
 
-template <int NLOC>
+// LINEAR: the pixels are taken 64 at a time in ROW-MAJOR order instead of as
+// 8 x 8 tiles -- for batches whose stamps fill 8 x 8 tiles badly (a 25 x 25 psf
+// stamp is 16 such tiles for 625 pixels, and 10 row-major ones); a tile is then
+// the rows it touches, whole, for the box test.  Chosen per launch from the
+// batch's largest shape; correct for any shape.
+template <int NLOC, bool LINEAR>
 // three waves per SIMD up to ten parameters (168 VGPRs, no spills; measured
-// 9.0 -> 8.1 ms per 20k 'bdf' fits against two), two beyond
+// 9.0 -> 8.1 ms per 20k 'bdf' fits against two), two beyond -- and for ten
+// parameters on row-major tiles, which needs two registers more than 168
 __global__ __launch_bounds__(WAVE)
-__attribute__((amdgpu_waves_per_eu(NLOC <= 10 ? 3 : 2, NLOC <= 10 ? 3 : 2)))
+__attribute__((amdgpu_waves_per_eu(NLOC <= 10 && !(LINEAR && NLOC == 10) ? 3 : 2,
+                                   NLOC <= 10 && !(LINEAR && NLOC == 10) ? 3 : 2)))
 void lm_eval_fd_kernel(
     const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
     const double *__restrict__ ierr, const ngmix_jacobian *__restrict__ jacs,
@@ -957,9 +964,22 @@ void lm_eval_fd_kernel(
         r.c = -gc.drc;
         r.pa = gc.pnorm * area;
         ev[k * G + i] = r;
-        if (k == 0)
-            boxes[i] = tile_box(no_skip ? full_box() : gauss_pixel_box(gc, jac),
-                                TILE_H, TILE_W);
+        if (k == 0) {
+            if constexpr (LINEAR) {
+                // rows a row-major tile of 64 pixels can touch; every column:
+                // the test is on the rows alone (c0 = 0 passes)
+                TileBox tb = tile_box(no_skip ? full_box() : gauss_pixel_box(gc, jac),
+                                      (WAVE + ncol - 2) / ncol + 1, TILE_W);
+                if (tb.r_lo != (1 << 30)) {
+                    tb.c_lo = 0;
+                    tb.c_span = 0xffffffffu;
+                }
+                boxes[i] = tb;
+            } else {
+                boxes[i] = tile_box(no_skip ? full_box() : gauss_pixel_box(gc, jac),
+                                    TILE_H, TILE_W);
+            }
+        }
     }
     if (__ballot(bad != 0) != 0ull) {
         // out of range at (or one step from) the trial point: LOWVAL residuals
@@ -1007,14 +1027,32 @@ void lm_eval_fd_kernel(
     }
 
     auto load_tile = [&](int ty, int tx, double &pv, double &pe) {
-        const int row = ty * TILE_H + lrow, col = tx * TILE_W + lcol;
-        pv = 0.0;
-        pe = 0.0;
-        if (ty < nty && row < nrow && col < ncol) {
-            pv = sval[row * ncol + col];
-            pe = sierr[row * ncol + col];
+        if constexpr (LINEAR) {
+            // (ty counts the row-major tiles, tx stays 0)
+            const int p = ty * WAVE + lane;
+            pv = 0.0;
+            pe = 0.0;
+            if (p < nrow * ncol) {
+                pv = sval[p];
+                pe = sierr[p];
+            }
+        } else {
+            const int row = ty * TILE_H + lrow, col = tx * TILE_W + lcol;
+            pv = 0.0;
+            pe = 0.0;
+            if (ty < nty && row < nrow && col < ncol) {
+                pv = sval[row * ncol + col];
+                pe = sierr[row * ncol + col];
+            }
         }
     };
+    // LINEAR: this lane's pixel in a row-major tile, (row, col) of pixel
+    // T * 64 + lane, advanced by 64 pixels per tile without a division
+    int prow = 0, pcol = 0;
+    if constexpr (LINEAR) {
+        prow = lane / ncol;
+        pcol = lane - prow * ncol;
+    }
 
     // the tile loop; COCEN: one centre per set (see above)
     auto tiles = [&](auto cocen_c) {
@@ -1022,18 +1060,35 @@ void lm_eval_fd_kernel(
         int ty = 0, tx = 0;
         double nval, nierr;
         load_tile(ty, tx, nval, nierr);
-        while (ty < nty) {
+        while (ty < (LINEAR ? (nrow * ncol + WAVE - 1) / WAVE : nty)) {
             const double pval = nval, pierr = nierr;
             int ty2 = ty, tx2 = tx + 1;
-            if (tx2 == ntx) {
+            if (LINEAR || tx2 == ntx) {
                 tx2 = 0;
                 ty2++;
             }
             load_tile(ty2, tx2, nval, nierr);
 
-            const int r0 = ty * TILE_H, c0 = tx * TILE_W;
-            const double rowd = (double)(r0 + lrow) - jac.row0;
-            const double cold = (double)(c0 + lcol) - jac.col0;
+            int r0, c0;
+            double rowd, cold;
+            if constexpr (LINEAR) {
+                // the first row the tile touches (lane 0's), column 0 (see the boxes)
+                r0 = __builtin_amdgcn_readfirstlane(prow);
+                c0 = 0;
+                rowd = (double)prow - jac.row0;
+                cold = (double)pcol - jac.col0;
+                pcol += WAVE % ncol;
+                prow += WAVE / ncol;
+                if (pcol >= ncol) {
+                    pcol -= ncol;
+                    prow++;
+                }
+            } else {
+                r0 = ty * TILE_H;
+                c0 = tx * TILE_W;
+                rowd = (double)(r0 + lrow) - jac.row0;
+                cold = (double)(c0 + lcol) - jac.col0;
+            }
             const double v = fma(jac.dvdrow, rowd, jac.dvdcol * cold);
             const double u = fma(jac.dudrow, rowd, jac.dudcol * cold);
             // dv^2, du^2, dv du about the three centres
@@ -1639,16 +1694,31 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *stat
         set_last_error_msg("lm_eval: too many composed gaussians for LDS");
         return NGMIX_ERR_BAD_ARG;
     }
-#define NGMIX_FD_LAUNCH(N)                                                              \
+    // row-major tiles when the batch's largest shape needs a fifth fewer of them
+    // than 8 x 8 tiles (NGMIX_LM_FD_TILES = 2d | linear forces one form: A/B)
+    bool linear = false;
+    {
+        const int ntl = (b->max_nrow * b->max_ncol + WAVE - 1) / WAVE;
+        const int nt2d = ((b->max_ncol + TILE_W - 1) / TILE_W) * ((b->max_nrow + TILE_H - 1) / TILE_H);
+        linear = b->max_nrow > 0 && b->max_ncol > 0 && 5 * ntl <= 4 * nt2d;
+        const char *e = getenv("NGMIX_LM_FD_TILES");
+        if (e) linear = e[0] == 'l';
+    }
+#define NGMIX_FD_LAUNCH1(N, L)                                                          \
     do {                                                                                \
-        census("lm_eval_fd_kernel<" #N ">");                                            \
+        census(L ? "lm_eval_fd_kernel<" #N ", linear>" : "lm_eval_fd_kernel<" #N ">");  \
         if (lds > 48 * 1024)                                                            \
             NGMIX_HIP_CHECK(hipFuncSetAttribute(                                        \
-                (const void *)lm_eval_fd_kernel<N>,                                     \
+                (const void *)lm_eval_fd_kernel<N, L>,                                  \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
-        hipLaunchKernelGGL(lm_eval_fd_kernel<N>, grid, block, lds, s, b->stamps, b->val, \
-                           b->ierr, b->jac, model, ng0, states, stamp_obj, stamp_band,  \
-                           psf, npsf, sums, status, no_skip);                           \
+        hipLaunchKernelGGL((lm_eval_fd_kernel<N, L>), grid, block, lds, s, b->stamps,   \
+                           b->val, b->ierr, b->jac, model, ng0, states, stamp_obj,      \
+                           stamp_band, psf, npsf, sums, status, no_skip);               \
+    } while (0)
+#define NGMIX_FD_LAUNCH(N)                                                              \
+    do {                                                                                \
+        if (linear) NGMIX_FD_LAUNCH1(N, true);                                          \
+        else NGMIX_FD_LAUNCH1(N, false);                                                \
     } while (0)
     if (nloc == 6) NGMIX_FD_LAUNCH(6);
     else if (nloc == 7) NGMIX_FD_LAUNCH(7);
@@ -1656,6 +1726,7 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *stat
     else if (nloc <= 10) NGMIX_FD_LAUNCH(10);
     else if (nloc <= 12) NGMIX_FD_LAUNCH(12);
     else NGMIX_FD_LAUNCH(14);
+#undef NGMIX_FD_LAUNCH1
 #undef NGMIX_FD_LAUNCH
     NGMIX_HIP_CHECK(hipGetLastError());
     return NGMIX_OK;

@@ -576,6 +576,76 @@ def test_lm_eval_skipping_is_exact(model, fd, npsf, offset):
     np.testing.assert_array_equal(out[0], out[1])
 
 
+@pytest.mark.parametrize("model,dim", [("bdf", 25), ("turb", 33), ("exp", 27)])
+def test_lm_eval_fd_row_major_tiles(model, dim, monkeypatch):
+    """the forward-difference pixel pass takes the pixels of stamps that fill
+    8 x 8 tiles badly (25 x 25: 16 tiles for 625 pixels) 64 at a time in row-major
+    order (10 tiles): the normal-equation sums are those of the 8 x 8 form to
+    the rounding of a different order of addition, skipping is still exact (the
+    row-range box test), masked pixels and the jacobian phase included; the
+    launch census names the form, and NGMIX_LM_FD_TILES forces either"""
+    import ctypes
+    import torch
+    from ngmix_amd.batch import _dptr, _stream
+    from ngmix_amd.gmix import get_model_num
+    L = _lib.lib()
+    rng = np.random.RandomState(600 + dim)
+    n = 48
+    psf_rows, psf = _multi_gauss_psf(n, 2, True, rng)
+    extra = rng.uniform(0.3, 0.7, size=n) if model == "bdf" else None
+    pars, guess, images, weights, jobj, sb = _objects_with_psf(n, model, psf, rng, dim=dim,
+                                                              extra=extra)
+    weights[::5, 3:7, 2:11] = 0.0
+    jac = np.array([(dim - 1) / 2.0, (dim - 1) / 2.0, 0.263, 0.0, 0.0, 0.263, 0.263 ** 2, 0.263])
+    sb = StampBatch.from_images(images, weights, jac)
+    guess[:, 2:4] = rng.uniform(-0.5, 0.5, size=(n, 2))
+    npars = guess.shape[1]
+    nsum = npars * (npars + 1) // 2 + npars + 1
+
+    def sums_of(tiles, no_skip):
+        if tiles is None:
+            monkeypatch.delenv("NGMIX_LM_FD_TILES", raising=False)
+        else:
+            monkeypatch.setenv("NGMIX_LM_FD_TILES", tiles)
+        st = torch.empty((n, _lib.LM_STATE_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+        dg = torch.from_numpy(np.ascontiguousarray(guess)).cuda()
+        _lib.check(L.ngmix_lm_init_batch(_dptr(st), n, npars, _dptr(dg), 1e-8, 1e-8, 0.0, 100,
+                                         100.0, _lib.LM_MODE_FD, None, None, _stream()), "init")
+        sobj = torch.arange(n, dtype=torch.int32, device="cuda")
+        sband = torch.zeros(n, dtype=torch.int32, device="cuda")
+        sums = torch.zeros((n, nsum), dtype=torch.float64, device="cuda")
+        status = torch.zeros(n, dtype=torch.int32, device="cuda")
+        b = sb._batch(1, no_skip=no_skip)
+        _lib.launch_census(reset=True)
+        _lib.check(L.ngmix_lm_eval_batch(ctypes.byref(b), get_model_num(model), 1, _dptr(st),
+                                         _dptr(sobj), _dptr(sband), _dptr(psf.data), 2,
+                                         _dptr(sums), _dptr(status), None, _stream()), "eval")
+        torch.cuda.synchronize()
+        seen = _lib.launch_census(reset=True)
+        assert int(status.abs().sum()) == 0
+        return sums.cpu().numpy(), seen
+    auto, seen = sums_of(None, False)
+    assert any("lm_eval_fd_kernel<%d, linear>" % npars in k for k in seen), seen
+    lin, _ = sums_of("linear", False)
+    lin_ns, _ = sums_of("linear", True)
+    two, seen2 = sums_of("2d", False)
+    assert any(k == "lm_eval_fd_kernel<%d>" % npars for k in seen2), seen2
+    np.testing.assert_array_equal(auto, lin)
+    np.testing.assert_array_equal(lin, lin_ns)          # skipping is exact
+    scale = np.abs(two).max(axis=1, keepdims=True)
+    assert np.all(np.isfinite(two)) and scale.min() > 0
+    np.testing.assert_allclose(lin, two, rtol=0, atol=1e-12 * scale.max())
+    assert np.all(np.abs(lin - two) <= 1e-11 * scale)
+    # a 32 x 32 batch keeps the 8 x 8 tiles
+    monkeypatch.delenv("NGMIX_LM_FD_TILES", raising=False)
+    rng2 = np.random.RandomState(9)
+    p2, g2, im2, w2, j2, sb2, psf2 = _make_objects(8, "exp", rng2)
+    _lib.launch_census(reset=True)
+    LMBatchFitter("exp", analytic_jacobian=False).go(sb2, g2, psf=psf2)
+    seen3 = _lib.launch_census(reset=True)
+    assert "lm_eval_fd_kernel<6>" in seen3 and not any("linear" in k for k in seen3), seen3
+
+
 def test_bootstrap_batch_on_ragged_and_selected_stamps():
     """the flux guess of bootstrap_batch on stamps of different shapes (a
     segmented sum on the device) and on a selection that shares its parent's
