@@ -6,7 +6,8 @@
 // of ~2,000 dependent scratch accesses, 0.5-2.3 ms per launch for fits of
 // 11-14 parameters however few fits there are (multi-band fits, co-elliptical
 // psf fits with 4 / 5 gaussians).  The register form (lm_core_reg.hpp) removes
-// the memory latency for up to 10 parameters and does not fit beyond.
+// the memory latency for 6-8 parameters, spills at 9 and 10 and does not fit
+// beyond; this form serves 9-14.
 //
 // Here a fit belongs to 16 lanes and its arrays live in LDS:
 //
@@ -594,7 +595,7 @@ struct Step {
 
     // lmcore::lm_advance with the evaluation folded into f.M (A), f.g (g), ff.
     // new_jacobian and propose have ONE call site each (the branches say what
-    // they want): the step is ~4k instructions instead of three times that.
+    // they want): 9k instructions instead of 14k.
     static __device__ __forceinline__ void lm_advance(Fit &f, double ff)
     {
         const int n = f.s.n;

@@ -1,8 +1,8 @@
 // lm_team.hip -- the lmder step of the lock-step fits by a TEAM of 16 lanes per
-// fit with the fit's arrays in LDS (lm_core_team.hpp): what fits of 11-14
-// parameters run, whose arrays fit no register file and whose generic
-// one-thread form (lmfit.hip, lm_core.hpp) is a chain of private-memory round
-// trips.  Reference: scipy's lmder / lmdif as ngmix/fitting/leastsqbound.py:
+// fit with the fit's arrays in LDS (lm_core_team.hpp): what fits of 9-14
+// parameters run, whose arrays fit no register file (9, 10: not without
+// spilling) and whose generic one-thread form (lmfit.hip, lm_core.hpp) is a
+// chain of private-memory round trips.  Reference: scipy's lmder / lmdif as ngmix/fitting/leastsqbound.py:
 // 289-552 drives them; records byte-identical to the generic form's
 // (tests/test_gpu_lm_team.py).
 #include <stdio.h>
@@ -23,11 +23,7 @@ __device__ __forceinline__ double lm_team_fold(
     using lmteam::TEAM;
     const int n = f.s.n, ld = f.ld;
     const int ntri = nloc * (nloc + 1) / 2, nsum = ntri + nloc + 1;
-    TFOR(i, 0, n) {
-        for (int j = 0; j < n; j++) f.M[i * ld + j] = 0.0;
-        f.g[i] = 0.0;
-    }
-    lmteam::tsync();
+    // (M and g start as +0.0: the kernel zero-fills the team's block)
     // this lane's entries k = lane, lane + 16, ...: (a, b) of the triangle, or
     // a gradient entry (b = -1)
     constexpr int KMAX = (NGMIX_LM_NSUMS(LM_NPMAX) + TEAM - 1) / TEAM;
@@ -156,6 +152,7 @@ __global__ __launch_bounds__(TEAMS * lmteam::TEAM) void lm_advance_team_kernel(
     // the block starts as +0.0 everywhere: the batched loads of lm_core_team.hpp
     // read whole rows / columns / vectors of NP elements and select afterwards
     for (int i = f.lane; i < lmteam::team_lds_doubles(np); i += TEAM) block[i] = 0.0;
+    lmteam::tsync();
     const int n = G.n;
     if (n > np || n < 1) {
         // the caller's parameter-count hint was wrong for this fit: end it as
