@@ -218,6 +218,76 @@ def test_c2_pixel_indices_beyond_2_31(bench):
     assert torch.equal(o2, ref[torch.from_numpy(pick % base).cuda()])
 
 
+def test_lm_and_moments_with_pixel_indices_beyond_2_31(bench):
+    """the iterative kernels on planes beyond 2^31 pixels: 960,000 lock-step LM
+    fits (48x48) and 2,100,000 adaptive-moment / EM fits (32x32) in one batch
+    each, tiled from small batches -- every block reproduces the small batch's
+    results to the bit (the fits are independent of where a stamp sits)"""
+    import torch
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    from ngmix_amd.lm_batch import LMBatchFitter
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120 * 2 ** 30:
+        pytest.skip("needs 120 GB of free device memory")
+    # ---- config 3 shaped: LM
+    base, reps = 20000, 48
+    n, npix = base * reps, 48 * 48
+    sb0, _, pars = bench.make_workload(base, 7, "cuda")
+    rng = np.random.RandomState(17)
+    guess0 = pars * rng.uniform(0.9, 1.1, size=pars.shape)
+    guess0[:, 0:2] = pars[:, 0:2] + rng.uniform(-0.05, 0.05, size=(base, 2))
+    guess0[:, 2:4] = pars[:, 2:4] + rng.uniform(-0.03, 0.03, size=(base, 2))
+    psf0, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (base, 1)), "gauss")
+    ref = LMBatchFitter("exp").go(sb0, guess0, psf=psf0)
+    sb = StampBatch(sb0.val.repeat(reps), sb0.ierr.repeat(reps), sb0.jac.repeat(reps, 1),
+                    np.full(n, 48), np.full(n, 48), np.arange(n, dtype=np.int64) * npix, True)
+    assert n * npix > 2 ** 31
+    psf = GMixBatch(psf0.data.repeat(reps, 1), n, 1)
+    res = LMBatchFitter("exp").go(sb, np.tile(guess0, (reps, 1)), psf=psf)
+    assert np.all(res["flags"] == np.tile(ref["flags"], reps))
+    for key in ("nfev", "ier", "pars", "pars_err", "lnprob", "s2n"):
+        got = res[key].reshape((reps, base) + res[key].shape[1:])
+        for r in (0, reps // 2, reps - 1):
+            np.testing.assert_array_equal(got[r], ref[key], err_msg="%s block %d" % (key, r))
+    del sb, psf, res
+    torch.cuda.empty_cache()
+    # ---- config 4 shaped: adaptive moments and EM
+    base, reps = 30000, 70
+    n = base * reps
+    w = bench.make_c4(base, 5, "cuda")
+    dim = w["dim"]
+    npix = dim * dim
+    assert n * npix > 2 ** 31
+    a0 = w["sb"].admom(w["wt0"].clone())
+    conv0, _ = w["gm0"].convolve(w["psf"])
+    e0 = w["sb_em"].em(w["gm0"].clone(), w["psf"], conv=conv0, sky=w["sky"])
+
+    def tile(s):
+        return StampBatch(s.val.repeat(reps), s.ierr.repeat(reps), s.jac.repeat(reps, 1),
+                          np.full(n, dim), np.full(n, dim), np.arange(n, dtype=np.int64) * npix,
+                          True)
+    big = tile(w["sb"])
+    wt = GMixBatch(w["wt0"].data.repeat(reps, 1), n, w["wt0"].ngauss)
+    a = big.admom(wt)
+    for x, x0 in zip(a, a0):
+        if torch.is_tensor(x):
+            xr = x.reshape((reps, base) + tuple(x.shape[1:]))
+            assert torch.equal(xr[0], x0) and torch.equal(xr[reps - 1], x0)
+    del big, a
+    torch.cuda.empty_cache()
+    big = tile(w["sb_em"])
+    gm = GMixBatch(w["gm0"].data.repeat(reps, 1), n, w["gm0"].ngauss)
+    psf = GMixBatch(w["psf"].data.repeat(reps, 1), n, w["psf"].ngauss)
+    conv, _ = gm.convolve(psf)
+    sky = w["sky"].repeat(reps) if torch.is_tensor(w["sky"]) else w["sky"]
+    e = big.em(gm, psf, conv=conv, sky=sky)
+    for x, x0 in zip(e, e0):
+        if torch.is_tensor(x):
+            xr = x.reshape((reps, base) + tuple(x.shape[1:]))
+            assert torch.equal(xr[0], x0) and torch.equal(xr[reps - 1], x0)
+    assert torch.equal(gm.data.reshape(reps, -1)[reps - 1], gm.data.reshape(reps, -1)[0])
+
+
 def test_c3_full_size(bench):
     """BASELINE configs[2]: 100,000 psf-convolved 'exp' fits in lock step"""
     import ngmix_amd as ngmix

@@ -31,8 +31,13 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
                     "pixpass_wave_kernel<0" in row["Kernel_Name"]:
                 c5acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
         continue
+    team_dir = os.path.basename(d).startswith("pmc_team")
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0].replace("void ngmix::", "")
+        # (the team passes run another workload -- tools/team_probe.py, 20,000
+        # objects x 9 bands: only the team kernel is taken from them)
+        if team_dir != k.startswith("lm_advance_team"):
+            continue
         if "pixpass" in k or "admom" in k or "em_" in k or "lm_" in k:
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 
@@ -80,7 +85,7 @@ if "FETCH_SIZE" in c5acc and "WRITE_SIZE" in c5acc:
                 "pixpass_wave_kernel7<0, false, 8>", c, len(vals), sum(vals) / len(vals)))
 for sub, name in (("bench_stats", "bench"), ("c3_stats", "c3"), ("c4_stats", "c4"),
                   ("c5_stats", "c5"),
-                  ("iter_stats", "iter"), ("lm_stats", "lm")):
+                  ("iter_stats", "iter"), ("lm_stats", "lm"), ("team_stats", "team")):
     f = os.path.join(src, sub, "run_kernel_stats.csv")
     if not os.path.exists(f):
         continue
@@ -94,7 +99,8 @@ for sub, name in (("bench_stats", "bench"), ("c3_stats", "c3"), ("c4_stats", "c4
                     "c4": "python3 bench.py --config C4 --steps 20 --warmup 5",
                     "c5": "python3 bench.py --config C5 --steps 50 --warmup 10",
                     "iter": "python3 tools/bench_iter.py 200000 3",
-                    "lm": "python3 tools/bench_lm.py 100000 0"}[name])
+                    "lm": "python3 tools/bench_lm.py 100000 0",
+                    "team": "python3 tools/lm_advance_share.py 10000"}[name])
     for r in keep[1:]:
         lines.append("%-60s calls %5s avg %12.0f ns" % (
             r[0].split("(")[0].replace("void ngmix::", "")[:60], r[1], float(r[3])))
@@ -102,11 +108,12 @@ for bname in ("bench", "bench_c3", "bench_c4", "bench_c5"):
     bj = os.path.join(src, bname + ".json")
     if os.path.exists(bj):
         shutil.copy(bj, os.path.join(out, "%s_%s.json" % (tag, bname)))
-for logname in ("iter.log", "lm.log"):
+for logname in ("iter.log", "lm.log", "team.log"):
     f = os.path.join(src, logname)
     if os.path.exists(f):
         txt = [l for l in open(f).read().splitlines()
-               if l.startswith(("admom", "em_run", "batched LM", "   mean"))]
+               if l.startswith(("admom", "em_run", "batched LM", "   mean", "exp x", "bdf x",
+                                "coellip-"))]
         lines.append("# %s" % logname)
         lines.extend(txt)
 # ---- instruction-issue figures of the VALU-bound kernels, read by bench.py
@@ -138,7 +145,10 @@ valu = {"source": "profiles/%s_pmc_summary.txt" % tag,
                   "launch with every fit running and the full pass); rocprofv3 --pmc "
                   "passes of tools/run_prof.sh / run_prof_all.sh"}
 for k, cs in sorted(acc.items()):
-    fig = issue_figures(cs, nstamps, busiest=k.startswith("lm_eval"))
+    # (the team form of lm_advance is profiled on tools/team_probe.py: 20,000
+    # fits of 14 parameters per launch)
+    n_k = 20000 if k.startswith("lm_advance_team") else nstamps
+    fig = issue_figures(cs, n_k, busiest=k.startswith(("lm_eval", "lm_advance_team")))
     if fig:
         valu[k] = fig
 fig = issue_figures(c5acc, 200000)
