@@ -14,7 +14,10 @@ tests hammer the same kernels on the benchmark's own full-size workloads:
   * the untracked (hand-counted) and compiler-tracked load paths bit for bit
     on the full C2 and C5 batches, both directions, repeated;
   * order independence under a fresh permutation per repeat (a stamp's result
-    must not depend on its neighbours in the launch or on the launch).
+    must not depend on its neighbours in the launch or on the launch);
+  * the team form of the lmder step (lanes of a fit talking through LDS behind
+    compiler fences): ten complete runs of 20,000 twelve-parameter fits, a
+    permuted run, and the one-thread step, all the same to the bit.
 """
 import numpy as np
 import pytest
@@ -179,6 +182,58 @@ def test_c3_repeated_fits(bench):
     got = fit(perm)
     for a, b in zip(first, got):
         assert np.array_equal(a[perm], b, equal_nan=True)
+
+
+def test_team_step_repeated_fits(bench):
+    """the team form of the lmder step (lm_team.hip: 16 lanes per fit talking
+    through LDS behind compiler fences, four fits per wave each at its own
+    point of the control flow) under load: 20,000 objects x 7 bands (12
+    parameters), ten complete runs the same to the bit, a permuted run the
+    permuted results, and the generic one-thread step the same fits"""
+    from ngmix_amd.batch import GMixBatch
+    from ngmix_amd.lm_batch import LMBatchFitter
+    nobj, nband = 20000, 7
+    ns = nobj * nband
+    sb, _, pars = bench.make_workload(ns, 31, "cuda")
+    rng = np.random.RandomState(5)
+    guess = np.concatenate([pars[::nband, :5], pars[:, 5].reshape(nobj, nband)], axis=1)
+    guess = guess * rng.uniform(0.85, 1.15, size=guess.shape)
+    psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (ns, 1)), "gauss")
+    sobj = np.repeat(np.arange(nobj), nband).astype(np.int32)
+    sband = np.tile(np.arange(nband), nobj).astype(np.int32)
+    fitter = LMBatchFitter("exp")
+
+    def fit(f, sel=None):
+        if sel is None:
+            s, g, p = sb, guess, psf
+        else:
+            sidx = (sel[:, None] * nband + np.arange(nband)[None, :]).reshape(-1)
+            s, g, p = sb.select(sidx), guess[sel], psf.select(sidx)
+            so = np.repeat(np.arange(sel.size), nband).astype(np.int32)
+            sbd = np.tile(np.arange(nband), sel.size).astype(np.int32)
+            r = f.go(s, g, psf=p, stamp_obj=so, stamp_band=sbd)
+            return r["nfev"].copy(), r["pars"].copy(), r["pars_cov"].copy(), r["flags"].copy()
+        r = f.go(s, g, psf=p, stamp_obj=sobj, stamp_band=sband)
+        return r["nfev"].copy(), r["pars"].copy(), r["pars_cov"].copy(), r["flags"].copy()
+
+    from ngmix_amd import _lib
+    _lib.launch_census(reset=True)
+    first = fit(fitter)
+    seen = _lib.launch_census(reset=True)
+    assert any(k.startswith("lm_advance_team_kernel<4, 12>") for k in seen), seen
+    for rep in range(9):
+        got = fit(fitter)
+        for a, b in zip(first, got):
+            assert np.array_equal(a, b, equal_nan=True), "fit %d differs" % (rep + 1)
+    perm = np.random.RandomState(8).permutation(nobj)[:7001]
+    got = fit(fitter, perm)
+    for a, b in zip(first, got):
+        assert np.array_equal(a[perm], b, equal_nan=True)
+    generic = LMBatchFitter("exp")
+    generic.advance_hint = False
+    got = fit(generic)
+    for a, b in zip(first, got):
+        assert np.array_equal(a, b, equal_nan=True)
 
 
 @pytest.mark.parametrize("ngauss", [4, 6])
