@@ -346,6 +346,16 @@ int ngmix_weight_to_ierr_batch(const double *weight, double *ierr, int64_t n,
 int ngmix_count_kept_batch(ngmix_stamp *stamps, int64_t nstamps,
                            const double *ierr, void *stream);
 
+/* The pixel sums of the linear template (psf) flux fit of
+   PSFFluxFitModel.go (ngmix/fitting/results.py:700-770), one pass over the
+   planes: model (total_pix doubles, the stamps' template images laid out as
+   val), mult (nstamps,) or NULL (1): with mm = mult[s] * model,
+   out[s] (nstamps, 4) = { sum(mm I w), sum(mm mm w), sum((mm - I)^2 w),
+   #(ierr > 0) }, w = ierr^2.  First call with the templates' norms: xcorr and
+   msq; second call with flux * norm: chi2. */
+int ngmix_template_sums_batch(const ngmix_batch *batch, const double *model,
+                              const double *mult, double *out, void *stream);
+
 /* per-stamp model fill: pars is (nstamps, npars) row-major; gmix gets
    nstamps*ngauss records.  cm_extra is (nstamps,3) [fracdev,TdByTe,Tfactor]
    for NGMIX_MODEL_CM, else NULL. */

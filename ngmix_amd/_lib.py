@@ -218,6 +218,7 @@ SIGNATURES = {
     # batch forms
     "ngmix_weight_to_ierr_batch": (_i32, [_vp, _vp, _i64, _vp]),
     "ngmix_count_kept_batch": (_i32, [_vp, _i64, _vp, _vp]),
+    "ngmix_template_sums_batch": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "ngmix_fill_model_batch": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp,
                                       _vp, _vp]),
     "ngmix_convolve_fill_batch": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _vp,

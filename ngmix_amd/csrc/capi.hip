@@ -515,6 +515,12 @@ int ngmix_weight_to_ierr_batch(const double *weight, double *ierr, int64_t n,
     return launch_weight_to_ierr(weight, ierr, n, (hipStream_t)stream);
 }
 
+int ngmix_template_sums_batch(const ngmix_batch *batch, const double *model,
+                              const double *mult, double *out, void *stream)
+{
+    return launch_template_sums(batch, model, mult, out, (hipStream_t)stream);
+}
+
 int ngmix_count_kept_batch(ngmix_stamp *stamps, int64_t nstamps,
                            const double *ierr, void *stream)
 {

@@ -30,6 +30,10 @@ int launch_weight_to_ierr(const double *w, double *ierr, int64_t n, hipStream_t 
 int launch_count_kept(ngmix_stamp *stamps, int64_t nstamps, const double *ierr,
                       hipStream_t s);
 
+// template.hip
+int launch_template_sums(const ngmix_batch *b, const double *model, const double *mult,
+                         double *out, hipStream_t s);
+
 // gmixprep.hip
 int launch_fill_model(ngmix_gauss2d *gmix, int64_t nstamps, int ngauss, int model,
                       const double *pars, int npars, const double *cm_extra,

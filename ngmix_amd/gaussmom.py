@@ -73,16 +73,19 @@ class MomBatchResult(object):
     res["T"] is (N,), res["e"] (N, 2), res["sums_cov"] (N, nm, nm): every key of
     GaussMom.go's dict but the flag strings (moments.make_mom_result_batch, one
     vectorised pass); by position, res[i] is exactly the dict GaussMom.go returns
-    for stamp i (built on request).  len() and iteration are over the stamps.
+    for stamp i (built on request from the kernel's records, which come down
+    from the device when the first one is asked for).  len() and iteration are
+    over the stamps.
     """
 
-    def __init__(self, arrays, records, area):
+    def __init__(self, arrays, records, area, n=None):
         self._arrays = arrays
-        self._records = records
+        self._records = records         # a record array, or a callable that fetches it
         self._area = area
+        self._n = n if n is not None else records.size
 
     def __len__(self):
-        return self._records.size
+        return self._n
 
     def keys(self):
         return self._arrays.keys()
@@ -98,6 +101,8 @@ class MomBatchResult(object):
             i += len(self)
         if not 0 <= i < len(self):
             raise IndexError(key)
+        if callable(self._records):
+            self._records = self._records()
         r = get_weighted_moments_stats(self._records[i])
         if r["flags"] == 0:
             _remove_area(r, self._area[i])
@@ -109,9 +114,11 @@ class MomBatchResult(object):
 
 class GaussMomBatch(object):
     """
-    GaussMom over a StampBatch: one weighted-sums launch for all stamps and
-    one vectorised pass of make_mom_result's statistics.  go() returns a
-    MomBatchResult: arrays by key, GaussMom.go's dict by stamp index.
+    GaussMom over a StampBatch: one weighted-sums launch for all stamps, the
+    statistics of make_mom_result for all of them ON THE DEVICE (moments.
+    make_mom_result_batch on the records where the kernel left them) and ONE
+    download of every array.  go() returns a MomBatchResult: arrays by key,
+    GaussMom.go's dict by stamp index.
     """
 
     def __init__(self, fwhm, with_higher_order=False):
@@ -120,8 +127,9 @@ class GaussMomBatch(object):
         self.weight = _make_weight(fwhm)
 
     def go(self, stamps):
-        from .batch import GMixBatch, records_to_numpy
+        from .batch import GMixBatch
         from . import _lib
+        import torch
         n = stamps.n
         nmom = 17 if self.with_higher_order else 6
         wt = np.tile(self.weight.get_data(), (n, 1))
@@ -129,25 +137,52 @@ class GaussMomBatch(object):
         wtb.set_norms()
         maxrad = np.full(n, 100.0 * np.sqrt(self.weight.get_T() / 2.0))
         res, status = stamps.weighted_sums(wtb, maxrad, nmom=nmom)
-        # the records through pinned memory (PyTorch's caching host allocator):
-        # a pageable .cpu() of 45 MB took ten times the kernel
-        import torch
-        staged = torch.empty(res.shape, dtype=res.dtype, pin_memory=True)
-        staged.copy_(res)
-        rec = staged.numpy().reshape(-1).view(_lib.moments_result_dtype(nmom))
-        area = stamps.jac[:, 6].abs().cpu().numpy()
-        arrays = moments.make_mom_result_batch(rec["sums"], rec["sums_cov"], rec["wsum"])
-        arrays["npix"] = rec["npix"].copy()
-        arrays["wsum"] = rec["wsum"].copy()
+        dtype = _lib.moments_result_dtype(nmom)
+        off = {k: v[1] // 8 for k, v in dtype.fields.items()}
+        d_sums = res[:, off["sums"]:off["sums"] + nmom]
+        d_cov = res[:, off["sums_cov"]:off["sums_cov"] + nmom * nmom].reshape(n, nmom, nmom)
+        d_wsum = res[:, off["wsum"]]
+        d_npix = res.view(torch.int32)[:, 1]
+        d_area = stamps.jac[:, 6].abs()
+        arrays = moments.make_mom_result_batch(d_sums, d_cov, d_wsum)
+        arrays["npix"] = d_npix
+        arrays["wsum"] = d_wsum
         # the record's own flags (the kernel's) are 0 in the reference's record too;
         # the pixel area out of the flux-like quantities of the successful ones
         # (gaussmom.py:62-74)
         good = arrays["flags"] == 0
-        fac = np.where(good, 1.0 / area, 1.0)
+        fac = torch.where(good, 1.0 / d_area, torch.ones_like(d_area))
         for key in ("flux", "flux_err", "sums_norm", "wsum"):
             arrays[key] = arrays[key] * fac
-        arrays["pars"][:, 5] *= fac
+        pars = arrays["pars"].clone()
+        pars[:, 5] *= fac
+        arrays["pars"] = pars
         arrays["sums"] = arrays["sums"] * fac[:, None]
         arrays["sums_err"] = arrays["sums_err"] * fac[:, None]
-        arrays["sums_cov"] = arrays["sums_cov"] * (fac ** 2)[:, None, None]
-        return MomBatchResult(arrays, rec, area)
+        arrays["sums_cov"] = arrays["sums_cov"] * (fac * fac)[:, None, None]
+        arrays["_area"] = d_area
+        # every array a contiguous segment of ONE flat float64 buffer, in its own
+        # (N, ...) layout: one download through pinned memory (a pageable copy
+        # of this size takes ten times the kernel), the host arrays views of it
+        ints = ("flags", "flux_flags", "T_flags", "npix")
+        layout, total = [], 0
+        for key, t in arrays.items():
+            layout.append((key, tuple(t.shape[1:]), total, t.numel()))
+            total += t.numel()
+        packed = torch.empty(total, dtype=torch.float64, device=res.device)
+        for (key, shape, o, m), t in zip(layout, arrays.values()):
+            packed[o:o + m] = t.reshape(-1)
+        staged = torch.empty(total, dtype=torch.float64, pin_memory=True)
+        staged.copy_(packed)
+        host = staged.numpy()
+        out = {}
+        for key, shape, o, m in layout:
+            a = host[o:o + m].reshape((n,) + shape)
+            out[key] = a.astype(np.int64) if key in ints else a
+        area = out.pop("_area")
+
+        def records():
+            staged_r = torch.empty(res.shape, dtype=res.dtype, pin_memory=True)
+            staged_r.copy_(res)
+            return staged_r.numpy().reshape(-1).view(dtype)
+        return MomBatchResult(out, records, area, n=n)

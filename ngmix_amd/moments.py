@@ -245,16 +245,106 @@ def regularize_mom_shapes(res, fwhm_reg):
     return out
 
 
-def _ratio_error_arrays(a, b, var_a, var_b, cov_ab, where):
+class _NumpyOps(object):
+    """the array operations make_mom_result_batch is written in, for numpy"""
+    nan = np.nan
+
+    @staticmethod
+    def f64(x):
+        return np.asarray(x, dtype="f8")
+
+    where = staticmethod(np.where)
+    sqrt = staticmethod(np.sqrt)
+    isfinite = staticmethod(np.isfinite)
+
+    @staticmethod
+    def clip_lo(x):
+        return np.clip(x, 0.0, np.inf)
+
+    @staticmethod
+    def full(shape, val, like):
+        return np.full(shape, val)
+
+    @staticmethod
+    def zeros_int(n, like):
+        return np.zeros(n, dtype=np.int64)
+
+    @staticmethod
+    def stack(cols, axis):
+        return np.stack(cols, axis=axis)
+
+    @staticmethod
+    def rows(x):
+        """x (N, k) -> (k, N) contiguous: each column a contiguous vector"""
+        return np.ascontiguousarray(x.T)
+
+    @staticmethod
+    def diagonal(x):
+        return np.diagonal(x, axis1=1, axis2=2)
+
+    @staticmethod
+    def all0(x):
+        return np.all(x, axis=0)
+
+    @staticmethod
+    def quiet():
+        return np.errstate(divide="ignore", invalid="ignore")
+
+
+class _TorchOps(object):
+    """the same operations on torch tensors (the device of the inputs)"""
+    nan = float("nan")
+
+    def __init__(self):
+        import contextlib
+        import torch
+        self.t = torch
+        self.where = torch.where
+        self.sqrt = torch.sqrt
+        self.isfinite = torch.isfinite
+        self._null = contextlib.nullcontext
+
+    def f64(self, x):
+        return x.to(self.t.float64)
+
+    def clip_lo(self, x):
+        # (numpy's clip passes nan through; so does clamp)
+        return self.t.clamp(x, min=0.0)
+
+    def full(self, shape, val, like):
+        return self.t.full(shape if isinstance(shape, tuple) else (shape,), val,
+                           dtype=self.t.float64, device=like.device)
+
+    def zeros_int(self, n, like):
+        return self.t.zeros(n, dtype=self.t.int64, device=like.device)
+
+    def stack(self, cols, axis):
+        return self.t.stack(cols, dim=axis)
+
+    def rows(self, x):
+        return x.T.contiguous()
+
+    def diagonal(self, x):
+        return self.t.diagonal(x, dim1=1, dim2=2)
+
+    def all0(self, x):
+        return x.all(dim=0)
+
+    def quiet(self):
+        return self._null()
+
+
+def _ratio_error_arrays(a, b, var_a, var_b, cov_ab, where, B=_NumpyOps):
     """get_ratio_error over arrays, evaluated only where `where` (elsewhere nan);
     util.get_ratio_var's expression (equal to the scalar routine to the last
     bit or two: numpy squares arrays by multiplying and scalars through pow)"""
     # evaluated everywhere (masked gathers cost more than the arithmetic), kept
     # where asked: the elementwise values do not depend on their neighbours
-    with np.errstate(divide="ignore", invalid="ignore"):
-        var = (a / b) ** 2 * (var_a / a ** 2 + var_b / b ** 2 - 2 * cov_ab / (a * b))
-        err = np.sqrt(np.clip(var, 0.0, np.inf))
-    return np.where(where, err, np.nan)
+    with B.quiet():
+        ratio = a / b
+        var = (ratio * ratio) * (var_a / (a * a) + var_b / (b * b) - 2 * cov_ab / (a * b))
+        err = B.sqrt(B.clip_lo(var))
+    return B.where(where, err, B.full(err.shape[0], B.nan, err))
 
 
 def make_mom_result_batch(sums, sums_cov, sums_norm=None):
@@ -267,91 +357,105 @@ def make_mom_result_batch(sums, sums_cov, sums_norm=None):
     the values make_mom_result(sums[i], sums_cov[i], sums_norm[i]) gives (flags and
     ratios identical, the propagated errors to the last bit or two; the flag
     strings are left to the per-object view).
+
+    numpy arrays in, numpy arrays out; torch tensors in (GaussMomBatch: the
+    records still on the device), tensors on the same device out -- one code,
+    IEEE operations only: flags and ratios agree to the bit, what holds a square
+    root to an ulp.
     """
-    sums = np.asarray(sums, dtype="f8")
-    sums_cov = np.asarray(sums_cov, dtype="f8")
+    if isinstance(sums, np.ndarray) or not hasattr(sums, "device"):
+        B = _NumpyOps
+        sums = np.asarray(sums, dtype="f8")
+        sums_cov = np.asarray(sums_cov, dtype="f8")
+        if sums_norm is not None:
+            sums_norm = np.asarray(sums_norm, dtype="f8")
+    else:
+        B = _TorchOps()
     n, nm = sums.shape
-    if nm not in (6, 17) or sums_cov.shape != (n, nm, nm):
+    if nm not in (6, 17) or tuple(sums_cov.shape) != (n, nm, nm):
         raise ValueError("sums must be (N, 6 | 17) and sums_cov (N, nm, nm)")
     iv, iu, i1, i2, it, iflux = 0, 1, 2, 3, 4, 5
-    nan = np.full(n, np.nan)
+    where, sqrt = B.where, B.sqrt
+    nan = B.full(n, B.nan, sums)
+    one = B.full(n, 1.0, sums)
     # The columns the statistics read, each as a contiguous (N,) vector (the
     # inputs are usually strided views of a record array: arithmetic on 448-byte
     # strides costs ten times the arithmetic): sums by moment, and of the
     # covariance its diagonal and the columns of MF and MT.
-    sT = np.ascontiguousarray(sums.T)
-    diagT = np.ascontiguousarray(np.diagonal(sums_cov, axis1=1, axis2=2).T)
-    cov_fT = np.ascontiguousarray(sums_cov[:, :, iflux].T)
-    cov_tT = np.ascontiguousarray(sums_cov[:, :, it].T)
-    flux = sT[iflux].copy()
+    sT = B.rows(sums)
+    diagT = B.rows(B.diagonal(sums_cov))
+    cov_fT = B.rows(sums_cov[:, :, iflux])
+    cov_tT = B.rows(sums_cov[:, :, it])
+    flux = sT[iflux] + 0.0
     var_f = diagT[iflux]
     var_t = diagT[it]
-    flags = np.zeros(n, dtype=np.int64)
-    flux_flags = np.zeros(n, dtype=np.int64)
-    T_flags = np.zeros(n, dtype=np.int64)
+    flags = B.zeros_int(n, sums)
+    flux_flags = B.zeros_int(n, sums)
+    T_flags = B.zeros_int(n, sums)
 
     fpos = var_f > 0
-    with np.errstate(invalid="ignore", divide="ignore"):
-        flux_err = np.where(fpos, np.sqrt(np.where(fpos, var_f, 1.0)), np.nan)
-        s2n = np.where(fpos, flux / flux_err, np.nan)
+    with B.quiet():
+        flux_err = where(fpos, sqrt(where(fpos, var_f, one)), nan)
+        s2n = where(fpos, flux / flux_err, nan)
     flux_flags[~fpos] |= ngflags.NONPOS_VAR
 
     both = fpos & (var_t > 0)
     t_ok = both & (flux > 0)
-    with np.errstate(invalid="ignore", divide="ignore"):
-        T = np.where(t_ok, sT[it] / np.where(t_ok, flux, 1.0), np.nan)
-    T_err = _ratio_error_arrays(sT[it], flux, var_t, var_f, cov_fT[it], t_ok)
+    with B.quiet():
+        T = where(t_ok, sT[it] / where(t_ok, flux, one), nan)
+    T_err = _ratio_error_arrays(sT[it], flux, var_t, var_f, cov_fT[it], t_ok, B)
     T_flags[both & ~(flux > 0)] |= ngflags.NONPOS_FLUX
     T_flags[~both] |= ngflags.NONPOS_VAR
 
-    dpos = np.all(diagT > 0, axis=0)
+    dpos = B.all0(diagT > 0)
     # (N, nm): sqrt(diag) where every diagonal entry is positive, else nan
-    sums_err = np.where(dpos[:, None], np.sqrt(np.where(diagT > 0, diagT, 1.0)).T, np.nan)
+    with B.quiet():
+        sq = sqrt(where(diagT > 0, diagT, B.full(tuple(diagT.shape), 1.0, sums))).T
+    sums_err = where(dpos[:, None], sq, B.full(tuple(sq.shape), B.nan, sums))
     flags[~dpos] |= ngflags.NONPOS_VAR
 
     ok = flags == 0
-    with np.errstate(invalid="ignore"):
+    with B.quiet():
         shape_ok = ok & (flux > 0) & (T > 0)
     flags[ok & ~(flux > 0)] |= ngflags.NONPOS_FLUX
-    with np.errstate(invalid="ignore"):
+    with B.quiet():
         flags[ok & (flux > 0) & ~(T > 0)] |= ngflags.NONPOS_SIZE
-    with np.errstate(invalid="ignore", divide="ignore"):
-        mt = np.where(shape_ok, sT[it], 1.0)
-        e1 = np.where(shape_ok, sT[i1] / mt, np.nan)
-        e2 = np.where(shape_ok, sT[i2] / mt, np.nan)
-    pars = np.full((n, 6), np.nan)
-    pars[shape_ok] = np.stack([sT[iv], sT[iu], e1, e2, T, flux], axis=1)[shape_ok]
-    e1_err = _ratio_error_arrays(sT[i1], sT[it], diagT[i1], var_t, cov_tT[i1], shape_ok)
-    e2_err = _ratio_error_arrays(sT[i2], sT[it], diagT[i2], var_t, cov_tT[i2], shape_ok)
-    err_ok = shape_ok & np.isfinite(e1_err) & np.isfinite(e2_err)
+    with B.quiet():
+        mt = where(shape_ok, sT[it], one)
+        e1 = where(shape_ok, sT[i1] / mt, nan)
+        e2 = where(shape_ok, sT[i2] / mt, nan)
+    pars = where(shape_ok[:, None], B.stack([sT[iv], sT[iu], e1, e2, T, flux], 1),
+                 B.full((n, 6), B.nan, sums))
+    e1_err = _ratio_error_arrays(sT[i1], sT[it], diagT[i1], var_t, cov_tT[i1], shape_ok, B)
+    e2_err = _ratio_error_arrays(sT[i2], sT[it], diagT[i2], var_t, cov_tT[i2], shape_ok, B)
+    err_ok = shape_ok & B.isfinite(e1_err) & B.isfinite(e2_err)
     flags[shape_ok & ~err_ok] |= ngflags.NONPOS_SHAPE_VAR
-    e_err = np.full((n, 2), np.nan)
-    e_err[err_ok, 0], e_err[err_ok, 1] = e1_err[err_ok], e2_err[err_ok]
-    e_cov = np.full((n, 2, 2), np.nan)
-    e_cov[:, 0, 1] = e_cov[:, 1, 0] = 0.0
-    e_cov[err_ok, 0, 0] = e1_err[err_ok] ** 2
-    e_cov[err_ok, 1, 1] = e2_err[err_ok] ** 2
+    e1e = where(err_ok, e1_err, nan)
+    e2e = where(err_ok, e2_err, nan)
+    e_err = B.stack([e1e, e2e], 1)
+    zero = B.full(n, 0.0, sums)
     # (np.diag(nan2) of the scalar routine: nan on the diagonal, zeros off it)
+    e_cov = B.stack([B.stack([e1e * e1e, zero], 1), B.stack([zero, e2e * e2e], 1)], 1)
 
     res = {
         "flags": flags, "flux_flags": flux_flags, "T_flags": T_flags,
         "flux": flux, "flux_err": flux_err, "s2n": s2n, "T": T, "T_err": T_err,
-        "e1": e1, "e2": e2, "e": np.stack([e1, e2], axis=1), "e_err": e_err, "e_cov": e_cov,
+        "e1": e1, "e2": e2, "e": B.stack([e1, e2], 1), "e_err": e_err, "e_cov": e_cov,
         "pars": pars, "sums": sums, "sums_cov": sums_cov,
-        "sums_norm": np.asarray(sums_norm, dtype="f8") if sums_norm is not None else nan.copy(),
+        "sums_norm": B.f64(sums_norm) if sums_norm is not None else nan + 0.0,
         "sums_err": sums_err,
     }
-    with np.errstate(invalid="ignore"):
-        fsum_err = np.sqrt(var_f)
+    with B.quiet():
+        fsum_err = sqrt(var_f)
     fgood = flux > 0
     for name, ind in MOMENTS_NAME_MAP.items():
         if ind > nm - 1:
             continue
         if name in ("MF", "M00"):
-            res[name], res[name + "_err"] = flux.copy(), fsum_err
+            res[name], res[name + "_err"] = flux + 0.0, fsum_err
             continue
-        with np.errstate(invalid="ignore", divide="ignore"):
-            res[name] = np.where(fgood, sT[ind] / np.where(fgood, flux, 1.0), np.nan)
+        with B.quiet():
+            res[name] = where(fgood, sT[ind] / where(fgood, flux, one), nan)
         res[name + "_err"] = _ratio_error_arrays(sT[ind], flux, diagT[ind], var_f,
-                                                 cov_fT[ind], fgood)
+                                                 cov_fT[ind], fgood, B)
     return res

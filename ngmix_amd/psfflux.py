@@ -118,8 +118,9 @@ class PSFFluxBatch(object):
     """
     PSFFluxFitter over a device-resident batch: one exact render of every
     stamp's (flux-normalised) psf mixture, then the zero-lag cross-correlation
-    sums of PSFFluxFitModel.go (results.py:700-770) as segmented reductions on
-    the device.  Objects may own several stamps (epochs), as an ObsList does.
+    sums of PSFFluxFitModel.go (results.py:700-770) by a fused kernel (one
+    pass over the model, image and ierr planes per call: csrc/template.hip).
+    Objects may own several stamps (epochs), as an ObsList does.
 
         res = PSFFluxBatch().go(stamps, psf_gmixes, stamp_obj=None)
 
@@ -188,32 +189,46 @@ class PSFFluxBatch(object):
                 raise ValueError("stamp_obj must be (nstamps,) and non-decreasing")
         nobj = int(sobj.max()) + 1 if ns else 0
         d_sobj = torch.from_numpy(sobj).to(dev)
-        lengths = torch.from_numpy(stamps.npix).to(dev)
-        if norm is not None:
-            model = model * torch.repeat_interleave(norm, lengths)
-        wt = stamps.ierr * stamps.ierr
+        # Two launches of one fused kernel (csrc/template.hip: one pass over the
+        # model, image and ierr planes each) instead of a dozen torch passes
+        # over them: the first with the templates' norms gives sum(m I w) and
+        # sum(m m w) per stamp -- the flux is their ratio over the object's
+        # stamps --, the second with flux * norm the chi2 of the scaled template.
+        import ctypes
+        from . import _lib
+        from .batch import _dptr, _stream, _on_device
+        L = _lib.lib()
+        b = stamps._batch(1)
+        model = model.contiguous()
+
+        def sums_with(mult):
+            out = torch.empty((ns, 4), dtype=torch.float64, device=dev)
+            with _on_device(dev):
+                _lib.check(L.ngmix_template_sums_batch(
+                    ctypes.byref(b), _dptr(model), _dptr(mult) if mult is not None else None,
+                    _dptr(out), _stream()), "ngmix_template_sums_batch")
+            return out
 
         def per_object(x):
-            s = torch.segment_reduce(x, "sum", lengths=lengths)
             out = torch.zeros(nobj, dtype=torch.float64, device=dev)
-            return out.index_add_(0, d_sobj, s)
+            return out.index_add_(0, d_sobj, x)
 
-        xcorr = per_object(model * stamps.val * wt)
-        msq = per_object(model * model * wt)
+        first = sums_with(norm)
+        xcorr = per_object(first[:, 0])
+        msq = per_object(first[:, 1])
         zero = msq == 0
         flux = torch.where(zero, torch.full_like(msq, PDEF),
                            xcorr / torch.where(zero, torch.ones_like(msq), msq))
         # second pass: chi2 of the scaled template (linear in the flux)
-        fl = torch.repeat_interleave(flux[d_sobj], lengths)
-        chi2 = per_object((fl * model - stamps.val) ** 2 * wt)
+        fl = flux[d_sobj] if norm is None else flux[d_sobj] * norm
+        chi2 = per_object(sums_with(fl.contiguous())[:, 2])
         chi2 = torch.where(zero, torch.zeros_like(chi2), chi2)
+        positive = first[:, 3].cpu().numpy()
 
         xcorr, msq, flux, chi2 = (t.cpu().numpy() for t in (xcorr, msq, flux, chi2))
         kept = np.zeros(nobj, dtype=np.int64)
         np.add.at(kept, sobj, stamps.npix_kept.astype(np.int64))
         eff = np.zeros(nobj, dtype=np.int64)
-        positive = torch.segment_reduce((stamps.ierr > 0).to(torch.float64), "sum",
-                                        lengths=lengths).cpu().numpy()
         np.add.at(eff, sobj, positive.astype(np.int64))
         dof = (eff - 1).astype("f8")
         flags = np.zeros(nobj, dtype=np.int64)

@@ -569,3 +569,47 @@ def test_small_host_helpers_vs_reference(golden):
         mb.append([gm])
     assert len(mb) == 1 and len(mb[0]) == 1
     assert ngmix.fitting.PSFFluxFitter is ngmix.PSFFluxFitter
+
+
+@pytest.mark.parametrize("nm", [6, 17])
+def test_make_mom_result_batch_on_torch_tensors_is_the_numpy_pass(nm):
+    """moments.make_mom_result_batch is written in operations numpy and torch
+    share: handed tensors (GaussMomBatch: the kernel's records still on the
+    device) it returns tensors whose every value is the numpy pass's -- flags
+    and ratios bit for bit, whatever holds a square root to an ulp -- every
+    flag path included"""
+    import torch
+    from ngmix_amd import moments
+    rng = np.random.RandomState(40 + nm)
+    N = 500
+    sums = rng.normal(size=(N, nm))
+    sums[:, 5] = rng.normal(1.0, 1.0, size=N)
+    sums[:, 4] = rng.normal(0.5, 0.6, size=N)
+    A = rng.normal(size=(N, nm, nm))
+    cov = np.einsum("nij,nkj->nik", A, A) * 0.01
+    cov[::7, 5, 5] = -1.0
+    cov[1::11, 4, 4] = 0.0
+    cov[2::13, 2, 2] = -0.5
+    norm = rng.uniform(1, 2, size=N)
+    a = moments.make_mom_result_batch(sums, cov, norm)
+    b = moments.make_mom_result_batch(torch.from_numpy(sums), torch.from_numpy(cov),
+                                      torch.from_numpy(norm))
+    assert set(a) == set(b)
+    assert len(np.unique(a["flags"])) >= 3
+    for k, v in a.items():
+        t = b[k]
+        assert isinstance(t, torch.Tensor), k
+        got = t.numpy()
+        assert got.shape == v.shape, k
+        if k.endswith("_err") or k in ("s2n", "e_cov"):
+            # (a square root in them: torch's and numpy's differ by an ulp at most)
+            np.testing.assert_allclose(got, v, rtol=5e-16, atol=0, equal_nan=True, err_msg=k)
+        else:
+            assert np.array_equal(got.astype(v.dtype), v, equal_nan=True), k
+    # strided views of a record matrix, as GaussMomBatch hands them over
+    rec = torch.from_numpy(np.concatenate([norm[:, None], sums, cov.reshape(N, -1)], axis=1))
+    c = moments.make_mom_result_batch(rec[:, 1:1 + nm], rec[:, 1 + nm:].reshape(N, nm, nm),
+                                      rec[:, 0])
+    for k in ("flags", "T", "T_err", "e_err", "pars", "sums_err", "MT_err"):
+        np.testing.assert_allclose(c[k].numpy().astype("f8"), np.asarray(a[k], dtype="f8"),
+                                   rtol=5e-16, atol=0, equal_nan=True, err_msg=k)
