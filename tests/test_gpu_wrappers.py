@@ -378,3 +378,48 @@ def test_noise_cov_batch_forced_central_differences(golden):
     ref = g["nc_fd_images_e0"]
     got = D.cpu().numpy().reshape(ref.shape)
     np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-11 * np.abs(ref).max())
+
+
+def test_template_sums_kernel_vs_numpy():
+    """ngmix_template_sums_batch (csrc/template.hip) on a ragged batch with
+    zero and negative weights, with and without multipliers, against the sums
+    written out in numpy (results.py:700-770's expressions); run to run the
+    same to the bit"""
+    import ctypes
+    import torch
+    from ngmix_amd import _lib
+    from ngmix_amd.batch import StampBatch, _dptr, _stream
+    rng = np.random.RandomState(12)
+    shapes = [(25, 25), (33, 31), (48, 48), (7, 64), (1, 1), (40, 17)]
+    imgs = [rng.normal(size=s) for s in shapes]
+    wts = [rng.uniform(0.5, 2.0, size=s) for s in shapes]
+    wts[1][3:6, 4:9] = 0.0
+    wts[3][2, :] = -1.0
+    jacs = [np.array([(s[0] - 1) / 2, (s[1] - 1) / 2, 0.263, 0.0, 0.0, 0.263, 0.263 ** 2, 0.263])
+            for s in shapes]
+    sb = StampBatch.from_arrays(imgs, wts, jacs, [True] * len(shapes))
+    models = [rng.uniform(0.0, 1.0, size=s) for s in shapes]
+    d_model = torch.from_numpy(np.concatenate([m.ravel() for m in models])).cuda()
+    mult = rng.uniform(0.5, 3.0, size=len(shapes))
+    d_mult = torch.from_numpy(mult).cuda()
+    L = _lib.lib()
+    b = sb._batch(1)
+
+    def run(dm):
+        out = torch.empty((len(shapes), 4), dtype=torch.float64, device="cuda")
+        _lib.check(L.ngmix_template_sums_batch(ctypes.byref(b), _dptr(d_model), _dptr(dm)
+                                               if dm is not None else None, _dptr(out),
+                                               _stream()), "template_sums")
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+    for dm, a in ((None, np.ones(len(shapes))), (d_mult, mult)):
+        got = run(dm)
+        assert np.array_equal(got, run(dm))
+        for i, s in enumerate(shapes):
+            ie = np.sqrt(np.clip(wts[i], 0.0, None))
+            w = ie * ie
+            mm = models[i] * a[i]
+            ref = [np.sum(mm * imgs[i] * w), np.sum(mm * mm * w),
+                   np.sum((mm - imgs[i]) ** 2 * w), float(np.sum(ie > 0))]
+            np.testing.assert_allclose(got[i], ref, rtol=1e-12, atol=1e-13)
+            assert got[i, 3] == ref[3]
