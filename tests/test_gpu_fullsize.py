@@ -15,6 +15,9 @@ batch.
       960,000 stamps: pixel indices beyond 2^31, 17.7 GB planes
   C3  100,000 LM fits: all converge, pulls, order independence, a sample
       against the per-object Fitter (scipy MINPACK driving the exact kernels)
+  C3+ 30,000 objects x 6 bands (11 parameters, the team form of the lmder
+      step): convergence, pulls, order independence, the one-thread form, a
+      sample against the per-object Fitter on MultiBandObsLists
   C4  125,000 32x32 stamps (the per-GPU share of 1M / 8): admom and em_run,
       order independence, a sample against the oracle
   C5  20,000 objects x 10 epochs of 64x64 x 16 gaussians: per-object sums ==
@@ -371,6 +374,102 @@ def test_c3_full_size(bench):
         np.testing.assert_allclose(res["pars_err"][i], one["pars_err"], rtol=1e-3)
         np.testing.assert_allclose(res["lnprob"][i], one["lnprob"], rtol=1e-6)
     assert same_nfev >= len(idx) - 1
+
+
+def test_multiband_fits_full_size(bench):
+    """joint fits over bands at scale -- 30,000 objects x 6 bands of 48x48
+    stamps (11 parameters: the lmder step runs as the team form, lm_team.hip):
+    every fit converges, the truth is recovered with unit-width pulls in all
+    eleven parameters, a permuted subset reproduces the fits to the bit, the
+    one-thread form of the step gives the same fits to the bit, and a sample
+    equals the per-object Fitter on the MultiBandObsList (scipy's MINPACK over
+    the exact kernels)"""
+    import torch
+    import ngmix_amd as ngmix
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    from ngmix_amd.lm_batch import LMBatchFitter
+    nobj, nband, dim = 30000, 6, 48
+    ns = nobj * nband
+    rng = np.random.RandomState(61)
+    S = bench.SCALE
+    truth = np.zeros((nobj, 5 + nband))
+    truth[:, 0:2] = rng.uniform(-0.5, 0.5, size=(nobj, 2)) * S
+    truth[:, 2:4] = np.clip(rng.normal(scale=0.1, size=(nobj, 2)), -0.5, 0.5)
+    truth[:, 4] = rng.uniform(0.3, 1.5, size=nobj)
+    truth[:, 5:] = rng.uniform(50.0, 500.0, size=(nobj, 1)) * rng.uniform(0.5, 1.5,
+                                                                         size=(nobj, nband))
+    sobj = np.repeat(np.arange(nobj), nband).astype(np.int32)
+    sband = np.tile(np.arange(nband), nobj).astype(np.int32)
+    spars = np.concatenate([truth[sobj, :5], truth[sobj, 5 + sband][:, None]], axis=1)
+    gm0, _ = GMixBatch.from_pars(spars, "exp")
+    psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (ns, 1)), "gauss")
+    gm, _ = gm0.convolve(psf)
+    cen = (dim - 1) / 2.0
+    jac = np.array([cen, cen, S, 0.0, 0.0, S, S * S, S])
+    d_jac = torch.from_numpy(np.tile(jac, (ns, 1))).cuda()
+    shape = np.full(ns, dim)
+    off = np.arange(ns, dtype=np.int64) * dim * dim
+    model, _ = StampBatch(None, None, d_jac, shape, shape, off, True).render(gm, fast_exp=True)
+    sigma = 0.5
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    val = model + sigma * torch.randn(model.shape, generator=gen, device="cuda",
+                                      dtype=torch.float64)
+    sb = StampBatch(val, torch.full_like(val, 1.0 / sigma), d_jac, shape, shape, off, True)
+    guess = truth * rng.uniform(0.9, 1.1, size=truth.shape)
+    guess[:, 0:2] = truth[:, 0:2] + rng.uniform(-0.05, 0.05, size=(nobj, 2))
+    guess[:, 2:4] = truth[:, 2:4] + rng.uniform(-0.03, 0.03, size=(nobj, 2))
+    kw = dict(psf=psf, stamp_obj=sobj, stamp_band=sband)
+    box = {}
+    seen = _census(lambda: box.update(res=LMBatchFitter("exp").go(sb, guess, **kw)))
+    res = box["res"]
+    rounds = seen.get("lm_eval_kernel<true, true>", 0)
+    assert 4 <= rounds <= 12 and seen.get("lm_advance_team_kernel<4, 12>", 0) == rounds, seen
+    assert not any(k.startswith("lm_advance_kernel<") for k in seen), seen
+    assert np.all(res["flags"] == 0)
+    assert np.all(res["npix"] == nband * dim * dim)
+    pull = (res["pars"] - truth) / res["pars_err"]
+    assert np.all(np.abs(pull) < 7.0)
+    assert np.all(np.abs(pull.std(axis=0) - 1.0) < 0.06), pull.std(axis=0)
+    assert np.all(np.abs(pull.mean(axis=0)) < 0.06), pull.mean(axis=0)
+    assert abs(res["chi2per"].mean() - 1.0) < 0.01
+    # order independence, and the one-thread form of the step
+    sub = np.random.RandomState(8).choice(nobj, size=3000, replace=False)
+    sidx = (sub[:, None] * nband + np.arange(nband)[None, :]).reshape(-1)
+    so = np.repeat(np.arange(sub.size), nband).astype(np.int32)
+    sbd = np.tile(np.arange(nband), sub.size).astype(np.int32)
+    r2 = LMBatchFitter("exp").go(sb.select(sidx), guess[sub], psf=psf.select(sidx),
+                                 stamp_obj=so, stamp_band=sbd)
+    generic = LMBatchFitter("exp")
+    generic.advance_hint = False
+    r3 = generic.go(sb.select(sidx), guess[sub], psf=psf.select(sidx), stamp_obj=so,
+                    stamp_band=sbd)
+    for key in ("nfev", "njev", "ier", "flags", "pars", "pars_cov", "lnprob", "s2n"):
+        assert np.array_equal(r2[key], res[key][sub], equal_nan=True), key
+        assert np.array_equal(r3[key], r2[key], equal_nan=True), key
+    # a sample against the per-object Fitter on the MultiBandObsList
+    jobj = ngmix.Jacobian(row=jac[0], col=jac[1], dvdrow=jac[2], dvdcol=jac[3],
+                          dudrow=jac[4], dudcol=jac[5])
+    pgm = ngmix.GMixModel([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], "gauss")
+    h_val = sb.val.reshape(ns, dim, dim)
+    same_nfev = 0
+    sample = [0, nobj - 1] + list(sub[:4])
+    for i in sample:
+        mb = ngmix.MultiBandObsList()
+        for b in range(nband):
+            ol = ngmix.ObsList()
+            pobs = ngmix.Observation(np.zeros((5, 5)), jacobian=jobj, gmix=pgm)
+            ol.append(ngmix.Observation(h_val[i * nband + b].cpu().numpy(),
+                                        weight=np.full((dim, dim), 1.0 / sigma ** 2),
+                                        jacobian=jobj, psf=pobs))
+            mb.append(ol)
+        one = ngmix.fitting.Fitter(model="exp", batched=False).go(obs=mb, guess=guess[i])
+        assert one["flags"] == 0 and one["ier"] == res["ier"][i]
+        same_nfev += int(one["nfev"] == res["nfev"][i])
+        assert np.all(np.abs(res["pars"][i] - one["pars"]) <= 1e-4 * one["pars_err"])
+        np.testing.assert_allclose(res["pars_err"][i], one["pars_err"], rtol=1e-3)
+        np.testing.assert_allclose(res["lnprob"][i], one["lnprob"], rtol=1e-6)
+    assert same_nfev >= len(sample) - 1
 
 
 def _conv_rec(row, dtype):
