@@ -81,10 +81,11 @@ def _multiband(nobj, nband, model, rng):
     return sb, psf, g2, sobj, sband
 
 
-@pytest.mark.parametrize("nband, lazy, teams", [(6, True, 4), (7, False, 2), (9, True, 1)])
+@pytest.mark.parametrize("nband, lazy, teams", [(4, True, 4), (5, False, 4), (6, True, 4),
+                                                (7, False, 2), (9, True, 1)])
 def test_team_step_equals_generic_step_multiband_lmder(nband, lazy, teams, monkeypatch):
-    """'exp' over 6 / 7 / 9 bands: 11 / 12 / 14 parameters, lmder (lazy and
-    eager jacobians)"""
+    """'exp' over 4 / 5 / 6 / 7 / 9 bands: 9 / 10 / 11 / 12 / 14 parameters (the
+    kernel's builds for 10, 12 and 14), lmder (lazy and eager jacobians)"""
     monkeypatch.setenv("NGMIX_LM_TEAMS", str(teams))
     rng = np.random.RandomState(100 + nband)
     nobj = 37
