@@ -533,8 +533,11 @@ int ngmix_lm_eval_batch(const ngmix_batch *batch, int model, int fd,
    the head of the reference's fdiff (results.py:454, joint_prior.py:86-120);
    in forward-difference mode their jacobian is by the state's xstep / hstep.
    nloc may carry the fits' parameter count as nloc + 256 * npars (npars =
-   nloc - 1 + the number of bands; 0 = not said): the step then runs with a
-   private state sized for npars instead of NGMIX_LM_NPMAX.
+   nloc - 1 + the number of bands; 0 = not said), which selects the form of
+   the step: 6-8 parameters from registers, one fit per lane; 9-14 by a team
+   of 16 lanes per fit with the fit's arrays in LDS (csrc/lm_team.hip); not
+   said: the generic one-thread code with a private state of NGMIX_LM_NPMAX
+   parameters.  The three forms leave byte-identical state records.
    stamp_stats / obj_stats (both or neither, may be NULL): whenever a fit
    moves to its trial point (lmder counts an iteration; the starting point on
    the first call) obj_stats[i] (nobj, 2) takes the sum of its stamps'
