@@ -200,8 +200,10 @@ class _EventPool(object):
 # download, and the zeros of the statistics accumulator ride in the upload.
 SMALL_BATCH = 64
 # the most lock-step rounds queued blind from the last batch's count (a round
-# that finds every fit finished costs two empty launches, ~20 us)
-ROUNDS_HINT_CAP = 64
+# that finds every fit finished costs two empty launches, ~20 us; co-elliptical
+# psf fits run 60-70 rounds, their tails hundreds: a cap below the rounds a
+# workload needs makes every call take the miss path)
+ROUNDS_HINT_CAP = 256
 
 
 def _carve(torch, dev, pieces):
@@ -695,7 +697,7 @@ class LMBatchFitter(object):
                 _lib.check(_lib.lib().ngmix_event_synchronize(job.chunks[-1][4].handles[1]),
                            "ngmix_event_synchronize")
                 total += grow
-                grow = min(2 * grow, 32)
+                grow = min(2 * grow, ROUNDS_HINT_CAP)
             if redo:
                 with torch.cuda.device(job.dev), torch.cuda.stream(self._job_stream(job)):
                     self._queue_results(job)
