@@ -431,6 +431,7 @@ int ngmix_deriv_images_batch(const ngmix_batch *batch, const double *gpars,
 #define NGMIX_LM_NPMAX 14 /* parameters per object: bdf + 8 bands, bd + 7 bands, coellip with 5 gaussians */
 /* per stamp sums over its nloc local parameters (the shared shape parameters
    followed by the flux of the stamp's band): J^T J upper triangle | J^T f | f.f */
+#define NGMIX_LM_NPARS_GENERIC 255 /* ngmix_lm_advance_batch: the parameter-count hint that asks for the generic step */
 #define NGMIX_LM_NSUMS(nloc) ((nloc) * ((nloc) + 1) / 2 + (nloc) + 1)
 #define NGMIX_LM_NSUM NGMIX_LM_NSUMS(6) /* gauss / turb / exp / dev: 28 */
 
@@ -536,8 +537,11 @@ int ngmix_lm_eval_batch(const ngmix_batch *batch, int model, int fd,
    nloc - 1 + the number of bands; 0 = not said), which selects the form of
    the step: 6-8 parameters from registers, one fit per lane; 9-14 by a team
    of 16 lanes per fit with the fit's arrays in LDS (csrc/lm_team.hip); not
-   said: the generic one-thread code with a private state of NGMIX_LM_NPMAX
-   parameters.  The three forms leave byte-identical state records.
+   said: the team form built for NGMIX_LM_NPMAX parameters (any fit; ahead of
+   the one-thread code at every count); npars = NGMIX_LM_NPARS_GENERIC: the
+   generic one-thread code with a private state of NGMIX_LM_NPMAX parameters
+   (what the tests compare the other forms with).  The three forms leave
+   byte-identical state records.
    stamp_stats / obj_stats (both or neither, may be NULL): whenever a fit
    moves to its trial point (lmder counts an iteration; the starting point on
    the first call) obj_stats[i] (nobj, 2) takes the sum of its stamps'

@@ -95,6 +95,7 @@ def moments_result_dtype(nmom):
 
 
 LM_NPMAX = 14
+LM_NPARS_GENERIC = 255   # ngmix_lm_advance_batch: asks for the generic step
 LM_NSUM = 28
 LM_PHASE_DONE = 2
 LM_PHASE_JAC = 3

@@ -631,9 +631,11 @@ class LMBatchFitter(object):
         """the nloc argument of ngmix_lm_advance_batch carrying the fits'
         parameter count (nloc + 256 npars), which selects the step's kernel: the
         register form for 6-10 parameters, the team form for 11-14;
-        fitter.advance_hint = False leaves it out: the generic one-thread form
-        (what the tests compare the other two with, record by record)"""
-        return self.nloc + (256 * npars if getattr(self, "advance_hint", True) else 0)
+        fitter.advance_hint = False asks for the generic one-thread form
+        (NGMIX_LM_NPARS_GENERIC: what the tests compare the other two with,
+        record by record)"""
+        hint = npars if getattr(self, "advance_hint", True) else _lib.LM_NPARS_GENERIC
+        return self.nloc + 256 * hint
 
     def _timing_events(self, n):
         """n hipEvent_t handles when fitter.time_kernels is set (bench.py), else

@@ -299,3 +299,34 @@ def test_team_step_wrong_hint_ends_the_fit(monkeypatch):
     f.host_loop = True
     res = f.go(sb, guess, psf=psf, stamp_obj=sobj, stamp_band=sband)
     assert np.all(res["flags"] != 0) and f.rounds <= 2
+
+
+def test_no_parameter_count_hint_runs_the_team_form_for_any_count():
+    """ngmix_lm_advance_batch told nothing about the fits' parameter count
+    (nloc alone): the team form built for 14 parameters serves them -- six- and
+    twelve-parameter fits alike, the same fits as with the hint to the bit --
+    and the one-thread code runs only when asked for
+    (NGMIX_LM_NPARS_GENERIC, fitter.advance_hint = False)"""
+    rng = np.random.RandomState(33)
+    for nband in (1, 7):
+        nobj = 40
+        sb, psf, guess, sobj, sband = _multiband(nobj, nband, "exp", rng)
+        kw = dict(psf=psf, stamp_obj=sobj, stamp_band=sband)
+        ref = LMBatchFitter("exp").go(sb, guess, **kw)
+        bare = LMBatchFitter("exp")
+        bare._nloc_npars = lambda npars, f=bare: f.nloc
+        _lib.launch_census(reset=True)
+        got = bare.go(sb, guess, **kw)
+        seen = _lib.launch_census(reset=True)
+        assert _census_has(seen, "lm_advance_team_kernel<4, 14>"), seen
+        assert not _census_has(seen, "lm_advance_kernel<"), seen
+        for k in ("flags", "nfev", "njev", "ier", "pars", "pars_cov", "lnprob"):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+        generic = LMBatchFitter("exp")
+        generic.advance_hint = False
+        _lib.launch_census(reset=True)
+        gen = generic.go(sb, guess, **kw)
+        seen = _lib.launch_census(reset=True)
+        assert _census_has(seen, "lm_advance_kernel<14, false>") and not _census_has(seen, "team")
+        for k in ("flags", "nfev", "pars", "pars_cov"):
+            np.testing.assert_array_equal(gen[k], ref[k], err_msg=k)
