@@ -330,3 +330,53 @@ def test_no_parameter_count_hint_runs_the_team_form_for_any_count():
         assert _census_has(seen, "lm_advance_kernel<14, false>") and not _census_has(seen, "team")
         for k in ("flags", "nfev", "pars", "pars_cov"):
             np.testing.assert_array_equal(gen[k], ref[k], err_msg=k)
+
+
+@pytest.mark.parametrize("order", ["sorted", "interleaved", "ragged"])
+def test_team_fold_with_epochs_and_any_band_order(order, monkeypatch):
+    """objects with several epochs per band, the stamps of an object in band
+    order, interleaved ([0, 1, 2, 0, 1, 2, ...]) or ragged (another number of
+    epochs per band and per object): the team form's fold of the stamps' sums
+    keeps an entry in a register while the band stays and writes / reads it
+    when the band changes -- the state records after every round are the
+    generic form's, byte for byte (NGMIX_LM_TEAM_MIN = 6: with three bands the
+    fits have eight parameters)"""
+    monkeypatch.setenv("NGMIX_LM_TEAM_MIN", "6")
+    rng = np.random.RandomState({"sorted": 1, "interleaved": 2, "ragged": 3}[order])
+    nobj, nband = 23, 3
+    if order == "ragged":
+        nep = rng.randint(1, 4, size=(nobj, nband))
+    else:
+        nep = np.full((nobj, nband), 3)
+    sobj, sband = [], []
+    for o in range(nobj):
+        bands = np.concatenate([np.full(nep[o, b], b) for b in range(nband)])
+        if order != "sorted":
+            bands = rng.permutation(bands) if order == "ragged" else \
+                np.tile(np.arange(nband), 3)
+        sobj += [o] * bands.size
+        sband += list(bands)
+    sobj = np.array(sobj, dtype=np.int32)
+    sband = np.array(sband, dtype=np.int32)
+    ns = sobj.size
+    pars, guess, images, weights, jac, sb, psf = _make_objects(ns, "exp", rng)
+    # one shape per object, one flux per band
+    first = np.searchsorted(sobj, np.arange(nobj))
+    g2 = np.concatenate([guess[first, :5], np.stack(
+        [guess[first + 0, 5], guess[first + 0, 5] * 1.1, guess[first + 0, 5] * 0.9], axis=1)],
+        axis=1)
+
+    def go(f):
+        return f.go(sb, g2, psf=psf, stamp_obj=sobj, stamp_band=sband)
+    _lib.launch_census(reset=True)
+    rt, st = _rounds(LMBatchFitter("exp"), go, True)
+    assert _census_has(_lib.launch_census(reset=True), "lm_advance_team_kernel<4, 8>")
+    rg, sg = _rounds(LMBatchFitter("exp"), go, False)
+    _assert_same_rounds(st, sg)
+    for k in ("flags", "nfev", "ier", "pars", "pars_cov", "lnprob"):
+        np.testing.assert_array_equal(rt[k], rg[k], err_msg=k)
+    # and the register form (the default for eight parameters)
+    monkeypatch.delenv("NGMIX_LM_TEAM_MIN")
+    rr = LMBatchFitter("exp").go(sb, g2, psf=psf, stamp_obj=sobj, stamp_band=sband)
+    for k in ("flags", "nfev", "ier", "pars"):
+        np.testing.assert_array_equal(rr[k], rt[k], err_msg=k)
