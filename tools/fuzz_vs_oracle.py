@@ -2,8 +2,8 @@
 suite's own oracle comparisons (tests/test_gpu_pixpass.py::
 test_batch_random_vs_oracle -- loglike / fill_fdiff / render, exact and fused,
 sheared jacobians, masks, both pixel-list modes --, tests/test_gpu_iter.py::
-test_admom_kernel_variants_vs_oracle and ::test_em_kernel_variants_vs_oracle --
-exact numiter / flags) over RANDOM stamp shapes and mixture sizes instead of
+test_admom_kernel_variants_vs_oracle, ::test_em_kernel_variants_vs_oracle and
+::test_em_many_gaussians_vs_oracle -- exact numiter / flags, every EM kind) over RANDOM stamp shapes and mixture sizes instead of
 the suite's dozen fixed ones.  Every case derives its own data seed from its
 shape, so a failure is reproduced by its printed (shape, ngauss).
 
@@ -39,7 +39,7 @@ def dim():
 
 
 t0 = time.time()
-counts = {"pixpass": 0, "admom": 0, "em": 0}
+counts = {"pixpass": 0, "admom": 0, "em": 0, "em_many": 0}
 failures = []
 while time.time() - t0 < budget:
     u = rng.uniform()
@@ -58,12 +58,20 @@ while time.time() - t0 < budget:
             case = ("admom", shape)
             ti.test_admom_kernel_variants_vs_oracle(shape)
             counts["admom"] += 1
-        else:
+        elif u < 0.9:
             shape = (min(max(dim(), 20), 64), min(max(dim(), 20), 64))
             ng = int(rng.randint(1, 3))
             case = ("em", shape, ng)
             ti.test_em_kernel_variants_vs_oracle(shape, ng)
             counts["em"] += 1
+        else:
+            # every run kind, up to nine object gaussians, 1- and 3-gaussian psfs
+            # (with the comparison's own assertion of which kernel served it)
+            shape = (min(max(dim(), 20), 80), min(max(dim(), 20), 80))
+            ng, npsf, kind = int(rng.randint(1, 10)), int(rng.choice([1, 3])), int(rng.randint(4))
+            case = ("em_many", shape, ng, npsf, kind)
+            ti.test_em_many_gaussians_vs_oracle(shape, ng, npsf, kind)
+            counts["em_many"] += 1
     except Exception:
         failures.append((case, traceback.format_exc(limit=3)))
         print("FAIL", case)
