@@ -130,6 +130,89 @@ def admom_noisy(seed):
     return nflag, nill
 
 
+def wsums_and_derivs(seed):
+    """get_weighted_sums / get_higher_order_weighted_sums (true exp, no cut,
+    maxrad, the ierr > 0 test of the 6-moment form) and deriv_images (the LM
+    jacobian's images, masked layout) on a ragged batch with sheared jacobians
+    against the oracle: sums to 1e-11 of their scale, images to 2e-13 of peak"""
+    import torch
+    from ngmix_amd import _lib
+    from ngmix_amd.batch import StampBatch, GMixBatch, records_to_numpy
+    from oracle import oracle as ora
+    r = np.random.RandomState(seed)
+    n, scale = 6, 0.263
+    shapes = [(int(r.randint(3, 72)), int(r.randint(3, 72))) for _ in range(n)]
+    imgs = [r.normal(size=sh) + 5.0 for sh in shapes]
+    wts = [r.uniform(0.5, 2.0, size=sh) for sh in shapes]
+    for w in wts:
+        w[r.uniform(size=w.shape) < 0.03] = 0.0
+    jacs = []
+    for sh in shapes:
+        a, d = scale * (1 + r.uniform(-0.1, 0.1, size=2))
+        b, c = r.uniform(-0.03, 0.03, size=2)
+        jacs.append(np.array([(sh[0] - 1) / 2 + r.uniform(-0.5, 0.5),
+                              (sh[1] - 1) / 2 + r.uniform(-0.5, 0.5), a, b, c, d, a * d - b * c,
+                              np.sqrt(abs(a * d - b * c))]))
+    # the 17-moment form divides by ierr^2 with no test (gmix_nb.py:772): no zeros there
+    for nmom, izw in ((6, True), (6, False), (17, True)):
+        ww = wts if nmom == 6 else [np.where(w > 0, w, 1.0) for w in wts]
+        sb = StampBatch.from_arrays(imgs, ww, jacs, [izw] * n)
+        wpars = np.zeros((n, 6))
+        wpars[:, 0:2] = r.uniform(-1, 1, size=(n, 2)) * scale
+        wpars[:, 2:4] = r.uniform(-0.2, 0.2, size=(n, 2))
+        wpars[:, 4] = r.uniform(0.2, 2.0, size=n)
+        wpars[:, 5] = 1.0
+        wt, _ = GMixBatch.from_pars(wpars, "gauss")
+        wt.set_norms()
+        wt_h = wt.to_numpy()
+        maxrad = r.uniform(1.0, 12.0, size=n)
+        res, status = sb.weighted_sums(wt, maxrad, nmom=nmom)
+        assert int(status.abs().sum()) == 0
+        rec = records_to_numpy(res, _lib.moments_result_dtype(nmom))
+        for i in range(n):
+            j = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+            j[0] = tuple(jacs[i])
+            pix = ora.make_pixels(imgs[i], ww[i], j, izw)
+            ref = np.zeros(1, dtype=ora.moments_result_dtype(nmom))
+            w = ti.conv_rec(wt_h[i], ora.GAUSS2D_DTYPE)
+            assert ora.get_weighted_sums(w, pix, ref, float(maxrad[i])) == 0
+            assert rec["npix"][i] == ref["npix"][0], ("npix", nmom, i)
+            for f in ("wsum", "sums", "sums_cov"):
+                a_, b_ = np.asarray(rec[f][i], dtype="f8"), np.asarray(ref[f][0], dtype="f8")
+                np.testing.assert_allclose(a_, b_, rtol=0, atol=1e-11 * max(np.abs(b_).max(), 1e-300),
+                                           err_msg="%s nmom %d stamp %d" % (f, nmom, i))
+    # deriv_images: gauss / exp / dev mixtures (x) a psf, the masked layout
+    sb = StampBatch.from_arrays(imgs, wts, jacs, [True] * n)
+    model = str(r.choice(["gauss", "exp", "dev"]))
+    pars = np.zeros((n, 6))
+    pars[:, 0:2] = r.uniform(-1, 1, size=(n, 2)) * scale
+    pars[:, 2:4] = r.uniform(-0.4, 0.4, size=(n, 2))
+    pars[:, 4] = r.uniform(0.1, 1.5, size=n)
+    pars[:, 5] = r.uniform(1.0, 100.0, size=n)
+    gm0, _ = GMixBatch.from_pars(pars, model)
+    psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.02, -0.01, 0.27, 1.0], (n, 1)), "gauss")
+    gmc, _ = gm0.convolve(psf)
+    G = gmc.ngauss
+    GC = gmc.data.reshape(n, G, 13)
+    gpars = GC[:, :, 0:6].contiguous()
+    dcov = torch.from_numpy(r.normal(size=(n, G, 3, 3))).cuda()
+    out = sb.deriv_images(gpars.reshape(-1, 6), dcov.reshape(-1, 3, 3), G).cpu().numpy()
+    gp, dc = gpars.cpu().numpy(), dcov.cpu().numpy()
+    at = 0
+    for i in range(n):
+        j = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+        j[0] = tuple(jacs[i])
+        pix = ora.make_pixels(imgs[i], wts[i], j, True)
+        ref = np.zeros((6, pix.size))
+        ora.deriv_images(gp[i], dc[i], pix["v"], pix["u"], pix["area"], ref)
+        got = out[at:at + 6 * pix.size].reshape(6, pix.size)
+        at += 6 * pix.size
+        for k in range(6):
+            np.testing.assert_allclose(got[k], ref[k], rtol=0,
+                                       atol=2e-13 * max(np.abs(ref[k]).max(), 1e-300),
+                                       err_msg="deriv image %d stamp %d" % (k, i))
+
+
 if os.environ.get("FUZZ_ADMOM_SEEDS"):
     for sd in os.environ["FUZZ_ADMOM_SEEDS"].split(","):
         try:
@@ -138,7 +221,7 @@ if os.environ.get("FUZZ_ADMOM_SEEDS"):
             print(sd, "AssertionError", e)
     sys.exit(0)
 t0 = time.time()
-counts = {"pixpass": 0, "admom": 0, "em": 0, "em_many": 0, "admom_noisy": 0,
+counts = {"pixpass": 0, "admom": 0, "em": 0, "em_many": 0, "wsums_derivs": 0, "admom_noisy": 0,
           "admom_noisy_flagged_stamps": 0, "admom_noisy_ill_conditioned_stamps": 0}
 failures = []
 while time.time() - t0 < budget:
@@ -151,6 +234,11 @@ while time.time() - t0 < budget:
             case = ("pixpass", dims, ng, exact)
             tp.test_batch_random_vs_oracle(dims, ng, exact)
             counts["pixpass"] += 1
+        elif u < 0.65:
+            seed = int(rng.randint(1 << 30))
+            case = ("wsums_derivs", seed)
+            wsums_and_derivs(seed)
+            counts["wsums_derivs"] += 1
         elif u < 0.7:
             seed = int(rng.randint(1 << 30))
             case = ("admom_noisy", seed)
