@@ -2,7 +2,8 @@
 exp / dev with the analytic jacobian or forward differences; turb, bdf by
 forward differences), 1-9 bands, 1-3 epochs per band in any order, 1-3 psf
 gaussians (co-centred or not), stamp sizes 24-48 with masked pixels, guesses
-from good to bad -- run through the form of the lmder step the launcher picks
+from good to bad, for up to three bands half of the time the separable prior
+with random terms and bounds -- run through the form of the lmder step the launcher picks
 (registers for 6-8 parameters, the team form for 9-14) and through the generic
 one-thread form: flags, nfev, njev, ier, parameters, covariance and lnprob must
 be the same TO THE BIT.  A failure prints its case seed.
@@ -65,18 +66,51 @@ def one_case(seed):
     g2[rng.uniform(size=nobj) < 0.1, 2:4] = rng.uniform(-0.7, 0.7, size=2)
     pars_lm = {"maxfev": int(rng.choice([40, 200, 4000])), "ftol": 1e-5, "xtol": 1e-5}
     kw = dict(psf=psf, stamp_obj=sobj, stamp_band=sband)
-    picked = LMBatchFitter(model, analytic_jacobian=analytic, fit_pars=pars_lm)
+    prior = None
+    if nband <= 3 and model != "bdf" and rng.uniform() < 0.5:
+        # the separable prior of the reference (its rows join the normal
+        # equations; the kernel form holds three bands), with random terms and,
+        # half of the time, leastsqbound's bounds on T and the fluxes
+        from ngmix_amd import prior_batch as pb
+        bounded = rng.uniform() < 0.5
+
+        def term(lo, hi, centre, width):
+            kind = int(rng.randint(3))
+            b = None
+            if bounded:
+                b = [(lo, hi), (lo, None), (None, hi)][int(rng.randint(3))]
+            if kind == 0:
+                return pb.Flat(lo, hi, bounds=b)
+            if kind == 1:
+                return pb.TwoSidedErf(lo, 0.1 * width, hi, width, bounds=b)
+            return pb.Normal(centre, width, bounds=b)
+        prior = pb.PriorSimpleSepBatch(
+            pb.GaussianCen(0.0, 0.0, float(rng.uniform(0.05, 0.5)), float(rng.uniform(0.05, 0.5))),
+            pb.GPriorBA(float(rng.uniform(0.1, 0.5))),
+            term(-1.0, 50.0, 0.6, 1.0),
+            [term(-100.0, 1.0e5, 150.0, 300.0) for _ in range(nband)])
+        kw_fit = dict(prior=prior)
+    else:
+        kw_fit = {}
+    picked = LMBatchFitter(model, analytic_jacobian=analytic, fit_pars=pars_lm, **kw_fit)
+    # (half of the small fits through the team form too: priors and bounds only
+    # exist for up to three bands, which the launcher gives to the register form)
+    os.environ.pop("NGMIX_LM_TEAM_MIN", None)
+    if rng.uniform() < 0.5:
+        os.environ["NGMIX_LM_TEAM_MIN"] = "6"
     _lib.launch_census(reset=True)
     a = picked.go(sb, g2, **kw)
     seen = _lib.launch_census(reset=True)
+    os.environ.pop("NGMIX_LM_TEAM_MIN", None)
     form = [k for k in seen if k.startswith("lm_advance")]
-    generic = LMBatchFitter(model, analytic_jacobian=analytic, fit_pars=pars_lm)
+    generic = LMBatchFitter(model, analytic_jacobian=analytic, fit_pars=pars_lm, **kw_fit)
     generic.advance_hint = False
     b = generic.go(sb, g2, **kw)
     for k in KEYS:
         if not np.array_equal(a[k], b[k], equal_nan=True):
             raise AssertionError("%s differs (model %s, n %d, %s)" % (k, model, g2.shape[1], form))
-    return g2.shape[1], form[0] if form else "?", float(np.mean(a["flags"] == 0)), picked.rounds
+    return (g2.shape[1], (form[0] if form else "?") + (" +prior" if prior is not None else ""),
+            float(np.mean(a["flags"] == 0)), picked.rounds)
 
 
 t0 = time.time()
