@@ -99,7 +99,20 @@ def admom_noisy(seed):
         if len(keys) != 1:
             nill += 1
             continue
-        assert st == status[i], ("status", i, st, status[i])
+        diverged = 2 | 4 | 8 | 16
+        if st != status[i]:
+            # a range error raised by the norms of a collapsed weight (status 1 /
+            # 2: det / T too low) is one more exit of a diverging iteration: seen
+            # once in 22,000 noisy stamps, against the oracle's LOW_DET two
+            # iterations earlier; anything else is a failure
+            g_div = int(status[i]) in (1, 2) or (status[i] == 0 and res["flags"][i] & diverged)
+            o_div = st in (1, 2) or (st == 0 and ref["flags"][0] & diverged)
+            assert g_div and o_div, ("status", i, st, int(status[i]), "oracle flags / numiter",
+                                     int(ref["flags"][0]), int(ref["numiter"][0]),
+                                     "gpu flags / numiter", int(res["flags"][i]),
+                                     int(res["numiter"][i]))
+            nill += 1
+            continue
         if st != 0:
             continue
         # (CEN_SHIFT | NONPOS_FLUX | NONPOS_SIZE | LOW_DET: the exits of an
@@ -108,7 +121,6 @@ def admom_noisy(seed):
         # stamps in 160,000 took LOW_DET in the oracle and NONPOS_SIZE, CEN_SHIFT
         # or MAXITER here.  A fit that SUCCEEDS on one side and not on the other
         # would be a failure.)
-        diverged = 2 | 4 | 8 | 16
         gf, rf = int(res["flags"][i]), int(ref["flags"][0])
         assert gf == rf or (gf and rf and ((gf | rf) & diverged)), ("flags", i, gf, rf)
         # (a fit that diverges -- LOW_DET, NONPOS_FLUX / SIZE, CEN_SHIFT -- trips
@@ -213,6 +225,86 @@ def wsums_and_derivs(seed):
                                        err_msg="deriv image %d stamp %d" % (k, i))
 
 
+def seam_forms(seed):
+    """the per-object entry points the reference's njit seam binds to
+    (ngmix_fill_pixels / fill_coords / get_loglike / fill_fdiff / render /
+    get_model_s2n_sum on host arrays): pixel and coordinate arrays, fdiff, the
+    fast render and the norms written into the caller's mixture BIT-IDENTICAL to
+    the oracle's; the sums to 1e-12"""
+    import ctypes
+    from ngmix_amd import _lib
+    from oracle import oracle as ora
+    L = _lib.lib()
+    r = np.random.RandomState(seed)
+    nrow, ncol = int(r.randint(1, 70)), int(r.randint(1, 70))
+    scale = 0.263
+    a, d = scale * (1 + r.uniform(-0.1, 0.1, size=2))
+    b, c = r.uniform(-0.03, 0.03, size=2)
+    jv = (float((nrow - 1) / 2 + r.uniform(-0.5, 0.5)), float((ncol - 1) / 2 + r.uniform(-0.5, 0.5)),
+          float(a), float(b), float(c), float(d), float(a * d - b * c),
+          float(np.sqrt(abs(a * d - b * c))))
+    jac = np.zeros(1, dtype=_lib.JACOBIAN_DTYPE)
+    jac[0] = jv
+    joc = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+    joc[0] = jv
+    image = r.normal(size=(nrow, ncol))
+    weight = r.uniform(0.5, 2.0, size=(nrow, ncol))
+    weight[r.uniform(size=weight.shape) < 0.05] = 0.0
+    weight[0, 0] = 1.0
+    izw = bool(r.randint(2))
+    ref_pix = ora.make_pixels(image, weight, joc, izw)
+    pix = np.zeros(ref_pix.size, dtype=_lib.PIXEL_DTYPE)
+    assert L.ngmix_fill_pixels(_lib.ptr(pix), pix.size, _lib.ptr(image), _lib.ptr(weight), nrow,
+                               ncol, _lib.ptr(jac), int(izw)) == 0
+    for f in ("u", "v", "area", "val", "ierr"):
+        assert np.array_equal(pix[f], ref_pix[f]), f
+    ng = int(r.randint(1, 20))
+    gmh = tp._random_mixtures(r, 1, ng, scale)[0]
+    gm = gmh.copy()
+    gmo = np.zeros(ng, dtype=ora.GAUSS2D_DTYPE)
+    for nm in ora.GAUSS2D_DTYPE.names:
+        gmo[nm] = gmh[nm]
+    ll, sn, sd = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    npix = ctypes.c_int64()
+    st = L.ngmix_get_loglike(_lib.ptr(gm), gm.size, _lib.ptr(pix), pix.size, ctypes.byref(ll),
+                             ctypes.byref(sn), ctypes.byref(sd), ctypes.byref(npix))
+    sto, res = ora.get_loglike(gmo, ref_pix)
+    assert st == sto == 0
+    for nm in ora.GAUSS2D_DTYPE.names:        # the lazy norms, written in place
+        assert np.array_equal(gm[nm], gmo[nm], equal_nan=True), nm
+    assert npix.value == res[3]
+    np.testing.assert_allclose([ll.value, sn.value, sd.value], res[:3], rtol=1e-12, atol=1e-300)
+    start = int(r.randint(0, 20))
+    fd = np.full(start + pix.size, 7.0)
+    rfd = np.full(start + pix.size, 7.0)
+    assert L.ngmix_fill_fdiff(_lib.ptr(gm), gm.size, _lib.ptr(pix), pix.size, _lib.ptr(fd),
+                              start) == 0
+    ora.fill_fdiff(gmo, ref_pix, rfd, start)
+    assert np.array_equal(fd, rfd)
+    s2n = ctypes.c_double()
+    assert L.ngmix_get_model_s2n_sum(_lib.ptr(gm), gm.size, _lib.ptr(pix), pix.size,
+                                     ctypes.byref(s2n)) == 0
+    np.testing.assert_allclose(s2n.value, ora.get_model_s2n_sum(gmo, ref_pix)[1], rtol=1e-12)
+    coords = np.zeros(nrow * ncol, dtype=_lib.COORD_DTYPE)
+    assert L.ngmix_fill_coords(_lib.ptr(coords), nrow, ncol, _lib.ptr(jac)) == 0
+    rco = ora.make_coords((nrow, ncol), joc)
+    for f in ("u", "v", "area"):
+        assert np.array_equal(coords[f], rco[f]), f
+    base = r.normal(size=coords.size)
+    im, rim = base.copy(), base.copy()
+    assert L.ngmix_render(_lib.ptr(gm), gm.size, _lib.ptr(coords), coords.size, _lib.ptr(im),
+                          1) == 0
+    ora.render(gmo, rco, rim, 1)
+    assert np.array_equal(im, rim)              # accumulate-into, fast exp: to the bit
+    im, rim = np.zeros(coords.size), np.zeros(coords.size)
+    assert L.ngmix_render(_lib.ptr(gm), gm.size, _lib.ptr(coords), coords.size, _lib.ptr(im),
+                          0) == 0
+    ora.render(gmo, rco, rim, 0)
+    # (true exp: the device's libm and the host's, a few ulp per term; the
+    # random mixtures have amplitudes of both signs, so relative to the image)
+    np.testing.assert_allclose(im, rim, rtol=1e-14, atol=1e-14 * np.abs(rim).max() + 1e-300)
+
+
 if os.environ.get("FUZZ_ADMOM_SEEDS"):
     for sd in os.environ["FUZZ_ADMOM_SEEDS"].split(","):
         try:
@@ -221,7 +313,7 @@ if os.environ.get("FUZZ_ADMOM_SEEDS"):
             print(sd, "AssertionError", e)
     sys.exit(0)
 t0 = time.time()
-counts = {"pixpass": 0, "admom": 0, "em": 0, "em_many": 0, "wsums_derivs": 0, "admom_noisy": 0,
+counts = {"pixpass": 0, "admom": 0, "em": 0, "em_many": 0, "wsums_derivs": 0, "seam": 0, "admom_noisy": 0,
           "admom_noisy_flagged_stamps": 0, "admom_noisy_ill_conditioned_stamps": 0}
 failures = []
 while time.time() - t0 < budget:
@@ -234,6 +326,11 @@ while time.time() - t0 < budget:
             case = ("pixpass", dims, ng, exact)
             tp.test_batch_random_vs_oracle(dims, ng, exact)
             counts["pixpass"] += 1
+        elif u < 0.62:
+            seed = int(rng.randint(1 << 30))
+            case = ("seam", seed)
+            seam_forms(seed)
+            counts["seam"] += 1
         elif u < 0.65:
             seed = int(rng.randint(1 << 30))
             case = ("wsums_derivs", seed)
