@@ -380,3 +380,59 @@ def test_team_fold_with_epochs_and_any_band_order(order, monkeypatch):
     rr = LMBatchFitter("exp").go(sb, g2, psf=psf, stamp_obj=sobj, stamp_band=sband)
     for k in ("flags", "nfev", "ier", "pars"):
         np.testing.assert_array_equal(rr[k], rt[k], err_msg=k)
+
+
+@pytest.mark.parametrize("nband", [1, 2, 3, 4, 5, 6, 7])
+def test_reference_multiband_fits_for_every_parameter_count(golden, nband):
+    """tests/golden/lm_mb.npz (oracle/gen_golden_mb.py): the REFERENCE's Fitter
+    (MINPACK lmder on MultiBandObsLists) on objects of 1-7 bands -- 6 to 12
+    parameters -- with one or two epochs per band, a gaussian or three-gaussian
+    psf, DEFAULT_LM_PARS and tolerances of 1e-10, against the lock-step driver:
+    the same nfev / ier / flags, pars / covariance / statistics to the
+    tolerances the other reference fits are held to.  Four bands and up run the
+    team form of the step (9+ parameters), which this pins to the reference
+    directly and not through the generic form"""
+    g = golden("lm_mb")
+    per = int(g["per"])
+    groups = {}
+    for k in range(per):
+        tag = "b%d_o%d_" % (nband, k)
+        groups.setdefault((g[tag + "psf_pars"].size, float(g[tag + "tol"])), []).append(tag)
+    for (_, tol), tags in sorted(groups.items()):
+        obs, psfs, sobj, sband = [], [], [], []
+        for o, tag in enumerate(tags):
+            jac = g[tag + "jac"]
+            rec = ngmix.GMix(pars=g[tag + "psf_pars"]).get_data().copy()
+            for s, b in enumerate(g[tag + "band"]):
+                r = jac[s]
+                j = ngmix.Jacobian(row=float(r["row0"]), col=float(r["col0"]),
+                                   dvdrow=float(r["dvdrow"]), dvdcol=float(r["dvdcol"]),
+                                   dudrow=float(r["dudrow"]), dudcol=float(r["dudcol"]))
+                im = g[tag + "images"][s]
+                obs.append(ngmix.Observation(
+                    im, weight=np.full(im.shape, 1.0 / g[tag + "sigma"][s] ** 2), jacobian=j))
+                psfs.append(rec)
+                sobj.append(o)
+                sband.append(int(b))
+        sb = StampBatch.from_observations(obs)
+        psf = GMixBatch.from_numpy(np.stack(psfs))
+        fit_pars = None if tol == 1.0e-5 else {"ftol": tol, "xtol": tol, "maxfev": 4000}
+        _lib.launch_census(reset=True)
+        res = LMBatchFitter("exp", fit_pars=fit_pars).go(
+            sb, np.stack([g[t + "guess"] for t in tags]), psf=psf,
+            stamp_obj=np.array(sobj, dtype=np.int32), stamp_band=np.array(sband, dtype=np.int32))
+        seen = _lib.launch_census(reset=True)
+        assert _census_has(seen, "lm_advance_team_kernel") == (5 + nband >= 9), seen
+        for o, tag in enumerate(tags):
+            assert res["flags"][o] == int(g[tag + "flags"]) == 0
+            assert res["nfev"][o] == int(g[tag + "nfev"]), (tag, res["nfev"][o])
+            assert res["ier"][o] == int(g[tag + "ier"])
+            np.testing.assert_allclose(res["pars"][o], g[tag + "pars"], rtol=1e-6, atol=1e-8)
+            refcov = g[tag + "pars_cov"]
+            sig = np.sqrt(np.diag(refcov))
+            lim = 1e-4 * np.abs(refcov) + 1e-7 * np.outer(sig, sig)
+            assert np.all(np.abs(res["pars_cov"][o] - refcov) <= lim), tag
+            np.testing.assert_allclose(res["pars_err"][o], g[tag + "pars_err"], rtol=1e-4)
+            for k in ("lnprob", "chi2per", "s2n"):
+                np.testing.assert_allclose(res[k][o], float(g[tag + k]), rtol=1e-5)
+            assert res["dof"][o] == int(g[tag + "dof"]) and res["npix"][o] == int(g[tag + "npix"])
