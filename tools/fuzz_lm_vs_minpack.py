@@ -1,5 +1,6 @@
 """The lock-step LM driver against scipy's MINPACK on random fits: each case's
-objects (gauss / exp / dev, analytic jacobian: the reference's lmder path; 1-4
+objects (gauss / exp / dev with the analytic jacobian: the reference's lmder
+path; the same models and turb by forward differences: its lmdif path; 1-4
 bands, 1-2 epochs per band, 1-3 psf gaussians, masked pixels, stamps of 24-48
 pixels) are fitted as one batch by LMBatchFitter and one by one by
 Fitter(batched=False) -- MINPACK's own lmder (its QR of the jacobian; the
@@ -25,14 +26,16 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 master = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 9)
 
 t0 = time.time()
-nfit = same_ier = same_nfev = both_ok = 0
+nfit = nfd = same_ier = same_nfev = both_ok = 0
 worst = 0.0
 worst_case = None
 odd = []
+odd_nfev = []
 while time.time() - t0 < budget:
     seed = int(master.randint(1 << 30))
     rng = np.random.RandomState(seed)
-    model = str(rng.choice(["exp", "gauss", "dev"]))
+    model = str(rng.choice(["exp", "gauss", "dev", "turb"]))
+    analytic = model != "turb" and rng.uniform() < 0.6
     nband = int(rng.randint(1, 5))
     nobj = int(rng.randint(2, 6))
     npsf = int(rng.randint(1, 4))
@@ -53,7 +56,7 @@ while time.time() - t0 < budget:
     flux = np.stack([guess[first, 5] * rng.uniform(0.9, 1.1, size=nobj) for _ in range(nband)],
                     axis=1)
     g2 = np.concatenate([guess[first, :5], flux], axis=1)
-    res = LMBatchFitter(model).go(sb, g2, psf=psf, stamp_obj=sobj, stamp_band=sband)
+    res = LMBatchFitter(model, analytic_jacobian=analytic).go(sb, g2, psf=psf, stamp_obj=sobj, stamp_band=sband)
     for o in range(nobj):
         mb = ngmix.MultiBandObsList()
         for b in range(nband):
@@ -64,21 +67,27 @@ while time.time() - t0 < budget:
                 ol.append(ngmix.Observation(images[s], weight=weights[s], jacobian=jobj,
                                             psf=pobs))
             mb.append(ol)
-        one = ngmix.fitting.Fitter(model=model, batched=False).go(obs=mb, guess=g2[o])
+        one = ngmix.fitting.Fitter(model=model, analytic_jacobian=analytic,
+                                  batched=False).go(obs=mb, guess=g2[o])
         nfit += 1
+        nfd += int(not analytic)
         same = int(one["ier"] == res["ier"][o] and one["flags"] == res["flags"][o])
         same_ier += same
         same_nfev += int(one["nfev"] == res["nfev"][o])
+        if same and one["nfev"] != res["nfev"][o]:
+            odd_nfev.append((seed, o, model, analytic, int(one["nfev"]), int(res["nfev"][o])))
         if not same:
-            odd.append((seed, o, int(one["ier"]), int(res["ier"][o]), int(one["flags"]),
+            odd.append((seed, o, model, analytic, int(one["ier"]), int(res["ier"][o]), int(one["flags"]),
                         int(res["flags"][o])))
         if one["flags"] == 0 and res["flags"][o] == 0:
             both_ok += 1
             d = float(np.max(np.abs(res["pars"][o] - one["pars"]) / one["pars_err"]))
             if d > worst:
-                worst, worst_case = d, (seed, o, model, nband)
-print("fuzz_lm_vs_minpack: %.0f s, %d fits; ier and flags agree: %d; nfev agree exactly: %d; "
+                worst, worst_case = d, (seed, o, model, nband, analytic)
+print("fuzz_lm_vs_minpack: %.0f s, %d fits (%d of them by forward differences); ier and flags agree: %d; nfev agree exactly: %d; "
       "both converged: %d, largest |dpars| / pars_err among them: %.2e %s"
-      % (time.time() - t0, nfit, same_ier, same_nfev, both_ok, worst, worst_case))
+      % (time.time() - t0, nfit, nfd, same_ier, same_nfev, both_ok, worst, worst_case))
 for rec in odd[:20]:
-    print("   differs: seed %d object %d: ier %d / %d, flags %d / %d (MINPACK / driver)" % rec)
+    print("   differs: seed %d object %d (%s, analytic %s): ier %d / %d, flags %d / %d (MINPACK / driver)" % rec)
+for rec in odd_nfev[:20]:
+    print("   nfev differs: seed %d object %d (%s, analytic %s): %d / %d (MINPACK / driver)" % rec)

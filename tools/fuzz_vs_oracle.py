@@ -142,6 +142,165 @@ def admom_noisy(seed):
     return nflag, nill
 
 
+def _em_case(seed):
+    """the inputs of one em_noisy case, numpy only (a failure can be studied
+    against the oracle on the CPU): 8 stamps of one shape, each one or two
+    elliptical gaussians (fluxes 0.3-300 x the pixel noise) + noise; 'prepped'
+    cases (two in three) shift the image as the reference's prep_image does
+    (em.py:95-120: no pixel below 0.001 of the range, sky = the shift), the
+    others keep a sky inside the noise -- negative pixels, which em_run's
+    val / gtot weights take as they come"""
+    r = np.random.RandomState(seed)
+    n, scale = 8, 0.263
+    nrow, ncol = int(r.randint(16, 65)), int(r.randint(16, 65))
+    ngauss, kind = int(r.randint(1, 4)), int(r.choice([0, 0, 1, 2, 3]))
+    cen = r.uniform(-1.0, 1.0, size=(n, 2)) * scale
+    e = r.normal(scale=0.2, size=(n, 2)).clip(-0.6, 0.6)
+    T = r.uniform(0.2, 1.5, size=n)
+    flux = 10.0 ** r.uniform(-0.5, 2.5, size=n)
+    row0, col0 = (nrow - 1) / 2.0 + r.uniform(-0.5, 0.5), (ncol - 1) / 2.0 + r.uniform(-0.5, 0.5)
+    jac = np.array([row0, col0, scale, 0, 0, scale, scale ** 2, scale])
+    v = ((np.arange(nrow) - row0) * scale)[None, :, None] - cen[:, 0, None, None]
+    u = ((np.arange(ncol) - col0) * scale)[None, None, :] - cen[:, 1, None, None]
+    truth = np.zeros((n, nrow, ncol))
+    for frac, grow in ((0.6, 1.0), (0.4, 2.5)):
+        irr = (0.5 * T * grow * (1 - e[:, 0]))[:, None, None]
+        icc = (0.5 * T * grow * (1 + e[:, 0]))[:, None, None]
+        irc = (0.5 * T * grow * e[:, 1])[:, None, None]
+        det = irr * icc - irc ** 2
+        chi2 = (icc * v * v + irr * u * u - 2 * irc * u * v) / det
+        truth += frac * flux[:, None, None] * np.exp(-0.5 * chi2) / (2 * np.pi * np.sqrt(det)) \
+            * scale ** 2
+    sigma = 10.0 ** r.uniform(-2.5, 0.0)
+    images = truth + r.normal(scale=sigma, size=truth.shape)
+    prepped = r.uniform() < 0.67
+    if prepped:
+        lo, hi = images.min(), images.max()
+        sky = 0.001 * (hi - lo) - lo
+    else:
+        sky = sigma * 10.0 ** r.uniform(-0.5, 2.0)
+    images = images + sky
+    weights = np.full(images.shape, 1.0 / sigma ** 2)
+    weights[r.uniform(size=weights.shape) < 0.01] = 0.0
+    full = np.zeros((n, ngauss, 6))
+    for i in range(ngauss):
+        full[:, i, 0] = flux * scale ** 2 / ngauss * r.uniform(0.5, 2.0, size=n)
+        full[:, i, 1:3] = cen + r.uniform(-0.3, 0.3, size=(n, 2)) * scale
+        full[:, i, 3] = 0.5 * T * (0.5 + 1.2 * i) * r.uniform(0.5, 2.0, size=n)
+        full[:, i, 5] = 0.5 * T * (0.5 + 1.2 * i) * r.uniform(0.5, 2.0, size=n)
+    npsf = int(r.choice([1, 3]))
+    if npsf == 1:
+        psf = np.array([[1.0, 0.0, 0.0, 0.0, 0.0, 0.0]])
+    else:
+        psf = np.array([[0.55, 0.0, 0.0, 0.06, 0.002, 0.07], [0.3, 0.0, 0.0, 0.15, -0.004, 0.14],
+                        [0.15, 0.0, 0.0, 0.4, 0.01, 0.42]])
+    return dict(n=n, nrow=nrow, ncol=ncol, ngauss=ngauss, kind=kind, jac=jac, images=images,
+                weights=weights, sky=float(sky), full=full, npsf=npsf, psf=psf, prepped=prepped,
+                tol=float(r.choice([1e-3, 1e-5, 1e-6, 1e-7])),
+                maxiter=int(r.choice([10, 100, 2000])), miniter=int(r.choice([0, 20, 40])))
+
+
+def _em_oracle(c, i, wiggle):
+    """the oracle's em_run on stamp i of a case, its image moved by `wiggle`
+    (0: as is; k: a relative perturbation of 1e-13 drawn from k -- the size of
+    a change of summation order over a stamp's pixels)"""
+    from oracle import oracle as ora
+    j = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+    j[0] = tuple(c["jac"])
+    im = c["images"][i]
+    if wiggle:
+        im = im * (1.0 + 1.0e-13 * np.random.RandomState(7919 * wiggle).uniform(-1, 1,
+                                                                              size=im.shape))
+    pix = ora.make_pixels(im, c["weights"][i], j, True)
+
+    def recs(rows):
+        g = np.zeros(len(rows), dtype=ora.GAUSS2D_DTYPE)
+        for k, f in enumerate(("p", "row", "col", "irr", "irc", "icc")):
+            g[f] = np.asarray(rows)[:, k]
+        return g
+    g, p = recs(c["full"][i]), recs(c["psf"])
+    cv = np.zeros(g.size * p.size, dtype=ora.GAUSS2D_DTYPE)
+    ora.gmix_convolve_fill(cv, g, p)
+    econf = np.zeros(1, dtype=ora.EM_CONF_DTYPE)
+    econf["tol"], econf["maxiter"], econf["miniter"], econf["sky"] = (
+        c["tol"], c["maxiter"], c["miniter"], c["sky"])
+    sums = np.zeros((g.size, ora.EM_SUMS_NDOUBLE[c["kind"]]))
+    st, numiter, frac, _ = ora.em_run(c["kind"], econf, pix, sums, g, p, cv)
+    return st, numiter, frac, g
+
+
+EM_FIELDS = ("p", "row", "col", "irr", "irc", "icc")
+
+
+def _em_same(c, i, status, out, gm_out, ref, rtol, atol):
+    """None when the kernel's result on stamp i is the oracle run `ref`'s, else
+    what differs"""
+    st, numiter, frac, g = ref
+    if st != status[i]:
+        return ("status", st, int(status[i]), "numiter", numiter, int(out[i, 0]))
+    if st != 0:
+        return None
+    if int(out[i, 0]) != numiter:
+        return ("numiter", int(out[i, 0]), numiter, "tol", c["tol"], "frac", frac,
+                float(out[i, 1]))
+    for f in EM_FIELDS:
+        if not np.allclose(gm_out[i][f], g[f], rtol=rtol, atol=atol):
+            return (f, gm_out[i][f].tolist(), g[f].tolist())
+    return None
+
+
+def em_noisy(seed):
+    """em_run at every signal-to-noise, 1-3 gaussians from guesses good to poor,
+    one- and three-gaussian psfs, tol 1e-3 ... 1e-7, maxiter 10 ... 2000, every
+    run kind, prepared images and images with negative pixels (_em_case):
+    status and numiter equal to the oracle's, the mixture to 1e-9.
+
+    Where that does not hold the stamp is tried against the oracle's OWN scatter:
+    em_run's stopping rule compares sums of a per-pixel logL that jumps when a
+    pixel crosses chi2 = 25, a run at low signal-to-noise takes 2000 iterations,
+    a gaussian that has lost its pixels collapses, and with val / gtot weights of
+    both signs (no prep_image) the iteration is not a contraction -- the oracle
+    run on the image moved by 1e-13 (the size of a change of summation order)
+    then stops elsewhere, or ends somewhere else altogether (neutral directions
+    of a broad gaussian on noise: seen, five runs agreeing to 1e-8 and the sixth
+    with p = 12.06 for 8.78 -- the kernel's 12.06).  The kernel's result has to
+    be one the oracle gives for one of 40 such images (same status and numiter,
+    mixture to 1e-6), or the oracle's own runs have to scatter (another status
+    or numiter, or a mixture moved by > 1e-7: the 1e-13 amplified a million
+    times); a kernel that differs where the oracle is steady is a failure.
+    Returns (stamps the oracle raises on, stamps settled by the scatter)."""
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    c = _em_case(seed)
+    n, ngauss, npsf = c["n"], c["ngauss"], c["npsf"]
+    sb = StampBatch.from_images(c["images"], c["weights"], c["jac"])
+    gm0, _ = GMixBatch.from_pars(c["full"].reshape(n, -1), "full", ngauss=ngauss)
+    psf, _ = GMixBatch.from_pars(np.tile(c["psf"].reshape(1, -1), (n, 1)), "full", ngauss=npsf)
+    out, status, conv = sb.em(gm0, psf, sky=c["sky"], miniter=c["miniter"], maxiter=c["maxiter"],
+                              tol=c["tol"], kind=c["kind"])
+    status = status.cpu().numpy()
+    out = out.cpu().numpy()
+    gm_out = gm0.to_numpy().reshape(n, ngauss)
+    nraise = nill = 0
+    for i in range(n):
+        ref = _em_oracle(c, i, 0)
+        nraise += int(ref[0] != 0)
+        why = _em_same(c, i, status, out, gm_out, ref, 1e-9, 1e-11)
+        if why is None:
+            continue
+        unsteady = False
+        for k in range(1, 41):
+            other = _em_oracle(c, i, k)
+            if _em_same(c, i, status, out, gm_out, other, 1e-6, 1e-8) is None:
+                break
+            unsteady = unsteady or other[:2] != ref[:2] or (ref[0] == 0 and any(
+                not np.allclose(other[3][f], ref[3][f], rtol=1e-7, atol=1e-9) for f in EM_FIELDS))
+        else:
+            assert unsteady, (i, "prepped" if c["prepped"] else "raw", "ngauss", ngauss,
+                              "kind", c["kind"], "the oracle is steady") + why
+        nill += 1
+    return nraise, nill
+
+
 def wsums_and_derivs(seed):
     """get_weighted_sums / get_higher_order_weighted_sums (true exp, no cut,
     maxrad, the ierr > 0 test of the 6-moment form) and deriv_images (the LM
@@ -305,6 +464,32 @@ def seam_forms(seed):
     np.testing.assert_allclose(im, rim, rtol=1e-14, atol=1e-14 * np.abs(rim).max() + 1e-300)
 
 
+if os.environ.get("FUZZ_EM_SEEDS"):
+    for sd in os.environ["FUZZ_EM_SEEDS"].split(","):
+        try:
+            print(sd, em_noisy(int(sd)))
+        except AssertionError as e:
+            print(sd, "AssertionError", e)
+    sys.exit(0)
+if os.environ.get("FUZZ_ONLY"):
+    # one family only: FUZZ_ONLY=em_noisy python tools/fuzz_vs_oracle.py 120
+    fn = {"em_noisy": em_noisy, "admom_noisy": admom_noisy, "seam": seam_forms,
+          "wsums_derivs": wsums_and_derivs}[os.environ["FUZZ_ONLY"]]
+    t0, nrun, bad, tally = time.time(), 0, [], np.zeros(2, dtype=int)
+    while time.time() - t0 < budget and len(bad) < 10:
+        sd = int(rng.randint(1 << 30))
+        try:
+            got = fn(sd)
+            if isinstance(got, tuple):
+                tally += np.array(got)
+        except Exception:
+            bad.append(sd)
+            print("FAIL", sd)
+            print(traceback.format_exc(limit=3))
+        nrun += 1
+    print("fuzz_vs_oracle %s: %.0f s, %d cases, (flagged / raising, ill-conditioned) stamps %s, "
+          "failures %s" % (os.environ["FUZZ_ONLY"], time.time() - t0, nrun, tally, bad))
+    sys.exit(1 if bad else 0)
 if os.environ.get("FUZZ_ADMOM_SEEDS"):
     for sd in os.environ["FUZZ_ADMOM_SEEDS"].split(","):
         try:
@@ -313,7 +498,8 @@ if os.environ.get("FUZZ_ADMOM_SEEDS"):
             print(sd, "AssertionError", e)
     sys.exit(0)
 t0 = time.time()
-counts = {"pixpass": 0, "admom": 0, "em": 0, "em_many": 0, "wsums_derivs": 0, "seam": 0, "admom_noisy": 0,
+counts = {"pixpass": 0, "admom": 0, "em": 0, "em_many": 0, "wsums_derivs": 0, "seam": 0, "admom_noisy": 0, "em_noisy": 0,
+          "em_noisy_range_errors": 0, "em_noisy_unsteady_stamps": 0,
           "admom_noisy_flagged_stamps": 0, "admom_noisy_ill_conditioned_stamps": 0}
 failures = []
 while time.time() - t0 < budget:
@@ -343,6 +529,13 @@ while time.time() - t0 < budget:
             counts["admom_noisy_flagged_stamps"] += nflag
             counts["admom_noisy_ill_conditioned_stamps"] += nill
             counts["admom_noisy"] += 1
+        elif u < 0.75:
+            seed = int(rng.randint(1 << 30))
+            case = ("em_noisy", seed)
+            nfail, nill = em_noisy(seed)
+            counts["em_noisy_range_errors"] += nfail
+            counts["em_noisy_unsteady_stamps"] += nill
+            counts["em_noisy"] += 1
         elif u < 0.8:
             # (the iterative cases draw objects that fit the stamp: sides >= 16)
             shape = (max(dim(), 16), max(dim(), 16))
