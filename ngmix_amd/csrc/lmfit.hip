@@ -1436,23 +1436,37 @@ struct LmInitPars {
 // 3: a 290 MB hipMemsetAsync per 100k fits, 0.33 ms of HBM time per batch, 5 %
 // of a config-3 step) wrote 2 kB per six-parameter fit that nothing reads.
 // The dead part keeps whatever the allocation held.
-__global__ __launch_bounds__(WAVE) void lm_init_kernel(lm_state *states, int64_t nobj,
-                                                       const double *__restrict__ x0,
-                                                       LmInitPars P)
+//
+// Sixteen lanes per fit (round 5; one thread per fit before: 132 stores of 8
+// bytes, each 2.9 kB from its neighbour lane's -- 0.35 ms per 100k fits, a
+// twentieth of a config-3 fit).  Lane j writes entry j of every per-parameter
+// array, so a store instruction covers 48-112 contiguous bytes of each of the
+// wave's four records; the leading n rows of R are zeroed as one contiguous
+// run (their dead columns included), the ten double and ten int32 scalars by
+// lanes 0-9.
+constexpr int LM_INIT_LANES = 16;
+static_assert(LM_NPMAX <= LM_INIT_LANES, "a lane per parameter");
+static_assert(offsetof(lm_state, factor) - offsetof(lm_state, fnorm) == 9 * sizeof(double) &&
+                  offsetof(lm_state, fonly) - offsetof(lm_state, n) == 9 * sizeof(int32_t),
+              "lm_init_kernel writes the scalars as two runs of ten");
+
+__global__ __launch_bounds__(BLOCK) void lm_init_kernel(lm_state *states, int64_t nobj,
+                                                        const double *__restrict__ x0,
+                                                        LmInitPars P)
 {
-    const int64_t o = blockIdx.x * (int64_t)WAVE + threadIdx.x;
+    const int j = threadIdx.x & (LM_INIT_LANES - 1);
+    const int64_t o = (blockIdx.x * (int64_t)BLOCK + threadIdx.x) / LM_INIT_LANES;
     if (o >= nobj) return;
     lm_state &s = states[o];
     const int n = P.n;
-    int bounded = 0;
-    for (int j = 0; j < LM_NPMAX; j++) {
+    const int bounded = P.has_bounds;
+    if (j < LM_NPMAX) {
         s.lo[j] = P.lo[j];
         s.hi[j] = P.hi[j];
-        if (P.lo[j] > -INFINITY || P.hi[j] < INFINITY) bounded = 1;
         s.ipvt[j] = j;
     }
     constexpr double EPS = 1.4901161193847656e-08;  // sqrt(machine epsilon)
-    for (int j = 0; j < n; j++) {
+    if (j < n) {
         // i0 = e2i(x0); the first evaluation is at i2e(i0) (leastsqbound.py:454)
         const double x = x0[o * n + j];
         const double xi = bounded ? lmcore::e2i(x, P.lo[j], P.hi[j]) : x;
@@ -1472,21 +1486,23 @@ __global__ __launch_bounds__(WAVE) void lm_init_kernel(lm_state *states, int64_t
         s.diag[j] = 0.0;
         s.qtf[j] = 0.0;
         s.step[j] = 0.0;
-        for (int k = 0; k < n; k++) s.R[j * LM_NPMAX + k] = 0.0;
     }
-    s.fnorm = s.xnorm = s.delta = s.par = s.gnorm = s.pnorm = 0.0;
-    s.nfev = s.njev = s.info = 0;
-    s.phase = LM_PHASE_INIT;
-    s.fonly = 0;
-    s.ftol = P.ftol;
-    s.xtol = P.xtol;
-    s.gtol = P.gtol;
-    s.factor = P.factor;
-    s.n = n;
-    s.mode = P.mode;
-    s.bounded = bounded;
-    s.maxfev = P.maxfev;
-    s.iter = 1;
+    for (int e = j; e < n * LM_NPMAX; e += LM_INIT_LANES) s.R[e] = 0.0;
+    if (j < 10) {
+        // fnorm, xnorm, delta, par, gnorm, pnorm, ftol, xtol, gtol, factor
+        const double dv = j < 6 ? 0.0 : (j == 6 ? P.ftol : (j == 7 ? P.xtol : (j == 8 ? P.gtol
+                                                                                  : P.factor)));
+        (&s.fnorm)[j] = dv;
+        // n, iter, nfev, njev, info, phase, maxfev, mode, bounded, fonly
+        int iv = 0;
+        if (j == 0) iv = n;
+        else if (j == 1) iv = 1;
+        else if (j == 5) iv = LM_PHASE_INIT;
+        else if (j == 6) iv = P.maxfev;
+        else if (j == 7) iv = P.mode;
+        else if (j == 8) iv = bounded;
+        (&s.n)[j] = iv;
+    }
 }
 
 int launch_lm_init(lm_state *states, int64_t nobj, int npars, const double *x0,
@@ -1503,13 +1519,17 @@ int launch_lm_init(lm_state *states, int64_t nobj, int npars, const double *x0,
     P.n = npars;
     P.maxfev = maxfev;
     P.mode = mode;
-    P.has_bounds = (lo != nullptr || hi != nullptr) ? 1 : 0;
     for (int j = 0; j < LM_NPMAX; j++) {
         P.lo[j] = (lo && j < npars) ? lo[j] : -INFINITY;
         P.hi[j] = (hi && j < npars) ? hi[j] : INFINITY;
     }
-    hipLaunchKernelGGL(lm_init_kernel, dim3((unsigned)((nobj + WAVE - 1) / WAVE)),
-                       dim3(WAVE), 0, s, states, nobj, x0, P);
+    // (the states are bounded when any bound is finite, as lmcore::lm_init has it)
+    P.has_bounds = 0;
+    for (int j = 0; j < LM_NPMAX; j++)
+        if (P.lo[j] > -INFINITY || P.hi[j] < INFINITY) P.has_bounds = 1;
+    constexpr int PER_BLOCK = BLOCK / LM_INIT_LANES;
+    hipLaunchKernelGGL(lm_init_kernel, dim3((unsigned)((nobj + PER_BLOCK - 1) / PER_BLOCK)),
+                       dim3(BLOCK), 0, s, states, nobj, x0, P);
     NGMIX_HIP_CHECK(hipGetLastError());
     return NGMIX_OK;
 }
