@@ -21,8 +21,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import test_gpu_pixpass as tp  # noqa: E402
 import test_gpu_iter as ti  # noqa: E402
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 20261003)
+budget = 120.0
+rng = np.random.RandomState(20261003)
 
 
 def dim():
@@ -464,108 +464,118 @@ def seam_forms(seed):
     np.testing.assert_allclose(im, rim, rtol=1e-14, atol=1e-14 * np.abs(rim).max() + 1e-300)
 
 
-if os.environ.get("FUZZ_EM_SEEDS"):
-    for sd in os.environ["FUZZ_EM_SEEDS"].split(","):
+def main():
+    global budget, rng
+    if len(sys.argv) > 1:
+        budget = float(sys.argv[1])
+    if len(sys.argv) > 2:
+        rng = np.random.RandomState(int(sys.argv[2]))
+    if os.environ.get("FUZZ_EM_SEEDS"):
+        for sd in os.environ["FUZZ_EM_SEEDS"].split(","):
+            try:
+                print(sd, em_noisy(int(sd)))
+            except AssertionError as e:
+                print(sd, "AssertionError", e)
+        sys.exit(0)
+    if os.environ.get("FUZZ_ONLY"):
+        # one family only: FUZZ_ONLY=em_noisy python tools/fuzz_vs_oracle.py 120
+        fn = {"em_noisy": em_noisy, "admom_noisy": admom_noisy, "seam": seam_forms,
+              "wsums_derivs": wsums_and_derivs}[os.environ["FUZZ_ONLY"]]
+        t0, nrun, bad, tally = time.time(), 0, [], np.zeros(2, dtype=int)
+        while time.time() - t0 < budget and len(bad) < 10:
+            sd = int(rng.randint(1 << 30))
+            try:
+                got = fn(sd)
+                if isinstance(got, tuple):
+                    tally += np.array(got)
+            except Exception:
+                bad.append(sd)
+                print("FAIL", sd)
+                print(traceback.format_exc(limit=3))
+            nrun += 1
+        print("fuzz_vs_oracle %s: %.0f s, %d cases, (flagged / raising, ill-conditioned) stamps %s, "
+              "failures %s" % (os.environ["FUZZ_ONLY"], time.time() - t0, nrun, tally, bad))
+        sys.exit(1 if bad else 0)
+    if os.environ.get("FUZZ_ADMOM_SEEDS"):
+        for sd in os.environ["FUZZ_ADMOM_SEEDS"].split(","):
+            try:
+                print(sd, admom_noisy(int(sd)))
+            except AssertionError as e:
+                print(sd, "AssertionError", e)
+        sys.exit(0)
+    t0 = time.time()
+    counts = {"pixpass": 0, "admom": 0, "em": 0, "em_many": 0, "wsums_derivs": 0, "seam": 0, "admom_noisy": 0, "em_noisy": 0,
+              "em_noisy_range_errors": 0, "em_noisy_unsteady_stamps": 0,
+              "admom_noisy_flagged_stamps": 0, "admom_noisy_ill_conditioned_stamps": 0}
+    failures = []
+    while time.time() - t0 < budget:
+        u = rng.uniform()
         try:
-            print(sd, em_noisy(int(sd)))
-        except AssertionError as e:
-            print(sd, "AssertionError", e)
-    sys.exit(0)
-if os.environ.get("FUZZ_ONLY"):
-    # one family only: FUZZ_ONLY=em_noisy python tools/fuzz_vs_oracle.py 120
-    fn = {"em_noisy": em_noisy, "admom_noisy": admom_noisy, "seam": seam_forms,
-          "wsums_derivs": wsums_and_derivs}[os.environ["FUZZ_ONLY"]]
-    t0, nrun, bad, tally = time.time(), 0, [], np.zeros(2, dtype=int)
-    while time.time() - t0 < budget and len(bad) < 10:
-        sd = int(rng.randint(1 << 30))
-        try:
-            got = fn(sd)
-            if isinstance(got, tuple):
-                tally += np.array(got)
+            if u < 0.6:
+                dims = (dim(), dim())
+                ng = int(rng.choice([1, 2, 3, 4, 6, 8, 10, 16, 24, 33, 40, 48]))
+                exact = bool(rng.randint(2))
+                case = ("pixpass", dims, ng, exact)
+                tp.test_batch_random_vs_oracle(dims, ng, exact)
+                counts["pixpass"] += 1
+            elif u < 0.62:
+                seed = int(rng.randint(1 << 30))
+                case = ("seam", seed)
+                seam_forms(seed)
+                counts["seam"] += 1
+            elif u < 0.65:
+                seed = int(rng.randint(1 << 30))
+                case = ("wsums_derivs", seed)
+                wsums_and_derivs(seed)
+                counts["wsums_derivs"] += 1
+            elif u < 0.7:
+                seed = int(rng.randint(1 << 30))
+                case = ("admom_noisy", seed)
+                nflag, nill = admom_noisy(seed)
+                counts["admom_noisy_flagged_stamps"] += nflag
+                counts["admom_noisy_ill_conditioned_stamps"] += nill
+                counts["admom_noisy"] += 1
+            elif u < 0.75:
+                seed = int(rng.randint(1 << 30))
+                case = ("em_noisy", seed)
+                nfail, nill = em_noisy(seed)
+                counts["em_noisy_range_errors"] += nfail
+                counts["em_noisy_unsteady_stamps"] += nill
+                counts["em_noisy"] += 1
+            elif u < 0.8:
+                # (the iterative cases draw objects that fit the stamp: sides >= 16)
+                shape = (max(dim(), 16), max(dim(), 16))
+                shape = (min(shape[0], 96), min(shape[1], 96))
+                case = ("admom", shape)
+                ti.test_admom_kernel_variants_vs_oracle(shape)
+                counts["admom"] += 1
+            elif u < 0.9:
+                shape = (min(max(dim(), 20), 64), min(max(dim(), 20), 64))
+                ng = int(rng.randint(1, 3))
+                case = ("em", shape, ng)
+                ti.test_em_kernel_variants_vs_oracle(shape, ng)
+                counts["em"] += 1
+            else:
+                # every run kind, up to nine object gaussians, 1- and 3-gaussian psfs
+                # (with the comparison's own assertion of which kernel served it)
+                shape = (min(max(dim(), 20), 80), min(max(dim(), 20), 80))
+                ng, npsf, kind = int(rng.randint(1, 10)), int(rng.choice([1, 3])), int(rng.randint(4))
+                case = ("em_many", shape, ng, npsf, kind)
+                ti.test_em_many_gaussians_vs_oracle(shape, ng, npsf, kind)
+                counts["em_many"] += 1
         except Exception:
-            bad.append(sd)
-            print("FAIL", sd)
-            print(traceback.format_exc(limit=3))
-        nrun += 1
-    print("fuzz_vs_oracle %s: %.0f s, %d cases, (flagged / raising, ill-conditioned) stamps %s, "
-          "failures %s" % (os.environ["FUZZ_ONLY"], time.time() - t0, nrun, tally, bad))
-    sys.exit(1 if bad else 0)
-if os.environ.get("FUZZ_ADMOM_SEEDS"):
-    for sd in os.environ["FUZZ_ADMOM_SEEDS"].split(","):
-        try:
-            print(sd, admom_noisy(int(sd)))
-        except AssertionError as e:
-            print(sd, "AssertionError", e)
-    sys.exit(0)
-t0 = time.time()
-counts = {"pixpass": 0, "admom": 0, "em": 0, "em_many": 0, "wsums_derivs": 0, "seam": 0, "admom_noisy": 0, "em_noisy": 0,
-          "em_noisy_range_errors": 0, "em_noisy_unsteady_stamps": 0,
-          "admom_noisy_flagged_stamps": 0, "admom_noisy_ill_conditioned_stamps": 0}
-failures = []
-while time.time() - t0 < budget:
-    u = rng.uniform()
-    try:
-        if u < 0.6:
-            dims = (dim(), dim())
-            ng = int(rng.choice([1, 2, 3, 4, 6, 8, 10, 16, 24, 33, 40, 48]))
-            exact = bool(rng.randint(2))
-            case = ("pixpass", dims, ng, exact)
-            tp.test_batch_random_vs_oracle(dims, ng, exact)
-            counts["pixpass"] += 1
-        elif u < 0.62:
-            seed = int(rng.randint(1 << 30))
-            case = ("seam", seed)
-            seam_forms(seed)
-            counts["seam"] += 1
-        elif u < 0.65:
-            seed = int(rng.randint(1 << 30))
-            case = ("wsums_derivs", seed)
-            wsums_and_derivs(seed)
-            counts["wsums_derivs"] += 1
-        elif u < 0.7:
-            seed = int(rng.randint(1 << 30))
-            case = ("admom_noisy", seed)
-            nflag, nill = admom_noisy(seed)
-            counts["admom_noisy_flagged_stamps"] += nflag
-            counts["admom_noisy_ill_conditioned_stamps"] += nill
-            counts["admom_noisy"] += 1
-        elif u < 0.75:
-            seed = int(rng.randint(1 << 30))
-            case = ("em_noisy", seed)
-            nfail, nill = em_noisy(seed)
-            counts["em_noisy_range_errors"] += nfail
-            counts["em_noisy_unsteady_stamps"] += nill
-            counts["em_noisy"] += 1
-        elif u < 0.8:
-            # (the iterative cases draw objects that fit the stamp: sides >= 16)
-            shape = (max(dim(), 16), max(dim(), 16))
-            shape = (min(shape[0], 96), min(shape[1], 96))
-            case = ("admom", shape)
-            ti.test_admom_kernel_variants_vs_oracle(shape)
-            counts["admom"] += 1
-        elif u < 0.9:
-            shape = (min(max(dim(), 20), 64), min(max(dim(), 20), 64))
-            ng = int(rng.randint(1, 3))
-            case = ("em", shape, ng)
-            ti.test_em_kernel_variants_vs_oracle(shape, ng)
-            counts["em"] += 1
-        else:
-            # every run kind, up to nine object gaussians, 1- and 3-gaussian psfs
-            # (with the comparison's own assertion of which kernel served it)
-            shape = (min(max(dim(), 20), 80), min(max(dim(), 20), 80))
-            ng, npsf, kind = int(rng.randint(1, 10)), int(rng.choice([1, 3])), int(rng.randint(4))
-            case = ("em_many", shape, ng, npsf, kind)
-            ti.test_em_many_gaussians_vs_oracle(shape, ng, npsf, kind)
-            counts["em_many"] += 1
-    except Exception:
-        failures.append((case, traceback.format_exc(limit=3)))
-        print("FAIL", case)
-        print(failures[-1][1])
-        sys.stdout.flush()
-        if len(failures) >= 10:
-            break
-print("fuzz_vs_oracle: %.0f s, cases run %s, failures %d" % (time.time() - t0, counts,
-                                                             len(failures)))
-for case, tb in failures:
-    print("  ", case)
-sys.exit(1 if failures else 0)
+            failures.append((case, traceback.format_exc(limit=3)))
+            print("FAIL", case)
+            print(failures[-1][1])
+            sys.stdout.flush()
+            if len(failures) >= 10:
+                break
+    print("fuzz_vs_oracle: %.0f s, cases run %s, failures %d" % (time.time() - t0, counts,
+                                                                 len(failures)))
+    for case, tb in failures:
+        print("  ", case)
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()
