@@ -257,6 +257,8 @@ int launch_lm_advance_team(lm_state *states, int64_t nobj, const int64_t *obj_st
                            hipStream_t s)
 {
     const int np = npars <= 8 ? 8 : npars <= 10 ? 10 : npars <= 12 ? 12 : LM_NPMAX;
+    // (fits per wave: 1, 2 or 4 -- anything else an A/B knob says is the default)
+    if (teams != 1 && teams != 2) teams = 4;
     char name[64];
     snprintf(name, sizeof(name), "lm_advance_team_kernel<%d, %d>", teams, np);
     census(name);
