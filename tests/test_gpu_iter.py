@@ -848,3 +848,57 @@ sys.stdout.buffer.write(out.cpu().numpy().tobytes() + gm0.to_numpy().tobytes() +
                        capture_output=True, timeout=280)
     assert b.returncode == 0, b.stderr[-2000:]
     assert len(a.stdout) > 64 * 3 * 8 and a.stdout == b.stdout
+
+
+def test_c4_shaped_batch_against_the_reference(golden):
+    """tests/golden/c4.npz (oracle/gen_golden_c4.py): thirty-two objects of
+    config 4's shape -- 32x32, gaussian (x) gaussian psf, off-grid centres,
+    bench.py's guesses -- through the REFERENCE's admom (AdmomFitter's default
+    configuration) and em_run (40 iterations at config 4's settings; and with
+    a poorer guess and the stopping rule deciding: 15-23 iterations), against
+    ONE batch of the kernels each: flags / numiter exact, the moment sums and
+    their covariance to 1e-10, the mixtures to 1e-9 -- the direct link of
+    config 4 to the reference that lm_c3.npz is for config 3"""
+    from ngmix_amd.batch import StampBatch, GMixBatch, records_to_numpy
+    g = golden("c4")
+    n = g["images"].shape[0]
+    weights = np.full(g["images"].shape, 1.0 / float(g["noise"]) ** 2)
+    sb = StampBatch.from_images(g["images"], weights, g["jac"])
+    wt, _ = GMixBatch.from_pars(g["admom_wt_in"].reshape(n, 6), "full", ngauss=1)
+    maxiter, shiftmax, etol, Ttol = g["admom_conf"]
+    _lib.launch_census(reset=True)
+    res, status = sb.admom(wt, maxiter=int(maxiter), shiftmax=float(shiftmax), etol=float(etol),
+                           Ttol=float(Ttol))
+    seen = _lib.launch_census(reset=True)
+    assert any(k.startswith("admom_grid_kernel<64") for k in seen), seen
+    assert int(status.abs().sum()) == 0
+    res = records_to_numpy(res, _lib.ADMOM_RESULT_DTYPE)
+    wt_out = wt.to_numpy()
+    np.testing.assert_array_equal(res["flags"], g["admom_flags"])
+    np.testing.assert_array_equal(res["numiter"], g["admom_numiter"])
+    np.testing.assert_array_equal(res["npix"], g["admom_npix"])
+    for i in range(n):
+        for f in ("wsum", "sums", "sums_cov", "pars"):
+            close(res[f][i], g["admom_" + f][i], err_msg="%s object %d" % (f, i))
+        for k, f in enumerate(("row", "col", "irr", "irc", "icc")):
+            close(wt_out[f][i], g["admom_wt_out"][i, 0, k + 1], scale=1.0,
+                  err_msg="weight %s object %d" % (f, i))
+    sky = float(g["sky"])
+    sb_em = StampBatch.from_images(g["images"] + sky, weights, g["jac"])
+    psf, _ = GMixBatch.from_pars(np.tile(g["psf"].reshape(1, 6), (n, 1)), "full", ngauss=1)
+    for tag in ("em", "em2"):
+        tol, miniter, maxiter = g[tag + "_conf"]
+        gm, _ = GMixBatch.from_pars(g[tag + "_gmix_in"].reshape(n, 6), "full", ngauss=1)
+        _lib.launch_census(reset=True)
+        out, status, conv = sb_em.em(gm, psf, sky=sky, tol=float(tol), miniter=int(miniter),
+                                     maxiter=int(maxiter))
+        seen = _lib.launch_census(reset=True)
+        assert any(k.startswith("em_wave_kernel<64") for k in seen), seen
+        assert int(status.abs().sum()) == 0
+        out = out.cpu().numpy()
+        np.testing.assert_array_equal(out[:, 0].astype(int), g[tag + "_numiter"])
+        np.testing.assert_array_equal(out[:, 2], g[tag + "_sky"])
+        gm_out = gm.to_numpy().reshape(n)
+        for k, f in enumerate(("p", "row", "col", "irr", "irc", "icc")):
+            np.testing.assert_allclose(gm_out[f], g[tag + "_gmix_out"][:, 0, k], rtol=1e-9,
+                                       atol=1e-12, err_msg="%s %s" % (tag, f))

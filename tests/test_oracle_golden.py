@@ -379,3 +379,49 @@ def test_cpu_lm_leg_is_the_reference_fit(golden):
         np.testing.assert_allclose(out[0], g["pars"][i], rtol=1e-8, atol=1e-10)
         # leastsq's cov_x is the reference's pars_cov0
         np.testing.assert_allclose(out[1], g["pars_cov0"][i], rtol=1e-6)
+
+
+# ------------------------------------------------- config 4's shape, at scale
+def _c4_records(rows):
+    g = np.zeros(len(rows), dtype=ora.GAUSS2D_DTYPE)
+    for k, f in enumerate(("p", "row", "col", "irr", "irc", "icc")):
+        g[f] = np.asarray(rows)[:, k]
+    g["det"] = g["irr"] * g["icc"] - g["irc"] ** 2
+    return g
+
+
+def test_c4_shaped_objects_against_the_reference(golden):
+    """tests/golden/c4.npz (oracle/gen_golden_c4.py): thirty-two objects of
+    config 4's shape through the REFERENCE's admom and em_run; the oracle
+    reproduces the adaptive moments bit for bit and EM's numiter and mixtures"""
+    g = golden("c4")
+    n = g["images"].shape[0]
+    weight = np.full(g["images"].shape[1:], 1.0 / float(g["noise"]) ** 2)
+    conf = np.zeros(1, dtype=ora.ADMOM_CONF_DTYPE)
+    conf["maxiter"], conf["shiftmax"], conf["etol"], conf["Ttol"] = g["admom_conf"]
+    psf = _c4_records(g["psf"])
+    for i in range(n):
+        j = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+        j[0] = tuple(g["jac"][i])
+        pix = ora.make_pixels(g["images"][i], weight, j, True)
+        wt = _c4_records(g["admom_wt_in"][i])
+        res = np.zeros(1, dtype=ora.ADMOM_RESULT_DTYPE)
+        assert ora.admom(conf, wt, pix, res) == 0
+        for f in ("flags", "numiter", "npix", "wsum", "sums", "sums_cov", "pars"):
+            np.testing.assert_array_equal(res[f][0], g["admom_" + f][i], err_msg="%d %s" % (i, f))
+        for k, f in enumerate(("p", "row", "col", "irr", "irc", "icc")):
+            assert wt[f][0] == g["admom_wt_out"][i, 0, k], (i, f)
+        pix_e = ora.make_pixels(g["images"][i] + float(g["sky"]), weight, j, True)
+        for tag in ("em", "em2"):
+            econf = np.zeros(1, dtype=ora.EM_CONF_DTYPE)
+            econf["tol"], econf["miniter"], econf["maxiter"] = g[tag + "_conf"]
+            econf["sky"] = float(g["sky"])
+            gm = _c4_records(g[tag + "_gmix_in"][i])
+            conv = np.zeros(1, dtype=ora.GAUSS2D_DTYPE)
+            ora.gmix_convolve_fill(conv, gm, psf)
+            sums = np.zeros((1, ora.EM_SUMS_NDOUBLE[0]))
+            st, numiter, frac, sky = ora.em_run(0, econf, pix_e, sums, gm, psf, conv)
+            assert st == 0 and numiter == int(g[tag + "_numiter"][i]), (tag, i, numiter)
+            assert sky == float(g[tag + "_sky"][i])
+            for k, f in enumerate(("p", "row", "col", "irr", "irc", "icc")):
+                assert gm[f][0] == g[tag + "_gmix_out"][i, 0, k], (tag, i, f)
