@@ -925,3 +925,82 @@ def test_batch_beyond_4_gib():
     assert np.array_equal(sb.fill_fdiff(gm)[0][-base * npix:].cpu().numpy(), fd0)
     im0 = sb0.render(gm0)[0].cpu().numpy()
     assert np.array_equal(sb.render(gm)[0][-base * npix:].cpu().numpy(), im0)
+
+
+def test_c5_shaped_batch_against_the_reference(golden):
+    """tests/golden/c5.npz (oracle/gen_golden_c5.py; inputs rebuilt by
+    helpers/c5_inputs.py): six objects of ten 64x64 epochs, the 16-gaussian
+    'bdf' (x) gaussian psf -- config 5's shape -- through the REFERENCE's
+    GMix.get_loglike, against ONE batch of sixty stamps summed over each
+    object's epochs as bench.py's C5 step does: loglike / s2n_numer / s2n_denom
+    to 1e-10 per epoch and per object, npix exact, with the census naming
+    the kernel of the C5 leg"""
+    from helpers import c5_inputs as c5
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    g = golden("c5")
+    pars, moved, jac, images = c5.objects()
+    np.testing.assert_allclose(images.sum(axis=(2, 3)), g["image_sums"], rtol=1e-13)
+    ns = c5.NOBJ * c5.NEPOCH
+    weights = np.full((ns, c5.DIM, c5.DIM), 1.0 / c5.NOISE ** 2)
+    sb = StampBatch.from_images(images.reshape(ns, c5.DIM, c5.DIM), weights, jac.reshape(ns, 8))
+    psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, c5.TPSF, 1.0], (ns, 1)), "gauss")
+    obj_start = np.arange(c5.NOBJ + 1) * c5.NEPOCH
+    for tag, pp in (("truth", pars), ("moved", moved)):
+        gm0, st = GMixBatch.from_pars(np.repeat(pp, c5.NEPOCH, axis=0), "bdf")
+        gm, _ = gm0.convolve(psf)
+        _lib.launch_census(reset=True)
+        out, status = sb.loglike(gm)
+        seen = _lib.launch_census(reset=True)
+        assert any(k.startswith("pixpass_wave_kernel7<loglike>") for k in seen), seen
+        assert int(status.abs().sum()) == 0
+        per_obj = sb.sum_over_epochs(out, obj_start).cpu().numpy()
+        out = out.cpu().numpy().reshape(c5.NOBJ, c5.NEPOCH, 4)
+        np.testing.assert_allclose(out[:, :, :3], g[tag + "_per_epoch"][:, :, :3], rtol=1e-10)
+        np.testing.assert_array_equal(out[:, :, 3], g[tag + "_per_epoch"][:, :, 3])
+        np.testing.assert_allclose(per_obj[:, :3], g[tag + "_per_object"][:, :3], rtol=1e-10)
+        np.testing.assert_array_equal(per_obj[:, 3], g[tag + "_per_object"][:, 3])
+
+
+@pytest.mark.parametrize("exact", [True, False], ids=["exact", "fused"])
+def test_c2_shaped_batch_against_the_reference(golden, exact):
+    """tests/golden/c2.npz (oracle/gen_golden_c2.py; inputs rebuilt by
+    helpers/c2_inputs.py): eight stamps of config 2's shape through the
+    REFERENCE's get_loglike / fill_fdiff / _fill_image (accumulating into a
+    given image, fast exp) at two parameter sets, against ONE batch of the
+    kernels from the model parameters on (device model fill, convolution,
+    pixel pass): the four loglike numbers to 1e-10, fdiff and the rendered
+    images to north_star's per-pixel tolerance (the model fill goes through
+    tanh / atanh: the exact kernels are held to it too, not to the bit)"""
+    import torch
+    from helpers import c2_inputs as c2
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    g = golden("c2")
+    pars, moved, jac, images, sigma, base = c2.stamps()
+    np.testing.assert_allclose(images.sum(axis=(1, 2)), g["image_sums"], rtol=1e-13)
+    weights = np.broadcast_to((1.0 / sigma ** 2)[:, None, None], images.shape).copy()
+    sb = StampBatch.from_images(images, weights, jac)
+    psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, c2.TPSF, 1.0], (c2.N, 1)), "gauss")
+    for tag, pp in (("truth", pars), ("moved", moved)):
+        gm0, _ = GMixBatch.from_pars(pp, "exp")
+        gm, _ = gm0.convolve(psf)
+        _lib.launch_census(reset=True)
+        out, status = sb.loglike(gm, exact=exact)
+        seen = _lib.launch_census(reset=True)
+        if not exact:
+            assert seen.get("pixpass_wave_kernel7<loglike>", 0) == 1, seen
+        assert int(status.abs().sum()) == 0
+        out = out.cpu().numpy()
+        np.testing.assert_allclose(out[:, :3], g[tag + "_loglike"][:, :3], rtol=1e-10)
+        np.testing.assert_array_equal(out[:, 3], g[tag + "_loglike"][:, 3])
+        fd, _ = sb.fill_fdiff(gm, exact=exact)
+        fd = fd.cpu().numpy().reshape(c2.N, -1)
+        acc = torch.from_numpy(base.reshape(-1).copy()).cuda()
+        sb.render(gm, image=acc, fast_exp=True, exact=exact)
+        acc = acc.cpu().numpy().reshape(c2.N, -1)
+        for i in range(c2.N):
+            assert_pixels(fd[i], g[tag + "_fdiff"][i], False, err_msg="fdiff %d" % i)
+            # (the render adds to a base of order one: relative to the model's peak)
+            ref = g[tag + "_rendered"][i].ravel()
+            model = ref - base[i].ravel()
+            np.testing.assert_allclose(acc[i] - base[i].ravel(), model, rtol=0,
+                                       atol=1e-10 * np.abs(model).max(), err_msg="render %d" % i)

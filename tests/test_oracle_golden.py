@@ -425,3 +425,69 @@ def test_c4_shaped_objects_against_the_reference(golden):
             assert sky == float(g[tag + "_sky"][i])
             for k, f in enumerate(("p", "row", "col", "irr", "irc", "icc")):
                 assert gm[f][0] == g[tag + "_gmix_out"][i, 0, k], (tag, i, f)
+
+
+def test_c5_shaped_objects_against_the_reference(golden):
+    """tests/golden/c5.npz (oracle/gen_golden_c5.py; inputs rebuilt by
+    helpers/c5_inputs.py): the REFERENCE's GMix.get_loglike on six objects of
+    ten 64x64 epochs, 'bdf' (x) gaussian psf -- config 5's shape -- at two
+    parameter sets; the oracle's model fill, convolution and loglike give the
+    same four numbers per epoch"""
+    from helpers import c5_inputs as c5
+    g = golden("c5")
+    pars, moved, jac, images = c5.objects()
+    np.testing.assert_allclose(images.sum(axis=(2, 3)), g["image_sums"], rtol=1e-13)
+    weight = np.full((c5.DIM, c5.DIM), 1.0 / c5.NOISE ** 2)
+    psf = np.zeros(1, dtype=ora.GAUSS2D_DTYPE)
+    assert ora.gmix_fill(psf, [0.0, 0.0, 0.0, 0.0, c5.TPSF, 1.0], "gauss") == 0
+    for tag, pp in (("truth", pars), ("moved", moved)):
+        for o in range(c5.NOBJ):
+            gm = np.zeros(16, dtype=ora.GAUSS2D_DTYPE)
+            assert ora.gmix_fill(gm, pp[o], "bdf") == 0
+            conv = np.zeros(16, dtype=ora.GAUSS2D_DTYPE)
+            ora.gmix_convolve_fill(conv, gm, psf)
+            for e in range(c5.NEPOCH):
+                j = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+                j[0] = tuple(jac[o, e])
+                pix = ora.make_pixels(images[o, e], weight, j, True)
+                st, res = ora.get_loglike(conv, pix)
+                assert st == 0
+                np.testing.assert_allclose(res[:3], g[tag + "_per_epoch"][o, e, :3], rtol=1e-12,
+                                           err_msg="%s object %d epoch %d" % (tag, o, e))
+                assert res[3] == g[tag + "_per_epoch"][o, e, 3]
+
+
+def test_c2_shaped_stamps_against_the_reference(golden):
+    """tests/golden/c2.npz (oracle/gen_golden_c2.py; inputs rebuilt by
+    helpers/c2_inputs.py): the REFERENCE's get_loglike / fill_fdiff /
+    _fill_image (accumulating, fast exp) on eight stamps of config 2's shape at
+    two parameter sets; the oracle's model fill, convolution and pixel loops
+    give the same numbers (the model fill goes through libm's tanh / atanh:
+    to rounding, not to the bit)"""
+    from helpers import c2_inputs as c2
+    g = golden("c2")
+    pars, moved, jac, images, sigma, base = c2.stamps()
+    np.testing.assert_allclose(images.sum(axis=(1, 2)), g["image_sums"], rtol=1e-13)
+    psf = np.zeros(1, dtype=ora.GAUSS2D_DTYPE)
+    assert ora.gmix_fill(psf, [0.0, 0.0, 0.0, 0.0, c2.TPSF, 1.0], "gauss") == 0
+    for tag, pp in (("truth", pars), ("moved", moved)):
+        for i in range(c2.N):
+            gm = np.zeros(6, dtype=ora.GAUSS2D_DTYPE)
+            assert ora.gmix_fill(gm, pp[i], "exp") == 0
+            conv = np.zeros(6, dtype=ora.GAUSS2D_DTYPE)
+            ora.gmix_convolve_fill(conv, gm, psf)
+            j = np.zeros(1, dtype=ora.JACOBIAN_DTYPE)
+            j[0] = tuple(jac[i])
+            weight = np.full(images[i].shape, 1.0 / sigma[i] ** 2)
+            pix = ora.make_pixels(images[i], weight, j, True)
+            st, res = ora.get_loglike(conv, pix)
+            assert st == 0 and res[3] == g[tag + "_loglike"][i, 3]
+            np.testing.assert_allclose(res[:3], g[tag + "_loglike"][i, :3], rtol=1e-11)
+            fd = np.zeros(pix.size)
+            ora.fill_fdiff(conv, pix, fd, 0)
+            ref = g[tag + "_fdiff"][i]
+            np.testing.assert_allclose(fd, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+            im = base[i].copy().ravel()
+            ora.render(conv, ora.make_coords((c2.DIM, c2.DIM), j), im, 1)
+            ref = g[tag + "_rendered"][i].ravel()
+            np.testing.assert_allclose(im, ref, rtol=0, atol=1e-13 * np.abs(ref).max())
