@@ -11,7 +11,10 @@
  * IEEE-754 double operation matches the un-contracted LLVM code numba emits.
  *
  * Parity pinned: checked against golden vectors produced by importing the
- * reference itself (oracle/gen_golden.py -> tests/golden/ *.npz); see
+ * reference itself (oracle/gen_golden*.py -> tests/golden/ *.npz; per-function
+ * vectors and, at the shape of every BASELINE config, the reference's own
+ * render / loglike / fdiff (c2, c5), admom and em_run (c4: bit for bit) and
+ * complete fits (lm_c3 through bench.py's CPU leg)); see
  * tests/test_oracle_golden.py.
  *
  * Struct layouts are the reference's numpy dtypes.
