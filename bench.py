@@ -616,6 +616,11 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
     eval_ms = state["eval_ms"] / nl
     stamps_per_launch = state["eval_stamps"] / nl
     achieved = eval_bytes * state["eval_stamps"] / (state["eval_ms"] * 1e-3) / 1e9
+    # HBM bytes of the lm_eval launches of ONE fit from the committed PMC pass
+    # (tools/run_prof_all.sh: FETCH_SIZE / WRITE_SIZE passes over tools/bench_lm.py,
+    # the same 100k stamps and guesses), spread over this run's launches per fit
+    # -- per launch, like `achieved`
+    fit_traffic, _ = load_traffic("c3_lm_eval", n, key="c3_nstamps", field="_hbm_bytes_per_fit")
     return {
         "metric": "LM fits/sec ('exp' (x) gaussian psf, 48x48 stamps), 1/2/4/8 GPU",
         "value": world * n * K / elapsed,
@@ -634,7 +639,8 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
         "roofline": {
             "bound": "hbm", "kernel": "ngmix::lm_eval_kernel<true, true>",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": fit_traffic / (nl / K) if fit_traffic else None,
             "algorithmic_bytes_per_launch": eval_bytes * stamps_per_launch,
             "avg_launch_ms": eval_ms, "stamps_per_launch": stamps_per_launch,
             "launches_per_fit": nl / K, "pieces": state.get("nsplit", 1),
@@ -1390,7 +1396,7 @@ def baseline_metric():
                 "1/2/4/8 GPU")
 
 
-def load_traffic(kernel, nstamps, key="nstamps"):
+def load_traffic(kernel, nstamps, key="nstamps", field="_hbm_bytes_per_launch"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC pass
     (counters cannot be read from inside the timed run: rocprofv3 --pmc is a
     separate, serialising pass).  Returns (bytes or None, source or None)."""
@@ -1402,7 +1408,7 @@ def load_traffic(kernel, nstamps, key="nstamps"):
         return None, None
     if t.get(key) != nstamps:
         return None, None
-    v = t.get(kernel + "_hbm_bytes_per_launch")
+    v = t.get(kernel + field)
     if v is None:
         return None, None
     return v, "profiles/pmc_traffic.json (%s)" % t.get("source", "rocprofv3 --pmc pass")

@@ -38,6 +38,12 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         # objects x 9 bands: only the team kernel is taken from them)
         if team_dir != k.startswith("lm_advance_team"):
             continue
+        # (the traffic passes of config 3 bring FETCH_SIZE / WRITE_SIZE only: their
+        # GRBM_GUI_ACTIVE belongs to other launches than the SQ passes' and must not
+        # enter the issue figures' mean)
+        if os.path.basename(d) in ("pmc_lmfetch", "pmc_lmwrite") and (
+                row["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE") or "pixpass" in k):
+            continue
         if "pixpass" in k or "admom" in k or "em_" in k or "lm_" in k:
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 
@@ -67,6 +73,22 @@ for k, cs in sorted(acc.items()):
             traffic[name + "_hbm_bytes_per_launch"] = 2 * fetch * 1024 + write * 1024
             traffic[name + "_fetch_size_kb"] = fetch
             traffic[name + "_write_size_kb"] = write
+# config 3: the HBM bytes of the lm_eval launches of one complete fit (the FETCH_SIZE
+# and WRITE_SIZE passes run the same deterministic program, tools/bench_lm.py: the
+# i-th launch of one pass is the i-th of the other)
+ev = acc.get("lm_eval_kernel<true, true>", {})
+ninit = [len(cs["FETCH_SIZE"]) for k, cs in acc.items() if "lm_init_kernel" in k and
+         "FETCH_SIZE" in cs]
+if "FETCH_SIZE" in ev and "WRITE_SIZE" in ev and len(ev["FETCH_SIZE"]) == len(ev["WRITE_SIZE"]) \
+        and ninit and ninit[0] > 0:
+    per = [2 * f * 1024 + w * 1024 for f, w in zip(ev["FETCH_SIZE"], ev["WRITE_SIZE"])]
+    traffic["c3_lm_eval_hbm_bytes_per_fit"] = sum(per) / ninit[0]
+    traffic["c3_lm_eval_full_pass_hbm_bytes"] = max(per)
+    traffic["c3_lm_eval_launches_per_fit"] = len(per) / float(ninit[0])
+    traffic["c3_nstamps"] = nstamps
+    lines.append("# config 3 (tools/bench_lm.py %d 0): lm_eval_kernel<true, true>, %d launches over "
+                 "%d fits: HBM bytes per fit %.4g, of the fullest launch %.4g"
+                 % (nstamps, len(per), ninit[0], sum(per) / ninit[0], max(per)))
 # kernel-trace --stats of the bench command itself and of the other configs'
 # drivers, trimmed to this library's kernels
 if "FETCH_SIZE" in c5acc and "WRITE_SIZE" in c5acc:

@@ -27,6 +27,8 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/iter_st
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lm_stats -o run -- python3 $ROOT/tools/bench_lm.py 100000 0 > $OUT/lm.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_iter -o run -- python3 $ROOT/tools/bench_iter.py 100000 1 > $OUT/pmc_iter.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_lm -o run -- python3 $ROOT/tools/bench_lm.py 100000 0 > $OUT/pmc_lm.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_lmfetch -o run -- python3 $ROOT/tools/bench_lm.py 100000 0 > $OUT/pmc_lmfetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_lmwrite -o run -- python3 $ROOT/tools/bench_lm.py 100000 0 > $OUT/pmc_lmwrite.log 2>&1
 # 4. round 5: the team form of the lmder step (multi-band and co-elliptical fits)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/team_stats -o run -- python3 $ROOT/tools/lm_advance_share.py 10000 > $OUT/team.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_team -o run -- python3 $ROOT/tools/team_probe.py 20000 9 > $OUT/pmc_team.log 2>&1
