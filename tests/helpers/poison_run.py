@@ -1,0 +1,80 @@
+"""
+One pass through the batch entry points (lock-step LM with 6 and 11 parameters
+and by forward differences, the pixel-pass kernels, adaptive moments, EM,
+weighted moments), the results written to an .npz -- for
+test_gpu_stress.py::test_results_do_not_depend_on_what_the_allocations_held,
+which runs it twice: as is, and with the allocator POISONED first.
+
+usage: python tests/helpers/poison_run.py out.npz 0|1
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.dirname(os.path.dirname(HERE)), os.path.dirname(HERE)]
+
+
+def poison():
+    """before anything else is allocated: 8 GiB of the large pool and 1 GiB of
+    the small pool filled with NaN and handed back to the caching allocator --
+    with no live tensor, every cached block is a poisoned one, and what the
+    process allocates from here on is carved out of them"""
+    big = torch.full((1 << 30,), float("nan"), dtype=torch.float64, device="cuda")
+    small = [torch.full((1 << 17,), float("nan"), dtype=torch.float64, device="cuda")
+             for _ in range(1024)]                  # 1 MiB each: the small pool's largest
+    torch.cuda.synchronize()
+    del big, small
+    # (looked at on the host: a device-side reduction would allocate, write and free
+    # a workspace of its own, which the next probe would be handed)
+    for numel in (8, 1 << 12, 1 << 18, 1 << 24):
+        probe = torch.empty(numel, dtype=torch.float64, device="cuda")
+        assert np.isnan(probe.cpu().numpy()).all(), "torch.empty(%d) is not poisoned" % numel
+        del probe
+
+
+def main(out, poisoned):
+    if poisoned:
+        poison()
+    import bench
+    from ngmix_amd.batch import GMixBatch
+    from ngmix_amd.lm_batch import LMBatchFitter
+    from ngmix_amd.gaussmom import GaussMomBatch
+    from test_gpu_lm_team import _multiband
+    rng = np.random.RandomState(77)
+    n = 3000
+    sb, gm, pars = bench.make_workload(n, 31, "cuda")
+    guess = pars * rng.uniform(0.95, 1.05, size=pars.shape)
+    psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (n, 1)), "gauss")
+    res = {}
+
+    def keep(prefix, d):
+        for k, v in d.items():
+            v = np.asarray(v)
+            if v.dtype.kind in "fiub":
+                res[prefix + k] = v
+    keep("lm6_", LMBatchFitter("exp").go(sb, guess, psf=psf))
+    sbm, psfm, g2, sobj, sband = _multiband(400, 6, "exp", np.random.RandomState(78))
+    keep("lm11_", LMBatchFitter("exp").go(sbm, g2, psf=psfm, stamp_obj=sobj, stamp_band=sband))
+    keep("fd_", LMBatchFitter("turb").go(sb, guess, psf=psf))       # forward differences
+    ll, _ = sb.loglike(gm)
+    fd, _ = sb.fill_fdiff(gm)
+    im, _ = sb.render(gm)
+    res.update(loglike=ll.cpu().numpy(), fdiff=fd.cpu().numpy(), render=im.cpu().numpy())
+    c4 = bench.make_c4(2000, 9, "cuda")
+    wt = c4["wt0"].clone()
+    ares, _ = c4["sb"].admom(wt)
+    res.update(admom=ares.cpu().numpy(), admom_wt=wt.data.cpu().numpy())
+    g0 = c4["gm0"].clone()
+    eo, _, conv = c4["sb_em"].em(g0, c4["psf"], sky=c4["sky"])
+    res.update(em=eo.cpu().numpy(), em_gm=g0.data.cpu().numpy(), em_conv=conv.data.cpu().numpy())
+    mom = GaussMomBatch(fwhm=1.2).go(c4["sb"])
+    for k in ("flags", "pars", "sums", "sums_cov", "T", "flux", "s2n"):
+        res["mom_" + k] = np.asarray(mom[k])
+    np.savez(out, **res)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] == "1")
