@@ -301,3 +301,100 @@ def test_results_do_not_depend_on_what_the_allocations_held(tmp_path):
         assert a.dtype == b.dtype and a.shape == b.shape, k
         assert a.tobytes() == b.tobytes(), k
     assert np.mean(first["lm6_flags"] == 0) > 0.99 and np.mean(first["lm11_flags"] == 0) > 0.9
+
+
+def test_kernels_write_only_inside_their_outputs():
+    """every output a caller can hand to the batch kernels is given as the
+    inside of a larger buffer with 32 kB of sentinel either side, on a ragged
+    batch whose stamps fill their tiles badly (7x5 ... 90x17, masked pixels):
+    after loglike / fill_fdiff / render / s2n / weighted sums / admom / EM the
+    sentinels are untouched and the insides equal what the same call writes
+    into plain tensors"""
+    import torch
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    from test_gpu_pixpass import _random_mixtures
+    rng = np.random.RandomState(404)
+    scale = 0.263
+    shapes = [(7, 5), (25, 27), (33, 31), (48, 48), (17, 90), (64, 64), (9, 64), (31, 8),
+              (40, 44), (65, 63), (1, 70), (3, 3)] * 3
+    n = len(shapes)
+    imgs = [rng.normal(size=sh) + 3.0 for sh in shapes]
+    wts = [rng.uniform(0.5, 2.0, size=sh) for sh in shapes]
+    for w in wts:
+        w[rng.uniform(size=w.shape) < 0.05] = 0.0
+        w.flat[0] = 1.0
+    jacs = [np.array([(sh[0] - 1) / 2 + rng.uniform(-0.5, 0.5), (sh[1] - 1) / 2 + rng.uniform(-0.5, 0.5),
+                      scale, 0.01, -0.01, scale, scale * scale + 1e-4, scale]) for sh in shapes]
+    sb = StampBatch.from_arrays(imgs, wts, jacs, [True] * n)
+    gm = GMixBatch.from_numpy(_random_mixtures(rng, n, 6, scale))
+    PAD, SENT = 4096, -1234.5
+
+    def guarded(numel, dtype=torch.float64, fill=0.0):
+        buf = torch.full((numel + 2 * PAD,), SENT, dtype=dtype, device="cuda")
+        buf[PAD:PAD + numel] = fill
+        return buf, buf[PAD:PAD + numel]
+
+    def intact(buf, numel, what):
+        sent = SENT if buf.dtype.is_floating_point else int(SENT)
+        assert bool((buf[:PAD] == sent).all()) and bool((buf[PAD + numel:] == sent).all()), what
+
+    # ---- pixel pass
+    for exact in (False, True):
+        ref_out, ref_st = sb.loglike(gm, exact=exact)
+        b1, out = guarded(n * 4)
+        b2, st = guarded(n, torch.int32)
+        sb.loglike(gm, out=out.view(n, 4), status=st, exact=exact)
+        intact(b1, n * 4, "loglike out")
+        intact(b2, n, "loglike status")
+        assert torch.equal(out.view(n, 4), ref_out) and torch.equal(st, ref_st)
+        ref_fd, _ = sb.fill_fdiff(gm, exact=exact)
+        b, fd = guarded(ref_fd.numel())
+        sb.fill_fdiff(gm, fdiff=fd, exact=exact)
+        intact(b, ref_fd.numel(), "fdiff")
+        assert torch.equal(fd, ref_fd)
+        base = torch.from_numpy(rng.normal(size=sb.total_pix)).cuda()
+        ref_im = base.clone()
+        sb.render(gm, image=ref_im, exact=exact)
+        b, im = guarded(sb.total_pix)
+        im.copy_(base)
+        sb.render(gm, image=im, exact=exact)
+        intact(b, sb.total_pix, "render")
+        assert torch.equal(im, ref_im)
+    # ---- weighted sums, adaptive moments, EM
+    wpars = np.zeros((n, 6))
+    wpars[:, 4] = rng.uniform(0.3, 1.0, size=n)
+    wpars[:, 5] = 1.0
+    for nmom in (6, 17):
+        wt, _ = GMixBatch.from_pars(wpars, "gauss")
+        wt.set_norms()
+        ww = wts if nmom == 6 else [np.where(w > 0, w, 1.0) for w in wts]
+        sbw = StampBatch.from_arrays(imgs, ww, jacs, [True] * n)
+        ref, _ = sbw.weighted_sums(wt, np.full(n, 8.0), nmom=nmom)
+        b, res = guarded(ref.numel())
+        sbw.weighted_sums(wt, np.full(n, 8.0), nmom=nmom, res=res.view(ref.shape))
+        intact(b, ref.numel(), "weighted sums %d" % nmom)
+        assert torch.equal(res.view(ref.shape).view(torch.int64), ref.view(torch.int64))
+    wt, _ = GMixBatch.from_pars(wpars, "gauss")
+    ref, ref_st = sb.admom(wt.clone(), maxiter=30)
+    b1, res = guarded(ref.numel())
+    b2, st = guarded(n, torch.int32)
+    sb.admom(wt.clone(), maxiter=30, res=res.view(ref.shape), status=st)
+    intact(b1, ref.numel(), "admom records")
+    intact(b2, n, "admom status")
+    assert torch.equal(res.view(ref.shape).view(torch.int64), ref.view(torch.int64))
+    epars = np.zeros((n, 6))
+    epars[:, 0] = 1.0
+    epars[:, 3] = epars[:, 5] = rng.uniform(0.1, 0.5, size=n)
+    delta = np.zeros((n, 6))
+    delta[:, 5] = 1.0
+    psf, _ = GMixBatch.from_pars(delta, "gauss")
+    sbe = StampBatch.from_arrays([im + 10.0 for im in imgs], wts, jacs, [True] * n)
+    g0, _ = GMixBatch.from_pars(epars, "full", ngauss=1)
+    ref, ref_st, _ = sbe.em(g0.clone(), psf, sky=10.0, miniter=5, maxiter=20)
+    b1, out = guarded(n * 3)
+    b2, st = guarded(n, torch.int32)
+    sbe.em(g0.clone(), psf, sky=10.0, miniter=5, maxiter=20, out=out.view(n, 3), status=st)
+    intact(b1, n * 3, "em out")
+    intact(b2, n, "em status")
+    assert torch.equal(out.view(n, 3).view(torch.int64), ref.view(torch.int64))
+    assert torch.equal(st, ref_st)
