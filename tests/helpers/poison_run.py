@@ -73,6 +73,28 @@ def main(out, poisoned):
     mom = GaussMomBatch(fwhm=1.2).go(c4["sb"])
     for k in ("flags", "pars", "sums", "sums_cov", "T", "flux", "s2n"):
         res["mom_" + k] = np.asarray(mom[k])
+    # ---- the pipelines of SURVEY 8(f): psf fit -> guess -> object fit (EM and
+    # co-elliptical psf fits: the team form on 25x25 row-major tiles), template fluxes
+    from ngmix_amd.batch import StampBatch
+    from ngmix_amd.pipeline import bootstrap_batch
+    from ngmix_amd.psfflux import PSFFluxBatch
+    nb, pdim = 600, 25
+    sbb, _, _ = bench.make_workload(nb, 41, "cuda")
+    tpsf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.02, -0.01, 0.4, 1.0], (nb, 1)), "turb")
+    pj = torch.from_numpy(np.tile([12.0, 12.0, bench.SCALE, 0.0, 0.0, bench.SCALE,
+                                   bench.SCALE ** 2, bench.SCALE], (nb, 1))).cuda()
+    off = np.arange(nb, dtype=np.int64) * pdim * pdim
+    geom = StampBatch(None, None, pj, np.full(nb, pdim), np.full(nb, pdim), off, True)
+    pim, _ = geom.render(tpsf)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    pim += 1e-5 * torch.randn(pim.shape, generator=gen, device="cuda", dtype=torch.float64)
+    psb = StampBatch(pim, torch.full_like(pim, 1e5), pj, np.full(nb, pdim), np.full(nb, pdim),
+                     off, True)
+    keep("boot_em2_", bootstrap_batch(sbb, psb, model="exp", psf_ngauss=2))
+    keep("boot_co3_", bootstrap_batch(sbb, psb, model="exp", psf_ngauss=3, psf_fitter="coellip",
+                                      fit_pars={"maxfev": 300, "ftol": 1e-5, "xtol": 1e-5}))
+    keep("psfflux_", PSFFluxBatch().go(sbb, tpsf))
     np.savez(out, **res)
 
 
