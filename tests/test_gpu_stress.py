@@ -398,3 +398,53 @@ def test_kernels_write_only_inside_their_outputs():
     intact(b2, n, "em status")
     assert torch.equal(out.view(n, 3).view(torch.int64), ref.view(torch.int64))
     assert torch.equal(st, ref_st)
+
+
+def test_results_on_a_side_stream(bench):
+    """the batch entry points under torch.cuda.stream(side) -- uploads, kernels,
+    downloads all follow the caller's current stream -- while the default
+    stream is kept busy with unrelated work: five rounds, the same bytes as on
+    the default stream"""
+    import torch
+    from ngmix_amd.batch import GMixBatch
+    from ngmix_amd.lm_batch import LMBatchFitter
+    from ngmix_amd.gaussmom import GaussMomBatch
+    rng = np.random.RandomState(91)
+    n = 4000
+    sb, gm, pars = bench.make_workload(n, 51, "cuda")
+    guess = pars * rng.uniform(0.95, 1.05, size=pars.shape)
+    psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (n, 1)), "gauss")
+    c4 = bench.make_c4(3000, 19, "cuda")
+
+    def everything():
+        out = {}
+        for k, v in LMBatchFitter("exp").go(sb, guess, psf=psf).items():
+            v = np.asarray(v)
+            if v.dtype.kind in "fiub":
+                out["lm_" + k] = v
+        ll, _ = sb.loglike(gm)
+        fd, _ = sb.fill_fdiff(gm)
+        im, _ = sb.render(gm)
+        out.update(loglike=ll.cpu().numpy(), fdiff=fd.cpu().numpy(), render=im.cpu().numpy())
+        wt = c4["wt0"].clone()
+        res, _ = c4["sb"].admom(wt)
+        out.update(admom=res.cpu().numpy(), admom_wt=wt.data.cpu().numpy())
+        g0 = c4["gm0"].clone()
+        eo, _, _ = c4["sb_em"].em(g0, c4["psf"], sky=c4["sky"])
+        out.update(em=eo.cpu().numpy(), em_gm=g0.data.cpu().numpy())
+        mom = GaussMomBatch(fwhm=1.2).go(c4["sb"])
+        out.update(mom_pars=np.asarray(mom["pars"]), mom_cov=np.asarray(mom["sums_cov"]))
+        return out
+
+    first = everything()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    noise = torch.randn(1 << 24, device="cuda")
+    for r in range(5):
+        for _ in range(20):                       # unrelated work queued on the default stream
+            noise = noise * 1.0000001 + 1e-9
+        with torch.cuda.stream(side):
+            again = everything()
+        for k in sorted(first):
+            assert first[k].tobytes() == again[k].tobytes(), "round %d: %s" % (r, k)
+    torch.cuda.synchronize()
