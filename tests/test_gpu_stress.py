@@ -400,21 +400,17 @@ def test_kernels_write_only_inside_their_outputs():
     assert torch.equal(st, ref_st)
 
 
-def test_results_on_a_side_stream(bench):
-    """the batch entry points under torch.cuda.stream(side) -- uploads, kernels,
-    downloads all follow the caller's current stream -- while the default
-    stream is kept busy with unrelated work: five rounds, the same bytes as on
-    the default stream"""
-    import torch
+def _entry_points(bench, seed, n=4000):
+    """a closure that runs the batch entry points on its own workload and
+    returns their results as host arrays"""
     from ngmix_amd.batch import GMixBatch
     from ngmix_amd.lm_batch import LMBatchFitter
     from ngmix_amd.gaussmom import GaussMomBatch
-    rng = np.random.RandomState(91)
-    n = 4000
-    sb, gm, pars = bench.make_workload(n, 51, "cuda")
+    rng = np.random.RandomState(seed)
+    sb, gm, pars = bench.make_workload(n, seed + 1, "cuda")
     guess = pars * rng.uniform(0.95, 1.05, size=pars.shape)
     psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (n, 1)), "gauss")
-    c4 = bench.make_c4(3000, 19, "cuda")
+    c4 = bench.make_c4(3 * n // 4, seed + 2, "cuda")
 
     def everything():
         out = {}
@@ -435,7 +431,16 @@ def test_results_on_a_side_stream(bench):
         mom = GaussMomBatch(fwhm=1.2).go(c4["sb"])
         out.update(mom_pars=np.asarray(mom["pars"]), mom_cov=np.asarray(mom["sums_cov"]))
         return out
+    return everything
 
+
+def test_results_on_a_side_stream(bench):
+    """the batch entry points under torch.cuda.stream(side) -- uploads, kernels,
+    downloads all follow the caller's current stream -- while the default
+    stream is kept busy with unrelated work: five rounds, the same bytes as on
+    the default stream"""
+    import torch
+    everything = _entry_points(bench, 91)
     first = everything()
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
@@ -447,4 +452,37 @@ def test_results_on_a_side_stream(bench):
             again = everything()
         for k in sorted(first):
             assert first[k].tobytes() == again[k].tobytes(), "round %d: %s" % (r, k)
+    torch.cuda.synchronize()
+
+
+def test_two_host_threads_on_their_own_streams(bench):
+    """two host threads, each with its own workload, fitter and stream, run the
+    batch entry points at the same time (ctypes drops the GIL inside the
+    library: its launchers, the census map, the per-thread workspaces and the
+    last-error string are entered concurrently): three rounds each, the same
+    bytes as each thread's workload gives alone"""
+    import threading
+    import torch
+    jobs = [_entry_points(bench, 201, 2500), _entry_points(bench, 301, 3100)]
+    alone = [j() for j in jobs]
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for r in range(3):
+                    again = jobs[i]()
+                    for k in sorted(alone[i]):
+                        assert alone[i][k].tobytes() == again[k].tobytes(), \
+                            "thread %d round %d: %s" % (i, r, k)
+        except BaseException as e:          # noqa: B902 -- reported by the main thread
+            errors.append(repr(e))
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=400)
+    assert not any(t.is_alive() for t in threads), "a thread did not finish"
+    assert not errors, errors
     torch.cuda.synchronize()
