@@ -262,3 +262,46 @@ def test_library_matches_sources():
     assert not _lib.library_is_stale()
     assert "pixpass.hip" in _lib._makefile_list("SRCS")
     assert "common.hpp" in _lib._makefile_list("HDRS")
+
+
+def test_no_fallback_when_the_library_is_missing(tmp_path):
+    """the product path fails loudly: a process told to load a library that is
+    not there (NGMIX_HIP_LIB) gets an exception from the first call that needs
+    it -- there is no CPU path to fall back to, and nothing under ngmix_amd/
+    imports the oracle"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NGMIX_HIP_LIB=str(tmp_path / "no_such_library.so"))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from ngmix_amd import _lib\n"
+            "_lib.lib()\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=300)
+    assert r.returncode != 0
+    assert b"no_such_library.so" in r.stderr and b"OSError" in r.stderr
+    # and no module of the package reaches for the oracle
+    pkg = os.path.join(root, "ngmix_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                with open(os.path.join(dirpath, f), errors="replace") as fh:
+                    text = fh.read()
+                assert "ngmix_oracle" not in text and "from oracle" not in text \
+                    and "import oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_compute_calls_need_a_gpu():
+    """without a GPU every compute entry point of the Python shell raises (the
+    host classes build, their pixel loops do not run anywhere else)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import ngmix_amd as ngmix
+    from ngmix_amd.batch import StampBatch
+    gm = ngmix.GMixModel([0.0, 0.0, 0.0, 0.0, 0.5, 1.0], "gauss")
+    with pytest.raises(RuntimeError, match="needs a GPU"):
+        gm.make_image((16, 16), jacobian=ngmix.DiagonalJacobian(row=7.5, col=7.5, scale=0.263))
+    with pytest.raises(RuntimeError, match="needs a GPU"):
+        StampBatch.from_images(np.zeros((2, 8, 8)), np.ones((2, 8, 8)),
+                               np.array([3.5, 3.5, 1.0, 0.0, 0.0, 1.0, 1.0, 1.0]))
