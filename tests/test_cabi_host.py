@@ -305,3 +305,47 @@ def test_compute_calls_need_a_gpu():
     with pytest.raises(RuntimeError, match="needs a GPU"):
         StampBatch.from_images(np.zeros((2, 8, 8)), np.ones((2, 8, 8)),
                                np.array([3.5, 3.5, 1.0, 0.0, 0.0, 1.0, 1.0, 1.0]))
+
+
+def test_bad_arguments_are_refused_before_anything_runs():
+    """the entry points that check their arguments return NGMIX_ERR_BAD_ARG
+    before the first device call: callable here, without a GPU (anything that
+    went on to a hip* call would come back with a runtime error instead)"""
+    L = _lib.lib()
+    bad = _lib.ERR_BAD_ARG
+    assert L.ngmix_events_create(-1, None) == bad
+    assert L.ngmix_events_create(3, None) == bad
+    assert L.ngmix_events_destroy(-2, None) == bad
+    assert L.ngmix_event_record(None, None) == bad
+    assert L.ngmix_event_synchronize(None) == bad
+    assert L.ngmix_event_elapsed_ms(None, None, None) == bad
+    gm = np.zeros(1, dtype=_lib.GAUSS2D_DTYPE)
+    pix = np.zeros(4, dtype=_lib.PIXEL_DTYPE)
+    pars = np.zeros(8)
+    # NGMIX_MODEL_CM = 9: the composite model has its own entry point (gmix_fill_cm)
+    assert L.ngmix_fill_model(_lib.ptr(gm), 1, 9, _lib.ptr(pars), 8) == bad
+    img = np.zeros((2, 2))
+    jac = np.zeros(1, dtype=_lib.JACOBIAN_DTYPE)
+    for nrow, ncol in ((0, 5), (-1, 4), (1 << 16, 1 << 16)):
+        assert L.ngmix_fill_pixels(_lib.ptr(pix), 4, _lib.ptr(img), _lib.ptr(img), nrow, ncol,
+                                   _lib.ptr(jac), 1) == bad
+    res = np.zeros(1, dtype=_lib.moments_result_dtype(6))
+    for nmom in (0, 7, 16, 18):
+        assert L.ngmix_get_weighted_sums(_lib.ptr(gm), 1, _lib.ptr(pix), 4, _lib.ptr(res), nmom,
+                                         10.0) == bad
+    conf = np.zeros(1, dtype=_lib.EM_CONF_DTYPE)
+    sums = np.zeros(14)
+    numiter, frac, sky = ctypes.c_int32(), ctypes.c_double(), ctypes.c_double()
+    for kind, ng, npsf in ((-1, 1, 1), (4, 1, 1), (0, 0, 1), (0, 1, 0)):
+        assert L.ngmix_em_run(kind, _lib.ptr(conf), _lib.ptr(pix), 4, _lib.ptr(sums), _lib.ptr(gm),
+                              ng, _lib.ptr(gm), npsf, _lib.ptr(gm), 0, ctypes.byref(numiter),
+                              ctypes.byref(frac), ctypes.byref(sky)) == bad
+    states = np.zeros(2, dtype=_lib.LM_STATE_DTYPE)
+    x0 = np.zeros((2, 6))
+    for npars in (0, -3, _lib.LM_NPMAX + 1):
+        assert L.ngmix_lm_init(_lib.ptr(states), 2, npars, _lib.ptr(x0), 1e-5, 1e-5, 0.0, 100,
+                               100.0, 0, None, None) == bad
+        assert L.ngmix_lm_init_batch(_lib.ptr(states), 2, npars, _lib.ptr(x0), 1e-5, 1e-5, 0.0,
+                                     100, 100.0, 0, None, None, None) == bad
+    assert L.ngmix_lm_init(_lib.ptr(states), -1, 6, _lib.ptr(x0), 1e-5, 1e-5, 0.0, 100, 100.0, 0,
+                           None, None) == bad
