@@ -162,6 +162,47 @@ def test_seam_render_loglike_fdiff(golden, name):
     np.testing.assert_array_equal(acc.reshape(shape), g[name + "_render_accum"])
 
 
+# SURVEY.md 8(d), "C1 single stamp" (oracle/gen_golden_c1.py: the reference's
+# own numbers for the survey's exact inputs)
+SURVEY_C1 = (-1158.1127300983387, 2798242.571962917, 2798842.226964671, 2304)
+
+
+@pytest.mark.parametrize("exact", [True, False], ids=["exact", "fused"])
+def test_c1_survey_values(golden, exact):
+    """config C1 as SURVEY.md states it -- RandomState(1), the true mixture --
+    through the seam form ngmix_get_loglike and through the batch kernel:
+    loglike / s2n sums to 1e-10 relative (north_star), npix exact"""
+    from ngmix_amd.batch import StampBatch, GMixBatch
+    g = golden("c1")
+    L = _lib.lib()
+    gm = as_gauss(g["gmix_in"])
+    jac = jac_rec(g["jac"])
+    st, pixels = seam_make_pixels(g["image"], g["weight"], jac, True)
+    assert st == 0 and pixels.size == SURVEY_C1[3]
+    ll, sn, sd = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    npix = ctypes.c_int64()
+    assert L.ngmix_get_loglike(_lib.ptr(gm), gm.size, _lib.ptr(pixels), pixels.size,
+                               ctypes.byref(ll), ctypes.byref(sn), ctypes.byref(sd),
+                               ctypes.byref(npix)) == 0
+    np.testing.assert_allclose([ll.value, sn.value, sd.value], SURVEY_C1[:3],
+                               rtol=1e-10, atol=0)
+    assert npix.value == SURVEY_C1[3]
+    for n in _lib.GAUSS2D_DTYPE.names:
+        np.testing.assert_array_equal(gm[n], g["gmix_normed"][n], err_msg=n)
+
+    sb = StampBatch.from_images(g["image"], g["weight"], g["jac"])
+    gmb = GMixBatch.from_numpy(as_gauss(g["gmix_in"]))
+    out, status = sb.loglike(gmb, exact=exact)
+    out = out.cpu().numpy()[0]
+    assert int(status.cpu()[0]) == 0
+    np.testing.assert_allclose(out[:3], SURVEY_C1[:3], rtol=1e-10, atol=0)
+    assert out[3] == SURVEY_C1[3]
+    fdiff, _ = sb.fill_fdiff(gmb, exact=exact)
+    assert_pixels(fdiff.cpu().numpy()[:2304], g["fdiff"], exact)
+    im, _ = sb.render(gmb, fast_exp=True, exact=exact)
+    assert_pixels(im.cpu().numpy().reshape(48, 48), g["render_fast"], exact)
+
+
 def test_seam_range_error():
     L = _lib.lib()
     gm = np.zeros(2, dtype=_lib.GAUSS2D_DTYPE)

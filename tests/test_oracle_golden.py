@@ -210,10 +210,35 @@ def test_render_loglike_fdiff(golden, name):
     np.testing.assert_array_equal(acc.reshape(image.shape), g[name + "_render_accum"])
 
 
+# SURVEY.md 8(d), "C1 single stamp": the numbers the survey measured from the
+# reference (oracle/gen_golden_c1.py asserts them before writing c1.npz)
+SURVEY_C1 = (-1158.1127300983387, 2798242.571962917, 2798842.226964671, 2304)
+
+
 def test_c1_survey_values(golden):
-    """values measured from the reference during the survey"""
-    ref = golden("render_loglike")["c1_exp48_loglike"]
-    assert int(ref[3]) == 2304
+    """SURVEY.md 8(d) C1 with the survey's exact inputs (RandomState(1), the
+    true mixture): the oracle returns the survey's numbers to the bit"""
+    g = golden("c1")
+    assert tuple(g["loglike"][:3]) + (int(g["loglike"][3]),) == SURVEY_C1
+    jac = g["jac"].astype(ora.JACOBIAN_DTYPE)
+    pixels = ora.make_pixels(g["image"], g["weight"], jac, True)
+    gm = np.zeros(6, dtype=ora.GAUSS2D_DTYPE)
+    assert ora.gmix_fill(gm, g["pars"], "exp") == 0
+    assert_gauss_equal(gm, g["gmix_in"], rtol=1e-14)
+    gm = as_gauss(g["gmix_in"])
+    st, (ll, sn, sd, npix) = ora.get_loglike(gm, pixels)
+    assert st == 0
+    assert (ll, sn, sd, npix) == SURVEY_C1
+    assert_gauss_equal(gm, g["gmix_normed"], fields=GFIELDS + NFIELDS)
+    fdiff = np.zeros(pixels.size)
+    assert ora.fill_fdiff(gm, pixels, fdiff, 0) == 0
+    np.testing.assert_array_equal(fdiff, g["fdiff"])
+    # loglike = -chi2 / 2 over the same residuals
+    assert abs(-0.5 * np.sum(fdiff ** 2) / SURVEY_C1[0] - 1.0) < 1e-13
+    coords = ora.make_coords(g["image"].shape, jac)
+    im = np.zeros(g["image"].size)
+    assert ora.render(gm, coords, im, 1) == 0
+    np.testing.assert_array_equal(im.reshape(g["image"].shape), g["render_fast"])
 
 
 # ----------------------------------------------------------- weighted sums
