@@ -130,8 +130,10 @@ class PSFFluxBatch(object):
     def __init__(self, normalize_psf=True):
         self.normalize_psf = normalize_psf
 
-    def go(self, stamps, gm, stamp_obj=None):
-        """gm: GMixBatch, one mixture per stamp (any flux)"""
+    def go(self, stamps, gm, stamp_obj=None, nobj=None):
+        """gm: GMixBatch, one mixture per stamp (any flux); stamp_obj: the
+        object (any order) each stamp belongs to; nobj: the number of objects
+        when the last ones may own no stamp (they come back DIV_ZERO)"""
         import torch
         ns = stamps.n
         assert gm.n == ns, "one mixture per stamp"
@@ -145,7 +147,7 @@ class PSFFluxBatch(object):
         model, status = stamps.render(g, fast_exp=False)
         # without normalisation the mixture keeps its own flux
         norm = None if self.normalize_psf else psum
-        res = self._solve(stamps, model, norm, stamp_obj)
+        res = self._solve(stamps, model, norm, stamp_obj, nobj)
         res["status"] = status.cpu().numpy()
         return res
 
@@ -164,7 +166,7 @@ class PSFFluxBatch(object):
         return self._solve(stamps, model, norms, stamp_obj)
 
     @staticmethod
-    def _solve(stamps, model, norm, stamp_obj):
+    def _solve(stamps, model, norm, stamp_obj, nobj=None):
         """flux = sum(m I w) / sum(m m w) per object, chi2 of the scaled
         template, and the flags / errors of PSFFluxFitModel.go
         (results.py:700-770) for every object at once.
@@ -185,9 +187,9 @@ class PSFFluxBatch(object):
             sobj = np.arange(ns, dtype=np.int64)
         else:
             sobj = np.ascontiguousarray(stamp_obj, dtype=np.int64)
-            if sobj.shape != (ns,) or np.any(np.diff(sobj) < 0):
-                raise ValueError("stamp_obj must be (nstamps,) and non-decreasing")
-        nobj = int(sobj.max()) + 1 if ns else 0
+            if sobj.shape != (ns,) or (ns and sobj.min() < 0):
+                raise ValueError("stamp_obj must be (nstamps,) object indices")
+        nobj = max(int(sobj.max()) + 1 if ns else 0, int(nobj or 0))
         d_sobj = torch.from_numpy(sobj).to(dev)
         # Two launches of one fused kernel (csrc/template.hip: one pass over the
         # model, image and ierr planes each) instead of a dozen torch passes
