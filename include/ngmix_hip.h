@@ -651,10 +651,31 @@ typedef struct {
     double prior_step;               /* step_rel of ngmix_lm_prior_sums_batch */
     int32_t model, fd, npsf;
     int32_t nloc_npars;              /* nloc + 256 * npars, as ngmix_lm_advance_batch */
+    double *jac_point;               /* (nobj, 3, NGMIX_LM_NPMAX) or NULL: forward-difference
+                                        passes that evaluate a jacobian leave xt | xstep |
+                                        hstep of the state there -- the point of the fit's
+                                        LAST jacobian once it has ended
+                                        (ngmix_lm_precise_cov_batch) */
 } ngmix_lm_problem;
 int ngmix_lm_rounds_batch(const ngmix_lm_problem *problem, int nrounds,
                           int32_t *counts, int32_t *counts_host, void **events,
                           void *stream);
+/* DEVICE: the covariance factor of ill-conditioned forward-difference fits.
+   scipy's leastsq takes cov_x from MINPACK's QR of the last jacobian
+   (leastsqbound.py:76-118,535-552); the rounds above carry the Cholesky factor
+   of J^T J in doubles, which stops existing numerically near cond(J) = 1e8 --
+   where the co-elliptical psf fits with three and more gaussians live
+   (CoellipFitter, fitters.py:120-141).  After the rounds of `problem` have
+   ended and before ngmix_lm_finalize_batch, this call re-makes R and ipvt of
+   every fit that ended with info 1-4: one more forward-difference pass at
+   jac_point with X^T X accumulated in double-double (error-free
+   transformations), then factor_normal's pivoted Cholesky in double-double
+   arithmetic, one wave per fit.  Serves nloc >= NGMIX_LM_PRECISE_MIN_NLOC;
+   psums: workspace (nstamps, 2, NGMIX_LM_NSUMS(nloc)).  The iterates, nfev
+   and ier are untouched */
+#define NGMIX_LM_PRECISE_MIN_NLOC 10
+int ngmix_lm_precise_cov_batch(const ngmix_lm_problem *problem, double *psums,
+                               void *stream);
 /* HOST: n timing events (hipEvent_t) for ngmix_lm_rounds_batch / to record
    on a stream; elapsed milliseconds between two recorded events (both must
    have completed: synchronise the stream or the later event first) */

@@ -95,6 +95,7 @@ def moments_result_dtype(nmom):
 
 
 LM_NPMAX = 14
+LM_PRECISE_MIN_NLOC = 10  # ngmix_lm_precise_cov_batch serves nloc >= this
 LM_NPARS_GENERIC = 255   # ngmix_lm_advance_batch: asks for the generic step
 LM_NSUM = 28
 LM_PHASE_DONE = 2
@@ -172,6 +173,7 @@ class LMProblem(ctypes.Structure):
         ("fd", ctypes.c_int32),
         ("npsf", ctypes.c_int32),
         ("nloc_npars", ctypes.c_int32),
+        ("jac_point", ctypes.c_void_p),
     ]
 
 
@@ -260,6 +262,7 @@ SIGNATURES = {
     "ngmix_launch_census": (_i64, [ctypes.c_char_p, _i64, _i32]),
     "ngmix_lm_pack_batch": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngmix_lm_rounds_batch": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp]),
+    "ngmix_lm_precise_cov_batch": (_i32, [_vp, _vp, _vp]),
     "ngmix_events_create": (_i32, [_i32, _vp]),
     "ngmix_events_destroy": (_i32, [_i32, _vp]),
     "ngmix_event_record": (_i32, [_vp, _vp]),

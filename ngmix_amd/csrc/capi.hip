@@ -717,6 +717,11 @@ int ngmix_lm_rounds_batch(const ngmix_lm_problem *problem, int nrounds, int32_t 
                             (hipStream_t)stream);
 }
 
+int ngmix_lm_precise_cov_batch(const ngmix_lm_problem *problem, double *psums, void *stream)
+{
+    return launch_lm_precise_cov(problem, psums, (hipStream_t)stream);
+}
+
 int ngmix_events_create(int n, void **events)
 {
     if (n < 0 || (n > 0 && !events)) return NGMIX_ERR_BAD_ARG;

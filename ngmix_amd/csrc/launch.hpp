@@ -48,7 +48,11 @@ int launch_set_norms(ngmix_gauss2d *gmix, int ngauss, int64_t nstamps,
 int launch_lm_eval(const ngmix_batch *b, int model, int fd, const ngmix_lm_state *states,
                    const int32_t *stamp_obj, const int32_t *stamp_band,
                    const ngmix_gauss2d *psf, int npsf, double *sums, int32_t *status,
-                   double *stamp_stats, hipStream_t s);
+                   double *stamp_stats, hipStream_t s, double *jac_point = nullptr,
+                   bool precise = false);
+// lm_precise.hip: the covariance factor of the ill-conditioned forward-difference
+// fits from double-double normal equations
+int launch_lm_precise_cov(const ngmix_lm_problem *p, double *psums, hipStream_t s);
 int launch_lm_advance(ngmix_lm_state *states, int64_t nobj, const int64_t *obj_start,
                       const int32_t *stamp_band, const double *sums, int nloc,
                       const double *obj_sums, int32_t *nactive, const double *stamp_stats,

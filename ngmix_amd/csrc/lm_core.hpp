@@ -656,7 +656,8 @@ NGMIX_HD bool simple_sep_rows(const ngmix_simple_sep_prior &P, const double *x,
 
 // the prior rows of one fit at its trial point as normal-equation sums
 // [J^T J upper triangle | J^T r | r.r] over the fit's n = 5 + nband parameters
-NGMIX_HD void simple_sep_normal_sums(const ngmix_simple_sep_prior &P, const lm_state &s,
+template <class State>
+NGMIX_HD void simple_sep_normal_sums(const ngmix_simple_sep_prior &P, const State &s,
                                      double step_rel, double *out)
 {
     constexpr int KMAX = 4 + NGMIX_PRIOR_MAXBAND;

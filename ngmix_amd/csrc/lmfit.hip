@@ -854,20 +854,33 @@ static_assert(sizeof(FdGauss) == 48, "FdGauss");
 // stamp is 16 such tiles for 625 pixels, and 10 row-major ones); a tile is then
 // the rows it touches, whole, for the box test.  Chosen per launch from the
 // batch's largest shape; correct for any shape.
-template <int NLOC, bool LINEAR>
+//
+// PRECISE: the pass behind the covariance of the ill-conditioned fits
+// (ngmix_lm_precise_cov_batch, lm_precise.hip).  It runs once, after the fits
+// have ended, at the point of every fit's LAST jacobian -- jac_point, the
+// record the ordinary passes leave there: (xt | xstep | hstep) of the state at
+// the time -- and accumulates X^T X, X = [J | f], in DOUBLE-DOUBLE: every lane
+// owns two entries of the triangle and adds the 64 pixels of a tile in pixel
+// order, product and sum by error-free transformations (TwoProd by fma,
+// TwoSum), so the sums are exact to ~1e-32 of their magnitude whatever the
+// cancellation.  J^T J of a jacobian with cond(J) ~ 1e8 (co-elliptical psf fits
+// with 3+ gaussians) has cond ~ 1e16: in plain doubles it is not numerically
+// positive definite, and the Cholesky factor MINPACK's QR of J stands for does
+// not exist.  sums: (nstamps, 2, NSUM) = high parts | low parts.
+template <int NLOC, bool LINEAR, bool PRECISE = false>
 // three waves per SIMD up to ten parameters (168 VGPRs, no spills; measured
 // 9.0 -> 8.1 ms per 20k 'bdf' fits against two), two beyond -- and for ten
 // parameters on row-major tiles, which needs two registers more than 168
 __global__ __launch_bounds__(WAVE)
-__attribute__((amdgpu_waves_per_eu(NLOC <= 10 && !(LINEAR && NLOC == 10) ? 3 : 2,
-                                   NLOC <= 10 && !(LINEAR && NLOC == 10) ? 3 : 2)))
+__attribute__((amdgpu_waves_per_eu(!PRECISE && NLOC <= 10 && !(LINEAR && NLOC == 10) ? 3 : 2,
+                                   !PRECISE && NLOC <= 10 && !(LINEAR && NLOC == 10) ? 3 : 2)))
 void lm_eval_fd_kernel(
     const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
     const double *__restrict__ ierr, const ngmix_jacobian *__restrict__ jacs,
     int model, int ng0, const lm_state *__restrict__ states,
     const int32_t *__restrict__ stamp_obj, const int32_t *__restrict__ stamp_band,
     const ngmix_gauss2d *__restrict__ psf, int npsf, double *__restrict__ sums,
-    int32_t *__restrict__ status, int no_skip)
+    int32_t *__restrict__ status, int no_skip, double *__restrict__ jac_point)
 {
     constexpr int NTRI = NLOC * (NLOC + 1) / 2;
     constexpr int NSUM = NTRI + NLOC + 1;
@@ -888,8 +901,13 @@ void lm_eval_fd_kernel(
     const int lane = threadIdx.x;
     const int obj = stamp_obj ? stamp_obj[s] : s;
     const lm_state &state = states[obj];
-    if (state.phase == LM_PHASE_DONE) return;
-    const bool want_jac = state.phase != LM_PHASE_TRIAL;
+    if constexpr (PRECISE) {
+        // the fits that ended with a covariance to make (leastsqbound.py:76-84)
+        if (state.phase != LM_PHASE_DONE || state.info < 1 || state.info > 4) return;
+    } else {
+        if (state.phase == LM_PHASE_DONE) return;
+    }
+    const bool want_jac = PRECISE || state.phase != LM_PHASE_TRIAL;
     const int band = stamp_band ? stamp_band[s] : 0;
     const ngmix_stamp st = stamps[s];
     const ngmix_jacobian jac = jacs[s];
@@ -897,7 +915,17 @@ void lm_eval_fd_kernel(
     const double area = jac.scale * jac.scale;
     const bool izw = (st.flags & NGMIX_STAMP_IGNORE_ZERO_WEIGHT) != 0;
     const bool masked = izw && st.npix_kept != nrow * ncol;
-    double *out = sums + (size_t)s * NSUM;
+    double *out = sums + (size_t)s * (PRECISE ? 2 * NSUM : NSUM);
+    // the point of this jacobian and its fdjac2 steps: kept for the PRECISE
+    // pass (every stamp of an object writes the same record)
+    double *jp = jac_point ? jac_point + (size_t)obj * 3 * LM_NPMAX : nullptr;
+    if constexpr (!PRECISE) {
+        if (jp && want_jac && lane < LM_NPMAX) {
+            jp[lane] = state.xt[lane];
+            jp[LM_NPMAX + lane] = state.xstep[lane];
+            jp[2 * LM_NPMAX + lane] = state.hstep[lane];
+        }
+    }
     const int npsf1 = npsf > 0 ? npsf : 1;
     const int G = ng0 * npsf1;
     FdGauss *ev = (FdGauss *)dyn;                    // [NSETS][G]
@@ -909,9 +937,15 @@ void lm_eval_fd_kernel(
 #pragma unroll
     for (int k = 0; k < NLOC; k++) {
         const int gk = k < NLOC - 1 ? k : NLOC - 1 + band;
-        p0[k] = state.xt[gk];
-        ps[k] = state.xstep[gk];
-        if (lane == 0) unif[k] = 1.0 / state.hstep[gk];
+        if constexpr (PRECISE) {
+            p0[k] = jp[gk];
+            ps[k] = jp[LM_NPMAX + gk];
+            if (lane == 0) unif[k] = 1.0 / jp[2 * LM_NPMAX + gk];
+        } else {
+            p0[k] = state.xt[gk];
+            ps[k] = state.xstep[gk];
+            if (lane == 0) unif[k] = 1.0 / state.hstep[gk];
+        }
     }
     // The model is linear in the flux (the last local parameter of every model
     // but coellip, gmix_nb.py:307-558: p_i = flux * pval_i, nothing else depends
@@ -986,6 +1020,8 @@ void lm_eval_fd_kernel(
         if (lane == 0) {
             for (int k = 0; k < NSUM - 1; k++) out[k] = 0.0;
             out[NSUM - 1] = INFINITY;
+            if constexpr (PRECISE)
+                for (int k = 0; k < NSUM; k++) out[NSUM + k] = 0.0;
             if (status) status[s] = NGMIX_ERR_G_RANGE;
         }
         return;
@@ -1020,6 +1056,29 @@ void lm_eval_fd_kernel(
     typedef double double4_t __attribute__((ext_vector_type(4)));
     double4_t M = {0.0, 0.0, 0.0, 0.0};
     double ff = 0.0;   // trial evaluations want only |f|^2
+    // PRECISE: this lane's entries (a <= b) of X^T X, X = [J | f], NX = NLOC + 1
+    // columns -- entry e = lane + 64 q of the row-major upper triangle -- as
+    // unevaluated sums hi + lo
+    constexpr int NX = NLOC + 1, NE = NX * (NX + 1) / 2, NQ = (NE + WAVE - 1) / WAVE;
+    int ea[NQ], eb[NQ];
+    double dhi[NQ], dlo[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        ea[q] = eb[q] = -1;
+        dhi[q] = dlo[q] = 0.0;
+        if constexpr (PRECISE) {
+            const int e = lane + WAVE * q;
+            if (e < NE) {
+                int a = 0, row = 0;
+                while (row + (NX - a) <= e) {
+                    row += NX - a;
+                    a++;
+                }
+                ea[q] = a;
+                eb[q] = a + (e - row);
+            }
+        }
+    }
     {
         double *jb = jbuf + lane * JSTRIDE;
 #pragma unroll
@@ -1176,7 +1235,26 @@ void lm_eval_fd_kernel(
                 }
                 jb[NLOC] = f;
                 __syncthreads();   // one wave: orders the LDS traffic, no s_barrier
-                if (PACKED) {
+                if constexpr (PRECISE) {
+                    // Dot2 (Ogita, Rump, Oishi): the product's rounding error by
+                    // fma, the sum's by TwoSum, both gathered in lo
+#pragma unroll 4
+                    for (int pix = 0; pix < WAVE; pix++) {
+                        const double *xr = jbuf + pix * JSTRIDE;
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) {
+                            if (ea[q] < 0) continue;
+                            const double xa = xr[ea[q]], xb = xr[eb[q]];
+                            const double pr = xa * xb;
+                            const double pe = __builtin_fma(xa, xb, -pr);
+                            const double sm = dhi[q] + pr;
+                            const double bb = sm - dhi[q];
+                            const double se = (dhi[q] - (sm - bb)) + (pr - bb);
+                            dhi[q] = sm;
+                            dlo[q] += se + pe;
+                        }
+                    }
+                } else if (PACKED) {
                     // X has at most 8 columns: two groups of four pixels side by
                     // side, X' = [X_a | X_b] -- the diagonal 8 x 8 blocks of
                     // X'^T X' are X_a^T X_a and X_b^T X_b (added at the end), and
@@ -1206,7 +1284,18 @@ void lm_eval_fd_kernel(
     if (cocen) tiles(std::true_type{});
     else tiles(std::false_type{});
 
-    if (!want_jac) {
+    if constexpr (PRECISE) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            if (ea[q] < 0) continue;
+            const int row = ea[q], col = eb[q];
+            const int k = col < NLOC ? row * NLOC - row * (row - 1) / 2 + (col - row)
+                                     : (row < NLOC ? NTRI + row : NSUM - 1);
+            const double hi = dhi[q] + dlo[q];
+            out[k] = hi;
+            out[NSUM + k] = dlo[q] - (hi - dhi[q]);
+        }
+    } else if (!want_jac) {
         const double tot = wave_total(ff);
         // (the jacobian slots are not read for a trial evaluation)
         if (lane == 0) out[NSUM - 1] = tot;
@@ -1645,9 +1734,13 @@ static int model_ngauss_npars(int model, int &ng0, int &nloc)
 int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *states,
                    const int32_t *stamp_obj, const int32_t *stamp_band,
                    const ngmix_gauss2d *psf, int npsf, double *sums, int32_t *status,
-                   double *stamp_stats, hipStream_t s)
+                   double *stamp_stats, hipStream_t s, double *jac_point, bool precise)
 {
     if (b->nstamps <= 0) return NGMIX_OK;
+    if (precise && (!fd || !jac_point)) {
+        set_last_error_msg("lm_eval: the precise pass is a forward-difference pass at jac_point");
+        return NGMIX_ERR_BAD_ARG;
+    }
     int ng0, nloc;
     if (model_ngauss_npars(model, ng0, nloc) != 0 || npsf < 0) {
         set_last_error_msg("lm_eval: model must be gauss, turb, exp, dev, bdf, bd or "
@@ -1724,17 +1817,38 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *stat
         const char *e = getenv("NGMIX_LM_FD_TILES");
         if (e) linear = e[0] == 'l';
     }
-#define NGMIX_FD_LAUNCH1(N, L)                                                          \
+#define NGMIX_FD_LAUNCH2(N, L, P, NAME)                                                 \
     do {                                                                                \
-        census(L ? "lm_eval_fd_kernel<" #N ", linear>" : "lm_eval_fd_kernel<" #N ">");  \
+        census(NAME);                                                                   \
         if (lds > 48 * 1024)                                                            \
             NGMIX_HIP_CHECK(hipFuncSetAttribute(                                        \
-                (const void *)lm_eval_fd_kernel<N, L>,                                  \
+                (const void *)lm_eval_fd_kernel<N, L, P>,                               \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
-        hipLaunchKernelGGL((lm_eval_fd_kernel<N, L>), grid, block, lds, s, b->stamps,   \
+        hipLaunchKernelGGL((lm_eval_fd_kernel<N, L, P>), grid, block, lds, s, b->stamps, \
                            b->val, b->ierr, b->jac, model, ng0, states, stamp_obj,      \
-                           stamp_band, psf, npsf, sums, status, no_skip);               \
+                           stamp_band, psf, npsf, sums, status, no_skip, jac_point);    \
     } while (0)
+#define NGMIX_FD_LAUNCH1(N, L)                                                          \
+    NGMIX_FD_LAUNCH2(N, L, false,                                                       \
+                     L ? "lm_eval_fd_kernel<" #N ", linear>" : "lm_eval_fd_kernel<" #N ">")
+    if (precise) {
+        // (built for the fits it serves: nine local parameters and up)
+        if (nloc < NGMIX_LM_PRECISE_MIN_NLOC) {
+            set_last_error_msg("lm_eval: the precise pass serves nloc >= 9");
+            return NGMIX_ERR_BAD_ARG;
+        }
+#define NGMIX_FD_PRECISE(N)                                                                  \
+    do {                                                                                     \
+        if (linear) NGMIX_FD_LAUNCH2(N, true, true, "lm_eval_fd_kernel<" #N ", linear, precise>"); \
+        else NGMIX_FD_LAUNCH2(N, false, true, "lm_eval_fd_kernel<" #N ", precise>");        \
+    } while (0)
+        if (nloc <= 10) NGMIX_FD_PRECISE(10);
+        else if (nloc <= 12) NGMIX_FD_PRECISE(12);
+        else NGMIX_FD_PRECISE(14);
+#undef NGMIX_FD_PRECISE
+        NGMIX_HIP_CHECK(hipGetLastError());
+        return NGMIX_OK;
+    }
 #define NGMIX_FD_LAUNCH(N)                                                              \
     do {                                                                                \
         if (linear) NGMIX_FD_LAUNCH1(N, true);                                          \
@@ -1746,6 +1860,7 @@ int launch_lm_eval(const ngmix_batch *b, int model, int fd, const lm_state *stat
     else if (nloc <= 10) NGMIX_FD_LAUNCH(10);
     else if (nloc <= 12) NGMIX_FD_LAUNCH(12);
     else NGMIX_FD_LAUNCH(14);
+#undef NGMIX_FD_LAUNCH2
 #undef NGMIX_FD_LAUNCH1
 #undef NGMIX_FD_LAUNCH
     NGMIX_HIP_CHECK(hipGetLastError());
@@ -1860,7 +1975,7 @@ int launch_lm_rounds(const ngmix_lm_problem *p, int nrounds, int32_t *counts,
         if (events) NGMIX_HIP_CHECK(hipEventRecord((hipEvent_t)events[3 * r], s));
         int rc = launch_lm_eval(p->batch, p->model, p->fd, p->states, p->stamp_obj,
                                 p->stamp_band, p->psf, p->npsf, p->sums, p->status,
-                                p->stamp_stats, s);
+                                p->stamp_stats, s, p->fd ? p->jac_point : nullptr);
         if (rc != NGMIX_OK) return rc;
         if (events) NGMIX_HIP_CHECK(hipEventRecord((hipEvent_t)events[3 * r + 1], s));
         if (p->prior) {

@@ -543,6 +543,18 @@ class LMBatchFitter(object):
                                   dtype=torch.float64, device=dev)
         self.prior_path = ("kernel" if prior_desc is not None else
                            "torch" if self.prior is not None else None)
+        # Forward-difference fits of ten and more local parameters (co-elliptical
+        # psf fits with 3+ gaussians: cond(J) ~ 1e8 at the solution) take their
+        # covariance from a double-double factorisation of the last jacobian's
+        # normal equations (ngmix_lm_precise_cov_batch): the pixel passes leave
+        # the point of every jacobian in d_jacpt.  fitter.precise_cov = False
+        # (NGMIX_LM_NO_PRECISE_COV): the factor the iteration left, as before
+        d_jacpt = None
+        if self.fd and self.nloc >= _lib.LM_PRECISE_MIN_NLOC and \
+                getattr(self, "precise_cov", True) and \
+                not os.environ.get("NGMIX_LM_NO_PRECISE_COV") and \
+                (self.prior is None or prior_desc is not None):
+            d_jacpt = torch.zeros((nobj, 3, _lib.LM_NPMAX), dtype=torch.float64, device=dev)
         if self.prior is not None and prior_desc is None:
             nsplit = 1
         nsplit = max(1, min(int(nsplit), nobj))
@@ -554,6 +566,7 @@ class LMBatchFitter(object):
             d_sband=d_sband, d_start=d_start, d_sums=d_sums, d_status=d_status,
             d_sstats=d_sstats, d_ostats=d_ostats, d_osums=d_osums, modnum=modnum,
             prior_desc=prior_desc, loop_stats=loop_stats, nsplit=nsplit, nsum=nsum,
+            d_jacpt=d_jacpt,
             streaming=streaming, check_every=check_every, ev_init=ev_init,
             npix_obj=npix_obj, d_npix=d_npix, d_all=d_all, h_all=h_all, arena=arena,
             batch=stamps._batch(1), chunks=[], useful_rounds=None, ev_post=None,
@@ -625,6 +638,7 @@ class LMBatchFitter(object):
         P.fd = int(self.fd)
         P.npsf = job.npsf
         P.nloc_npars = self._nloc_npars(job.npars)
+        P.jac_point = opt(job.d_jacpt)
         return P
 
     def _nloc_npars(self, npars):
@@ -722,6 +736,8 @@ class LMBatchFitter(object):
         self.rounds = job.useful_rounds
         self.nsplit_used = job.nsplit
         self._d_states = job.d_states
+        if getattr(self, "keep_job", False):
+            self.last_job = job   # (tests: the device buffers of the batch)
         # (fitter.gmix belongs to the batch whose result is being returned)
         self._fit_ctx = job.fit_ctx
         self._gmix = None
@@ -987,6 +1003,15 @@ class LMBatchFitter(object):
                     stamps, psf, col("x"), obj_start, sband, nskip)
             d_ffx = d_ffx.contiguous()
         ev_post = self._timing_events(3)
+        if job.d_jacpt is not None and not job.host_loop:
+            # R / ipvt of the fits that ended, re-made from double-double normal
+            # equations at the point of their last jacobian
+            if not hasattr(job, "problem"):
+                job.problem = self._problem(job)
+            job.d_psums = torch.empty((job.ns, 2, job.nsum), dtype=torch.float64, device=dev)
+            _lib.check(L.ngmix_lm_precise_cov_batch(
+                ctypes.byref(job.problem), _dptr(job.d_psums), job.stream),
+                "ngmix_lm_precise_cov_batch")
         if True:
             self._record(ev_post, 0, job.stream)
             _lib.check(L.ngmix_lm_finalize_batch(
