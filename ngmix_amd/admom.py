@@ -17,7 +17,8 @@ from .observation import Observation
 from .shape import e1e2_to_g1g2
 from .util import get_ratio_error
 
-__all__ = ["run_admom", "find_cen_admom", "AdmomFitter", "AdmomResult"]
+__all__ = ["run_admom", "run_admom_many", "find_cen_admom", "AdmomFitter", "AdmomResult",
+           "AdmomManyResults"]
 
 DEFAULT_MAXITER = 200
 DEFAULT_SHIFTMAX = 5.0  # pixels
@@ -34,6 +35,16 @@ def run_admom(obs, guess, maxiter=DEFAULT_MAXITER, shiftmax=DEFAULT_SHIFTMAX,
     am = AdmomFitter(maxiter=maxiter, shiftmax=shiftmax, etol=etol, Ttol=Ttol,
                      cenonly=cenonly, rng=rng)
     return am.go(obs=obs, guess=guess)
+
+
+def run_admom_many(obs, guess, maxiter=DEFAULT_MAXITER, shiftmax=DEFAULT_SHIFTMAX,
+                   etol=DEFAULT_ETOL, Ttol=DEFAULT_TTOL, cenonly=False, rng=None):
+    """run_admom over a sequence of Observations as ONE batch (the loop over a
+    catalogue the reference's callers write around run_admom, admom.py:20-71);
+    guess: one T value for all, a sequence of T values, or a sequence of GMix"""
+    am = AdmomFitter(maxiter=maxiter, shiftmax=shiftmax, etol=etol, Ttol=Ttol,
+                     cenonly=cenonly, rng=rng)
+    return am.go_many(obs=obs, guess=guess)
 
 
 def find_cen_admom(obs, fwhm=None, gmix=None, maxiter=DEFAULT_MAXITER,
@@ -93,6 +104,29 @@ class AdmomResult(dict):
         return gm.make_image(obs.image.shape, jacobian=obs.jacobian)
 
 
+class AdmomManyResults(object):
+    """the AdmomResults of AdmomFitter.go_many, made on access from the batch's
+    584-byte records (.records)"""
+
+    def __init__(self, obs, records, wgt_norms):
+        self._obs = obs
+        self.records = records
+        self._norms = wgt_norms
+
+    def __len__(self):
+        return len(self._obs)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        o = self._obs[i]
+        return AdmomResult(obs=o, result=get_result(self.records[i:i + 1].copy(),
+                                                    o.jacobian.area, self._norms[i]))
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 class AdmomFitter(object):
     """adaptive moments fitter; .go(obs, guess) returns an AdmomResult"""
 
@@ -123,6 +157,53 @@ class AdmomFitter(object):
             _lib.check(status, "admom")
         result = get_result(ares, obs.jacobian.area, wt_gmix["norm"][0])
         return AdmomResult(obs=obs, result=result)
+
+    def go_many(self, obs, guess):
+        """the adaptive moments of MANY Observations by one launch of the batch
+        kernel (ngmix_admom_batch); returns an AdmomManyResults: element i is
+        the AdmomResult go(obs[i], guess[i]) returns.  Guesses given as T values
+        are drawn as go() draws them, object after object, from the same
+        stream (admom.py:376-404)"""
+        from .batch import StampBatch, GMixBatch
+        n = len(obs)
+        for o in obs:
+            if not isinstance(o, Observation):
+                raise ValueError("input obs must be an Observation")
+        if np.ndim(guess) == 0 and not isinstance(guess, GMix):
+            guess = np.full(n, float(guess))
+        if len(guess) != n:
+            raise ValueError("one guess per observation")
+        if isinstance(guess[0], GMix):
+            recs = np.stack([g._data for g in guess]).reshape(n)
+        else:
+            # _generate_guess for every object: five draws each, in its order
+            u = self._get_rng().uniform(size=(n, 5))
+            half = 0.5 * np.array([o._jacobian._data["scale"][0] for o in obs])
+            pars = np.zeros((n, 6))
+            pars[:, 0:2] = -half[:, None] + (2.0 * half[:, None]) * u[:, 0:2]
+            pars[:, 2:4] = -0.3 + 0.6 * u[:, 2:4]
+            pars[:, 4] = np.asarray(guess, dtype="f8") * (1.0 + (-0.1 + 0.2 * u[:, 4]))
+            pars[:, 5] = 1.0
+            recs = np.zeros(n, dtype=_lib.GAUSS2D_DTYPE)
+            for i in range(n):
+                # (the host fill of GMixModel: the same arithmetic as go()'s guess)
+                recs[i:i + 1] = GMixModel(pars[i], "gauss")._data
+        stamps = StampBatch.from_observations(list(obs))
+        wt = GMixBatch.from_numpy(recs.reshape(n, 1), device=stamps.device)
+        c = self.conf[0]
+        res, status = stamps.admom(wt, maxiter=int(c["maxiter"]), shiftmax=float(c["shiftmax"]),
+                                   etol=float(c["etol"]), Ttol=float(c["Ttol"]),
+                                   cenonly=bool(c["cenonly"]))
+        from .batch import records_to_numpy
+        ares = records_to_numpy(res, _admom_result_dtype)
+        status = status.cpu().numpy()
+        norms = wt.to_numpy()["norm"][:, 0]
+        bad = (status == _lib.ERR_DET_TOO_LOW) | (status == _lib.ERR_T_TOO_LOW)
+        ares["flags"][bad] = ngflags.GMIX_RANGE_ERROR
+        other = (status != 0) & ~bad
+        if other.any():
+            _lib.check(int(status[other][0]), "admom")
+        return AdmomManyResults(list(obs), ares, norms)
 
     def _get_guess(self, obs, guess):
         if isinstance(guess, GMix):

@@ -281,6 +281,20 @@ class StampBatch(object):
         # the Observations' own arrays (their public properties hand out
         # read-only views and a COPY of the jacobian: 10 us per object, more than
         # the packing itself)
+        n = len(obs_list)
+        if n >= 32:
+            shape = obs_list[0]._image.shape
+            if all(o._image.shape == shape for o in obs_list):
+                # one shape (a survey's stamps): the packing is three np.stack
+                # calls and the per-stamp work numpy's, not a Python loop
+                # (~10 us per object: 1e5 objects a second against the 1.6e7 the
+                # device fits)
+                return cls.from_stacked(
+                    np.stack([o._image for o in obs_list]),
+                    np.stack([o._weight for o in obs_list]),
+                    np.stack([o._jacobian._data for o in obs_list]),
+                    np.fromiter((o._ignore_zero_weight for o in obs_list), dtype=bool,
+                                count=n), device=device)
         return cls.from_arrays([o._image for o in obs_list],
                                [o._weight for o in obs_list],
                                [o._jacobian._data for o in obs_list],
@@ -335,6 +349,81 @@ class StampBatch(object):
                 _dptr(dw), _dptr(dw), dw.numel(), _stream())
         _lib.check(st, "ngmix_weight_to_ierr_batch")
         sb = cls(dval, dw, djac, nrow, ncol, off, izw, npix_kept=kept)
+        sb._stamp_tables[1] = dtab
+        return sb
+
+    @classmethod
+    def from_stacked(cls, images, weights, jac_records, ignore_zero_weight=True,
+                     device=None):
+        """
+        N stamps of ONE shape from HOST arrays -- images, weights (N, nrow,
+        ncol) float64, jacobian records (N,) of the reference dtype or (N, 8)
+        doubles.  What a host-resident catalogue costs is the PCIe transfer of
+        16 bytes per pixel:
+
+          * numpy arrays: one host-to-device copy of [val | weight | jacobians
+            | stamp table] assembled in a staging buffer, the listed pixels
+            counted from the host weights;
+          * torch CPU tensors (PINNED memory: a catalogue read into
+            torch.empty(..., pin_memory=True)): copied from where they lie,
+            asynchronously, with no staging pass over them on the host; the
+            listed pixels are counted by a kernel.
+        """
+        torch = _torch()
+        dev = _require_cuda(device)
+        if isinstance(images, torch.Tensor):
+            assert images.dtype == torch.float64 and weights.dtype == torch.float64
+            n, nrow, ncol = images.shape
+            assert weights.shape == images.shape, "image and weight must match"
+            dval = images.to(dev, non_blocking=True).reshape(-1)
+            dw = weights.to(dev, non_blocking=True).reshape(-1)
+            jr = jac_records if isinstance(jac_records, torch.Tensor) else \
+                torch.from_numpy(np.ascontiguousarray(jac_records).view(np.float64).reshape(n, 8))
+            djac = jr.to(dev, non_blocking=True).reshape(n, 8)
+            if dw.data_ptr() == weights.data_ptr():
+                dw = dw.clone()     # (already on the device: the caller keeps its weights)
+            with _on_device(dev):
+                st = _lib.lib().ngmix_weight_to_ierr_batch(
+                    _dptr(dw), _dptr(dw), dw.numel(), _stream())
+            _lib.check(st, "ngmix_weight_to_ierr_batch")
+            npix = nrow * ncol
+            return cls(dval, dw, djac, np.full(n, nrow), np.full(n, ncol),
+                       np.arange(n, dtype=np.int64) * npix, ignore_zero_weight)
+        images = np.asarray(images, dtype="f8")
+        weights = np.asarray(weights, dtype="f8")
+        n, nrow, ncol = images.shape
+        assert weights.shape == images.shape, "image and weight must match"
+        npix = nrow * ncol
+        tot = n * npix
+        jr = np.ascontiguousarray(jac_records)
+        if jr.dtype.names is not None:
+            jr = jr.view(np.float64)
+        jr = jr.reshape(n, 8)
+        izw = np.broadcast_to(np.asarray(ignore_zero_weight, dtype=bool), (n,))
+        kept = np.where(izw, np.count_nonzero(weights.reshape(n, -1) > 0.0, axis=1),
+                        npix).astype(np.int32)
+        off = np.arange(n, dtype=np.int64) * npix
+        tab = np.zeros(n, dtype=_lib.STAMP_DTYPE)
+        tab["pix_off"], tab["nrow"], tab["ncol"] = off, nrow, ncol
+        tab["gm_off"] = np.arange(n, dtype=np.int32)
+        tab["ngauss"] = 1
+        tab["flags"] = np.where(izw, _lib.STAMP_IGNORE_ZERO_WEIGHT, 0)
+        tab["npix_kept"] = kept
+        host = np.empty(2 * tot + 8 * n + 4 * n)
+        host[:tot] = images.reshape(-1)
+        host[tot:2 * tot] = weights.reshape(-1)
+        host[2 * tot:2 * tot + 8 * n] = jr.reshape(-1)
+        host[2 * tot + 8 * n:] = tab.view(np.float64)
+        dev_all = torch.from_numpy(host).to(dev)
+        dval = dev_all[:tot]
+        dw = dev_all[tot:2 * tot]
+        djac = dev_all[2 * tot:2 * tot + 8 * n].reshape(n, 8)
+        dtab = dev_all[2 * tot + 8 * n:].view(torch.int32).reshape(n, 8)
+        with _on_device(dev):
+            st = _lib.lib().ngmix_weight_to_ierr_batch(
+                _dptr(dw), _dptr(dw), dw.numel(), _stream())
+        _lib.check(st, "ngmix_weight_to_ierr_batch")
+        sb = cls(dval, dw, djac, np.full(n, nrow), np.full(n, ncol), off, izw, npix_kept=kept)
         sb._stamp_tables[1] = dtab
         return sb
 
@@ -741,6 +830,59 @@ class StampBatch(object):
                 _dptr(out_start), _stream())
         _lib.check(st, "ngmix_deriv_images_batch")
         return out
+
+
+def flatten_observations(obs):
+    """
+    a sequence of per-object Observation / ObsList / MultiBandObsList as ONE
+    StampBatch: returns (stamps, stamp_obj, stamp_band, nband, psf) with psf the
+    (nstamps, npsf) host gauss2d records of the stamps' psf mixtures, or None
+    when the observations carry none (FitModel._setup_fit's rule: the first
+    observation decides, results.py:289-296)
+    """
+    from .observation import Observation, ObsList, MultiBandObsList
+    flat, sobj, sband = [], [], []
+    if all(type(o) is Observation for o in obs):
+        flat = list(obs)
+        nobj = len(flat)
+        sobj = np.arange(nobj, dtype=np.int32)
+        sband = np.zeros(nobj, dtype=np.int32)
+        nband = 1
+    else:
+        nband = None
+        for i, o in enumerate(obs):
+            if isinstance(o, Observation):
+                bands = [[o]]
+            elif isinstance(o, ObsList):
+                bands = [o]
+            elif isinstance(o, MultiBandObsList):
+                bands = o
+            else:
+                raise ValueError("obs should be Observation, ObsList, or MultiBandObsList")
+            if nband is None:
+                nband = len(bands)
+            elif len(bands) != nband:
+                raise ValueError("every object of a batch needs the same number of bands")
+            for b, ol in enumerate(bands):
+                if len(ol) == 0:
+                    raise ValueError("object %d has no observation in band %d" % (i, b))
+                for e in ol:
+                    flat.append(e)
+                    sobj.append(i)
+                    sband.append(b)
+        sobj = np.array(sobj, dtype=np.int32)
+        sband = np.array(sband, dtype=np.int32)
+    if not flat:
+        raise ValueError("no observations")
+    stamps = StampBatch.from_observations(flat)
+    psf = None
+    if flat[0].has_psf_gmix():
+        recs = [o._psf._gmix._data for o in flat]
+        npsf = recs[0].size
+        if any(r.size != npsf for r in recs):
+            raise ValueError("the psf mixtures of a batch need one size")
+        psf = np.stack(recs)
+    return stamps, sobj, sband, nband, psf
 
 
 def records_to_numpy(t, dtype):

@@ -796,6 +796,89 @@ class Fitter(object):
     def _make_fit_model(self, obs, guess):
         return FitModel(obs=obs, model=self.model, guess=guess, prior=self.prior)
 
+    def go_many(self, obs, guess):
+        """
+        The fits of MANY objects as ONE batch of the lock-step driver: what a
+        caller of the reference writes as a loop of fitter.go(obs=o, guess=g)
+        over a catalogue (runners.py:116-150), without a Python step per
+        object between the observations and the device.
+
+        obs: a sequence of Observation / ObsList / MultiBandObsList (one per
+            object; every object with the same number of bands)
+        guess: (nobj, npars)
+
+        Returns a ManyResults: a sequence of per-object result dicts with the
+        keys Fitter.go sets (made when an element is read), over the arrays
+        of the batch (.arrays: the LMBatchFitter result).
+        """
+        from .lm_batch import LMBatchFitter
+        from .batch import flatten_observations
+        spec = self._batched_model()
+        if spec is None or self.use_noise_image:
+            raise ValueError("go_many runs the models of LMBatchFitter without the "
+                             "noise-image covariance")
+        guess = np.ascontiguousarray(np.atleast_2d(guess), dtype="f8")
+        stamps, sobj, sband, nband, psf = flatten_observations(obs)
+        if guess.shape[0] != len(obs):
+            raise ValueError("one guess per object")
+        prior = self.prior
+        if prior is not None and not hasattr(prior, "fill_fdiff_batch"):
+            from .prior_batch import PriorBatchAdapter
+            prior = PriorBatchAdapter(prior)
+        fitter = LMBatchFitter(spec[0], fit_pars=self.fit_pars, ngauss=spec[1],
+                               analytic_jacobian=self.analytic_jacobian, prior=prior)
+        trivial = stamps.n == len(obs) and nband == 1
+        res = fitter.go(stamps, guess, psf=psf,
+                        stamp_obj=None if trivial else sobj,
+                        stamp_band=None if trivial else sband)
+        return ManyResults(res, self.model_name, nband)
+
+
+class ManyResults(object):
+    """the per-object result dicts of Fitter.go_many, made on access from the
+    batch's arrays (.arrays).  Element i holds what Fitter.go returns for
+    object i: flags, nfev, ier, errmsg, pars, pars_err, pars_cov0, pars_cov and
+    -- when flags == 0 -- lnprob, s2n_numer, s2n_denom, npix, chi2per, dof,
+    s2n_w, s2n, g, g_cov, g_err, T, T_err, flux, flux_err (flux_cov with
+    several bands), as FitModel.set_fit_result leaves them (results.py:45-72)"""
+
+    _ALWAYS = ("flags", "nfev", "ier", "pars", "pars_err", "pars_cov0", "pars_cov")
+    _STATS = ("lnprob", "s2n_numer", "s2n_denom", "npix", "chi2per", "dof", "s2n_w", "s2n",
+              "g", "g_cov", "g_err", "T", "T_err", "flux", "flux_err", "flux_cov")
+
+    def __init__(self, arrays, model, nband):
+        self.arrays = arrays
+        self.model = model
+        self.nband = nband
+        self._n = len(arrays["flags"])
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        a = self.arrays
+        flags, ier = int(a["flags"][i]), int(a["ier"][i])
+        out = {"model": self.model, "flags": flags, "nfev": int(a["nfev"][i]), "ier": ier,
+               "errmsg": "" if flags == 0 else "lmder/lmdif ier %d, flags %d" % (ier, flags)}
+        for k in ("pars", "pars_err", "pars_cov0", "pars_cov"):
+            out[k] = np.array(a[k][i])
+        if flags != 0:
+            return out
+        for k in self._STATS:
+            if k in a:
+                v = a[k][i]
+                out[k] = np.array(v) if isinstance(v, np.ndarray) and v.ndim else v.item()
+        return out
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n))
+
 
 class CoellipFitter(Fitter):
     """LM fit of ngauss co-elliptical gaussians"""

@@ -6,7 +6,7 @@ get_gmix()), so it drives the HIP-backed fitters of this package unchanged.
 """
 from .observation import Observation, ObsList, MultiBandObsList
 
-__all__ = ["Runner", "PSFRunner", "run_fitter", "run_psf_fitter"]
+__all__ = ["Runner", "PSFRunner", "run_fitter", "run_psf_fitter", "run_fitter_many"]
 
 
 def run_fitter(obs, fitter, guesser=None, ntry=1):
@@ -20,6 +20,45 @@ def run_fitter(obs, fitter, guesser=None, ntry=1):
         if res["flags"] == 0:
             break
     return res
+
+
+def run_fitter_many(obs, fitter, guesser, ntry=1):
+    """
+    run_fitter over a catalogue as batches (fitter.go_many): every object is
+    fitted from guesser(obs=...) at once; the objects whose result has
+    flags != 0 are fitted again, as a batch of their own, from a fresh guess, up
+    to ntry attempts in all -- what the reference's loop over run_fitter does
+    object by object (runners.py:116-150).
+
+    obs: a sequence of Observation / ObsList / MultiBandObsList
+    guesser: called as guesser(obs=o) per object (the reference's interface),
+        or an object with guess_many(obs=sequence) -> (n, npars)
+
+    Returns a list of per-object result dicts (each object's LAST attempt;
+    'ntry' holds the attempts it took).
+    """
+    import numpy as np
+
+    def guesses(objs):
+        if hasattr(guesser, "guess_many"):
+            return np.asarray(guesser.guess_many(obs=objs), dtype="f8")
+        return np.array([guesser(obs=o) for o in objs], dtype="f8")
+
+    obs = list(obs)
+    out = [None] * len(obs)
+    todo = list(range(len(obs)))
+    for attempt in range(1, int(ntry) + 1):
+        if not todo:
+            break
+        sub = [obs[i] for i in todo]
+        res = fitter.go_many(sub, guesses(sub))
+        flags = np.asarray(res.arrays["flags"])
+        for k, i in enumerate(todo):
+            r = res[k]
+            r["ntry"] = attempt
+            out[i] = r
+        todo = [i for k, i in enumerate(todo) if flags[k] != 0]
+    return out
 
 
 def run_psf_fitter(obs, fitter, guesser=None, ntry=1, set_result=True):

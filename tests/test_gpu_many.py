@@ -1,0 +1,193 @@
+"""
+The many-object entry points -- Fitter.go_many, run_fitter_many,
+run_admom_many -- against the per-object interface they stand for: the
+reference's callers loop fitter.go / run_admom over a catalogue
+(ngmix/runners.py:116-150, admom/admom.py:20-71); here that loop is ONE batch,
+and element i of the result is what the per-object call returns for object i
+(and, on tests/golden/api.npz, what the REFERENCE's own Fitter.go returned).
+"""
+import numpy as np
+import pytest
+
+import ngmix_amd as ngmix
+from ngmix_amd.batch import StampBatch
+
+from test_gpu_api import _obs, _mbobs
+
+pytestmark = pytest.mark.gpu
+
+
+def _catalogue(n, seed, dim=32, with_psf=True, model="exp"):
+    rng = np.random.RandomState(seed)
+    scale = 0.263
+    psf_gm = ngmix.GMixModel([0.0, 0.0, 0.01, -0.02, 0.28, 1.0], "gauss")
+    obs, guesses, truth = [], [], []
+    for i in range(n):
+        pars = np.array([rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1),
+                         rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2),
+                         rng.uniform(0.3, 0.8), rng.uniform(80.0, 200.0)])
+        jac = ngmix.DiagonalJacobian(row=(dim - 1) / 2 + rng.uniform(-0.4, 0.4),
+                                     col=(dim - 1) / 2 + rng.uniform(-0.4, 0.4), scale=scale)
+        gm = ngmix.GMixModel(pars, model)
+        if with_psf:
+            gm = gm.convolve(psf_gm)
+        im = gm.make_image((dim, dim), jacobian=jac, fast_exp=True)
+        sigma = pars[5] / rng.uniform(100.0, 400.0)
+        im = im + sigma * rng.normal(size=im.shape)
+        wt = np.full(im.shape, 1.0 / sigma ** 2)
+        if i % 7 == 3:
+            wt[2, 3] = 0.0           # a masked pixel
+        psf = ngmix.Observation(np.zeros((5, 5)), jacobian=jac, gmix=psf_gm) if with_psf else None
+        obs.append(ngmix.Observation(im, weight=wt, jacobian=jac, psf=psf))
+        g = pars * rng.uniform(0.9, 1.1, size=6)
+        g[0:4] = pars[0:4] + rng.uniform(-0.03, 0.03, size=4)
+        guesses.append(g)
+        truth.append(pars)
+    return obs, np.array(guesses), np.array(truth)
+
+
+def _same_result(a, b, exact=True):
+    assert set(a.keys()) - {"ntry"} == set(b.keys()) - {"ntry"}, \
+        set(a.keys()) ^ set(b.keys())
+    for k in b.keys():
+        if k == "ntry":
+            continue
+        va, vb = a[k], b[k]
+        if isinstance(vb, str):
+            assert va == vb, k
+        elif exact:
+            np.testing.assert_array_equal(np.asarray(va), np.asarray(vb), err_msg=k)
+        else:
+            np.testing.assert_allclose(np.asarray(va), np.asarray(vb), rtol=1e-9, atol=1e-12,
+                                       err_msg=k)
+
+
+@pytest.mark.parametrize("with_psf", [True, False])
+def test_go_many_is_the_loop_over_go(with_psf):
+    """one batch of 40 Observations == forty Fitter.go calls: the same kernels
+    advance every fit, so each per-object dict is the per-object call's, key
+    for key and bit for bit"""
+    obs, guess, _ = _catalogue(40, 11, with_psf=with_psf)
+    fitter = ngmix.fitting.Fitter(model="exp", batched=True)
+    many = fitter.go_many(obs, guess)
+    assert len(many) == 40
+    assert np.all(np.asarray(many.arrays["flags"]) == 0)
+    for i in (0, 3, 17, 39):
+        one = fitter.go(obs=obs[i], guess=guess[i])
+        _same_result(many[i], dict(one))
+    # ... and MINPACK's, through the seam kernels (nfev / ier exact)
+    ref = ngmix.fitting.Fitter(model="exp", batched=False).go(obs=obs[5], guess=guess[5])
+    r = many[5]
+    assert r["nfev"] == ref["nfev"] and r["ier"] == ref["ier"]
+    np.testing.assert_allclose(r["pars"], ref["pars"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(r["pars_err"], ref["pars_err"], rtol=1e-4)
+
+
+def test_go_many_on_the_reference_goldens(golden):
+    """api.npz: the reference's OWN Fitter.go on a 2-band x 2-epoch
+    MultiBandObsList and on a single gaussian Observation -- as members of
+    go_many batches (the object repeated next to perturbed copies)"""
+    g = golden("api")
+    mb = _mbobs(g)
+    guess = np.array([g["lm_guess"], g["lm_guess"] * 1.01, g["lm_guess"]])
+    many = ngmix.fitting.Fitter(model="exp").go_many([mb, _mbobs(g), mb], guess)
+    tag = "lm_fit_analytic1"
+    for i in (0, 2):
+        r = many[i]
+        assert r["flags"] == int(g[tag + "_flags"]) == 0
+        assert r["nfev"] == int(g[tag + "_nfev"]) and r["ier"] == int(g[tag + "_ier"])
+        np.testing.assert_allclose(r["pars"], g[tag + "_pars"], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(r["pars_err"], g[tag + "_pars_err"], rtol=1e-4)
+        for k in ("lnprob", "chi2per", "s2n", "T", "T_err"):
+            np.testing.assert_allclose(r[k], float(g[tag + "_" + k]), rtol=1e-5)
+        assert r["dof"] == int(g[tag + "_dof"]) and r["npix"] == int(g[tag + "_npix"])
+        np.testing.assert_allclose(r["flux"], g[tag + "_flux"], rtol=1e-6)
+        assert r["flux_cov"].shape == (2, 2) and r["g_cov"].shape == (2, 2)
+    _same_result(many[0], many[2])
+    one = ngmix.fitting.Fitter(model="exp", batched=True).go(obs=mb, guess=g["lm_guess"])
+    _same_result(many[0], dict(one))
+    # single-gaussian Observation
+    o = _obs(g, "g1")
+    many = ngmix.fitting.Fitter(model="gauss").go_many([o] * 33, np.tile(g["g1_guess"], (33, 1)))
+    r = many[32]
+    assert r["flags"] == 0 and r["nfev"] == int(g["g1_fit_nfev"])
+    np.testing.assert_allclose(r["pars"], g["g1_fit_pars"], rtol=1e-6, atol=1e-8)
+    for k in ("lnprob", "chi2per", "s2n", "flux", "flux_err", "T", "T_err"):
+        np.testing.assert_allclose(r[k], float(g["g1_fit_" + k]), rtol=1e-5)
+
+
+def test_run_fitter_many_retries_only_the_failures():
+    obs, guess, truth = _catalogue(36, 23)
+
+    class Guesser(object):
+        """the first guess of every third object is far off"""
+        def __init__(self):
+            self.calls = {}
+
+        def __call__(self, obs):
+            k = self.calls.get(id(obs), 0)
+            self.calls[id(obs)] = k + 1
+            i = index[id(obs)]
+            g = guess[i].copy()
+            if k == 0 and i % 3 == 0:
+                g[4] *= 40.0
+                g[0:2] += 1.5
+                g[5] *= 0.01
+            return g
+    index = {id(o): i for i, o in enumerate(obs)}
+    guesser = Guesser()
+    fitter = ngmix.fitting.Fitter(model="exp", fit_pars={"maxfev": 10, "ftol": 1e-5,
+                                                          "xtol": 1e-5})
+    res = ngmix.runners.run_fitter_many(obs, fitter, guesser, ntry=2)
+    ntry = np.array([r["ntry"] for r in res])
+    assert np.all(ntry[np.arange(36) % 3 == 0] == 2) and np.all(ntry[np.arange(36) % 3 != 0] == 1)
+    assert all(r["flags"] == 0 for r in res)
+    # object by object, the reference's way
+    for i in (0, 1, 9):
+        g2 = Guesser()
+        one = ngmix.runners.run_fitter(obs[i], ngmix.fitting.Fitter(
+            model="exp", fit_pars={"maxfev": 10, "ftol": 1e-5, "xtol": 1e-5}, batched=True), g2,
+            ntry=2)
+        assert g2.calls[id(obs[i])] == ntry[i]
+        _same_result(res[i], dict(one))
+
+
+def test_run_admom_many_is_the_loop_over_run_admom():
+    obs, _, _ = _catalogue(40, 31, with_psf=False, model="gauss")
+    many = ngmix.admom.run_admom_many(obs, 0.5, rng=np.random.RandomState(5))
+    rng = np.random.RandomState(5)
+    assert len(many) == 40
+    for i in range(40):
+        one = ngmix.admom.run_admom(obs[i], 0.5, rng=rng)
+        r = many[i]
+        assert set(r.keys()) == set(one.keys())
+        for k in one.keys():
+            if isinstance(one[k], str):
+                assert r[k] == one[k], k
+            else:
+                np.testing.assert_array_equal(np.asarray(r[k]), np.asarray(one[k]), err_msg=k)
+    assert many[3].get_gmix().get_T() > 0
+    # guesses given as mixtures
+    gms = [ngmix.GMixModel([0.0, 0.0, 0.0, 0.0, 0.6, 1.0], "gauss") for _ in obs]
+    many2 = ngmix.admom.AdmomFitter().go_many(obs, gms)
+    one = ngmix.admom.AdmomFitter().go(obs[7], gms[7].copy())
+    np.testing.assert_array_equal(many2[7]["pars"], one["pars"])
+    assert many2[7]["numiter"] == one["numiter"]
+
+
+def test_stacked_ingestion_equals_the_per_object_packing():
+    """StampBatch.from_observations on a one-shape catalogue (np.stack, no
+    Python step per stamp) holds the bytes the ragged packing holds"""
+    obs, _, _ = _catalogue(40, 41)
+    a = StampBatch.from_observations(obs)
+    b = StampBatch.from_arrays([o._image for o in obs], [o._weight for o in obs],
+                               [o._jacobian._data for o in obs],
+                               [o._ignore_zero_weight for o in obs])
+    for name in ("val", "ierr", "jac"):
+        np.testing.assert_array_equal(getattr(a, name).cpu().numpy(),
+                                      getattr(b, name).cpu().numpy(), err_msg=name)
+    for name in ("nrow", "ncol", "pix_off", "flags", "npix_kept"):
+        np.testing.assert_array_equal(getattr(a, name), getattr(b, name), err_msg=name)
+    np.testing.assert_array_equal(a._stamp_tables[1].cpu().numpy(),
+                                  b._stamp_tables[1].cpu().numpy())
+    assert int(a.npix_kept.sum()) < a.total_pix      # (the masked pixels are counted out)
