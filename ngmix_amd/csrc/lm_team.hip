@@ -207,6 +207,24 @@ __global__ __launch_bounds__(TEAMS * lmteam::TEAM) void lm_advance_team_kernel(
     }
     const int64_t s0 = obj_start ? obj_start[o] : o;
     const int64_t s1 = obj_start ? obj_start[o + 1] : o + 1;
+    {
+        // a band the fit has no flux for (or nloc inconsistent with the state):
+        // its sums would land outside the team's block, in a neighbouring fit's
+        // arrays.  End the fit as for a wrong parameter-count hint.
+        bool bad = nloc > n;
+        for (int64_t st = s0 + f.lane; st < s1 && stamp_band; st += TEAM) {
+            const int band = stamp_band[st];
+            if (band < 0 || nloc - 1 + band >= n) bad = true;
+        }
+        const unsigned long long team_mask = 0xffffull << (TEAM * team);
+        if (__ballot(bad) & team_mask) {
+            if (f.lane == 0) {
+                G.info = 0;
+                G.phase = LM_PHASE_DONE;
+            }
+            return;
+        }
+    }
     const double ff = lm_team_fold(
         f, s0, s1, stamp_band, sums, nloc,
         obj_sums ? obj_sums + o * (int64_t)(n * (n + 1) / 2 + n + 1) : nullptr);

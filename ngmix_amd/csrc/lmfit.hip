@@ -669,6 +669,17 @@ __device__ __forceinline__ void lm_advance_one(
     const int64_t s0 = obj_start ? obj_start[o] : o;
     const int64_t s1 = obj_start ? obj_start[o + 1] : o + 1;
     for (int64_t st = s0; st < s1; st++) {
+        const int band = stamp_band ? stamp_band[st] : 0;
+        if (band < 0 || nloc - 1 + band >= s.n || nloc > s.n) {
+            // a band the fit has no flux for (or nloc inconsistent with the
+            // state): its sums would land outside A.  End the fit as MINPACK ends
+            // a call with improper input (see lm_advance_dispatch)
+            states[o].info = 0;
+            states[o].phase = LM_PHASE_DONE;
+            return;
+        }
+    }
+    for (int64_t st = s0; st < s1; st++) {
         const double *v = sums + st * nsum;
         const int band = stamp_band ? stamp_band[st] : 0;
         int k = 0;
@@ -777,9 +788,10 @@ __device__ __forceinline__ void lm_advance_dispatch(
     const double *__restrict__ obj_sums, int32_t *nactive);
 
 // NP = LM_NPMAX serves any fit (the generic code, private memory); when the
-// launcher is told that every fit has 6 .. 10 parameters it runs the
-// register form (9 and 10 spill part of their arrays to fixed private slots and
-// are still 10-20 % ahead of the generic code on 4- and 5-band fits).
+// launcher is told that every fit has 6 .. 8 parameters it runs the register
+// form.  (9 and 10 parameters go to the team form of lm_team.hip by default;
+// their register instantiations -- which spill part of their arrays to fixed
+// private slots -- are reachable through NGMIX_LM_TEAM_MIN only: A/B.)
 template <int NP, bool REG>
 __global__ __launch_bounds__(WAVE) void lm_advance_kernel(
     lm_state *states, int64_t nobj, const int64_t *__restrict__ obj_start,
@@ -853,7 +865,11 @@ static_assert(sizeof(FdGauss) == 48, "FdGauss");
 // 8 x 8 tiles -- for batches whose stamps fill 8 x 8 tiles badly (a 25 x 25 psf
 // stamp is 16 such tiles for 625 pixels, and 10 row-major ones); a tile is then
 // the rows it touches, whole, for the box test.  Chosen per launch from the
-// batch's largest shape; correct for any shape.
+// batch's largest shape; correct for any shape.  The two forms add a stamp's
+// pixels in different orders (sums equal to ~1e-11 relative): the low bits of a
+// forward-difference fit's sums -- and, rarely, the nfev of an lmdif fit that
+// sits on a decision threshold -- therefore depend on which form the BATCH
+// chose, i.e. on the largest stamp it holds (NGMIX_LM_FD_TILES pins the form).
 //
 // PRECISE: the pass behind the covariance of the ill-conditioned fits
 // (ngmix_lm_precise_cov_batch, lm_precise.hip).  It runs once, after the fits
@@ -1899,8 +1915,11 @@ int launch_lm_advance(lm_state *states, int64_t nobj, const int64_t *obj_start,
     // NGMIX_LM_TEAM_MIN = the smallest parameter count that goes to the team form
     // (6 = every count said), NGMIX_LM_TEAMS = fits per wave (1, 2, 4).
     // (read at every launch: the tests switch them between calls)
+    // (getenv is not safe against a concurrent setenv: switch the knobs from one
+    // thread, between calls; a value outside 6..LM_NPMAX + 1 is ignored)
     const char *e_min = getenv("NGMIX_LM_TEAM_MIN"), *e_teams = getenv("NGMIX_LM_TEAMS");
-    const int team_min = e_min ? atoi(e_min) : 9;
+    int team_min = e_min ? atoi(e_min) : 9;
+    if (team_min < 6 || team_min > LM_NPMAX + 1) team_min = 9;
     const int teams = e_teams ? atoi(e_teams) : 4;
     // (a count not said: the team form built for LM_NPMAX parameters serves any
     // fit and is ahead of the one-thread code at every count and batch size --

@@ -178,7 +178,10 @@ class GaussMomBatch(object):
         out = {}
         for key, shape, o, m in layout:
             a = host[o:o + m].reshape((n,) + shape)
-            out[key] = a.astype(np.int64) if key in ints else a
+            # (npix keeps the record's int32, the flag columns are int64 as the
+            # per-object results make them)
+            out[key] = (a.astype(np.int32) if key == "npix" else
+                        a.astype(np.int64) if key in ints else a)
         area = out.pop("_area")
 
         def records():

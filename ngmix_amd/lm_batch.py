@@ -644,7 +644,7 @@ class LMBatchFitter(object):
     def _nloc_npars(self, npars):
         """the nloc argument of ngmix_lm_advance_batch carrying the fits'
         parameter count (nloc + 256 npars), which selects the step's kernel: the
-        register form for 6-10 parameters, the team form for 11-14;
+        register form for 6-8 parameters, the team form for 9-14;
         fitter.advance_hint = False asks for the generic one-thread form
         (NGMIX_LM_NPARS_GENERIC: what the tests compare the other two with,
         record by record)"""

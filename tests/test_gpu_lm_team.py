@@ -436,3 +436,34 @@ def test_reference_multiband_fits_for_every_parameter_count(golden, nband):
             for k in ("lnprob", "chi2per", "s2n"):
                 np.testing.assert_allclose(res[k][o], float(g[tag + k]), rtol=1e-5)
             assert res["dof"][o] == int(g[tag + "dof"]) and res["npix"][o] == int(g[tag + "npix"])
+
+
+@pytest.mark.parametrize("hint", [True, False], ids=["team", "generic"])
+def test_a_band_the_fit_has_no_flux_for_ends_that_fit_alone(hint):
+    """a stamp_band beyond the fit's fluxes (nloc - 1 + band >= n: a caller of
+    ngmix_lm_advance_batch's mistake, LMBatchFitter validates its maps) would put
+    the stamp's sums outside the fit's arrays -- in the team form, inside a
+    NEIGHBOURING fit's LDS block.  The step ends that fit as it ends one with a
+    wrong parameter-count hint (info 0) and every other fit of the wave is what
+    it is without the corruption, to the bit"""
+    rng = np.random.RandomState(13)
+    nobj, nband = 8, 7
+    sb, psf, guess, sobj, sband = _multiband(nobj, nband, "exp", rng)
+
+    def run(corrupt):
+        f = LMBatchFitter("exp")
+        f.host_loop = True
+        f.advance_hint = hint
+
+        def hook(job, r):
+            if corrupt and r == 0:
+                first = int(np.nonzero(sobj == 3)[0][0])
+                job.d_sband[first] = 9        # 5 + 9 = 14 >= n = 12
+        f.round_hook = hook
+        return f.go(sb, guess, psf=psf, stamp_obj=sobj, stamp_band=sband)
+    clean, bad = run(False), run(True)
+    assert np.all(clean["flags"] == 0)
+    assert bad["flags"][3] == ngmix.flags.LM_FUNC_NOTFINITE and bad["ier"][3] == 0
+    others = np.arange(nobj) != 3
+    for k in ("flags", "nfev", "ier", "pars", "pars_err"):
+        np.testing.assert_array_equal(bad[k][others], clean[k][others], err_msg=k)
