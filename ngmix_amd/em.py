@@ -13,7 +13,7 @@ from .flags import EM_RANGE_ERROR, EM_MAXITER
 from .gmix import GMix, GMixModel
 from .observation import Observation
 
-__all__ = ["run_em", "prep_image", "prep_obs", "EMResult", "EMFitter",
+__all__ = ["run_em", "run_em_many", "prep_image", "prep_obs", "EMResult", "EMManyResults", "EMFitter",
            "EMFitterFixCen", "EMFitterFixCov", "EMFitterFluxOnly", "fit_em"]
 
 logger = logging.getLogger(__name__)
@@ -45,6 +45,21 @@ def run_em(obs, guess, sky=None, fixcen=False, fixcov=False, fluxonly=False,
 
 
 fit_em = run_em
+
+
+def run_em_many(obs, guess, fixcen=False, fixcov=False, fluxonly=False, **kws):
+    """run_em over a sequence of Observations as ONE batch (the loop over a
+    catalogue the reference's callers write around run_em, em.py:30-107);
+    guess: a sequence of GMix (pre-psf), one per observation, all of one size"""
+    if fixcen:
+        fitter = EMFitterFixCen(**kws)
+    elif fixcov:
+        fitter = EMFitterFixCov(**kws)
+    elif fluxonly:
+        fitter = EMFitterFluxOnly(**kws)
+    else:
+        fitter = EMFitter(**kws)
+    return fitter.go_many(obs=obs, guess=guess)
 
 
 def prep_image(im0):
@@ -156,6 +171,100 @@ class EMFitter(object):
         else:
             _lib.check(status, "em_run")
         return EMResult(obs=obs, result=result, gm=gm, gm_conv=gm_conv)
+
+
+def _em_go_many(self, obs, guess):
+    """EMFitter.go for MANY Observations by one launch of the batch kernel
+    (ngmix_em_batch): prep_obs' sky per stamp, the psf mixtures normalised to
+    unit flux (or a delta function where an observation has none), the guess
+    convolved, the run kind of this fitter.  Returns an EMManyResults: element i
+    is the EMResult go(obs[i], guess[i]) returns"""
+    from .batch import StampBatch, GMixBatch
+    n = len(obs)
+    for o in obs:
+        if not isinstance(o, Observation):
+            raise ValueError("input obs must be an instance of Observation")
+    if len(guess) != n:
+        raise ValueError("one guess per observation")
+    ng = len(guess[0])
+    if any(len(g) != ng for g in guess):
+        raise ValueError("the guesses of a batch need one size")
+    stamps = StampBatch.from_observations(list(obs))
+    skyb, sky = stamps.prep_em()
+    grec = np.stack([g._data for g in guess]).reshape(n, ng)
+    has = [o.has_psf() and o.psf.has_gmix() for o in obs]
+    if any(has) and not all(has):
+        raise ValueError("either every observation of a batch carries a psf mixture or none")
+    if all(has):
+        prec = np.stack([o._psf._gmix._data for o in obs])
+        if prec.ndim != 2:
+            raise ValueError("the psf mixtures of a batch need one size")
+        prec = prec.copy()
+        # gmix_psf.set_flux(1.0) (em.py:259; gmix.py set_flux: p *= flux / psum, norms unset)
+        psum = prec["p"].sum(axis=1)
+        prec["p"] *= (1.0 / psum)[:, None]
+        prec["norm_set"] = 0
+    else:
+        delta = GMixModel([0.0, 0.0, 0.0, 0.0, 0.0, 1.0], "gauss")._data
+        prec = np.tile(delta, (n, 1))
+    gm = GMixBatch.from_numpy(grec.copy(), device=stamps.device)
+    psf = GMixBatch.from_numpy(prec, device=stamps.device)
+    fill = bool(np.any([(not o.ignore_zero_weight) and bool(np.any(o.weight <= 0.0))
+                        for o in obs]))
+    out, status, conv = skyb.em(gm, psf, sky=sky, kind=self._kind, miniter=self.miniter,
+                                maxiter=self.maxiter, tol=self.tol, vary_sky=self.vary_sky,
+                                fill_zero_weight=fill)
+    out = out.cpu().numpy()
+    status = status.cpu().numpy()
+    for st in np.unique(status):
+        if st != 0 and int(st) not in _STATUS_MESSAGES:
+            _lib.check(int(st), "em_run")
+    numiter = out[:, 0].astype(np.int64)
+    flags = np.where(numiter >= self.maxiter, EM_MAXITER, 0)
+    return EMManyResults(list(obs), flags, numiter, out[:, 1], out[:, 2], status,
+                         gm.to_numpy(), conv.to_numpy(), self.maxiter)
+
+
+EMFitter.go_many = _em_go_many
+
+
+class EMManyResults(object):
+    """the EMResults of EMFitter.go_many, made on access from the batch's
+    arrays"""
+
+    def __init__(self, obs, flags, numiter, fdiff, sky, status, gm, conv, maxiter):
+        self._obs = obs
+        self.flags, self.numiter, self.fdiff, self.sky = flags, numiter, fdiff, sky
+        self._status, self._gm, self._conv = status, gm, conv
+
+    def __len__(self):
+        return len(self._obs)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        st = int(self._status[i])
+        if st == 0:
+            flags = int(self.flags[i])
+            result = {"flags": flags, "numiter": int(self.numiter[i]),
+                      "fdiff": float(self.fdiff[i]), "sky": float(self.sky[i]),
+                      "message": "OK" if flags == 0 else "maxit"}
+            # (through full parameters, as go() builds them: det recomputed, norms unset)
+            gm = GMix(pars=_full_pars(self._gm[i]))
+            gm_conv = GMix(pars=_full_pars(self._conv[i]))
+            return EMResult(obs=self._obs[i], result=result, gm=gm, gm_conv=gm_conv)
+        message = _STATUS_MESSAGES[st]
+        return EMResult(obs=self._obs[i], result={"flags": EM_RANGE_ERROR, "message": message})
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+def _full_pars(recs):
+    out = np.empty(6 * recs.size)
+    for k, name in enumerate(("p", "row", "col", "irr", "irc", "icc")):
+        out[k::6] = recs[name]
+    return out
 
 
 class EMFitterFixCen(EMFitter):

@@ -191,3 +191,39 @@ def test_stacked_ingestion_equals_the_per_object_packing():
     np.testing.assert_array_equal(a._stamp_tables[1].cpu().numpy(),
                                   b._stamp_tables[1].cpu().numpy())
     assert int(a.npix_kept.sum()) < a.total_pix      # (the masked pixels are counted out)
+
+
+@pytest.mark.parametrize("with_psf,kind", [(False, {}), (True, {}), (True, {"fixcen": True}),
+                                           (False, {"fluxonly": True})])
+def test_run_em_many_is_the_loop_over_run_em(with_psf, kind):
+    obs, _, truth = _catalogue(36, 51, with_psf=with_psf, model="gauss")
+    rng = np.random.RandomState(9)
+    guesses = []
+    for i in range(len(obs)):
+        T = truth[i, 4] + (0.28 if not with_psf else 0.0)
+        pars = []
+        for frac, fac in ((0.6, 0.7), (0.4, 1.5)):
+            s2 = 0.5 * T * fac * rng.uniform(0.9, 1.1)
+            pars += [frac * truth[i, 5] * rng.uniform(0.9, 1.1), truth[i, 0] + rng.uniform(-0.02, 0.02),
+                     truth[i, 1] + rng.uniform(-0.02, 0.02), s2, 0.0, s2]
+        guesses.append(ngmix.GMix(pars=pars))
+    many = ngmix.em.run_em_many(obs, guesses, maxiter=300, tol=1.0e-4, **kind)
+    assert len(many) == len(obs)
+    nok = 0
+    for i in range(len(obs)):
+        one = ngmix.em.run_em(obs[i], guesses[i], maxiter=300, tol=1.0e-4, **kind)
+        r = many[i]
+        assert r["flags"] == one["flags"] and r["message"] == one["message"]
+        if "numiter" in one:
+            assert r["numiter"] == one["numiter"]
+            np.testing.assert_allclose(r["fdiff"], one["fdiff"], rtol=1e-9, atol=1e-14)
+            np.testing.assert_allclose(r["sky"], one["sky"], rtol=1e-12)
+            np.testing.assert_allclose(r.get_gmix().get_full_pars(),
+                                       one.get_gmix().get_full_pars(), rtol=1e-11, atol=1e-14)
+            np.testing.assert_allclose(r.get_convolved_gmix().get_full_pars(),
+                                       one.get_convolved_gmix().get_full_pars(), rtol=1e-11,
+                                       atol=1e-14)
+            nok += int(r["flags"] == 0)
+        else:
+            assert not r.has_gmix()
+    assert nok >= 18      # (the rest stop at maxiter, on both routes alike)
