@@ -857,9 +857,11 @@ def test_reference_coellip_fits_batched(golden, ngauss):
     for i in range(nrep):
         assert res["flags"][i] == int(g[pre + "flags"]) == 0
         assert res["ier"][i] in (1, 2, 3)
-        assert abs(res["nfev"][i] - int(g[pre + "nfev"])) <= 4 * (4 + 2 * ngauss)
-        assert np.all(np.abs(res["pars"][i] - g[pre + "pars"]) <= 1e-2 * err), i
-        np.testing.assert_allclose(res["pars_err"][i], err, rtol=1e-2)
+        # (round 6: the reference's evaluation count to the unit, the solution to
+        # 1e-3 sigma -- measured: equal nfev, 1e-6 / 7e-6 sigma, errors to 1e-5)
+        assert res["nfev"][i] == int(g[pre + "nfev"])
+        assert np.all(np.abs(res["pars"][i] - g[pre + "pars"]) <= 1e-3 * err), i
+        np.testing.assert_allclose(res["pars_err"][i], err, rtol=1e-3)
         np.testing.assert_allclose(res["lnprob"][i], float(g[pre + "lnprob"]), rtol=1e-6)
     np.testing.assert_array_equal(res["pars"][0], res["pars"][1])
     fitted = fitter.gmix.to_numpy()[0]
@@ -893,11 +895,15 @@ def test_reference_coellip_four_and_five_gaussians(golden, ngauss):
     for i in range(nrep):
         assert res["flags"][i] == 0
         assert res["ier"][i] in (1, 2, 3)
-        # lmdif's path through a nearly degenerate valley: the evaluation count
-        # may drift by a few iterations, the solution may not
-        assert abs(res["nfev"][i] - int(g[pre + "nfev"])) <= 6 * (4 + 2 * ngauss)
-        assert np.all(np.abs(res["pars"][i] - g[pre + "pars"]) <= 3e-2 * err), i
-        np.testing.assert_allclose(res["pars_err"][i], err, rtol=3e-2)
+        # round 6: on these fits the driver follows lmdif's path to the unit of
+        # nfev (measured: 53 / 53 and 121 / 121, parameters to 4e-5 sigma, errors
+        # to 2e-5 -- the covariance from the double-double factor of
+        # lm_precise.hip); over random fits of this kind the count drifts in the
+        # degenerate valleys (profiles/r06_fuzz_lm_fd_vs_minpack.log), so one
+        # jacobian of slack is left
+        assert abs(res["nfev"][i] - int(g[pre + "nfev"])) <= 4 + 2 * ngauss + 1
+        assert np.all(np.abs(res["pars"][i] - g[pre + "pars"]) <= 1e-3 * err), i
+        np.testing.assert_allclose(res["pars_err"][i], err, rtol=1e-3)
         np.testing.assert_allclose(res["lnprob"][i], float(g[pre + "lnprob"]), rtol=1e-6)
     np.testing.assert_array_equal(res["pars"][0], res["pars"][2])
     one = ngmix.fitting.CoellipFitter(ngauss=ngauss).go(obs=obs[0], guess=guess)
