@@ -40,6 +40,7 @@ from .observation import (  # noqa: F401
 from . import admom  # noqa: F401
 from . import em  # noqa: F401
 from . import fitting  # noqa: F401
+from . import guessers  # noqa: F401
 from . import runners  # noqa: F401
 from . import bootstrap  # noqa: F401
 from . import gaussmom  # noqa: F401
