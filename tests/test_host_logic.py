@@ -613,3 +613,116 @@ def test_make_mom_result_batch_on_torch_tensors_is_the_numpy_pass(nm):
     for k in ("flags", "T", "T_err", "e_err", "pars", "sums_err", "MT_err"):
         np.testing.assert_allclose(c[k].numpy().astype("f8"), np.asarray(a[k], dtype="f8"),
                                    rtol=5e-16, atol=0, equal_nan=True, err_msg=k)
+
+
+# ---- round 6: the many-object entry points and the batched bootstrap's host logic
+def test_many_results_are_the_per_object_dicts():
+    """fitting.ManyResults: element i carries Fitter.go's keys for object i --
+    the statistics only where flags == 0 (results.py:45-72)"""
+    from ngmix_amd.fitting import ManyResults
+    n, npars = 3, 7
+    rng = np.random.RandomState(2)
+    cov = rng.uniform(size=(n, npars, npars))
+    arrays = {"flags": np.array([0, 1 << 12, 0]), "nfev": np.array([4, 9, 5]),
+              "ier": np.array([1, 5, 2]), "pars": rng.uniform(size=(n, npars)),
+              "pars_err": rng.uniform(size=(n, npars)), "pars_cov0": cov, "pars_cov": cov * 2,
+              "lnprob": np.array([-1.0, np.nan, -3.0]), "s2n": np.array([10.0, np.nan, 30.0]),
+              "npix": np.array([100, 100, 90]), "dof": np.array([93, 93, 83]),
+              "chi2per": np.array([1.0, np.nan, 1.1]), "s2n_w": np.array([10.0, np.nan, 30.0]),
+              "s2n_numer": np.ones(n), "s2n_denom": np.ones(n),
+              "g": rng.uniform(size=(n, 2)), "g_err": rng.uniform(size=(n, 2)),
+              "g_cov": cov[:, 2:4, 2:4], "T": np.ones(n), "T_err": np.ones(n),
+              "flux": rng.uniform(size=(n, 2)), "flux_err": rng.uniform(size=(n, 2)),
+              "flux_cov": cov[:, 5:, 5:]}
+    res = ManyResults(arrays, "exp", 2)
+    assert len(res) == 3 and len(list(res)) == 3 and len(res[0:2]) == 2
+    ok, bad = res[0], res[1]
+    assert ok["flags"] == 0 and ok["errmsg"] == "" and ok["model"] == "exp"
+    assert isinstance(ok["nfev"], int) and isinstance(ok["lnprob"], float)
+    assert ok["npix"] == 100 and ok["flux"].shape == (2,) and ok["flux_cov"].shape == (2, 2)
+    np.testing.assert_array_equal(ok["pars_cov"], arrays["pars_cov"][0])
+    assert bad["flags"] == 1 << 12 and "ier 5" in bad["errmsg"]
+    assert "lnprob" not in bad and "flux" not in bad and bad["pars"].shape == (npars,)
+    assert res[-1]["nfev"] == 5
+    with pytest.raises(IndexError):
+        res[3]
+
+
+def test_run_fitter_many_retries_only_the_failures_with_a_stub():
+    from ngmix_amd.fitting import ManyResults
+    from ngmix_amd.runners import run_fitter_many
+
+    class ManyStub(object):
+        """object k fails on its first k attempts"""
+
+        def __init__(self):
+            self.attempt = {}
+            self.batches = []
+
+        def go_many(self, obs, guess):
+            self.batches.append([o.meta["k"] for o in obs])
+            flags = []
+            for o in obs:
+                a = self.attempt.get(o.meta["k"], 0)
+                self.attempt[o.meta["k"]] = a + 1
+                flags.append(0 if a >= o.meta["k"] else 1)
+            n = len(obs)
+            z = np.zeros((n, 6))
+            return ManyResults({"flags": np.array(flags), "nfev": np.ones(n, dtype=int),
+                                "ier": np.ones(n, dtype=int), "pars": np.asarray(guess),
+                                "pars_err": z, "pars_cov0": np.zeros((n, 6, 6)),
+                                "pars_cov": np.zeros((n, 6, 6))}, "exp", 1)
+    obs = []
+    for k in (0, 2, 1, 0, 5):
+        o = _obs(with_psf=False)
+        o.meta["k"] = k
+        obs.append(o)
+    calls = []
+
+    def guesser(obs):
+        calls.append(obs.meta["k"])
+        return np.full(6, float(len(calls)))
+    fitter = ManyStub()
+    res = run_fitter_many(obs, fitter, guesser, ntry=3)
+    assert fitter.batches == [[0, 2, 1, 0, 5], [2, 1, 5], [2, 5]]
+    assert [r["ntry"] for r in res] == [1, 3, 2, 1, 3]
+    assert [r["flags"] for r in res] == [0, 0, 0, 0, 1]     # (the last one never passes)
+    # every attempt drew a fresh guess, for the objects still failing only
+    assert calls == [0, 2, 1, 0, 5, 2, 1, 5, 2, 5]
+    assert res[1]["pars"][0] == 9.0        # the guess of its third attempt
+
+
+def test_bootstrap_batch_host_pieces():
+    """the bookkeeping of pipeline.bootstrap_batch that needs no device"""
+    from ngmix_amd import pipeline as P
+    # caller's guesses: (n, npars) is one attempt
+    assert P._tries(np.zeros((4, 6)), "guess").shape == (1, 4, 6)
+    assert P._tries(np.zeros((2, 4, 6)), "guess").shape == (2, 4, 6)
+    with pytest.raises(ValueError):
+        P._tries(np.zeros(6), "guess")
+    # results of the fitted objects laid out over all objects
+    res = {"flags": np.array([0, 3]), "pars": np.ones((2, 6)), "nfev": np.array([4, 7]),
+           "model": "exp"}
+    full = P._scatter(res, np.array([0, 2]), 4, 6)
+    np.testing.assert_array_equal(full["flags"], [0, 0, 3, 0])
+    np.testing.assert_array_equal(full["nfev"], [4, 0, 7, 0])
+    assert np.all(np.isnan(full["pars"][[1, 3]])) and np.all(full["pars"][[0, 2]] == 1.0)
+    assert full["model"] == "exp"
+    empty = P._scatter({"model": "exp"}, np.array([], dtype=int), 3, 6)
+    assert empty["pars"].shape == (3, 6) and np.all(empty["nfev"] == 0)
+    # TPSFFluxGuesser's recipe for every object at once
+    rng = np.random.RandomState(1)
+    flux = np.array([[10.0, 20.0], [30.0, 40.0], [50.0, 60.0]])
+    for model, nshape in (("exp", 5), ("bdf", 6), ("bd", 7)):
+        g = P._psfflux_guess(model, 3, 2, 0.5, flux, rng)
+        assert g.shape == (3, nshape + 2)
+        assert np.all(np.abs(g[:, :2]) <= 0.01) and np.all(np.abs(g[:, 2:4]) <= 0.02)
+        assert np.all(np.abs(g[:, 4] / 0.5 - 1) <= 0.1)
+        assert np.all(np.abs(g[:, nshape:] / flux - 1) <= 0.1)
+    assert np.all((P._psfflux_guess("bdf", 3, 2, 0.5, flux, rng)[:, 5] >= 0.4))
+    # e -> g of the moments' ellipticities
+    g1, g2 = P._e1e2_to_g1g2(np.array([0.0, 0.3]), np.array([0.0, -0.4]))
+    assert g1[0] == 0.0 and abs(np.hypot(g1[1], g2[1]) - np.tanh(0.5 * np.arctanh(0.5))) < 1e-15
+    with pytest.raises(ValueError):
+        P.bootstrap_batch(type("S", (), {"n": 1})(), type("S", (), {"n": 1})(), model="spergel")
+    assert P.BOOT_PSF_FAILURE == 1 << 30
