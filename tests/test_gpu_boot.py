@@ -205,3 +205,57 @@ def test_keep_failed_psf_epochs_flags_the_object(golden):
     assert np.all(res["nfev"] > 0) and np.all(res["ntry"] == 1)
     clean = ~bad_obj
     assert np.all(res["flags"][clean] == 0) and np.all(np.isfinite(res["pars"][clean]))
+
+
+def test_bootstrap_batch_edge_cases(golden):
+    """every object lost to failed psf fits; the psf model fitters without a
+    caller's guess (their start comes from the adaptive moments); the models
+    with extra shape parameters from either guesser"""
+    g = golden("boot")
+    # ---- set D with every psf guess far off and one attempt: all psf fits fail
+    sb, psb, kw = _set(g, "D")
+    far = g["D_psf_guess"].copy()
+    far[..., 0:2] = [2.0, -2.0]
+    far[..., 4] = 20.0
+    kw.update(psf_guess=far, psf_ntry=1)
+    res = bootstrap_batch(sb, psb, guess=g["D_guess"], **kw)
+    assert res["boot_failed"].all() and not res["kept"].any()
+    assert np.all(res["flags"] == BOOT_PSF_FAILURE) and np.all(res["nfev"] == 0)
+    assert res["pars"].shape == g["D_guess"][0].shape and np.all(np.isnan(res["pars"]))
+    assert np.all(res["ntry"] == 0) and res["rounds"] == 0
+
+    # ---- psf model fits started from the adaptive moments, on the good stamps of set A
+    sb, psb, kw = _set(g, "A")
+    good = np.nonzero(g["A_ref_kept"] & ~g["A_ref_obj_boot_failed"][g["A_stamp_obj"]])[0]
+    sobj = g["A_stamp_obj"][good]
+    _, sobj = np.unique(sobj, return_inverse=True)
+    sband = g["A_stamp_band"][good]
+    gs, gp = sb.select(good), psb.select(good)
+    truth = g["A_truth"][~g["A_ref_obj_boot_failed"]]
+    for fitter in ("gauss", "turb", "admom"):
+        res = bootstrap_batch(gs, gp, model="exp", psf_fitter=fitter, stamp_obj=sobj,
+                              stamp_band=sband, rng=np.random.RandomState(4))
+        assert np.all(res["psf_flags"] == 0) and res["kept"].all()
+        assert np.all(res["flags"] == 0)
+        # (a one-gaussian psf model for a turbulent psf: the size is biased, the
+        # centre and the fluxes are not)
+        assert np.all(np.abs(res["pars"][:, 0:2] - truth[:, 0:2]) < 5 * res["pars_err"][:, 0:2])
+        np.testing.assert_allclose(res["pars"][:, 5:], truth[:, 5:], rtol=0.15)
+    np.testing.assert_allclose(res["psf_T"], 0.3, rtol=0.35)
+
+    # ---- 'bdf' and 'bd' from either guesser (set B's stamps: two bands)
+    sb, psb, kw = _set(g, "B")
+    keep = np.nonzero(g["B_ref_kept"])[0]
+    sobj, sband = g["B_stamp_obj"][keep], g["B_stamp_band"][keep]
+    gs, gp = sb.select(keep), psb.select(keep)
+    for model, npars in (("bdf", 8), ("bd", 9)):
+        for guesser in ("admom", "psfflux"):
+            res = bootstrap_batch(gs, gp, model=model, psf_fitter="coellip", psf_ngauss=2,
+                                  guesser=guesser, Tguess=0.5, ntry=3, stamp_obj=sobj,
+                                  stamp_band=sband, rng=np.random.RandomState(8))
+            assert res["pars"].shape == (3, npars) and res["guess"].shape == (3, npars)
+            assert np.all(res["psf_flags"] == 0)
+            ok = res["flags"] == 0
+            assert ok.sum() >= 2
+            np.testing.assert_allclose(res["pars"][ok][:, npars - 2:],
+                                       g["B_truth"][ok][:, 6:8], rtol=0.1)

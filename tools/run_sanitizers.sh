@@ -7,10 +7,10 @@
 # points (seam forms' host arithmetic, record layouts, error paths), the lmder
 # iteration in both forms (ngmix_lm_advance_host) and the oracle against the
 # reference's golden vectors.
-# usage: bash tools/run_sanitizers.sh [log file]     (default profiles/r05_sanitizers.log)
+# usage: bash tools/run_sanitizers.sh [log file]     (default profiles/r06_sanitizers.log)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-LOG=${1:-$ROOT/profiles/r05_sanitizers.log}
+LOG=${1:-$ROOT/profiles/r06_sanitizers.log}
 CLANG=/opt/rocm/lib/llvm/bin/clang
 make -C "$ROOT/oracle" asan > /dev/null
 make -C "$ROOT/ngmix_amd/csrc" -j4 asan > /dev/null 2>&1
