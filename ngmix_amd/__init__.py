@@ -52,6 +52,6 @@ from . import prior_batch  # noqa: F401
 from . import lm_batch  # noqa: F401
 from .lm_batch import LMBatchFitter  # noqa: F401
 from . import pipeline  # noqa: F401
-from .pipeline import bootstrap_batch  # noqa: F401
+from .pipeline import bootstrap_batch, bootstrap_many  # noqa: F401
 
 __version__ = "0.1.0"

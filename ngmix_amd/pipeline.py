@@ -31,7 +31,7 @@ from .batch import GMixBatch
 from .flags import EM_MAXITER, EM_RANGE_ERROR
 from .lm_batch import LMBatchFitter, MODEL_NLOC
 
-__all__ = ["bootstrap_batch", "BOOT_PSF_FAILURE", "BOOT_PSF_FLUX_FAILURE"]
+__all__ = ["bootstrap_batch", "bootstrap_many", "BOOT_PSF_FAILURE", "BOOT_PSF_FLUX_FAILURE"]
 
 # an object one of whose bands lost every epoch to failed psf fits
 # (BootPSFFailure, bootstrap.py:118-154)
@@ -595,6 +595,47 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
     return res
 
 
+def bootstrap_many(obs, model="exp", set_psf_results=False, **kw):
+    """
+    bootstrap_batch for a catalogue of reference-style objects: `obs` is a
+    sequence of Observation / ObsList / MultiBandObsList whose observations
+    carry their psf OBSERVATIONS (obs.psf with an image) -- what the reference's
+    Bootstrapper.go takes one at a time (bootstrap.py:24-103).  The object and
+    psf stamps are packed into two batches, **kw goes to bootstrap_batch (psf
+    fitter, guesser, attempts, prior, fit_pars ...).
+
+    set_psf_results: store each psf fit's flags in obs.psf.meta['result'] and,
+    where it passed, its mixture in obs.psf.gmix, as PSFRunner does
+    (runners.py:205-215).
+
+    Returns a fitting.ManyResults: element i is the result dict of object i
+    (flags = BOOT_PSF_FAILURE and NaN parameters where the reference raises
+    BootPSFFailure); .arrays holds bootstrap_batch's arrays.
+    """
+    from .batch import flatten_observations, StampBatch
+    from .fitting import ManyResults
+    from .observation import get_mb_obs
+    stamps, sobj, sband, nband, _ = flatten_observations(obs)
+    flat = [e for o in obs for ol in get_mb_obs(o) for e in ol]
+    for e in flat:
+        if not e.has_psf():
+            raise ValueError("bootstrap_many: every observation needs its psf observation")
+    psf_stamps = StampBatch.from_observations([e.psf for e in flat])
+    res = bootstrap_batch(stamps, psf_stamps, model=model, stamp_obj=sobj, stamp_band=sband, **kw)
+    if set_psf_results:
+        recs = res["psf_gmix"].to_numpy()
+        from .gmix import GMix
+        for i, e in enumerate(flat):
+            flags = int(res["psf_flags"][i])
+            e.psf.meta["result"] = {"flags": flags, "nfev": int(res["psf_nfev"][i]),
+                                    "ntry": int(res["psf_ntry"][i])}
+            if flags == 0:
+                gm = GMix(ngauss=recs[i].size)
+                gm._data[:] = recs[i]
+                e.psf.set_gmix(gm)
+    return ManyResults(res, model, nband)
+
+
 def _scatter(res, fit_obj, nobj, npars):
     """the result arrays of the fitted objects laid out over all nobj objects:
     the others hold 0 (integers) / NaN (floats)"""
@@ -614,6 +655,9 @@ def _scatter(res, fit_obj, nobj, npars):
         # nothing was fitted at all
         out["flags"] = np.zeros(nobj, dtype=np.int64)
         out["nfev"] = np.zeros(nobj, dtype=np.int64)
+        out["ier"] = np.zeros(nobj, dtype=np.int64)
         out["pars"] = np.full((nobj, npars), np.nan)
         out["pars_err"] = np.full((nobj, npars), np.nan)
+        out["pars_cov0"] = np.full((nobj, npars, npars), np.nan)
+        out["pars_cov"] = np.full((nobj, npars, npars), np.nan)
     return out

@@ -257,5 +257,56 @@ def test_bootstrap_batch_edge_cases(golden):
             assert np.all(res["psf_flags"] == 0)
             ok = res["flags"] == 0
             assert ok.sum() >= 2
+            # (data drawn from a 'bdf' profile: 'bd' has a size ratio to spend)
             np.testing.assert_allclose(res["pars"][ok][:, npars - 2:],
-                                       g["B_truth"][ok][:, 6:8], rtol=0.1)
+                                       g["B_truth"][ok][:, 6:8], rtol=0.2)
+
+
+def test_bootstrap_many_from_reference_style_objects(golden):
+    """bootstrap_many: set A of boot.npz as a list of MultiBandObsLists whose
+    observations carry their psf observations -- what the reference's
+    Bootstrapper.go takes one at a time -- gives bootstrap_batch's result for the
+    same stamps, per object, and leaves the psf results on the observations"""
+    import ngmix_amd as ngmix
+    from ngmix_amd.pipeline import bootstrap_many
+    g = golden("boot")
+    sb, psb, kw = _set(g, "A")
+    sobj, sband = g["A_stamp_obj"], g["A_stamp_band"]
+    objs = []
+    for o in range(int(sobj.max()) + 1):
+        mb = ngmix.MultiBandObsList()
+        for b in range(int(sband.max()) + 1):
+            ol = ngmix.ObsList()
+            for s in np.nonzero((sobj == o) & (sband == b))[0]:
+                def jac_of(rec):
+                    return ngmix.Jacobian(row=float(rec["row0"]), col=float(rec["col0"]),
+                                          dvdrow=float(rec["dvdrow"]), dvdcol=float(rec["dvdcol"]),
+                                          dudrow=float(rec["dudrow"]), dudcol=float(rec["dudcol"]))
+                pim = g["A_psf_images"][s]
+                pobs = ngmix.Observation(pim, weight=np.full(pim.shape, 1.0 / g["A_psf_sigma"][s] ** 2),
+                                         jacobian=jac_of(g["A_psf_jac"][s]))
+                im = g["A_images"][s]
+                ol.append(ngmix.Observation(im, weight=np.full(im.shape, 1.0 / g["A_sigma"][s] ** 2),
+                                            jacobian=jac_of(g["A_jac"][s]), psf=pobs))
+            mb.append(ol)
+        objs.append(mb)
+    kw.pop("stamp_obj")
+    kw.pop("stamp_band")
+    many = bootstrap_many(objs, guess=g["A_guess"], set_psf_results=True, **kw)
+    ref = bootstrap_batch(sb, psb, guess=g["A_guess"], stamp_obj=sobj, stamp_band=sband, **kw)
+    assert len(many) == len(objs)
+    for i in range(len(objs)):
+        r = many[i]
+        assert r["flags"] == ref["flags"][i] and r["nfev"] == ref["nfev"][i]
+        np.testing.assert_array_equal(r["pars"], ref["pars"][i])
+        if r["flags"] == 0:
+            assert r["flux"].shape == (3,) and r["s2n"] == ref["s2n"][i]
+        elif r["flags"] == BOOT_PSF_FAILURE:
+            assert np.all(np.isnan(r["pars"])) and "lnprob" not in r
+    # the psf stage's results on the psf observations (PSFRunner's side effect)
+    flat = [e for mb in objs for ol in mb for e in ol]
+    for s, e in enumerate(flat):
+        assert e.psf.meta["result"]["flags"] == ref["psf_flags"][s]
+        assert e.psf.has_gmix() == (ref["psf_flags"][s] == 0)
+    k = int(np.nonzero(ref["psf_flags"] == 0)[0][0])
+    np.testing.assert_allclose(flat[k].psf.gmix.get_T(), ref["psf_T"][k], rtol=1e-12)
