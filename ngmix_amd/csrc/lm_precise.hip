@@ -21,8 +21,7 @@
 //      forward-difference jacobian once more at the point of the fit's last
 //      jacobian (jac_point: recorded by the ordinary passes) and accumulates
 //      J^T J in double-double -- exact to ~1e-32 of each sum;
-//   2. lm_factor_dd_kernel below folds the stamps' sums (and the prior's rows)
-//      into the object's matrix and runs factor_normal's pivoted Cholesky
+//   2. lm_factor_dd_kernel below folds the stamps' sums into the object's matrix and runs factor_normal's pivoted Cholesky
 //      (lm_core.hpp: qrfac's pivot rule) in double-double arithmetic, one wave
 //      per fit, the matrices in LDS; R rounded to doubles and ipvt go into the
 //      state record, where ngmix_lm_finalize_batch reads them.
@@ -115,25 +114,15 @@ __device__ __forceinline__ dd_t sqrt_dd(dd_t a)
 
 }  // namespace dd
 
-// the (xt | xstep | hstep) record of a fit's last jacobian, as the state
-// members simple_sep_normal_sums reads
-struct JacPoint {
-    double xt[LM_NPMAX], xstep[LM_NPMAX], hstep[LM_NPMAX];
-    int32_t n, mode;
-};
-
 // One wave per fit.  LDS: S (the matrix, then its Schur complements) and R,
 // each as a plane of high and a plane of low parts, LM_NPMAX-strided.
 __global__ __launch_bounds__(WAVE) void lm_factor_dd_kernel(
     lm_state *states, int64_t nobj, const int64_t *__restrict__ obj_start,
-    const int32_t *__restrict__ stamp_band, const double *__restrict__ psums, int nloc,
-    const double *__restrict__ jac_point, ngmix_simple_sep_prior P, int has_prior,
-    double prior_step)
+    const int32_t *__restrict__ stamp_band, const double *__restrict__ psums, int nloc)
 {
     using dd::dd_t;
     constexpr int NP = LM_NPMAX, NN = NP * NP;
     __shared__ double Sh[NN], Sl[NN], Rh[NN], Rl[NN];
-    __shared__ double prow[NGMIX_LM_NSUMS(LM_NPMAX)];
     __shared__ int32_t piv[NP];
     __shared__ int bad_flag;
     const int64_t o = blockIdx.x;
@@ -178,37 +167,8 @@ __global__ __launch_bounds__(WAVE) void lm_factor_dd_kernel(
             Sl[e] = t.lo;
         }
     }
-    // ---- the prior's rows at the same point (ngmix_lm_prior_sums_batch's)
-    if (has_prior && lane == 0) {
-        JacPoint jp;
-        const double *src = jac_point + o * 3 * (int64_t)NP;
-        for (int j = 0; j < NP; j++) {
-            jp.xt[j] = src[j];
-            jp.xstep[j] = src[NP + j];
-            jp.hstep[j] = src[2 * NP + j];
-        }
-        jp.n = n;
-        jp.mode = NGMIX_LM_MODE_FD;
-        lmcore::simple_sep_normal_sums(P, jp, prior_step, prow);
-    }
     __syncthreads();
     if (bad_flag) return;   // (the state keeps the factor the iteration left)
-    if (has_prior) {
-        const int nt = n * (n + 1) / 2;
-        if (!(fabs(prow[nt + n]) < INFINITY)) return;
-        for (int k = lane; k < nt; k += WAVE) {
-            int a = 0, row = 0;
-            while (row + (n - a) <= k) {
-                row += n - a;
-                a++;
-            }
-            const int e = a * NP + a + (k - row);
-            const dd_t t = dd::add({Sh[e], Sl[e]}, {prow[k], 0.0});
-            Sh[e] = t.hi;
-            Sl[e] = t.lo;
-        }
-        __syncthreads();
-    }
     // the lower triangle
     for (int e = lane; e < NN; e += WAVE) {
         const int i = e / NP, j = e % NP;
@@ -324,18 +284,18 @@ int launch_lm_precise_cov(const ngmix_lm_problem *p, double *psums, hipStream_t 
         set_last_error_msg("lm_precise_cov: serves fits of 10-14 local parameters");
         return NGMIX_ERR_BAD_ARG;
     }
-    if (p->prior && (p->prior->nband < 1 || p->prior->nband > NGMIX_PRIOR_MAXBAND))
+    if (p->prior) {
+        // (the kernel prior serves models with five shape parameters, nloc = 6:
+        // no fit this pass serves carries one)
+        set_last_error_msg("lm_precise_cov: fits with a kernel prior are not served");
         return NGMIX_ERR_BAD_ARG;
+    }
     int rc = launch_lm_eval(p->batch, p->model, 1, p->states, p->stamp_obj, p->stamp_band,
                             p->psf, p->npsf, psums, nullptr, nullptr, s, p->jac_point, true);
     if (rc != NGMIX_OK) return rc;
     census("lm_factor_dd_kernel");
-    ngmix_simple_sep_prior prior;
-    if (p->prior) prior = *p->prior;
-    else memset(&prior, 0, sizeof(prior));
     hipLaunchKernelGGL(lm_factor_dd_kernel, dim3((unsigned)p->nobj), dim3(WAVE), 0, s,
-                       p->states, p->nobj, p->obj_start, p->stamp_band, psums, nloc,
-                       p->jac_point, prior, p->prior ? 1 : 0, p->prior_step);
+                       p->states, p->nobj, p->obj_start, p->stamp_band, psums, nloc);
     NGMIX_HIP_CHECK(hipGetLastError());
     return NGMIX_OK;
 }

@@ -552,8 +552,7 @@ class LMBatchFitter(object):
         d_jacpt = None
         if self.fd and self.nloc >= _lib.LM_PRECISE_MIN_NLOC and \
                 getattr(self, "precise_cov", True) and \
-                not os.environ.get("NGMIX_LM_NO_PRECISE_COV") and \
-                (self.prior is None or prior_desc is not None):
+                not os.environ.get("NGMIX_LM_NO_PRECISE_COV") and self.prior is None:
             d_jacpt = torch.zeros((nobj, 3, _lib.LM_NPMAX), dtype=torch.float64, device=dev)
         if self.prior is not None and prior_desc is None:
             nsplit = 1

@@ -191,3 +191,46 @@ def test_precise_cov_leaves_the_iteration_alone_and_matches_minpack(ngauss):
     # are good to their order of magnitude only; the driver's are checked
     # against 50 digits in the test above)
     assert np.median(rel) < (1e-3 if ngauss == 3 else 0.5)
+
+
+def test_precise_factor_of_objects_with_several_stamps():
+    """a co-elliptical fit over TWO stamps per object (two exposures of one
+    star): the object's matrix is the double-double sum of its stamps' sums, in
+    stamp order, and the factor in the record is its pivoted Cholesky factor"""
+    import mpmath as mp
+    mp.mp.dps = 50
+    ngauss, n, nobj = 3, 10, 12
+    obs, guess = _psf_fits(ngauss, 2 * nobj, 301)
+    # (the second exposure of each star: the same star, its own noise and jacobian)
+    for i in range(nobj):
+        guess[2 * i + 1] = guess[2 * i]
+    sb = StampBatch.from_observations(obs)
+    sobj = np.repeat(np.arange(nobj), 2).astype(np.int32)
+    fitter = LMBatchFitter("coellip", ngauss=ngauss, fit_pars=PSF_PARS)
+    fitter.keep_job = True
+    res = fitter.go(sb, guess[::2], stamp_obj=sobj, stamp_band=np.zeros(2 * nobj, dtype=np.int32))
+    job = fitter.last_job
+    st = fitter.states()
+    psums = job.d_psums.cpu().numpy()
+    ntri = n * (n + 1) // 2
+    iu = np.triu_indices(n)
+    checked = 0
+    for o in range(nobj):
+        if not 1 <= st["info"][o] <= 4:
+            continue
+        Amp = mp.zeros(n, n)
+        for s in (2 * o, 2 * o + 1):
+            assert np.isfinite(psums[s, 0, -1])
+            for k, (a, b) in enumerate(zip(*iu)):
+                Amp[a, b] += mp.mpf(float(psums[s, 0, k])) + mp.mpf(float(psums[s, 1, k]))
+                if a != b:
+                    Amp[b, a] = Amp[a, b]
+        Rref, piv, rank = _mp_pivoted_cholesky(Amp)
+        R = st["R"][o][:n, :n]
+        assert list(st["ipvt"][o][:rank]) == piv[:rank]
+        for a in range(rank):
+            for b in range(a, n):
+                assert abs(float(Rref[a, b]) - R[a, b]) <= 1e-13 * float(
+                    mp.sqrt(Rref[a, a] * Rref[b, b]) + abs(Rref[a, b])), (o, a, b)
+        checked += 1
+    assert checked >= 9 and np.mean(res["flags"] == 0) > 0.7
