@@ -66,6 +66,17 @@ class GaussMom(object):
             return res
         return _remove_area(res, obs.jacobian.area)
 
+    def go_many(self, obs):
+        """the moments of a sequence of Observations by ONE launch (the loop
+        over a catalogue around go()): a MomBatchResult -- arrays by key, go()'s
+        dict for observation i by position"""
+        from .batch import StampBatch
+        for o in obs:
+            if not isinstance(o, Observation):
+                raise ValueError("input obs must be an Observation")
+        return GaussMomBatch(self.fwhm, with_higher_order=self.with_higher_order).go(
+            StampBatch.from_observations(list(obs)))
+
 
 class MomBatchResult(object):
     """

@@ -113,6 +113,24 @@ class PSFFluxFitter(object):
         fit_model.go()
         return fit_model
 
+    def go_many(self, obs):
+        """the psf (template) fluxes of a sequence of objects -- Observation or
+        ObsList each, their psf mixtures set -- by one batch (PSFFluxBatch):
+        a dict of per-object arrays flags, flux, flux_err, chi2per, dof, equal to
+        go() per object (results.py:677-914)"""
+        from .batch import flatten_observations, GMixBatch
+        if not self.do_psf:
+            raise ValueError("go_many fits psf mixtures (do_psf=True); templates: "
+                             "PSFFluxBatch.go_templates")
+        stamps, sobj, sband, nband, psf = flatten_observations(obs)
+        if nband != 1:
+            raise ValueError("one band per call (PSFFluxFitter takes an Observation or an ObsList)")
+        if psf is None:
+            raise ValueError("the observations need their psf mixtures")
+        return PSFFluxBatch(normalize_psf=self.normalize_psf).go(
+            stamps, GMixBatch.from_numpy(psf, device=stamps.device), stamp_obj=sobj,
+            nobj=len(obs))
+
 
 class PSFFluxBatch(object):
     """

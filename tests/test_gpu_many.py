@@ -227,3 +227,39 @@ def test_run_em_many_is_the_loop_over_run_em(with_psf, kind):
         else:
             assert not r.has_gmix()
     assert nok >= 18      # (the rest stop at maxiter, on both routes alike)
+
+
+def test_gaussmom_and_psfflux_go_many():
+    obs, _, _ = _catalogue(36, 61, with_psf=True)
+    gmom = ngmix.GaussMom(fwhm=1.2)
+    many = gmom.go_many(obs)
+    assert len(many) == len(obs)
+    for i in (0, 7, 35):
+        one = gmom.go(obs[i])
+        r = many[i]
+        assert set(r.keys()) == set(one.keys())
+        for k in one.keys():
+            if isinstance(one[k], str):
+                assert r[k] == one[k], k
+            else:
+                np.testing.assert_allclose(np.asarray(r[k]), np.asarray(one[k]), rtol=1e-11,
+                                           atol=1e-300, err_msg=k)
+    np.testing.assert_allclose(many["T"][7], gmom.go(obs[7])["T"], rtol=1e-11)
+    # psf fluxes: single observations and two-epoch lists
+    f = ngmix.PSFFluxFitter()
+    res = f.go_many(obs)
+    for i in (0, 5, 35):
+        one = f.go(obs[i])
+        assert res["flags"][i] == one["flags"]
+        np.testing.assert_allclose(res["flux"][i], one["flux"], rtol=1e-11)
+        np.testing.assert_allclose(res["flux_err"][i], one["flux_err"], rtol=1e-9)
+    lists = []
+    for i in range(0, 36, 2):
+        ol = ngmix.ObsList()
+        ol.append(obs[i])
+        ol.append(obs[i + 1])
+        lists.append(ol)
+    res2 = f.go_many(lists)
+    one = f.go(lists[4])
+    np.testing.assert_allclose(res2["flux"][4], one["flux"], rtol=1e-11)
+    np.testing.assert_allclose(res2["flux_err"][4], one["flux_err"], rtol=1e-9)
