@@ -47,10 +47,12 @@ def run_em(obs, guess, sky=None, fixcen=False, fixcov=False, fluxonly=False,
 fit_em = run_em
 
 
-def run_em_many(obs, guess, fixcen=False, fixcov=False, fluxonly=False, **kws):
+def run_em_many(obs, guess, sky=None, fixcen=False, fixcov=False, fluxonly=False, **kws):
     """run_em over a sequence of Observations as ONE batch (the loop over a
     catalogue the reference's callers write around run_em, em.py:30-107);
-    guess: a sequence of GMix (pre-psf), one per observation, all of one size"""
+    guess: a sequence of GMix (pre-psf), one per observation, all of one size;
+    sky: as run_em's (a number or one per observation: the images are taken as
+    they are; None: prep_obs' sky per image)"""
     if fixcen:
         fitter = EMFitterFixCen(**kws)
     elif fixcov:
@@ -59,7 +61,7 @@ def run_em_many(obs, guess, fixcen=False, fixcov=False, fluxonly=False, **kws):
         fitter = EMFitterFluxOnly(**kws)
     else:
         fitter = EMFitter(**kws)
-    return fitter.go_many(obs=obs, guess=guess)
+    return fitter.go_many(obs=obs, guess=guess, sky=sky)
 
 
 def prep_image(im0):
@@ -173,7 +175,7 @@ class EMFitter(object):
         return EMResult(obs=obs, result=result, gm=gm, gm_conv=gm_conv)
 
 
-def _em_go_many(self, obs, guess):
+def _em_go_many(self, obs, guess, sky=None):
     """EMFitter.go for MANY Observations by one launch of the batch kernel
     (ngmix_em_batch): prep_obs' sky per stamp, the psf mixtures normalised to
     unit flux (or a delta function where an observation has none), the guess
@@ -190,7 +192,11 @@ def _em_go_many(self, obs, guess):
     if any(len(g) != ng for g in guess):
         raise ValueError("the guesses of a batch need one size")
     stamps = StampBatch.from_observations(list(obs))
-    skyb, sky = stamps.prep_em()
+    if sky is None:
+        skyb, sky = stamps.prep_em()
+    else:
+        skyb = stamps
+        sky = np.broadcast_to(np.asarray(sky, dtype="f8"), (n,)).copy()
     grec = np.stack([g._data for g in guess]).reshape(n, ng)
     has = [o.has_psf() and o.psf.has_gmix() for o in obs]
     if any(has) and not all(has):

@@ -263,3 +263,47 @@ def test_gaussmom_and_psfflux_go_many():
     one = f.go(lists[4])
     np.testing.assert_allclose(res2["flux"][4], one["flux"], rtol=1e-11)
     np.testing.assert_allclose(res2["flux_err"][4], one["flux_err"], rtol=1e-9)
+
+
+def test_many_object_calls_on_the_reference_c4_objects(golden):
+    """c4.npz: the REFERENCE's own admom and em_run results for thirty-two
+    config-4 objects -- through run_admom_many / run_em_many (reference-style
+    Observations in, per-object results out): flags and iteration counts exact"""
+    g = golden("c4")
+    n = g["images"].shape[0]
+    obs = []
+    for i in range(n):
+        j = g["jac"][i]      # row0, col0, dvdrow, dvdcol, dudrow, dudcol, det, scale
+        jac = ngmix.Jacobian(row=j[0], col=j[1], dvdrow=j[2], dvdcol=j[3], dudrow=j[4], dudcol=j[5])
+        im = g["images"][i]
+        psf = ngmix.Observation(np.zeros((5, 5)), jacobian=jac, gmix=ngmix.GMix(pars=g["psf"].reshape(6)))
+        obs.append(ngmix.Observation(im, weight=np.full(im.shape, 1.0 / float(g["noise"]) ** 2),
+                                     jacobian=jac, psf=psf))
+    maxiter, shiftmax, etol, Ttol = g["admom_conf"]
+    guesses = [ngmix.GMix(pars=g["admom_wt_in"].reshape(n, 6)[i]) for i in range(n)]
+    am = ngmix.admom.run_admom_many(obs, guesses, maxiter=int(maxiter), shiftmax=float(shiftmax),
+                                    etol=float(etol), Ttol=float(Ttol))
+    np.testing.assert_array_equal(am.records["numiter"], g["admom_numiter"])
+    np.testing.assert_array_equal(am.records["flags"], g["admom_flags"])
+    r = am[5]
+    np.testing.assert_allclose(r["sums"], g["admom_sums"][5], rtol=1e-10, atol=1e-12)
+    assert r["numiter"] == g["admom_numiter"][5] and r["flags"] == 0
+    # em_run with the sky the reference passed (image + sky, sky=0.05)
+    sky = float(g["sky"])
+    obs_sky = []
+    for o in obs:
+        o2 = o.copy()
+        o2.image = o.image + sky
+        obs_sky.append(o2)
+    tol, miniter, maxiter = g["em_conf"]
+    eg = [ngmix.GMix(pars=g["em_gmix_in"].reshape(n, 6)[i]) for i in range(n)]
+    em = ngmix.em.run_em_many(obs_sky, eg, sky=sky, tol=float(tol), miniter=int(miniter),
+                              maxiter=int(maxiter))
+    np.testing.assert_array_equal(em.numiter, g["em_numiter"])
+    np.testing.assert_array_equal(em.sky, g["em_sky"])
+    assert np.all(em.flags == 0)
+    one = ngmix.em.run_em(obs_sky[3], eg[3], sky=sky, tol=float(tol), miniter=int(miniter),
+                          maxiter=int(maxiter))
+    assert one["numiter"] == em[3]["numiter"] == g["em_numiter"][3]
+    np.testing.assert_allclose(em[3].get_gmix().get_full_pars(), g["em_gmix_out"][3, 0], rtol=1e-9,
+                               atol=1e-12)
