@@ -87,3 +87,17 @@ def test_lmdif_ill_conditioned_seed_vs_minpack(fzfd, cls, seed):
         assert one["ier"] == res["ier"][o]
         sing = lambda f: (int(f) & flags.LM_SINGULAR_MATRIX) != 0  # noqa: E731
         assert sing(one["flags"]) == sing(res["flags"][o]), (o, one["flags"], res["flags"][o])
+
+
+# ---- the batched bootstrap against the per-object Bootstrapper over MINPACK
+# (tools/fuzz_boot.py; profiles/r06_fuzz_boot.log)
+@pytest.mark.parametrize("seed", [71, 72, 73, 74])
+def test_bootstrap_batch_seed_vs_per_object_bootstrapper(seed):
+    """lmder object models, the lmder psf fitter: psf pass / fail, attempts and
+    nfev of every psf fit, the epochs dropped, BootPSFFailure, flags, attempts,
+    nfev and parameters (1e-4 sigma) of every object -- all equal"""
+    import fuzz_boot
+    stats = fuzz_boot.new_stats()
+    case = fuzz_boot.one_case(seed, models=("exp", "gauss", "dev"), psf_kinds=("gauss",))
+    fuzz_boot.compare(case, stats, seed)
+    assert stats["objects"] >= 3 and not stats["odd"], stats["odd"]

@@ -52,10 +52,10 @@ class Stored(object):
         return np.array(self.table[id(obs)][k])
 
 
-def one_case(seed):
+def one_case(seed, models=("exp", "gauss", "dev", "turb"), psf_kinds=("gauss", "coellip")):
     rng = np.random.RandomState(seed)
-    model = str(rng.choice(["exp", "gauss", "dev", "turb"]))
-    psf_kind = str(rng.choice(["gauss", "coellip"]))
+    model = str(rng.choice(list(models)))
+    psf_kind = str(rng.choice(list(psf_kinds)))
     psf_ng = 1 if psf_kind == "gauss" else 2
     nband = int(rng.randint(1, 4))
     nobj = int(rng.randint(3, 7))
@@ -220,12 +220,16 @@ def compare(case, stats, seed):
             stats["odd"].append((seed, i, case["model"], case["psf_kind"], bad))
 
 
+def new_stats():
+    return dict(objects=0, stamps=0, dropped=0, boot_failed=0, retried=0, worst=0.0, odd=[],
+                by_kind={"gauss": [0, 0], "coellip": [0, 0]},
+                worst_kind={"gauss": 0.0, "coellip": 0.0})
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     master = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 17)
-    stats = dict(objects=0, stamps=0, dropped=0, boot_failed=0, retried=0, worst=0.0, odd=[],
-                 by_kind={"gauss": [0, 0], "coellip": [0, 0]},
-                 worst_kind={"gauss": 0.0, "coellip": 0.0})
+    stats = new_stats()
     t0 = time.time()
     ncase = 0
     while time.time() - t0 < budget:
