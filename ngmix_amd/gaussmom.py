@@ -114,6 +114,8 @@ class MomBatchResult(object):
             raise IndexError(key)
         if callable(self._records):
             self._records = self._records()
+        if self._records is None:
+            raise RuntimeError("the per-stamp records were released (MomBatchResult.release)")
         r = get_weighted_moments_stats(self._records[i])
         if r["flags"] == 0:
             _remove_area(r, self._area[i])
@@ -121,6 +123,18 @@ class MomBatchResult(object):
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))
+
+    def release(self, fetch=False):
+        """Let go of the kernel's records on the DEVICE (2.7 kB per stamp at 17
+        moments: a result kept around pins them until the first per-stamp dict
+        is asked for).  fetch=True downloads them first, so that res[i] keeps
+        working; fetch=False drops them: the arrays by key stay, res[i] raises."""
+        if callable(self._records):
+            self._records = self._records() if fetch else None
+
+    @property
+    def holds_device_memory(self):
+        return callable(self._records)
 
 
 class GaussMomBatch(object):

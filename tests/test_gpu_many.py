@@ -307,3 +307,17 @@ def test_many_object_calls_on_the_reference_c4_objects(golden):
     assert one["numiter"] == em[3]["numiter"] == g["em_numiter"][3]
     np.testing.assert_allclose(em[3].get_gmix().get_full_pars(), g["em_gmix_out"][3, 0], rtol=1e-9,
                                atol=1e-12)
+
+
+def test_mom_batch_result_releases_its_device_records():
+    obs, _, _ = _catalogue(34, 71, with_psf=False)
+    res = ngmix.GaussMom(fwhm=1.2).go_many(obs)
+    assert res.holds_device_memory and res["npix"].dtype == np.int32
+    T = res["T"].copy()
+    res.release(fetch=True)
+    assert not res.holds_device_memory and res[3]["T"] == T[3]
+    res2 = ngmix.GaussMom(fwhm=1.2).go_many(obs)
+    res2.release()
+    np.testing.assert_array_equal(res2["T"], T)
+    with pytest.raises(RuntimeError):
+        res2[0]
