@@ -77,26 +77,37 @@ struct Fit {
     Scal s;
 };
 
-// doubles of LDS per team for fits of up to np parameters
+// R(i, j), j >= i, of a team's factor: the upper triangle packed row-major
+// (row i holds columns i .. np - 1) -- R[tri_row(np, i) + j].  Half the
+// matrix's LDS: the fits in flight per CU are bound by LDS (4 teams per wave).
+__host__ __device__ constexpr int tri_row(int np, int i)
+{
+    return i * (np - 1) - i * (i - 1) / 2;
+}
+
+// doubles of LDS per team for fits of up to np parameters: the work matrix M
+// (np x ld), the packed factor R, nine vectors (g shares its storage with sdiag
+// and acnorm with p: the first of each pair is dead before lmpar, the only user
+// of the second, starts -- see Step::new_jacobian / propose)
 __host__ __device__ inline int team_lds_doubles(int np)
 {
     const int ld = np | 1;
-    return 2 * np * ld + 11 * np;
+    return np * ld + np * (np + 1) / 2 + 9 * np;
 }
 
 __device__ __forceinline__ void carve(Fit &f, double *base, int np)
 {
     f.ld = np | 1;
-    f.R = base;
-    f.M = f.R + np * f.ld;
-    f.diag = f.M + np * f.ld;
+    f.M = base;
+    f.R = f.M + np * f.ld;
+    f.diag = f.R + np * (np + 1) / 2;
     f.qtf = f.diag + np;
     f.step = f.qtf + np;
     f.g = f.step + np;
     f.acnorm = f.g + np;
-    f.sdiag = f.acnorm + np;
-    f.p = f.sdiag + np;
-    f.wa1 = f.p + np;
+    f.sdiag = f.g;        // (g is consumed by qtf_from_gradient before lmpar runs)
+    f.p = f.acnorm;       // (acnorm's last reader is new_jacobian, before propose)
+    f.wa1 = f.acnorm + np;
     f.wa2 = f.wa1 + np;
     f.wa3 = f.wa2 + np;
     f.ipvt = (int32_t *)(f.wa3 + np);
@@ -153,6 +164,45 @@ struct Step {
         return s;
     }
 
+    // rows lo <= i < hi of COLUMN j of the packed factor (R(i, j), i <= j), +0.0
+    // elsewhere: one batch of loads with immediate offsets (tri_row is a
+    // compile-time constant per unrolled i; an address past the column's end
+    // falls inside an earlier row of the triangle: read and discarded)
+    static __device__ __forceinline__ void gather_col(double (&v)[NP], const double *R, int j,
+                                                      int lo, int hi)
+    {
+        const double *c = R + j;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const double t = c[tri_row(NP, i)];
+            v[i] = (i >= lo && i < hi) ? t : 0.0;
+        }
+    }
+
+    // dot / subdot with a column of the packed factor as the first operand
+    static __device__ __forceinline__ double dot_col(const double *R, int j, const double *b,
+                                                     int lo, int hi)
+    {
+        double av[NP], bv[NP];
+        gather_col(av, R, j, lo, hi);
+        gather(bv, b, 1, lo, hi);
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NP; i++) s += av[i] * bv[i];
+        return s;
+    }
+
+    static __device__ __forceinline__ double subdot_col(double s, const double *R, int j,
+                                                        const double *b, int lo, int hi)
+    {
+        double av[NP], bv[NP];
+        gather_col(av, R, j, lo, hi);
+        gather(bv, b, 1, lo, hi);
+#pragma unroll
+        for (int i = 0; i < NP; i++) s -= av[i] * bv[i];
+        return s;
+    }
+
     // lmcore::enorm on an LDS vector: every lane adds in index order
     static __device__ __forceinline__ double enorm(int n, const double *x)
     {
@@ -172,7 +222,7 @@ struct Step {
             f.acnorm[j] = d > 0.0 ? sqrt(d) : 0.0;
 #pragma unroll
             for (int k = 0; k < NP; k++)
-                if (k < n) R[j * ld + k] = 0.0;
+                if (k >= j && k < n) R[tri_row(NP, j) + k] = 0.0;
         }
         tsync();
         for (int k = 0; k < n; k++) {
@@ -198,9 +248,10 @@ struct Step {
                     S[i * ld + k] = u;
                     S[i * ld + kmax] = t;
                     if (i < k) {
-                        const double a = R[i * ld + k], b = R[i * ld + kmax];
-                        R[i * ld + k] = b;
-                        R[i * ld + kmax] = a;
+                        const int ri = tri_row(NP, i);
+                        const double a = R[ri + k], b = R[ri + kmax];
+                        R[ri + k] = b;
+                        R[ri + kmax] = a;
                     }
                 }
                 tsync();
@@ -222,21 +273,22 @@ struct Step {
                 TFOR(kk, k, n) {
 #pragma unroll
                     for (int j = 0; j < NP; j++)
-                        if (j >= kk && j < n) R[kk * ld + j] = 0.0;
+                        if (j >= kk && j < n) R[tri_row(NP, kk) + j] = 0.0;
                 }
                 tsync();
                 return;
             }
             const double rkk = sqrt(d);
             tsync();
-            LEAD R[k * ld + k] = rkk;
-            TFOR(j, k + 1, n) R[k * ld + j] = S[k * ld + j] / rkk;
+            const int rk0 = tri_row(NP, k);
+            LEAD R[rk0 + k] = rkk;
+            TFOR(j, k + 1, n) R[rk0 + j] = S[k * ld + j] / rkk;
             tsync();
             TFOR(i, k + 1, n) {
-                const double rki = R[k * ld + i];
+                const double rki = R[rk0 + i];
                 double sr[NP], rk[NP];
                 gather(sr, S + i * ld, 1, i, n);
-                gather(rk, R + k * ld, 1, i, n);
+                gather(rk, R + rk0, 1, i, n);
 #pragma unroll
                 for (int j = 0; j < NP; j++) {
                     if (j >= i && j < n) {
@@ -254,13 +306,12 @@ struct Step {
     static __device__ __forceinline__ void qtf_from_gradient(Fit &f)
     {
         const int n = f.s.n;
-        constexpr int ld = LD;
         // P^T g, once
         TFOR(j, 0, n) f.wa1[j] = f.g[f.ipvt[j]];
         tsync();
         for (int j = 0; j < n; j++) {
-            const double s = subdot(f.wa1[j], f.R + j, ld, f.qtf, 1, 0, j);
-            const double rjj = f.R[j * ld + j];
+            const double s = subdot_col(f.wa1[j], f.R, j, f.qtf, 0, j);
+            const double rjj = f.R[tri_row(NP, j) + j];
             const double q = rjj != 0.0 ? s / rjj : 0.0;
             tsync();
             LEAD f.qtf[j] = q;
@@ -495,11 +546,10 @@ struct Step {
     static __device__ __forceinline__ double r_times_step_norm(Fit &f)
     {
         const int n = f.s.n;
-        constexpr int ld = LD;
         tsync();
         TFOR(j, 0, n) f.wa2[j] = f.step[f.ipvt[j]];
         tsync();
-        TFOR(i, 0, n) f.wa3[i] = dot(f.R + i * ld, 1, f.wa2, 1, i, n);
+        TFOR(i, 0, n) f.wa3[i] = dot(f.R + tri_row(NP, i), 1, f.wa2, 1, i, n);
         tsync();
         return enorm(n, f.wa3) / f.s.fnorm;
     }
@@ -511,8 +561,10 @@ struct Step {
         constexpr int ld = LD;
         tsync();
         TFOR(i, 0, n) {
+            // (row i of the packed factor, +0.0 below the diagonal as the full
+            // matrix holds it)
             double row[NP];
-            gather(row, f.R + i * ld, 1, 0, n);
+            gather(row, f.R + tri_row(NP, i), 1, i, n);
 #pragma unroll
             for (int j = 0; j < NP; j++)
                 if (j < n) f.M[i * ld + j] = row[j];
@@ -544,7 +596,6 @@ struct Step {
     static __device__ __forceinline__ bool new_jacobian(Fit &f)
     {
         const int n = f.s.n;
-        constexpr int ld = LD;
         f.s.njev++;
         factor_normal(f);
         if (f.s.iter == 1) {
@@ -569,7 +620,7 @@ struct Step {
             tsync();
             TFOR(j, 0, n) {
                 const double al = f.acnorm[f.ipvt[j]];
-                const double sum = dot(f.R + j, ld, f.wa1, 1, 0, j + 1);
+                const double sum = dot_col(f.R, j, f.wa1, 0, j + 1);
                 // (a column lmder skips: any value fmax(gnorm, .) ignores)
                 f.wa2[j] = al == 0.0 ? -1.0 : fabs(sum / al);
             }

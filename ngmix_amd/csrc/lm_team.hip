@@ -203,7 +203,8 @@ __global__ __launch_bounds__(TEAMS * lmteam::TEAM) void lm_advance_team_kernel(
         f.qtf[j] = G.qtf[j];
         f.step[j] = G.step[j];
         f.ipvt[j] = G.ipvt[j];
-        for (int k = 0; k < n; k++) f.R[j * f.ld + k] = G.R[j * LM_NPMAX + k];
+        // (the factor lives packed in LDS: its upper triangle, lm_core_team.hpp)
+        for (int k = j; k < n; k++) f.R[lmteam::tri_row(np, j) + k] = G.R[j * LM_NPMAX + k];
     }
     const int64_t s0 = obj_start ? obj_start[o] : o;
     const int64_t s1 = obj_start ? obj_start[o + 1] : o + 1;
@@ -241,7 +242,9 @@ __global__ __launch_bounds__(TEAMS * lmteam::TEAM) void lm_advance_team_kernel(
         G.qtf[j] = f.qtf[j];
         G.step[j] = f.step[j];
         G.ipvt[j] = f.ipvt[j];
-        for (int k = 0; k < n; k++) G.R[j * LM_NPMAX + k] = f.R[j * f.ld + k];
+        // (below the diagonal the record holds the zeros the one-thread form writes)
+        for (int k = 0; k < n; k++)
+            G.R[j * LM_NPMAX + k] = k >= j ? f.R[lmteam::tri_row(np, j) + k] : 0.0;
     }
     if (f.lane != 0) return;
     G.iter = s.iter;
