@@ -309,14 +309,30 @@ struct Step {
         // P^T g, once
         TFOR(j, 0, n) f.wa1[j] = f.g[f.ipvt[j]];
         tsync();
-        for (int j = 0; j < n; j++) {
-            const double s = subdot_col(f.wa1[j], f.R, j, f.qtf, 0, j);
-            const double rjj = f.R[tri_row(NP, j) + j];
-            const double q = rjj != 0.0 ? s / rjj : 0.0;
-            tsync();
-            LEAD f.qtf[j] = q;
-            tsync();
+        // the forward substitution in registers, replicated on every lane (see
+        // qrsolv's back substitution): subdot()'s terms outside [0, j) are
+        // s - (+0.0) * (+0.0), which leaves every s as it is
+        double wv[NP], qv[NP];
+        gather(wv, f.wa1, 1, 0, n);
+#pragma unroll
+        for (int jj = 0; jj < NP; jj++) {
+            qv[jj] = 0.0;
+            if (jj < n) {
+                double s = wv[jj];
+#pragma unroll
+                for (int i = 0; i < jj; i++) s -= f.R[tri_row(NP, i) + jj] * qv[i];
+                const double rjj = f.R[tri_row(NP, jj) + jj];
+                qv[jj] = rjj != 0.0 ? s / rjj : 0.0;
+            }
         }
+        tsync();
+        TFOR(j, 0, n) {
+            double mine = 0.0;
+#pragma unroll
+            for (int i = 0; i < NP; i++) mine = i == j ? qv[i] : mine;
+            f.qtf[j] = mine;
+        }
+        tsync();
     }
 
     // lmcore::qrsolv on r = f.M, with diag = dvec (an LDS vector), qtb = f.qtf,
@@ -394,24 +410,45 @@ struct Step {
             }
             tsync();
         }
-        double sd[NP];
+        // The back substitution with the solution in REGISTERS, replicated on every
+        // lane (all lanes run the scalar chain anyway): w_j = (wa_j - sum_{i > j}
+        // r[i][j] w_i) / sdiag_j needs no LDS write / barrier / read between two
+        // elements -- the chain is the n divisions and their sums, the column loads
+        // are independent of it.  Element by element the operations and their
+        // order are the loop's above it replaces (dot()'s +0.0 terms outside the
+        // range included: a sum that starts at +0.0 is never -0.0, so leaving out
+        // the terms i <= j, which are all +0.0 * +0.0, changes no bit).
+        double sd[NP], wv[NP];
         gather(sd, sdiag, 1, 0, n);
+        gather(wv, wa, 1, 0, n);
         int nsing = n;
 #pragma unroll
         for (int j = 0; j < NP; j++)
             if (j < n && sd[j] == 0.0 && nsing == n) nsing = j;
-        tsync();
-        TFOR(j, nsing, n) wa[j] = 0.0;
-        tsync();
-        for (int k = 0; k < nsing; k++) {
-            const int j = nsing - 1 - k;
-            const double sum = dot(r + j, ld, wa, 1, j + 1, nsing);
-            const double w = (wa[j] - sum) / sdiag[j];
-            tsync();
-            LEAD wa[j] = w;
-            tsync();
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+            if (j >= nsing) wv[j] = 0.0;
+#pragma unroll
+        for (int jj = NP - 1; jj >= 0; jj--) {
+            if (jj < nsing) {
+                double sum = 0.0;
+#pragma unroll
+                for (int i = jj + 1; i < NP; i++) {
+                    const double a = r[i * ld + jj];
+                    const bool in = i < nsing;
+                    sum += (in ? a : 0.0) * (in ? wv[i] : 0.0);
+                }
+                wv[jj] = (wv[jj] - sum) / sd[jj];
+            }
         }
-        TFOR(j, 0, n) x[f.ipvt[j]] = wa[j];
+        // (wa itself is dead: lmpar overwrites it next)
+        tsync();
+        TFOR(j, 0, n) {
+            double mine = 0.0;
+#pragma unroll
+            for (int i = 0; i < NP; i++) mine = i == j ? wv[i] : mine;
+            x[f.ipvt[j]] = mine;
+        }
         tsync();
     }
 
@@ -432,18 +469,28 @@ struct Step {
             for (int j = 0; j < NP; j++)
                 if (j < n && dg[j] == 0.0 && nsing == n) nsing = j;
         }
-        TFOR(j, 0, n) wa1[j] = j < nsing ? f.qtf[j] : 0.0;
-        tsync();
-        for (int k = 0; k < nsing; k++) {
-            const int j = nsing - 1 - k;
-            const double temp = wa1[j] / r[j * ld + j];
+        {
+            // the gauss-newton direction by back substitution in registers
+            double wv[NP];
+            gather(wv, f.qtf, 1, 0, nsing);
+#pragma unroll
+            for (int jj = NP - 1; jj >= 0; jj--) {
+                if (jj < nsing) {
+                    const double temp = wv[jj] / r[jj * ld + jj];
+                    wv[jj] = temp;
+#pragma unroll
+                    for (int i = 0; i < jj; i++) wv[i] -= r[i * ld + jj] * temp;
+                }
+            }
             tsync();
-            LEAD wa1[j] = temp;
-            TFOR(i, 0, j) wa1[i] -= r[i * ld + j] * temp;
+            TFOR(j, 0, n) {
+                double mine = 0.0;
+#pragma unroll
+                for (int i = 0; i < NP; i++) mine = i == j ? wv[i] : mine;
+                x[f.ipvt[j]] = mine;
+            }
             tsync();
         }
-        TFOR(j, 0, n) x[f.ipvt[j]] = wa1[j];
-        tsync();
 
         int iter = 0;
         TFOR(j, 0, n) wa2[j] = f.diag[j] * x[j];
@@ -463,14 +510,21 @@ struct Step {
                 wa1[j] = f.diag[l] * (wa2[l] / dxnorm);
             }
             tsync();
-            for (int j = 0; j < n; j++) {
-                const double sum = dot(r + j, ld, wa1, 1, 0, j);
-                const double w = (wa1[j] - sum) / r[j * ld + j];
-                tsync();
-                LEAD wa1[j] = w;
-                tsync();
+            double wv[NP];
+            gather(wv, wa1, 1, 0, n);
+#pragma unroll
+            for (int jj = 0; jj < NP; jj++) {
+                if (jj < n) {
+                    double sum = 0.0;
+#pragma unroll
+                    for (int i = 0; i < jj; i++) sum += r[i * ld + jj] * wv[i];
+                    wv[jj] = (wv[jj] - sum) / r[jj * ld + jj];
+                }
             }
-            const double temp = enorm(n, wa1);
+            double ss = 0.0;
+#pragma unroll
+            for (int i = 0; i < NP; i++) ss += wv[i] * wv[i];
+            const double temp = sqrt(ss);
             parl = ((fp / delta) / temp) / temp;
         }
         // upper bound
@@ -511,14 +565,30 @@ struct Step {
                 wa1[j] = f.diag[l] * (wa2[l] / dxnorm);
             }
             tsync();
-            for (int j = 0; j < n; j++) {
-                const double t = wa1[j] / f.sdiag[j];
-                tsync();
-                LEAD wa1[j] = t;
-                TFOR(i, j + 1, n) wa1[i] -= r[i * ld + j] * t;
-                tsync();
+            {
+                // the forward substitution in registers (see qrsolv's back
+                // substitution): wa1 is not read again before it is overwritten
+                double sd[NP], wv[NP];
+                gather(sd, f.sdiag, 1, 0, n);
+                gather(wv, wa1, 1, 0, n);
+#pragma unroll
+                for (int jj = 0; jj < NP; jj++) {
+                    if (jj < n) {
+                        const double t = wv[jj] / sd[jj];
+                        wv[jj] = t;
+#pragma unroll
+                        for (int i = jj + 1; i < NP; i++) {
+                            const double a = r[i * ld + jj];
+                            if (i < n) wv[i] -= a * t;
+                        }
+                    }
+                }
+                // enorm(n, wa1): the squares added in index order from +0.0
+                double ss = 0.0;
+#pragma unroll
+                for (int i = 0; i < NP; i++) ss += wv[i] * wv[i];
+                temp = sqrt(ss);
             }
-            temp = enorm(n, wa1);
             const double parc = ((fp / delta) / temp) / temp;
             if (fp > 0.0) parl = fmax(parl, par);
             if (fp < 0.0) paru = fmin(paru, par);
