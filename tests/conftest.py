@@ -15,6 +15,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # lock-step driver (and of the reference goldens' exact nfev).  Outside the
 # tests Fitter.go defaults to the one-object batch of that driver; the tests of
 # that route ask for it explicitly (batched=True).
+# (setdefault: `NGMIX_FITTER_BATCHED=1 pytest -m gpu` runs the whole suite through
+# the shipped default route instead -- green too: profiles/r06_gputest_batched_route.log)
 os.environ.setdefault("NGMIX_FITTER_BATCHED", "0")
 
 
