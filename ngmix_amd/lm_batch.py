@@ -1308,13 +1308,14 @@ class LMBatchFitter(object):
         res["g_err"] = perr[:, 2:4]
         # (blocks of pars_cov: read when asked for, like pars_cov itself)
         res.set_lazy("g_cov", lambda r: r["pars_cov"][:, 2:4, 2:4])
-        if self.model == "coellip":
-            # CoellipFitModel._set_flux is a no-op (results.py:648-652)
-            return
         # pars_err is sqrt(diag(pars_cov)) (fitters.py:333-339), made by the
         # finalize kernel with the same IEEE square root
         res["T"] = pars[:, 4]
         res["T_err"] = perr[:, 4]
+        if self.model == "coellip":
+            # CoellipFitModel._set_flux is a no-op (results.py:648-652); _set_T
+            # is not overridden: T is pars[4], the first component's
+            return
         if nband == 1:
             res["flux"] = pars[:, nshape]
             res["flux_err"] = perr[:, nshape]

@@ -321,3 +321,31 @@ def test_mom_batch_result_releases_its_device_records():
     np.testing.assert_array_equal(res2["T"], T)
     with pytest.raises(RuntimeError):
         res2[0]
+
+
+def test_coellip_fitter_go_many(golden):
+    """CoellipFitter.go_many: the psf fits of a catalogue as one batch -- each
+    element the per-object fit's dict; on the reference's own coellip-3 golden
+    (lmfd.npz) nfev and the solution are the reference's"""
+    from test_gpu_lm_precise import _psf_fits
+    obs, guess = _psf_fits(3, 34, 501)
+    fitter = ngmix.fitting.CoellipFitter(ngauss=3, fit_pars={"maxfev": 4000, "ftol": 1e-5,
+                                                             "xtol": 1e-5}, batched=True)
+    many = fitter.go_many(obs, guess)
+    assert len(many) == 34
+    for i in (0, 9, 33):
+        one = fitter.go(obs=obs[i], guess=guess[i])
+        _same_result(many[i], dict(one))
+    assert "flux" not in many[0] and many[0]["pars"].shape == (10,)
+    g = golden("lmfd")
+    j = g["coellip_jac"]
+    j = j[0] if j.ndim else j
+    jac = ngmix.Jacobian(row=float(j["row0"]), col=float(j["col0"]), dvdrow=float(j["dvdrow"]),
+                         dvdcol=float(j["dvdcol"]), dudrow=float(j["dudrow"]),
+                         dudcol=float(j["dudcol"]))
+    im = g["coellip_image"]
+    o = ngmix.Observation(im, weight=np.full(im.shape, 1.0 / 2.0e-4 ** 2), jacobian=jac)
+    res = ngmix.fitting.CoellipFitter(ngauss=3).go_many([o] * 33, np.tile(g["coellip3_guess"], (33, 1)))
+    r = res[17]
+    assert r["flags"] == 0 and r["nfev"] == int(g["coellip3_nfev"])
+    assert np.all(np.abs(r["pars"] - g["coellip3_pars"]) <= 1e-3 * g["coellip3_pars_err"])
