@@ -89,7 +89,9 @@ class PSFFluxFitModel(dict):
             res = batch.go(stamps, gm, stamp_obj=same_object)
         for k in _RESULT_KEYS:
             v = res[k][0]
-            self[k] = int(v) if k == "flags" else float(v)
+            # dof is npix - 1, an integer, unless floored at 1e-6
+            # (results.py:806-814)
+            self[k] = int(v) if k == "flags" or (k == "dof" and v >= 1.0) else float(v)
 
     def get_effective_npix(self):
         """pixels with positive weight, over all epochs"""
