@@ -15,7 +15,7 @@ from . import flags  # noqa: F401
 from . import defaults  # noqa: F401
 from . import gexceptions  # noqa: F401
 from .gexceptions import (  # noqa: F401
-    GMixRangeError, GMixFatalError, GMixMaxIterEM, PSFFluxFailure,
+    NGmixBaseException, GMixRangeError, GMixFatalError, GMixMaxIterEM, PSFFluxFailure,
     BootPSFFailure, BootGalFailure, FFTRangeError,
 )
 from . import _lib  # noqa: F401

@@ -539,8 +539,14 @@ class GMixList(_TypedList):
     _item_type = GMix
     _what = "gmix"
 
+    def append(self, gmix):
+        super().append(gmix)
+
 
 class MultiBandGMixList(_TypedList):
     """one GMixList per band (reference: ngmix/gmix/gmix_lists.py:30-57)"""
     _item_type = GMixList
     _what = "gmix_list"
+
+    def append(self, gmix_list):
+        super().append(gmix_list)

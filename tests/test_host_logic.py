@@ -726,3 +726,110 @@ def test_bootstrap_batch_host_pieces():
     with pytest.raises(ValueError):
         P.bootstrap_batch(type("S", (), {"n": 1})(), type("S", (), {"n": 1})(), model="spergel")
     assert P.BOOT_PSF_FAILURE == 1 << 30
+
+
+# ---------------------------------------------------------------------------
+# the reference's public names, module by module (tests/golden/api_surface.json,
+# read off the reference by oracle/gen_golden_surface.py)
+
+# what ngmix_amd does NOT offer, and why (SURVEY.md section 8 "out of scope"):
+_SURFACE_OUT_OF_SCOPE = {
+    # galsim-backed fitters / objects: galsim is not the pixel hot path
+    "fitting": {"GalsimFitModel", "GalsimFitter", "GalsimMoffatFitModel", "GalsimMoffatFitter",
+                "GalsimPSFFitModel", "GalsimPSFFluxFitter", "GalsimSpergelFitModel",
+                "GalsimSpergelFitter"},
+    "guessers": {"R50NuFluxGuesser"},            # the Spergel (galsim) fitter's guesser
+    # k-space observations feed the galsim fitters only
+    "observation": {"KMultiBandObsList", "KObsList", "KObservation", "get_kmb_obs",
+                    "make_iilist", "make_kobs"},
+}
+_ATTRS_OUT_OF_SCOPE = {"make_galsim_object", "get_galsim_wcs"}
+_TOP_OUT_OF_SCOPE = {"GMixND", "gmix_ndim", "priors", "joint_prior",   # prior pdfs: SURVEY 8 "next"
+                     "gaussap", "simobs", "metacal", "ksigmamom", "prepsfmom",
+                     "fastexp_nb",            # the numba module; its function is a HIP device fn
+                     "NumbaExperimentalFeatureWarning", "warnings"}
+
+
+def test_public_surface_covers_the_reference():
+    import importlib
+    import os
+    import json
+    import ngmix_amd
+    with open(os.path.join(os.path.dirname(__file__), "golden", "api_surface.json")) as f:
+        ref = json.load(f)
+    missing = []
+    for mod_name, names in ref.items():
+        if mod_name == "__top__":
+            missing += ["ngmix." + n for n in names
+                        if not hasattr(ngmix_amd, n) and n not in _TOP_OUT_OF_SCOPE]
+            continue
+        mod = importlib.import_module("ngmix_amd." + mod_name)
+        skip = _SURFACE_OUT_OF_SCOPE.get(mod_name, set())
+        for n, attrs in names.items():
+            if n in skip:
+                continue
+            if not hasattr(mod, n):
+                missing.append("%s.%s" % (mod_name, n))
+                continue
+            if attrs != "function":
+                obj = getattr(mod, n)
+                missing += ["%s.%s.%s" % (mod_name, n, a) for a in attrs
+                            if not hasattr(obj, a) and a not in _ATTRS_OUT_OF_SCOPE]
+    assert not missing, missing
+    # and the out-of-scope list is not stale: none of it quietly exists
+    for mod_name, names in _SURFACE_OUT_OF_SCOPE.items():
+        mod = importlib.import_module("ngmix_amd." + mod_name)
+        assert not [n for n in names if hasattr(mod, n)]
+
+
+def _param_names(f):
+    import inspect
+    try:
+        ps = inspect.signature(f).parameters.values()
+    except (ValueError, TypeError):
+        return None, False
+    names = [p.name for p in ps if p.name != "self"]
+    catch_all = any(p.kind == p.VAR_KEYWORD for p in ps)
+    return names, catch_all
+
+
+def test_call_signatures_take_the_reference_argument_names():
+    """every function, constructor and method the reference defines in these
+    modules takes, here, every parameter NAME the reference's takes
+    (tests/golden/api_signatures.json), so a call written against the reference
+    with keywords binds; extra batch-only keywords are allowed"""
+    import importlib
+    import inspect
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "api_signatures.json")) as f:
+        ref = json.load(f)
+    bad = []
+    for qual, want in ref.items():
+        mod_name, name = qual.split(".")
+        if name in _SURFACE_OUT_OF_SCOPE.get(mod_name, set()):
+            continue
+        obj = getattr(importlib.import_module("ngmix_amd." + mod_name), name)
+        if isinstance(want, list):
+            cases = [(qual, obj, want)]
+        elif want is None:
+            continue
+        else:
+            cases = []
+            for attr, w in want.items():
+                if w is None or attr in _ATTRS_OUT_OF_SCOPE:
+                    continue
+                f = obj.__init__ if attr == "__init__" else inspect.getattr_static(obj, attr)
+                if isinstance(f, (staticmethod, classmethod)):
+                    f = f.__func__
+                if not inspect.isfunction(f):
+                    continue                     # a property here, a method there: names only
+                cases.append(("%s.%s" % (qual, attr), f, w))
+        for label, f, w in cases:
+            have, catch_all = _param_names(f)
+            if have is None or catch_all:
+                continue
+            miss = [a for a in w if a not in have and a not in ("args", "kw", "kwargs", "keys")]
+            if miss:
+                bad.append((label, miss))
+    assert not bad, bad
