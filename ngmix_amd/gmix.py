@@ -222,12 +222,19 @@ class GMix(object):
 
     def _second_moments(self):
         """flux-weighted covariance of the whole mixture about its centroid: the
-        mean of the components' own covariances plus the scatter of their centres"""
+        mean of the components' own covariances plus the scatter of their
+        centres.  Each moment is a numpy sum of (second moment) * p times
+        1 / sum(p), as gmix.py:181-266 writes it, so the getters agree with the
+        reference to the bit."""
         gm = self._data
-        w = gm["p"] / gm["p"].sum()
-        dr = gm["row"] - w @ gm["row"]
-        dc = gm["col"] - w @ gm["col"]
-        return w @ (gm["irr"] + dr * dr), w @ (gm["irc"] + dr * dc), w @ (gm["icc"] + dc * dc)
+        row0, col0 = self.get_cen()
+        dr = gm["row"] - row0
+        dc = gm["col"] - col0
+        p = gm["p"]
+        ipsum = 1.0 / p.sum()
+        return (((gm["irr"] + dr ** 2) * p).sum() * ipsum,
+                ((gm["irc"] + dr * dc) * p).sum() * ipsum,
+                ((gm["icc"] + dc ** 2) * p).sum() * ipsum)
 
     def get_T(self):
         irr, _, icc = self._second_moments()

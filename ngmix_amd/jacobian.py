@@ -29,10 +29,10 @@ class Jacobian(object):
     def __init__(self, **kw):
         self._data = np.zeros(1, dtype=_jacobian_dtype)
         if "x" in kw:
-            row0, col0, req = kw["y"], kw["x"], _XY_REQ
+            cen, req = ("y", "x"), _XY_REQ
             names = ("dvdy", "dvdx", "dudy", "dudx")
         elif "row" in kw:
-            row0, col0, req = kw["row"], kw["col"], _ROWCOL_REQ
+            cen, req = ("row", "col"), _ROWCOL_REQ
             names = ("dvdrow", "dvdcol", "dudrow", "dudcol")
         else:
             raise ValueError("send by row,col or x,y")
@@ -40,11 +40,13 @@ class Jacobian(object):
             wcs = kw["wcs"]
             derivs = (wcs.dvdy, wcs.dvdx, wcs.dudy, wcs.dudx)
         else:
+            # a missing keyword -- the other half of the centre included -- is
+            # a ValueError naming it (jacobian.py:262-292)
             for k in req:
                 if k not in kw:
                     raise ValueError("missing keyword: '%s'" % k)
             derivs = tuple(kw[n] for n in names)
-        self._fill(row0, col0, *derivs)
+        self._fill(kw[cen[0]], kw[cen[1]], *derivs)
 
     def _fill(self, row0, col0, dvdrow, dvdcol, dudrow, dudcol):
         d = self._data

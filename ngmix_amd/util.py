@@ -24,7 +24,9 @@ def srandu(num=None, rng=None):
 
 
 def format_pars(pars, fmt="%8.3g"):
-    return " ".join(fmt % p for p in pars)
+    """the parameters on one line: each number in `fmt`, two blanks after
+    each but the last, one after that (util.py:38-54)"""
+    return "  ".join(fmt % p for p in pars) + " " if len(pars) else ""
 
 
 def print_pars(pars, fmt="%8.3g", front=None, stream=None, logger=None):

@@ -833,3 +833,28 @@ def test_call_signatures_take_the_reference_argument_names():
             if miss:
                 bad.append((label, miss))
     assert not bad, bad
+
+
+def test_host6_behaviours_found_by_the_side_by_side_audit():
+    """tests/golden/host6.json (oracle/gen_golden_host6.py): format_pars
+    strings, Jacobian's exception for a missing keyword, the mixture summary
+    getters to the bit"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "host6.json")) as f:
+        g = json.load(f)
+    for case in g["format_pars"]:
+        kw = {} if case["fmt"] is None else {"fmt": case["fmt"]}
+        assert ngmix.util.format_pars(np.array(case["pars"]), **kw) == case["expected"], case
+    for case in g["jacobian_errors"]:
+        try:
+            ngmix.Jacobian(**case["kw"])
+            got = None
+        except Exception as e:      # noqa: BLE001
+            got = type(e).__name__
+        assert got == case["expected"], (case, got)
+    for case in g["getters"]:
+        gm = ngmix.GMix(pars=np.array([float.fromhex(p) for p in case["pars"]]))
+        for name, want in case["expected"].items():
+            got = [float(v).hex() for v in np.atleast_1d(getattr(gm, name)())]
+            assert got == want, (name, got, want)
