@@ -821,12 +821,8 @@ class Fitter(object):
         stamps, sobj, sband, nband, psf = flatten_observations(obs)
         if guess.shape[0] != len(obs):
             raise ValueError("one guess per object")
-        prior = self.prior
-        if prior is not None and not hasattr(prior, "fill_fdiff_batch"):
-            from .prior_batch import PriorBatchAdapter
-            prior = PriorBatchAdapter(prior)
         fitter = LMBatchFitter(spec[0], fit_pars=self.fit_pars, ngauss=spec[1],
-                               analytic_jacobian=self.analytic_jacobian, prior=prior)
+                               analytic_jacobian=self.analytic_jacobian, prior=self.prior)
         trivial = stamps.n == len(obs) and nband == 1
         res = fitter.go(stamps, guess, psf=psf,
                         stamp_obj=None if trivial else sobj,

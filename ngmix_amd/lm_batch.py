@@ -40,7 +40,7 @@ from .batch import GMixBatch, _dptr, _stream, _torch, _on_device
 from .defaults import PDEF, CDEF, DEFAULT_LM_PARS
 from .gmix import get_model_num
 from .fitting import get_lm_n_prior_pars, STEP_PRIOR
-from .prior_batch import bounds_arrays, prior_normal_sums
+from .prior_batch import as_batch_prior, bounds_arrays, prior_normal_sums
 
 __all__ = ["LMBatchFitter"]
 
@@ -235,13 +235,17 @@ class LMBatchFitter(object):
         DEFAULT_LM_PARS, ngmix/defaults.py:17)
     analytic_jacobian: False forces forward differences for gauss/exp/dev
         too (Fitter's switch of the same name)
-    prior: a batch prior (prior_batch.PriorSimpleSepBatch, PriorBatchAdapter
-        around a reference-style prior, or anything with their three members)
+    prior: a joint prior as the reference's callers build it
+        (joint_prior.PriorSimpleSep ... of priors.py terms: put in its batch
+        form by prior_batch.as_batch_prior), or a batch prior
+        (prior_batch.PriorSimpleSepBatch, PriorBatchAdapter, or anything with
+        their three members)
     """
 
     def __init__(self, model, fit_pars=None, analytic_jacobian=True, prior=None,
                  device_prior=True, ngauss=None):
-        self.prior = prior
+        # host joint priors (joint_prior.py) are put in their batch form
+        self.prior = as_batch_prior(prior)
         # evaluate a PriorSimpleSepBatch inside one kernel (False: torch ops)
         self.device_prior = device_prior
         self.ngauss = None

@@ -326,7 +326,9 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
         perturbed one without `guess`) up to ntry times in all, as Runner does
         object by object (runners.py:95-150); 'ntry' of the result counts the
         attempts
-    prior: a batch prior for the object fits (prior_batch.PriorSimpleSepBatch ...)
+    prior: the joint prior of the object fits: a joint_prior.PriorSimpleSep
+        (...) of priors.py terms as a caller of the reference builds it, or a
+        batch prior (prior_batch.PriorSimpleSepBatch ...)
     stamp_obj / stamp_band: as for LMBatchFitter.go -- objects with several
         epochs and bands (a MultiBandObsList each).  Every stamp gets its own
         psf fit.

@@ -28,7 +28,7 @@ import numpy as np
 from .gexceptions import GMixRangeError
 
 __all__ = ["GaussianCen", "GPriorBA", "Flat", "TwoSidedErf", "Normal", "PriorSimpleSepBatch",
-           "PriorBatchAdapter", "prior_normal_sums"]
+           "PriorBatchAdapter", "as_batch_prior", "prior_normal_sums"]
 
 
 def _torch():
@@ -204,22 +204,25 @@ class PriorBatchAdapter(object):
     a reference-style joint prior (fill_fdiff(pars, fdiff) -> nrows,
     get_lnprob_scalar(pars), optional .bounds) evaluated object by object on
     the host: correct for any prior, at one Python call per object and
-    evaluation
+    evaluation.  max_rows: the length of the buffer handed to fill_fdiff (its
+    return value says how many rows it wrote); by default two more than there
+    are parameters, which holds every joint prior of joint_prior.py.
     """
 
-    def __init__(self, prior, max_rows):
+    def __init__(self, prior, max_rows=None):
         self.prior = prior
-        self.max_rows = int(max_rows)
+        self.max_rows = None if max_rows is None else int(max_rows)
         self.bounds = getattr(prior, "bounds", None)
 
     def fill_fdiff_batch(self, pars):
         torch = _torch()
         p = pars.detach().cpu().numpy()
         n = p.shape[0]
-        rows = np.zeros((n, self.max_rows))
+        max_rows = self.max_rows if self.max_rows is not None else p.shape[1] + 2
+        rows = np.zeros((n, max_rows))
         bad = np.zeros(n, dtype=bool)
-        buf = np.zeros(self.max_rows)
-        nrows = self.max_rows
+        buf = np.zeros(max_rows)
+        nrows = max_rows
         for i in range(n):
             buf[:] = 0.0
             try:
@@ -240,6 +243,50 @@ class PriorBatchAdapter(object):
             except GMixRangeError:
                 out[i] = -np.inf
         return torch.from_numpy(out).to(pars.device)
+
+
+def _batch_term(p):
+    """the batch form of a 1-d host prior of priors.py, or None"""
+    from . import priors as P
+    kind = type(p)
+    if kind is P.FlatPrior:
+        return Flat(p.minval, p.maxval, bounds=p.bounds)
+    if kind is P.TwoSidedErf:
+        return TwoSidedErf(p.minval, p.width_at_min, p.maxval, p.width_at_max, bounds=p.bounds)
+    if kind is P.Normal:
+        return Normal(p.mean, p.sigma, bounds=p.bounds)
+    return None
+
+
+def as_batch_prior(prior):
+    """
+    What a caller passed as prior=, in the form the lock-step driver takes
+    (fill_fdiff_batch / get_lnprob_batch / bounds):
+
+      None or a batch prior        unchanged
+      joint_prior.PriorSimpleSep   of a CenPrior, a GPriorBA and FlatPrior /
+        (or PriorGalsimSimpleSep)  TwoSidedErf / Normal terms: the
+                                   PriorSimpleSepBatch of the same densities,
+                                   evaluated for all fits at once on the device
+      any other object with        PriorBatchAdapter: fill_fdiff /
+        fill_fdiff                 get_lnprob_scalar per object on the host
+    """
+    if prior is None or hasattr(prior, "fill_fdiff_batch"):
+        return prior
+    from . import priors as P
+    from . import joint_prior as J
+    if type(prior) in (J.PriorSimpleSep, J.PriorGalsimSimpleSep) and \
+            type(prior.cen_prior) is P.CenPrior and type(prior.g_prior) is P.GPriorBA:
+        terms = [_batch_term(p) for p in [prior.T_prior] + list(prior.F_priors)]
+        if all(t is not None for t in terms):
+            cen = prior.cen_prior
+            return PriorSimpleSepBatch(
+                GaussianCen(cen.cen1, cen.cen2, cen.sigma1, cen.sigma2),
+                GPriorBA(prior.g_prior.sigma), terms[0],
+                terms[1:] if len(terms) > 2 else terms[1])
+    if not hasattr(prior, "fill_fdiff"):
+        raise TypeError("prior must offer fill_fdiff_batch or fill_fdiff, got %r" % (prior,))
+    return PriorBatchAdapter(prior)
 
 
 def bounds_arrays(bounds, npars):

@@ -350,3 +350,94 @@ def _as_mb(obs, band):
                 ol.append(o)
         mb.append(ol)
     return mb
+
+
+def _host_prior(g, tag, seed=1):
+    """the joint prior of oracle/gen_golden_prior.py built from ngmix_amd's
+    own priors / joint_prior classes"""
+    from ngmix_amd import priors, joint_prior
+    rng = np.random.RandomState(seed)
+    nband = 2 if tag == "b2" else 1
+    cs, gs = float(g["cen_sigma"]), float(g["g_sigma"])
+    if tag == "bb":
+        Tp = priors.Normal(*g["T_normal"], rng=rng, bounds=tuple(g["T_bounds"]))
+        Fp = [priors.Normal(*g["F_normal"], rng=rng, bounds=(float(g["F_lower_bound"]), None))]
+    else:
+        Tp = priors.TwoSidedErf(*g["T_erf"], rng=rng)
+        Fp = [priors.TwoSidedErf(*g["F_erf"], rng=rng) for _ in range(nband)]
+    return joint_prior.PriorSimpleSep(priors.CenPrior(0.0, 0.0, cs, cs, rng=rng),
+                                      priors.GPriorBA(gs, rng=rng), Tp,
+                                      Fp if nband > 1 else Fp[0])
+
+
+@pytest.mark.parametrize("tag", ["b1", "b2", "bb"])
+def test_reference_prior_fits_with_the_host_joint_prior(golden, tag):
+    """tests/golden/prior.npz again, the prior now ngmix_amd.joint_prior's
+    PriorSimpleSep of ngmix_amd.priors terms -- what a caller of the reference
+    writes: its rows / ln p at the golden points are the reference prior's to
+    the bit; the per-object Fitter reproduces the reference's fit; and
+    LMBatchFitter / Fitter.go_many, handed the HOST prior, turn it into the
+    batch prior (prior_batch.as_batch_prior) and reproduce it too"""
+    g = golden("prior")
+    obs, band, batch_prior = _golden_prior_setup(g, tag)
+    prior = _host_prior(g, tag)
+    pts = g[tag + "_prior_pts"]
+    rows = np.zeros((pts.shape[0], g[tag + "_prior_rows"].shape[1]))
+    for i, p in enumerate(pts):
+        buf = np.zeros(12)
+        n = prior.fill_fdiff(p, buf)
+        assert n == rows.shape[1]
+        rows[i] = buf[:n]
+    np.testing.assert_array_equal(rows, g[tag + "_prior_rows"])
+    np.testing.assert_array_equal([prior.get_lnprob_scalar(p) for p in pts],
+                                  g[tag + "_prior_lnp"])
+    assert (prior.bounds is None) == (batch_prior.bounds is None)
+    conv = pb.as_batch_prior(prior)
+    assert isinstance(conv, pb.PriorSimpleSepBatch) and conv.descriptor() is not None
+    assert conv.bounds == batch_prior.bounds
+    mb = _as_mb(obs, band)
+    for mode, analytic in (("lmder", True), ("lmdif", False)):
+        pre = "%s_%s_" % (tag, mode)
+        ptol = 1e-6 if analytic else 2e-5
+        one = ngmix.fitting.Fitter(model="exp", prior=prior, analytic_jacobian=analytic).go(
+            obs=mb, guess=g[tag + "_guess"])
+        assert one["flags"] == 0 and one["ier"] == int(g[pre + "ier"])
+        if analytic:
+            assert one["nfev"] == int(g[pre + "nfev"])
+        np.testing.assert_allclose(one["pars"], g[pre + "pars"], rtol=ptol, atol=ptol * 1e-2)
+        np.testing.assert_allclose(one["lnprob"], float(g[pre + "lnprob"]), rtol=1e-7, atol=1e-6)
+        many = ngmix.fitting.Fitter(model="exp", prior=prior, analytic_jacobian=analytic,
+                                    batched=True).go_many([mb, mb], np.tile(g[tag + "_guess"],
+                                                                            (2, 1)))
+        for r in (many[0], many[1]):
+            assert r["flags"] == 0 and r["ier"] == int(g[pre + "ier"])
+            if analytic:
+                assert r["nfev"] == int(g[pre + "nfev"])
+            np.testing.assert_allclose(r["pars"], g[pre + "pars"], rtol=ptol, atol=ptol * 1e-2)
+            np.testing.assert_allclose(r["lnprob"], float(g[pre + "lnprob"]), rtol=1e-7,
+                                       atol=1e-6)
+
+
+def test_any_host_prior_reaches_the_batch_through_the_adapter(golden):
+    """a joint prior as_batch_prior has no batch form for (a LogNormal size
+    term) is served object by object on the host: go_many equals the
+    per-object fits"""
+    from ngmix_amd import priors, joint_prior
+    g = golden("prior")
+    obs, band, _ = _golden_prior_setup(g, "b1")
+    rng = np.random.RandomState(3)
+    prior = joint_prior.PriorSimpleSep(
+        priors.CenPrior(0.0, 0.0, 0.05, 0.05, rng=rng), priors.GPriorBA(0.2, rng=rng),
+        priors.LogNormal(0.5, 0.3, rng=rng), priors.FlatPrior(-10.0, 1.0e5, rng=rng))
+    assert isinstance(pb.as_batch_prior(prior), pb.PriorBatchAdapter)
+    with pytest.raises(TypeError):
+        pb.as_batch_prior(object())
+    fitter = ngmix.fitting.Fitter(model="exp", prior=prior, batched=True)
+    one = fitter.go(obs=obs[0], guess=g["b1_guess"])
+    many = fitter.go_many([obs[0]] * 3, np.tile(g["b1_guess"], (3, 1)))
+    assert one["flags"] == 0
+    for r in (many[0], many[2]):
+        assert r["flags"] == 0 and r["nfev"] == one["nfev"]
+        np.testing.assert_allclose(r["pars"], one["pars"], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(r["pars_err"], one["pars_err"], rtol=1e-4)
+        np.testing.assert_allclose(r["lnprob"], one["lnprob"], rtol=1e-9, atol=1e-7)

@@ -739,12 +739,13 @@ _SURFACE_OUT_OF_SCOPE = {
                 "GalsimPSFFitModel", "GalsimPSFFluxFitter", "GalsimSpergelFitModel",
                 "GalsimSpergelFitter"},
     "guessers": {"R50NuFluxGuesser"},            # the Spergel (galsim) fitter's guesser
+    "joint_prior": {"PriorSpergelSep"},          # and its joint prior
     # k-space observations feed the galsim fitters only
     "observation": {"KMultiBandObsList", "KObsList", "KObservation", "get_kmb_obs",
                     "make_iilist", "make_kobs"},
 }
 _ATTRS_OUT_OF_SCOPE = {"make_galsim_object", "get_galsim_wcs"}
-_TOP_OUT_OF_SCOPE = {"GMixND", "gmix_ndim", "priors", "joint_prior",   # prior pdfs: SURVEY 8 "next"
+_TOP_OUT_OF_SCOPE = {"GMixND", "gmix_ndim",          # the N-d mixture pdf (sklearn)
                      "gaussap", "simobs", "metacal", "ksigmamom", "prepsfmom",
                      "fastexp_nb",            # the numba module; its function is a HIP device fn
                      "NumbaExperimentalFeatureWarning", "warnings"}
