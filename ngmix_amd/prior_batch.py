@@ -27,13 +27,21 @@ import numpy as np
 
 from .gexceptions import GMixRangeError
 
-__all__ = ["GaussianCen", "GPriorBA", "Flat", "TwoSidedErf", "Normal", "PriorSimpleSepBatch",
-           "PriorBatchAdapter", "as_batch_prior", "prior_normal_sums"]
+__all__ = ["GaussianCen", "GPriorBA", "Flat", "TwoSidedErf", "Normal", "LogNormal",
+           "TruncatedGaussian", "PriorSepBatch", "PriorSimpleSepBatch", "PriorBatchAdapter",
+           "as_batch_prior", "prior_normal_sums"]
 
 
 def _torch():
     import torch
     return torch
+
+
+def _root_of_lnprob(lnp):
+    """sqrt(-2 ln p) with ln p > 0 counted as 0: the residual row of a term
+    whose density is not a gaussian in the parameter"""
+    torch = _torch()
+    return torch.sqrt(torch.clamp(-2.0 * lnp, min=0.0))
 
 
 class GaussianCen(object):
@@ -42,12 +50,17 @@ class GaussianCen(object):
 
     def __init__(self, cen1, cen2, sigma1, sigma2):
         self.cen1, self.cen2 = float(cen1), float(cen2)
+        self.sinv1, self.sinv2 = 1.0 / float(sigma1), 1.0 / float(sigma2)
         self.s2inv1, self.s2inv2 = 1.0 / float(sigma1) ** 2, 1.0 / float(sigma2) ** 2
 
     def lnprob_sep(self, x1, x2):
         d1 = self.cen1 - x1
         d2 = self.cen2 - x2
         return -0.5 * d1 * d1 * self.s2inv1, -0.5 * d2 * d2 * self.s2inv2
+
+    def fdiff(self, x1, x2):
+        """CenPrior.get_fdiff: signed (x - cen) / sigma"""
+        return (x1 - self.cen1) * self.sinv1, (x2 - self.cen2) * self.sinv2
 
 
 class GPriorBA(object):
@@ -65,6 +78,10 @@ class GPriorBA(object):
         safe = torch.where(bad, torch.ones_like(omgsq), omgsq)
         return 2.0 * torch.log(safe) - 0.5 * gsq * self.sig2inv, bad
 
+    def fdiff(self, g1, g2):
+        lnp, bad = self.lnprob2d(g1, g2)
+        return _root_of_lnprob(lnp), bad
+
 
 class Flat(object):
     """FlatPrior (priors/priors.py:49-100): ln p = 0 inside [minval, maxval],
@@ -77,6 +94,8 @@ class Flat(object):
     def lnprob(self, x):
         torch = _torch()
         return torch.zeros_like(x), (x < self.minval) | (x > self.maxval)
+
+    fdiff = lnprob          # the row is 0 inside, a range error outside
 
 
 class TwoSidedErf(object):
@@ -97,6 +116,10 @@ class TwoSidedErf(object):
                           torch.full_like(p, -math.inf))
         return lnp, torch.zeros_like(pos)
 
+    def fdiff(self, x):
+        lnp, bad = self.lnprob(x)
+        return _root_of_lnprob(lnp), bad
+
 
 class Normal(object):
     """Normal (priors/priors.py:395-434): ln p = -(x - mean)^2 / (2 sigma^2);
@@ -104,31 +127,89 @@ class Normal(object):
 
     def __init__(self, mean, sigma, bounds=None):
         self.mean, self.sigma = float(mean), float(sigma)
+        self.sinv = 1.0 / self.sigma
         self.s2inv = 1.0 / self.sigma ** 2
         self.bounds = bounds
 
     def lnprob(self, x):
         torch = _torch()
-        diff = x - self.mean
+        diff = self.mean - x
         return -0.5 * diff * diff * self.s2inv, torch.zeros_like(x, dtype=torch.bool)
 
+    def fdiff(self, x):
+        torch = _torch()
+        return (x - self.mean) * self.sinv, torch.zeros_like(x, dtype=torch.bool)
 
-class PriorSimpleSepBatch(object):
+
+class LogNormal(object):
+    """LogNormal (priors/priors.py:674-800): mean and sigma of the variate,
+    optional shift; ln p = 0 at the mode; x - shift <= 0 is a range error"""
+
+    def __init__(self, mean, sigma, shift=None, bounds=None):
+        if mean <= 0:
+            raise ValueError("mean %s is < 0" % mean)
+        self.mean, self.sigma = float(mean), float(sigma)
+        self.shift = None if shift is None else float(shift)
+        spread = 1 + self.sigma ** 2 / self.mean ** 2
+        self.logmean = math.log(self.mean) - 0.5 * math.log(spread)
+        self.logvar = math.log(spread)
+        self.logivar = 1.0 / self.logvar
+        log_mode = self.logmean - self.logvar
+        self.lnprob_max = -0.5 * self.logivar * (log_mode - self.logmean) ** 2 - log_mode
+        self.bounds = bounds
+
+    def lnprob(self, x):
+        torch = _torch()
+        if self.shift is not None:
+            x = x - self.shift
+        bad = ~(x > 0.0)
+        logx = torch.log(torch.where(bad, torch.ones_like(x), x))
+        chi2 = self.logivar * (logx - self.logmean) ** 2
+        return -0.5 * chi2 - logx - self.lnprob_max, bad
+
+    def fdiff(self, x):
+        lnp, bad = self.lnprob(x)
+        return _root_of_lnprob(lnp), bad
+
+
+class TruncatedGaussian(object):
+    """TruncatedGaussian (priors/priors.py:1046-1110): a gaussian on
+    [minval, maxval], a range error outside"""
+
+    def __init__(self, mean, sigma, minval, maxval, bounds=None):
+        self.mean, self.sigma = float(mean), float(sigma)
+        self.sinv = 1.0 / self.sigma
+        self.ivar = 1.0 / self.sigma ** 2
+        self.minval, self.maxval = float(minval), float(maxval)
+        self.bounds = bounds
+
+    def lnprob(self, x):
+        diff = x - self.mean
+        return -0.5 * diff * diff * self.ivar, (x < self.minval) | (x > self.maxval)
+
+    def fdiff(self, x):
+        return (x - self.mean) * self.sinv, (x < self.minval) | (x > self.maxval)
+
+
+class PriorSepBatch(object):
     """
-    PriorSimpleSep (joint_prior.py:10-120) over a batch: rows
-    [cen1, cen2, g, T, F_band...] = sqrt(clip(-2 ln p, 0)) and the bounds of
-    the T and flux terms.
+    A separable joint prior over a batch: a centre term (two parameters, two
+    rows), a shape term (two parameters, one row) and one 1-d term per
+    remaining parameter, in parameter order -- the row of terms
+    joint_prior.py's classes are made of.  rows_from_lnprob: every row is
+    sqrt(clip(-2 ln p, 0)) of its term (PriorSimpleSep, joint_prior.py:86-120)
+    or each term's own residual (PriorBDSep / PriorBDFSep: signed
+    (x - mean) / sigma for the gaussian terms, joint_prior.py:341-378).
     """
 
-    def __init__(self, cen_prior, g_prior, T_prior, F_prior):
+    def __init__(self, cen_prior, g_prior, terms, rows_from_lnprob=True):
         self.cen_prior = cen_prior
         self.g_prior = g_prior
-        self.T_prior = T_prior
-        self.F_priors = list(F_prior) if isinstance(F_prior, (list, tuple)) else [F_prior]
-        self.nband = len(self.F_priors)
+        self.terms = list(terms)
+        self.rows_from_lnprob = bool(rows_from_lnprob)
         bounds = [(None, None)] * 4
         some = False
-        for p in [self.T_prior] + self.F_priors:
+        for p in self.terms:
             b = getattr(p, "bounds", None)
             if b is not None:
                 some = True
@@ -136,6 +217,51 @@ class PriorSimpleSepBatch(object):
             else:
                 bounds.append((None, None))
         self.bounds = bounds if some else None
+
+    def _lnprobs(self, pars):
+        torch = _torch()
+        l1, l2 = self.cen_prior.lnprob_sep(pars[:, 0], pars[:, 1])
+        lg, bad = self.g_prior.lnprob2d(pars[:, 2], pars[:, 3])
+        cols = [l1, l2, lg]
+        for i, p in enumerate(self.terms):
+            lp, bp = p.lnprob(pars[:, 4 + i])
+            bad = bad | bp
+            cols.append(lp)
+        return torch.stack(cols, dim=1), bad
+
+    def fill_fdiff_batch(self, pars):
+        torch = _torch()
+        if self.rows_from_lnprob:
+            lnp, bad = self._lnprobs(pars)
+            return _root_of_lnprob(lnp), bad
+        r1, r2 = self.cen_prior.fdiff(pars[:, 0], pars[:, 1])
+        rg, bad = self.g_prior.fdiff(pars[:, 2], pars[:, 3])
+        cols = [r1, r2, rg]
+        for i, p in enumerate(self.terms):
+            rp, bp = p.fdiff(pars[:, 4 + i])
+            bad = bad | bp
+            cols.append(rp)
+        return torch.stack(cols, dim=1), bad
+
+    def get_lnprob_batch(self, pars):
+        torch = _torch()
+        lnp, bad = self._lnprobs(pars)
+        tot = lnp.sum(dim=1)
+        return torch.where(bad, torch.full_like(tot, -math.inf), tot)
+
+
+class PriorSimpleSepBatch(PriorSepBatch):
+    """
+    PriorSimpleSep (joint_prior.py:10-120) over a batch: rows
+    [cen1, cen2, g, T, F_band...] = sqrt(clip(-2 ln p, 0)) and the bounds of
+    the T and flux terms.
+    """
+
+    def __init__(self, cen_prior, g_prior, T_prior, F_prior):
+        self.T_prior = T_prior
+        self.F_priors = list(F_prior) if isinstance(F_prior, (list, tuple)) else [F_prior]
+        self.nband = len(self.F_priors)
+        super().__init__(cen_prior, g_prior, [T_prior] + self.F_priors, rows_from_lnprob=True)
 
     def descriptor(self):
         """the ngmix_simple_sep_prior record of this prior, for the kernel
@@ -172,31 +298,6 @@ class PriorSimpleSepBatch(object):
             d["F_kind"][0, i] = kind
             d["F_par"][0, i] = par
         return d
-
-    def _lnprobs(self, pars):
-        torch = _torch()
-        l1, l2 = self.cen_prior.lnprob_sep(pars[:, 0], pars[:, 1])
-        lg, bad = self.g_prior.lnprob2d(pars[:, 2], pars[:, 3])
-        lT, bT = self.T_prior.lnprob(pars[:, 4])
-        bad = bad | bT
-        cols = [l1, l2, lg, lT]
-        for i, Fp in enumerate(self.F_priors):
-            lF, bF = Fp.lnprob(pars[:, 5 + i])
-            bad = bad | bF
-            cols.append(lF)
-        return torch.stack(cols, dim=1), bad
-
-    def fill_fdiff_batch(self, pars):
-        torch = _torch()
-        lnp, bad = self._lnprobs(pars)
-        rows = torch.sqrt(torch.clamp(-2.0 * lnp, min=0.0))
-        return rows, bad
-
-    def get_lnprob_batch(self, pars):
-        torch = _torch()
-        lnp, bad = self._lnprobs(pars)
-        tot = lnp.sum(dim=1)
-        return torch.where(bad, torch.full_like(tot, -math.inf), tot)
 
 
 class PriorBatchAdapter(object):
@@ -255,6 +356,10 @@ def _batch_term(p):
         return TwoSidedErf(p.minval, p.width_at_min, p.maxval, p.width_at_max, bounds=p.bounds)
     if kind is P.Normal:
         return Normal(p.mean, p.sigma, bounds=p.bounds)
+    if kind is P.LogNormal:
+        return LogNormal(p.mean, p.sigma, shift=p.shift, bounds=p.bounds)
+    if kind is P.TruncatedGaussian:
+        return TruncatedGaussian(p.mean, p.sigma, p.minval, p.maxval, bounds=p.bounds)
     return None
 
 
@@ -264,10 +369,13 @@ def as_batch_prior(prior):
     (fill_fdiff_batch / get_lnprob_batch / bounds):
 
       None or a batch prior        unchanged
-      joint_prior.PriorSimpleSep   of a CenPrior, a GPriorBA and FlatPrior /
-        (or PriorGalsimSimpleSep)  TwoSidedErf / Normal terms: the
-                                   PriorSimpleSepBatch of the same densities,
-                                   evaluated for all fits at once on the device
+      joint_prior.PriorSimpleSep,  of a CenPrior, a GPriorBA and FlatPrior /
+        PriorGalsimSimpleSep,      TwoSidedErf / Normal / LogNormal /
+        PriorBDFSep, PriorBDSep    TruncatedGaussian terms: the batch prior of
+                                   the same densities, evaluated for all fits
+                                   at once on the device (PriorSimpleSepBatch:
+                                   in one kernel when its terms are flat / erf
+                                   / normal; PriorSepBatch: torch)
       any other object with        PriorBatchAdapter: fill_fdiff /
         fill_fdiff                 get_lnprob_scalar per object on the host
     """
@@ -275,15 +383,19 @@ def as_batch_prior(prior):
         return prior
     from . import priors as P
     from . import joint_prior as J
-    if type(prior) in (J.PriorSimpleSep, J.PriorGalsimSimpleSep) and \
-            type(prior.cen_prior) is P.CenPrior and type(prior.g_prior) is P.GPriorBA:
-        terms = [_batch_term(p) for p in [prior.T_prior] + list(prior.F_priors)]
+    simple = type(prior) in (J.PriorSimpleSep, J.PriorGalsimSimpleSep)
+    if (simple or type(prior) in (J.PriorBDFSep, J.PriorBDSep)) and \
+            type(prior.cen_prior) is P.CenPrior and type(prior.g_prior) is P.GPriorBA and \
+            isinstance(prior.F_priors, list):
+        terms = [_batch_term(p) for p in prior._scalar_terms()]
         if all(t is not None for t in terms):
-            cen = prior.cen_prior
-            return PriorSimpleSepBatch(
-                GaussianCen(cen.cen1, cen.cen2, cen.sigma1, cen.sigma2),
-                GPriorBA(prior.g_prior.sigma), terms[0],
-                terms[1:] if len(terms) > 2 else terms[1])
+            c = prior.cen_prior
+            cen = GaussianCen(c.cen1, c.cen2, c.sigma1, c.sigma2)
+            g = GPriorBA(prior.g_prior.sigma)
+            if simple:
+                return PriorSimpleSepBatch(cen, g, terms[0],
+                                           terms[1:] if len(terms) > 2 else terms[1])
+            return PriorSepBatch(cen, g, terms, rows_from_lnprob=False)
     if not hasattr(prior, "fill_fdiff"):
         raise TypeError("prior must offer fill_fdiff_batch or fill_fdiff, got %r" % (prior,))
     return PriorBatchAdapter(prior)

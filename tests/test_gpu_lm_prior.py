@@ -419,16 +419,19 @@ def test_reference_prior_fits_with_the_host_joint_prior(golden, tag):
 
 
 def test_any_host_prior_reaches_the_batch_through_the_adapter(golden):
-    """a joint prior as_batch_prior has no batch form for (a LogNormal size
-    term) is served object by object on the host: go_many equals the
-    per-object fits"""
+    """a joint prior as_batch_prior has no batch form for (a size term of a
+    class of the caller's own) is served object by object on the host: go_many
+    equals the per-object fits"""
     from ngmix_amd import priors, joint_prior
+
+    class MyLogNormal(priors.LogNormal):
+        pass
     g = golden("prior")
     obs, band, _ = _golden_prior_setup(g, "b1")
     rng = np.random.RandomState(3)
     prior = joint_prior.PriorSimpleSep(
         priors.CenPrior(0.0, 0.0, 0.05, 0.05, rng=rng), priors.GPriorBA(0.2, rng=rng),
-        priors.LogNormal(0.5, 0.3, rng=rng), priors.FlatPrior(-10.0, 1.0e5, rng=rng))
+        MyLogNormal(0.5, 0.3, rng=rng), priors.FlatPrior(-10.0, 1.0e5, rng=rng))
     assert isinstance(pb.as_batch_prior(prior), pb.PriorBatchAdapter)
     with pytest.raises(TypeError):
         pb.as_batch_prior(object())
@@ -441,3 +444,62 @@ def test_any_host_prior_reaches_the_batch_through_the_adapter(golden):
         np.testing.assert_allclose(r["pars"], one["pars"], rtol=1e-7, atol=1e-9)
         np.testing.assert_allclose(r["pars_err"], one["pars_err"], rtol=1e-4)
         np.testing.assert_allclose(r["lnprob"], one["lnprob"], rtol=1e-9, atol=1e-7)
+
+
+@pytest.mark.parametrize("model", ["bdf", "bd"])
+def test_bulge_disk_fits_with_the_host_joint_prior(golden, model):
+    """'bdf' / 'bd' fits with PriorBDFSep / PriorBDSep (the terms' own signed
+    residuals, a bounded fracdev, a log-normal size): go_many evaluates the
+    prior rows of all fits in torch on the device (PriorSepBatch) and agrees
+    with the per-object fits through MINPACK and the host prior"""
+    from ngmix_amd import priors, joint_prior
+    rng = np.random.RandomState(17)
+    dim, scale = 32, 0.263
+    psf_gm = ngmix.GMixModel([0.0, 0.0, 0.01, -0.02, 0.27, 1.0], "gauss")
+    obs, guesses = [], []
+    for i in range(24):
+        jac = ngmix.DiagonalJacobian(row=15.5 + rng.uniform(-0.3, 0.3),
+                                     col=15.5 + rng.uniform(-0.3, 0.3), scale=scale)
+        truth = [rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), rng.uniform(-0.2, 0.2),
+                 rng.uniform(-0.2, 0.2), rng.uniform(0.4, 0.9)]
+        fracdev = rng.uniform(0.2, 0.8)
+        flux = rng.uniform(80.0, 200.0)
+        pars = truth + ([fracdev, flux] if model == "bdf" else [0.1, fracdev, flux])
+        gm = ngmix.GMixModel(pars, model).convolve(psf_gm)
+        sigma = flux / 300.0
+        im = gm.make_image((dim, dim), jacobian=jac, fast_exp=True) + \
+            sigma * rng.normal(size=(dim, dim))
+        pobs = ngmix.Observation(np.zeros((5, 5)), jacobian=jac, gmix=psf_gm)
+        obs.append(ngmix.Observation(im, weight=np.full(im.shape, 1 / sigma ** 2), jacobian=jac,
+                                     psf=pobs))
+        gs = np.array(pars)
+        gs[4:] *= rng.uniform(0.95, 1.05, size=gs.size - 4)
+        guesses.append(gs)
+    guesses = np.array(guesses)
+    cen = priors.CenPrior(0.0, 0.0, scale, scale, rng=rng)
+    gp = priors.GPriorBA(0.3, rng=rng)
+    Tp = priors.LogNormal(0.7, 0.5, rng=rng)
+    fd = priors.Normal(0.5, 0.2, rng=rng, bounds=(0.0, 1.0))
+    Fp = priors.TwoSidedErf(-10.0, 1.0, 1.0e4, 100.0, rng=rng)
+    if model == "bdf":
+        prior = joint_prior.PriorBDFSep(cen, gp, Tp, fd, Fp)
+    else:
+        prior = joint_prior.PriorBDSep(cen, gp, Tp, priors.Normal(0.0, 0.3, rng=rng), fd, Fp)
+    bp = pb.as_batch_prior(prior)
+    assert type(bp) is pb.PriorSepBatch and bp.bounds == prior.bounds
+    fitter = ngmix.fitting.Fitter(model=model, prior=prior, batched=True)
+    many = fitter.go_many(obs, guesses)
+    nok = 0
+    for i in range(len(obs)):
+        one = fitter.go(obs=obs[i], guess=guesses[i])
+        r = many[i]
+        assert (r["flags"] == 0) == (one["flags"] == 0), i
+        if one["flags"] != 0:
+            continue
+        nok += 1
+        assert abs(r["nfev"] - one["nfev"]) <= 3 * (len(guesses[i]) + 1)
+        err = one["pars_err"]
+        assert np.all(np.abs(r["pars"] - one["pars"]) <= 2e-3 * err), (i, r["pars"], one["pars"])
+        np.testing.assert_allclose(r["pars_err"], err, rtol=2e-3)
+        np.testing.assert_allclose(r["lnprob"], one["lnprob"], rtol=1e-6, atol=1e-5)
+    assert nok >= 20

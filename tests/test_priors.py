@@ -63,3 +63,76 @@ def test_fitmodel_rows_are_the_joint_priors():
         p.fill_fdiff(np.array([0, 0, 0.8, 0.8, 0.7, 1.0, 1.0]), fdiff)
     s = p.sample(100)
     assert s.shape == (100, 7) and np.all(np.hypot(s[:, 2], s[:, 3]) < 1.0)
+
+
+def _joint_cases():
+    from ngmix_amd import priors, joint_prior
+
+    def rs(k):
+        return np.random.RandomState(900 + k)
+    cen = priors.CenPrior(0.01, -0.02, 0.05, 0.07, rng=rs(0))
+    g = priors.GPriorBA(0.25, rng=rs(1))
+    T_erf = priors.TwoSidedErf(-0.05, 0.03, 3.0, 0.3, rng=rs(2))
+    T_ln = priors.LogNormal(0.6, 0.3, rng=rs(3))
+    T_lns = priors.LogNormal(0.6, 0.3, rng=rs(3), shift=-0.1)
+    T_tg = priors.TruncatedGaussian(0.5, 0.3, 0.05, 2.0, rng=rs(4))
+    T_nb = priors.Normal(0.5, 0.3, rng=rs(5), bounds=(0.01, 4.0))
+    F = [priors.TwoSidedErf(-1.0, 0.5, 500.0, 20.0, rng=rs(6)),
+         priors.FlatPrior(-10.0, 400.0, rng=rs(7))]
+    fracdev = priors.Normal(0.5, 0.1, rng=rs(8), bounds=(0.0, 1.0))
+    fd_tg = priors.TruncatedGaussian(0.5, 0.1, 0.0, 1.0, rng=rs(9))
+    ltr = priors.Normal(0.0, 0.5, rng=rs(10))
+    return [
+        ("simple_erf", joint_prior.PriorSimpleSep(cen, g, T_erf, F), 7, True),
+        ("simple_lognormal", joint_prior.PriorSimpleSep(cen, g, T_ln, F[0]), 6, False),
+        ("simple_lognormal_shift", joint_prior.PriorSimpleSep(cen, g, T_lns, F), 7, False),
+        ("simple_truncgauss", joint_prior.PriorGalsimSimpleSep(cen, g, T_tg, F[1]), 6, False),
+        ("bdf", joint_prior.PriorBDFSep(cen, g, T_nb, fracdev, F), 8, False),
+        ("bdf_tg", joint_prior.PriorBDFSep(cen, g, T_ln, fd_tg, F[0]), 7, False),
+        ("bd", joint_prior.PriorBDSep(cen, g, T_erf, ltr, fracdev, F), 9, False),
+    ]
+
+
+@pytest.mark.parametrize("case", range(7))
+def test_batch_form_of_a_host_joint_prior(case):
+    """prior_batch.as_batch_prior: the rows, range errors, ln p and bounds of
+    the batch form (torch, here on the CPU) against the host joint prior it was
+    made from, point by point -- including points outside every term's range"""
+    import torch
+    from ngmix_amd import prior_batch as pb
+    tag, jp, npars, kernel = _joint_cases()[case]
+    bp = pb.as_batch_prior(jp)
+    assert isinstance(bp, pb.PriorSepBatch) and not isinstance(bp, pb.PriorBatchAdapter)
+    assert (getattr(bp, "descriptor", lambda: None)() is not None) == kernel
+    assert bp.bounds == jp.bounds
+    rng = np.random.RandomState(77 + case)
+    pts = np.zeros((400, npars))
+    pts[:, 0:2] = rng.normal(scale=0.05, size=(400, 2))
+    pts[:, 2:4] = rng.normal(scale=0.35, size=(400, 2))
+    pts[:, 4] = rng.uniform(-0.3, 2.5, size=400)
+    pts[:, 5:] = rng.uniform(-0.3, 1.4, size=(400, npars - 5))
+    pts[:, -1] = rng.uniform(-30.0, 450.0, size=400)
+    rows, bad = bp.fill_fdiff_batch(torch.from_numpy(pts))
+    lnp = bp.get_lnprob_batch(torch.from_numpy(pts)).numpy()
+    rows, bad = rows.numpy(), bad.numpy()
+    nbad = 0
+    for i, p in enumerate(pts):
+        buf = np.zeros(npars + 2)
+        try:
+            n = jp.fill_fdiff(p, buf)
+        except ngmix.GMixRangeError:
+            assert bad[i], (tag, i)
+            assert lnp[i] == -np.inf
+            nbad += 1
+            continue
+        assert not bad[i], (tag, i, p)
+        assert n == rows.shape[1]
+        fin = np.isfinite(buf[:n])
+        np.testing.assert_array_equal(np.isfinite(rows[i]), fin)
+        np.testing.assert_allclose(rows[i][fin], buf[:n][fin], rtol=1e-12, atol=1e-14)
+        want = jp.get_lnprob_scalar(p)
+        if np.isfinite(want):
+            np.testing.assert_allclose(lnp[i], want, rtol=1e-12, atol=1e-13)
+        else:
+            assert lnp[i] == want
+    assert 20 < nbad < 380
