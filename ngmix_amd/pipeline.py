@@ -244,14 +244,21 @@ def _mixture_moments(gm, n, ngauss):
     return T, g1, g2
 
 
-def _psfflux_guess(model, nobj, nband, Tguess, flux, rng):
+def _psfflux_guess(model, nobj, nband, Tguess, flux, rng, prior=None):
     """TPSFFluxGuesser.__call__ (guessers.py:107-145) for every object at
     once; for 'bdf' / 'bd' the extra columns as BDFPSFFluxGuesser / BDGuesser
-    fill them (guessers.py:344-377, 451-487: fracdev in [0.4, 0.6]; the
-    reference draws cen / g / logTratio of those two from the joint prior,
-    which a fit without a prior does not have: here they start near zero like
-    the simple models' do)"""
+    fill them (guessers.py:344-377, 451-487: fracdev in [0.4, 0.6]).
+
+    prior: a host joint prior (joint_prior.py: it has .sample): the guesses
+    are TPSFFluxAndPriorGuesser's (guessers.py:147-203) -- BDFPSFFluxGuesser's
+    for 'bdf' / 'bd' -- for every object at once: centre and shape (for the
+    bulge+disk models every parameter) drawn from the prior, the size within
+    10 % of Tguess, the fluxes within 10 % of the psf fluxes, and a guess the
+    prior gives no probability replaced by a draw from it.  Without one the
+    centre and shape start near zero."""
     nshape = MODEL_NLOC[model] - 1
+    if prior is not None:
+        return _psfflux_prior_guess(model, nobj, nband, nshape, Tguess, flux, rng, prior)
     guess = np.zeros((nobj, nshape + nband))
     guess[:, 0] = rng.uniform(-0.01, 0.01, size=nobj)
     guess[:, 1] = rng.uniform(-0.01, 0.01, size=nobj)
@@ -265,6 +272,34 @@ def _psfflux_guess(model, nobj, nband, Tguess, flux, rng):
         guess[:, 6] = rng.uniform(0.4, 0.6, size=nobj)
     for b in range(nband):
         guess[:, nshape + b] = flux[:, b] * rng.uniform(0.9, 1.1, size=nobj)
+    return guess
+
+
+def _psfflux_prior_guess(model, nobj, nband, nshape, Tguess, flux, rng, prior):
+    bulge_disk = model in ("bdf", "bd")
+    if bulge_disk:
+        rng = prior.cen_prior.rng            # BDFPSFFluxGuesser draws from the prior's
+    guess = np.array(prior.sample(nobj), dtype="f8")
+    if guess.shape != (nobj, nshape + nband):
+        raise ValueError("the prior samples %d parameters, model '%s' with %d band(s) has %d"
+                         % (guess.shape[1], model, nband, nshape + nband))
+    guess[:, 4] = Tguess * (1.0 + rng.uniform(low=-0.1, high=0.1, size=nobj))
+    if bulge_disk:
+        # column 5 for both models, as the reference's BDGuesser inherits it
+        guess[:, 5] = rng.uniform(low=0.4, high=0.6, size=nobj)
+    for b in range(nband):
+        if bulge_disk:
+            guess[:, nshape + b] = flux[:, b] * (1.0 + rng.uniform(low=-0.1, high=0.1, size=nobj))
+        else:
+            guess[:, nshape + b] = flux[:, b] * rng.uniform(low=0.9, high=1.1, size=nobj)
+    # _fix_guess / _fix_guess_TFlux: the rows the prior rejects, found for all
+    # objects at once through the batch form, repaired one by one
+    import torch
+    from .prior_batch import as_batch_prior
+    from .guessers import _fix_guess
+    lnp = as_batch_prior(prior).get_lnprob_batch(torch.from_numpy(guess)).numpy()
+    for j in np.nonzero(~(lnp > -np.inf))[0]:
+        _fix_guess(guess[j:j + 1], prior, keep_shape=not bulge_disk)
     return guess
 
 
@@ -321,7 +356,9 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
     guesser: 'admom' (Tguess: the starting size of the moments, default 2 x
         psf_Tguess; guess_admom: etol / Ttol / maxiter of that stage) or
         'psfflux' (Tguess: the size the guesses scatter around, as
-        TPSFFluxGuesser's T)
+        TPSFFluxGuesser's T; with a host joint prior the guesses are
+        TPSFFluxAndPriorGuesser's / BDFPSFFluxGuesser's: centre and shape
+        drawn from the prior)
     ntry: fits that end with flags != 0 are repeated from the next guess (a
         perturbed one without `guess`) up to ntry times in all, as Runner does
         object by object (runners.py:95-150); 'ntry' of the result counts the
@@ -472,9 +509,12 @@ def bootstrap_batch(stamps, psf_stamps, model="exp", psf_Tguess=0.3, Tguess=None
         kp = psf_gm if all_kept else psf_gm.select(kidx)
         psf_flux, pf_flags, none_good = psf_fluxes(ks, kp, sobj[kidx], sband[kidx],
                                                   nobj, nband, rng)
-        first_guess = _psfflux_guess(model, nobj, nband, Tguess, psf_flux, rng)
+        # (a host joint prior also shapes the guesses, as the reference's
+        # prior-drawing psf-flux guessers do)
+        gprior = prior if hasattr(prior, "sample") else None
+        first_guess = _psfflux_guess(model, nobj, nband, Tguess, psf_flux, rng, gprior)
         next_guess = lambda t, objs: _psfflux_guess(  # noqa: E731
-            model, nobj, nband, Tguess, psf_flux, rng)[objs]
+            model, nobj, nband, Tguess, psf_flux, rng, gprior)[objs]
     else:
         # adaptive moments of the object stamps, psf size taken out
         if o_launched is None:

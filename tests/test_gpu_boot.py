@@ -20,6 +20,7 @@ fits to 1e-3 sigma; psf fluxes 1e-7 relative.
 import numpy as np
 import pytest
 
+import ngmix_amd as ngmix
 from ngmix_amd import prior_batch as pb
 from ngmix_amd.batch import StampBatch
 from ngmix_amd.pipeline import bootstrap_batch, BOOT_PSF_FAILURE
@@ -202,7 +203,13 @@ def test_psf_flux_guess_vs_reference(golden, tag):
     npars = res["pars"].shape[1]
     nshape = npars - nband
     gs = res["guess"][ok]
-    assert np.all(np.abs(gs[:, 0:2]) <= 0.01) and np.all(np.abs(gs[:, 2:4]) <= 0.02)
+    if "prior" in kw:
+        # (set A: a host joint prior -- centre and shape are draws from it, as
+        # TPSFFluxAndPriorGuesser's are)
+        assert all(np.isfinite(kw["prior"].get_lnprob_scalar(p)) for p in gs)
+        assert np.abs(gs[:, 0:2]).max() > 0.01
+    else:
+        assert np.all(np.abs(gs[:, 0:2]) <= 0.01) and np.all(np.abs(gs[:, 2:4]) <= 0.02)
     assert np.all(np.abs(gs[:, 4] / 0.5 - 1.0) <= 0.1)
     assert np.all(np.abs(gs[:, nshape:] / res["psf_flux"][ok] - 1.0) <= 0.1)
     # the same minimum as the reference reached from its own guess
@@ -332,3 +339,72 @@ def test_bootstrap_many_from_reference_style_objects(golden):
         assert e.psf.has_gmix() == (ref["psf_flags"][s] == 0)
     k = int(np.nonzero(ref["psf_flags"] == 0)[0][0])
     np.testing.assert_allclose(flat[k].psf.gmix.get_T(), ref["psf_T"][k], rtol=1e-12)
+
+
+@pytest.mark.parametrize("model", ["exp", "bdf", "bd"])
+def test_bootstrap_batch_with_host_joint_priors_and_prior_guesses(golden, model):
+    """the whole pipeline as a caller of the reference sets it up for bulge +
+    disk fits: a host joint prior (PriorSimpleSep / PriorBDFSep / PriorBDSep),
+    psf-flux guesses drawn through it (TPSFFluxAndPriorGuesser /
+    BDFPSFFluxGuesser), the fits with the prior's rows evaluated on the device
+    (set B's two-band stamps, data drawn from a 'bdf' profile)"""
+    from ngmix_amd import priors, joint_prior
+    g = golden("boot")
+    sb, psb, kw = _set(g, "B")
+    keep = np.nonzero(g["B_ref_kept"])[0]
+    sobj, sband = g["B_stamp_obj"][keep], g["B_stamp_band"][keep]
+    gs, gp = sb.select(keep), psb.select(keep)
+    rng = np.random.RandomState(12)
+    scale = 0.263
+    cen = priors.CenPrior(0.0, 0.0, scale, scale, rng=rng)
+    gp_ = priors.GPriorBA(0.3, rng=rng)
+    Tp = priors.TwoSidedErf(-0.1, 0.03, 100.0, 1.0, rng=rng)
+    Fp = [priors.TwoSidedErf(-10.0, 1.0, 1.0e5, 100.0, rng=rng) for _ in range(2)]
+    fd = priors.Normal(0.5, 0.1, rng=rng, bounds=(0.0, 1.0))
+    if model == "exp":
+        prior, npars = joint_prior.PriorSimpleSep(cen, gp_, Tp, Fp), 7
+    elif model == "bdf":
+        prior, npars = joint_prior.PriorBDFSep(cen, gp_, Tp, fd, Fp), 8
+    else:
+        prior, npars = joint_prior.PriorBDSep(cen, gp_, Tp, priors.Normal(0.0, 0.3, rng=rng),
+                                              fd, Fp), 9
+    res = bootstrap_batch(gs, gp, model=model, psf_fitter="coellip", psf_ngauss=2,
+                          guesser="psfflux", Tguess=0.5, ntry=3, stamp_obj=sobj,
+                          stamp_band=sband, rng=np.random.RandomState(8), prior=prior)
+    assert res["pars"].shape == (3, npars) and res["guess"].shape == (3, npars)
+    assert np.all(res["psf_flags"] == 0)
+    ok = res["flags"] == 0
+    assert ok.sum() >= 2
+    np.testing.assert_allclose(res["pars"][ok][:, npars - 2:], g["B_truth"][ok][:, 6:8], rtol=0.2)
+    if model != "exp":
+        # the bounded fracdev stays inside its bounds
+        fcol = 5 if model == "bdf" else 6
+        assert np.all((res["pars"][ok][:, fcol] >= 0.0) & (res["pars"][ok][:, fcol] <= 1.0))
+    # every first guess is one the prior accepts, its centre drawn from the prior
+    assert all(np.isfinite(prior.get_lnprob_scalar(p)) for p in res["guess"])
+    # and the per-object Fitter from the same guesses and mixtures agrees
+    # (MINPACK, the host prior)
+    psf_gm = res["psf_gmix"].to_numpy()
+    for o in np.nonzero(ok)[0][:2]:
+        mb = ngmix.MultiBandObsList()
+        for b in range(2):
+            ol = ngmix.ObsList()
+            for i in np.nonzero((sobj == o) & (sband == b))[0]:
+                k = keep[i]
+                jr = g["B_jac"][k]
+                jac = ngmix.Jacobian(row=float(jr["row0"]), col=float(jr["col0"]),
+                                     dvdrow=float(jr["dvdrow"]), dvdcol=float(jr["dvdcol"]),
+                                     dudrow=float(jr["dudrow"]), dudcol=float(jr["dudcol"]))
+                pm = ngmix.GMix(ngauss=2)
+                pm.get_data()[:] = psf_gm[i]
+                pobs = ngmix.Observation(np.zeros((5, 5)), jacobian=jac, gmix=pm)
+                w = np.full(g["B_images"][k].shape, 1.0 / g["B_sigma"][k] ** 2)
+                ol.append(ngmix.Observation(g["B_images"][k], weight=w, jacobian=jac, psf=pobs))
+            mb.append(ol)
+        tries = int(res["ntry"][o])
+        if tries != 1:
+            continue
+        one = ngmix.fitting.Fitter(model=model, prior=prior).go(obs=mb, guess=res["guess"][o])
+        assert one["flags"] == 0
+        err = one["pars_err"]
+        assert np.all(np.abs(res["pars"][o] - one["pars"]) <= 5e-3 * err)

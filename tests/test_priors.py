@@ -136,3 +136,52 @@ def test_batch_form_of_a_host_joint_prior(case):
         else:
             assert lnp[i] == want
     assert 20 < nbad < 380
+
+
+@pytest.mark.parametrize("model", ["exp", "bdf", "bd"])
+def test_pipeline_prior_guess_is_the_prior_drawing_psf_flux_guessers(model):
+    """bootstrap_batch(guesser='psfflux', prior=<host joint prior>) builds its
+    guesses as TPSFFluxAndPriorGuesser / BDFPSFFluxGuesser do (whose draws are
+    pinned to the reference's above): for one object and the same generator
+    states the two give the same vector; for many objects every guess is one
+    the prior accepts"""
+    from ngmix_amd import priors, joint_prior, pipeline, guessers
+
+    def make(seed, tight=False):
+        rs = [np.random.RandomState(seed + k) for k in range(8)]
+        cen = priors.CenPrior(0.0, 0.0, 0.05, 0.05, rng=rs[0])
+        g = priors.GPriorBA(0.2, rng=rs[1])
+        T = priors.FlatPrior(0.47, 0.53, rng=rs[2]) if tight else \
+            priors.TwoSidedErf(-0.05, 0.03, 3.0, 0.3, rng=rs[2])
+        F = [priors.TwoSidedErf(-1.0, 0.5, 500.0, 20.0, rng=rs[3 + b]) for b in range(2)]
+        fd = priors.Normal(0.5, 0.1, rng=rs[5], bounds=(0.0, 1.0))
+        if model == "exp":
+            return joint_prior.PriorSimpleSep(cen, g, T, F)
+        if model == "bdf":
+            return joint_prior.PriorBDFSep(cen, g, T, fd, F)
+        return joint_prior.PriorBDSep(cen, g, T, priors.Normal(0.0, 0.5, rng=rs[6]), fd, F)
+
+    flux = np.array([[120.0, 80.0]])
+    nshape = pipeline.MODEL_NLOC[model] - 1
+    for tight in (False, True):
+        for seed in (10, 20, 30):
+            if model == "exp":
+                ref = guessers.TPSFFluxAndPriorGuesser(np.random.RandomState(seed + 99), 0.5,
+                                                       make(seed, tight))
+            else:
+                ref = guessers.BDFPSFFluxGuesser(0.5, make(seed, tight))
+                if model == "bd":
+                    ref.first_flux = 7
+            ref._get_psf_fluxes = lambda obs: flux[0]
+            want = ref(obs=None, nrand=1)
+            got = pipeline._psfflux_guess(model, 1, 2, 0.5, flux,
+                                          np.random.RandomState(seed + 99), make(seed, tight))
+            np.testing.assert_array_equal(got[0], want)
+    prior = make(77, tight=True)
+    many = pipeline._psfflux_guess(model, 500, 2, 0.5, np.tile(flux, (500, 1)),
+                                   np.random.RandomState(5), prior)
+    assert many.shape == (500, nshape + 2)
+    assert all(np.isfinite(prior.get_lnprob_scalar(p)) for p in many)
+    assert np.abs(many[:, 0]).max() > 0.05        # centres from the prior, not +-0.01
+    with pytest.raises(ValueError):
+        pipeline._psfflux_guess(model, 3, 3, 0.5, np.ones((3, 3)), np.random.RandomState(5), prior)
