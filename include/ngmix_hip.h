@@ -553,16 +553,32 @@ int ngmix_lm_advance_batch(ngmix_lm_state *states, int64_t nobj,
                            int32_t *nactive, const double *stamp_stats,
                            double *obj_stats, void *stream);
 
-/* The separable joint prior of the reference's PriorSimpleSep
-   (joint_prior.py:10-120) in a form a kernel can evaluate: gaussian centre
-   terms (priors/multivariate.py CenPrior), the Bernstein-Armstrong shape
-   prior (priors/shape.py GPriorBA), and per T / band flux either FlatPrior
-   (par = minval, maxval), TwoSidedErf (par = minval, width_at_min, maxval,
-   width_at_max) or Normal (par = mean, sigma) from priors/priors.py */
+/* The separable joint priors of the reference (joint_prior.py:
+   PriorSimpleSep :10-120, PriorBDFSep :484-674, PriorBDSep :267-481) in a
+   form a kernel can evaluate: gaussian centre terms (priors/multivariate.py
+   CenPrior), the Bernstein-Armstrong shape prior (priors/shape.py GPriorBA),
+   and one 1-d term of priors/priors.py per remaining parameter -- T, then
+   nmid "middle" terms (fracdev for 'bdf'; logTratio, fracdev for 'bd'), then
+   one flux term per band:
+     FLAT                par = minval, maxval
+     TWO_SIDED_ERF       par = minval, width_at_min, maxval, width_at_max
+     NORMAL              par = mean, sigma
+     LOGNORMAL           par = logmean, logivar, lnprob_max, shift (0: none)
+     TRUNCATED_GAUSSIAN  par = mean, sigma, minval, maxval
+   rows_mode ROWS_LNPROB: every row is sqrt(max(-2 ln p, 0)) of its term
+   (PriorSimpleSep.fill_fdiff); ROWS_FDIFF: each term's own get_fdiff -- the
+   signed (x - mean) / sigma of the gaussian terms, cen_sinv for the centre
+   (PriorBDFSep / PriorBDSep.fill_fdiff).  The first 188 bytes are the round-3
+   record; a record with nmid = 0, rows_mode = 0 is a PriorSimpleSep */
 #define NGMIX_PRIOR_FLAT 0
 #define NGMIX_PRIOR_TWO_SIDED_ERF 1
 #define NGMIX_PRIOR_NORMAL 2
+#define NGMIX_PRIOR_LOGNORMAL 3
+#define NGMIX_PRIOR_TRUNCATED_GAUSSIAN 4
 #define NGMIX_PRIOR_MAXBAND 3
+#define NGMIX_PRIOR_MAXMID 2
+#define NGMIX_PRIOR_ROWS_LNPROB 0
+#define NGMIX_PRIOR_ROWS_FDIFF 1
 typedef struct {
     double cen1, cen2, cen_s2inv1, cen_s2inv2;
     double g_sig2inv;
@@ -570,20 +586,25 @@ typedef struct {
     double F_par[NGMIX_PRIOR_MAXBAND][4];
     int32_t T_kind, nband;
     int32_t F_kind[NGMIX_PRIOR_MAXBAND];
+    int32_t nmid;
+    double cen_sinv1, cen_sinv2;
+    double mid_par[NGMIX_PRIOR_MAXMID][4];
+    int32_t mid_kind[NGMIX_PRIOR_MAXMID];
+    int32_t rows_mode;
     int32_t pad_;
-} ngmix_simple_sep_prior; /* 192 B */
-/* DEVICE: the prior rows [cen1, cen2, g, T, F_band...] = sqrt(max(-2 ln p, 0))
-   of every object at its trial point states[i].xt, their jacobian by
+} ngmix_simple_sep_prior; /* 288 B */
+/* DEVICE: the prior rows [cen1, cen2, g, T, mid..., F_band...] of every
+   object at its trial point states[i].xt, their jacobian by
    differences (analytic mode: the reference's one-sided steps
    step_rel * max(1, |x_j|), backward where the forward point is out of range,
    results.py:572-625; forward-difference mode: the state's xstep / hstep),
-   reduced to obj_sums (nobj, NGMIX_LM_NSUMS(5 + nband)) for
+   reduced to obj_sums (nobj, NGMIX_LM_NSUMS(5 + nmid + nband)) for
    ngmix_lm_advance_batch.  An out-of-range point (g >= 1, outside a flat
    prior) gives r.r = +inf: the reference's GMixRangeError -> -inf residuals */
 int ngmix_lm_prior_sums_batch(const ngmix_lm_state *states, int64_t nobj,
                               const ngmix_simple_sep_prior *prior, double step_rel,
                               double *obj_sums, void *stream);
-/* HOST: rows (max 4 + nband) and ln p of one parameter vector: returns the
+/* HOST: rows (max 4 + nmid + nband) and ln p of one parameter vector: returns the
    number of rows, or -1 when the point is out of range (testing aid; the same
    code the kernel runs) */
 int ngmix_simple_sep_prior_eval(const ngmix_simple_sep_prior *prior,

@@ -124,14 +124,21 @@ LM_STATE_DTYPE = np.dtype([
 PRIOR_FLAT = 0
 PRIOR_TWO_SIDED_ERF = 1
 PRIOR_NORMAL = 2
+PRIOR_LOGNORMAL = 3
+PRIOR_TRUNCATED_GAUSSIAN = 4
 PRIOR_MAXBAND = 3
+PRIOR_MAXMID = 2
+PRIOR_ROWS_LNPROB = 0
+PRIOR_ROWS_FDIFF = 1
 # ngmix_simple_sep_prior (include/ngmix_hip.h)
 SIMPLE_SEP_PRIOR_DTYPE = np.dtype([
     ("cen1", "f8"), ("cen2", "f8"), ("cen_s2inv1", "f8"), ("cen_s2inv2", "f8"),
     ("g_sig2inv", "f8"), ("T_par", "f8", 4), ("F_par", "f8", (PRIOR_MAXBAND, 4)),
-    ("T_kind", "i4"), ("nband", "i4"), ("F_kind", "i4", PRIOR_MAXBAND), ("pad_", "i4"),
+    ("T_kind", "i4"), ("nband", "i4"), ("F_kind", "i4", PRIOR_MAXBAND), ("nmid", "i4"),
+    ("cen_sinv1", "f8"), ("cen_sinv2", "f8"), ("mid_par", "f8", (PRIOR_MAXMID, 4)),
+    ("mid_kind", "i4", PRIOR_MAXMID), ("rows_mode", "i4"), ("pad_", "i4"),
 ], align=True)
-assert SIMPLE_SEP_PRIOR_DTYPE.itemsize == 192
+assert SIMPLE_SEP_PRIOR_DTYPE.itemsize == 288
 
 
 class Batch(ctypes.Structure):

@@ -643,10 +643,12 @@ int ngmix_lm_prior_sums_batch(const ngmix_lm_state *states, int64_t nobj,
 int ngmix_simple_sep_prior_eval(const ngmix_simple_sep_prior *prior, const double *pars,
                                 double *rows, double *lnprob)
 {
-    if (!prior || prior->nband < 1 || prior->nband > NGMIX_PRIOR_MAXBAND) return -2;
-    double r[4 + NGMIX_PRIOR_MAXBAND], lnp = 0.0;
+    if (!prior || prior->nband < 1 || prior->nband > NGMIX_PRIOR_MAXBAND || prior->nmid < 0 ||
+        prior->nmid > NGMIX_PRIOR_MAXMID)
+        return -2;
+    double r[lmcore::PRIOR_KMAX], lnp = 0.0;
     if (!lmcore::simple_sep_rows(*prior, pars, r, &lnp)) return -1;
-    const int k = 4 + prior->nband;
+    const int k = 4 + prior->nmid + prior->nband;
     for (int i = 0; i < k; i++) rows[i] = r[i];
     if (lnprob) *lnprob = lnp;
     return k;

@@ -607,8 +607,9 @@ NGMIX_HD void lm_advance(State &s, double ff, const double *g_in, const double *
 }
 
 // ---- the separable joint prior (ngmix_simple_sep_prior) --------------------
-// ln p of one T / flux term; returns false where the reference raises
-// GMixRangeError (FlatPrior outside its range, priors/priors.py:85-100)
+// ln p of one 1-d term (T, a middle term or a flux); returns false where the
+// reference raises GMixRangeError (FlatPrior / TruncatedGaussian outside their
+// range, LogNormal at or below its shift)
 NGMIX_HD bool prior_term_lnp(int kind, const double *par, double x, double &lnp)
 {
     if (kind == NGMIX_PRIOR_TWO_SIDED_ERF) {
@@ -623,45 +624,97 @@ NGMIX_HD bool prior_term_lnp(int kind, const double *par, double x, double &lnp)
         lnp = -0.5 * diff * diff * (1.0 / (par[1] * par[1]));
         return true;
     }
+    if (kind == NGMIX_PRIOR_LOGNORMAL) {
+        // priors/priors.py:732-756: ln p is 0 at the mode
+        const double v = x - par[3];
+        if (!(v > 0.0)) return false;
+        const double logv = log(v), d = logv - par[0];
+        lnp = -0.5 * (par[1] * (d * d)) - logv - par[2];
+        return true;
+    }
+    if (kind == NGMIX_PRIOR_TRUNCATED_GAUSSIAN) {
+        // priors/priors.py:1084-1096
+        if (x < par[2] || x > par[3]) return false;
+        const double diff = x - par[0];
+        lnp = -0.5 * diff * diff * (1.0 / (par[1] * par[1]));
+        return true;
+    }
     lnp = 0.0;
     return !(x < par[0] || x > par[1]);
 }
 
-// rows[k] = sqrt(max(-2 ln p_k, 0)) for k = cen1, cen2, g, T, F_0.. ; false
-// when out of range (joint_prior.py:86-120)
+NGMIX_HD double prior_root(double lnp)
+{
+    double chi2 = -2.0 * lnp;
+    if (chi2 < 0.0) chi2 = 0.0;
+    return sqrt(chi2);
+}
+
+// one term's residual row and ln p: sqrt(max(-2 ln p, 0)), or -- rows from the
+// terms' own get_fdiff -- the signed (x - mean) / sigma of the gaussian kinds
+NGMIX_HD bool prior_term_row(int kind, const double *par, double x, bool own_fdiff,
+                             double &row, double &lnp)
+{
+    if (!prior_term_lnp(kind, par, x, lnp)) return false;
+    if (own_fdiff && (kind == NGMIX_PRIOR_NORMAL || kind == NGMIX_PRIOR_TRUNCATED_GAUSSIAN))
+        row = (x - par[0]) * (1.0 / par[1]);
+    else
+        row = prior_root(lnp);
+    return true;
+}
+
+constexpr int PRIOR_KMAX = 4 + NGMIX_PRIOR_MAXMID + NGMIX_PRIOR_MAXBAND;
+
+// rows[k] for k = cen1, cen2, g, T, mid_0.., F_0.. ; false when out of range
+// (joint_prior.py:86-120, 341-378, 556-590)
 NGMIX_HD bool simple_sep_rows(const ngmix_simple_sep_prior &P, const double *x,
                               double *rows, double *lnp_total)
 {
-    double lnp[4 + NGMIX_PRIOR_MAXBAND];
+    const bool own = P.rows_mode == NGMIX_PRIOR_ROWS_FDIFF;
     const double d1 = P.cen1 - x[0], d2 = P.cen2 - x[1];
-    lnp[0] = -0.5 * d1 * d1 * P.cen_s2inv1;
-    lnp[1] = -0.5 * d2 * d2 * P.cen_s2inv2;
+    double tot = -0.5 * d1 * d1 * P.cen_s2inv1;
+    const double lnp2 = -0.5 * d2 * d2 * P.cen_s2inv2;
+    if (own) {
+        rows[0] = (x[0] - P.cen1) * P.cen_sinv1;
+        rows[1] = (x[1] - P.cen2) * P.cen_sinv2;
+    } else {
+        rows[0] = prior_root(tot);
+        rows[1] = prior_root(lnp2);
+    }
+    tot += lnp2;
     const double gsq = x[2] * x[2] + x[3] * x[3];
     const double omgsq = 1.0 - gsq;
     if (omgsq <= 0.0) return false;
-    lnp[2] = 2.0 * log(omgsq) - 0.5 * gsq * P.g_sig2inv;
-    if (!prior_term_lnp(P.T_kind, P.T_par, x[4], lnp[3])) return false;
-    for (int b = 0; b < P.nband; b++)
-        if (!prior_term_lnp(P.F_kind[b], P.F_par[b], x[5 + b], lnp[4 + b])) return false;
-    double tot = 0.0;
-    for (int k = 0; k < 4 + P.nband; k++) {
-        double chi2 = -2.0 * lnp[k];
-        if (chi2 < 0.0) chi2 = 0.0;
-        rows[k] = sqrt(chi2);
-        tot += lnp[k];
+    const double lng = 2.0 * log(omgsq) - 0.5 * gsq * P.g_sig2inv;
+    rows[2] = prior_root(lng);
+    tot += lng;
+    double lnp;
+    if (!prior_term_row(P.T_kind, P.T_par, x[4], own, rows[3], lnp)) return false;
+    tot += lnp;
+    for (int m = 0; m < P.nmid; m++) {
+        if (!prior_term_row(P.mid_kind[m], P.mid_par[m], x[5 + m], own, rows[4 + m], lnp))
+            return false;
+        tot += lnp;
+    }
+    for (int b = 0; b < P.nband; b++) {
+        if (!prior_term_row(P.F_kind[b], P.F_par[b], x[5 + P.nmid + b], own,
+                            rows[4 + P.nmid + b], lnp))
+            return false;
+        tot += lnp;
     }
     if (lnp_total) *lnp_total = tot;
     return true;
 }
 
 // the prior rows of one fit at its trial point as normal-equation sums
-// [J^T J upper triangle | J^T r | r.r] over the fit's n = 5 + nband parameters
+// [J^T J upper triangle | J^T r | r.r] over the fit's n = 5 + nmid + nband
+// parameters
 template <class State>
 NGMIX_HD void simple_sep_normal_sums(const ngmix_simple_sep_prior &P, const State &s,
                                      double step_rel, double *out)
 {
-    constexpr int KMAX = 4 + NGMIX_PRIOR_MAXBAND;
-    const int n = s.n, k = 4 + P.nband, nt = n * (n + 1) / 2;
+    constexpr int KMAX = PRIOR_KMAX;
+    const int n = s.n, k = 4 + P.nmid + P.nband, nt = n * (n + 1) / 2;
     double r0[KMAX], rj[KMAX], J[KMAX][LM_NPMAX];
     for (int i = 0; i < nt + n + 1; i++) out[i] = 0.0;
     double x[LM_NPMAX];

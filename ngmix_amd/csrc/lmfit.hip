@@ -1520,7 +1520,8 @@ int launch_lm_prior_sums(const lm_state *states, int64_t nobj,
                          double *obj_sums, hipStream_t s)
 {
     if (nobj <= 0) return NGMIX_OK;
-    if (!prior || prior->nband < 1 || prior->nband > NGMIX_PRIOR_MAXBAND)
+    if (!prior || prior->nband < 1 || prior->nband > NGMIX_PRIOR_MAXBAND || prior->nmid < 0 ||
+        prior->nmid > NGMIX_PRIOR_MAXMID)
         return NGMIX_ERR_BAD_ARG;
     hipLaunchKernelGGL(lm_prior_sums_kernel, dim3((unsigned)((nobj + BLOCK - 1) / BLOCK)),
                        dim3(BLOCK), 0, s, states, nobj, *prior, step_rel, obj_sums);

@@ -536,9 +536,12 @@ class LMBatchFitter(object):
                 raise ValueError("coellip fits one band: guess needs %d columns" % self.nloc)
         d_osums = None
         prior_desc = None
-        if self.prior is not None and self.device_prior and \
-                hasattr(self.prior, "descriptor") and nshape == 5:
+        if self.prior is not None and self.device_prior and hasattr(self.prior, "descriptor"):
             prior_desc = self.prior.descriptor()
+            if prior_desc is not None and nshape != 5 + int(prior_desc["nmid"][0]):
+                raise ValueError("the prior is laid out for %d parameters before the fluxes, "
+                                 "model '%s' has %d" % (5 + int(prior_desc["nmid"][0]),
+                                                        self.model, nshape))
             if prior_desc is not None and int(prior_desc["nband"][0]) != nband:
                 raise ValueError("the prior has %d flux terms, the guess %d bands"
                                  % (int(prior_desc["nband"][0]), nband))

@@ -218,6 +218,54 @@ class PriorSepBatch(object):
                 bounds.append((None, None))
         self.bounds = bounds if some else None
 
+    # how many 1-d terms stand between T and the fluxes (set by as_batch_prior
+    # for the bulge+disk priors; 0: [T, F_band...])
+    nmid = 0
+
+    def descriptor(self):
+        """the ngmix_simple_sep_prior record of this prior, for the kernel
+        that evaluates the prior rows of all fits in one launch
+        (ngmix_lm_prior_sums_batch); None when a term is not one of the
+        kinds the kernel knows or there are more terms than it holds, the
+        torch path then serves"""
+        from . import _lib
+        nband = len(self.terms) - 1 - self.nmid
+        if not isinstance(self.cen_prior, GaussianCen) or \
+                not isinstance(self.g_prior, GPriorBA) or nband < 1 or \
+                nband > _lib.PRIOR_MAXBAND or not 0 <= self.nmid <= _lib.PRIOR_MAXMID:
+            return None
+        d = np.zeros(1, dtype=_lib.SIMPLE_SEP_PRIOR_DTYPE)
+        d["cen1"], d["cen2"] = self.cen_prior.cen1, self.cen_prior.cen2
+        d["cen_s2inv1"], d["cen_s2inv2"] = self.cen_prior.s2inv1, self.cen_prior.s2inv2
+        d["cen_sinv1"], d["cen_sinv2"] = self.cen_prior.sinv1, self.cen_prior.sinv2
+        d["g_sig2inv"] = self.g_prior.sig2inv
+        d["nband"], d["nmid"] = nband, self.nmid
+        d["rows_mode"] = _lib.PRIOR_ROWS_LNPROB if self.rows_from_lnprob else _lib.PRIOR_ROWS_FDIFF
+
+        def term(p):
+            if isinstance(p, TwoSidedErf):
+                return _lib.PRIOR_TWO_SIDED_ERF, [p.minval, p.width_at_min, p.maxval,
+                                                  p.width_at_max]
+            if isinstance(p, Flat):
+                return _lib.PRIOR_FLAT, [p.minval, p.maxval, 0.0, 0.0]
+            if isinstance(p, Normal):
+                return _lib.PRIOR_NORMAL, [p.mean, p.sigma, 0.0, 0.0]
+            if isinstance(p, LogNormal):
+                return _lib.PRIOR_LOGNORMAL, [p.logmean, p.logivar, p.lnprob_max,
+                                              0.0 if p.shift is None else p.shift]
+            if isinstance(p, TruncatedGaussian):
+                return _lib.PRIOR_TRUNCATED_GAUSSIAN, [p.mean, p.sigma, p.minval, p.maxval]
+            return None, None
+        kinds = [term(p) for p in self.terms]
+        if any(k is None for k, _ in kinds):
+            return None
+        d["T_kind"], d["T_par"] = kinds[0]
+        for m in range(self.nmid):
+            d["mid_kind"][0, m], d["mid_par"][0, m] = kinds[1 + m]
+        for b in range(nband):
+            d["F_kind"][0, b], d["F_par"][0, b] = kinds[1 + self.nmid + b]
+        return d
+
     def _lnprobs(self, pars):
         torch = _torch()
         l1, l2 = self.cen_prior.lnprob_sep(pars[:, 0], pars[:, 1])
@@ -262,42 +310,6 @@ class PriorSimpleSepBatch(PriorSepBatch):
         self.F_priors = list(F_prior) if isinstance(F_prior, (list, tuple)) else [F_prior]
         self.nband = len(self.F_priors)
         super().__init__(cen_prior, g_prior, [T_prior] + self.F_priors, rows_from_lnprob=True)
-
-    def descriptor(self):
-        """the ngmix_simple_sep_prior record of this prior, for the kernel
-        that evaluates the prior rows of all fits in one launch
-        (ngmix_lm_prior_sums_batch); None when a term is not one of the
-        kinds the kernel knows, the torch path then serves"""
-        from . import _lib
-        if not isinstance(self.cen_prior, GaussianCen) or \
-                not isinstance(self.g_prior, GPriorBA) or self.nband > _lib.PRIOR_MAXBAND:
-            return None
-        d = np.zeros(1, dtype=_lib.SIMPLE_SEP_PRIOR_DTYPE)
-        d["cen1"], d["cen2"] = self.cen_prior.cen1, self.cen_prior.cen2
-        d["cen_s2inv1"], d["cen_s2inv2"] = self.cen_prior.s2inv1, self.cen_prior.s2inv2
-        d["g_sig2inv"] = self.g_prior.sig2inv
-        d["nband"] = self.nband
-
-        def term(p):
-            if isinstance(p, TwoSidedErf):
-                return _lib.PRIOR_TWO_SIDED_ERF, [p.minval, p.width_at_min, p.maxval,
-                                                  p.width_at_max]
-            if isinstance(p, Flat):
-                return _lib.PRIOR_FLAT, [p.minval, p.maxval, 0.0, 0.0]
-            if isinstance(p, Normal):
-                return _lib.PRIOR_NORMAL, [p.mean, p.sigma, 0.0, 0.0]
-            return None, None
-        kind, par = term(self.T_prior)
-        if kind is None:
-            return None
-        d["T_kind"], d["T_par"] = kind, par
-        for i, Fp in enumerate(self.F_priors):
-            kind, par = term(Fp)
-            if kind is None:
-                return None
-            d["F_kind"][0, i] = kind
-            d["F_par"][0, i] = par
-        return d
 
 
 class PriorBatchAdapter(object):
@@ -373,9 +385,9 @@ def as_batch_prior(prior):
         PriorGalsimSimpleSep,      TwoSidedErf / Normal / LogNormal /
         PriorBDFSep, PriorBDSep    TruncatedGaussian terms: the batch prior of
                                    the same densities, evaluated for all fits
-                                   at once on the device (PriorSimpleSepBatch:
-                                   in one kernel when its terms are flat / erf
-                                   / normal; PriorSepBatch: torch)
+                                   at once on the device, in one kernel inside
+                                   the device loop (up to three bands; torch
+                                   ops beyond)
       any other object with        PriorBatchAdapter: fill_fdiff /
         fill_fdiff                 get_lnprob_scalar per object on the host
     """
@@ -395,7 +407,9 @@ def as_batch_prior(prior):
             if simple:
                 return PriorSimpleSepBatch(cen, g, terms[0],
                                            terms[1:] if len(terms) > 2 else terms[1])
-            return PriorSepBatch(cen, g, terms, rows_from_lnprob=False)
+            batch = PriorSepBatch(cen, g, terms, rows_from_lnprob=False)
+            batch.nmid = len(prior._middle)
+            return batch
     if not hasattr(prior, "fill_fdiff"):
         raise TypeError("prior must offer fill_fdiff_batch or fill_fdiff, got %r" % (prior,))
     return PriorBatchAdapter(prior)

@@ -487,8 +487,24 @@ def test_bulge_disk_fits_with_the_host_joint_prior(golden, model):
         prior = joint_prior.PriorBDSep(cen, gp, Tp, priors.Normal(0.0, 0.3, rng=rng), fd, Fp)
     bp = pb.as_batch_prior(prior)
     assert type(bp) is pb.PriorSepBatch and bp.bounds == prior.bounds
+    assert bp.descriptor() is not None and int(bp.descriptor()["nmid"][0]) == len(guesses[0]) - 6
     fitter = ngmix.fitting.Fitter(model=model, prior=prior, batched=True)
     many = fitter.go_many(obs, guesses)
+    # the prior kernel inside the device loop (the default) and torch ops with
+    # host-driven rounds: the same fits
+    sb = StampBatch.from_observations(obs)
+    psf = GMixBatch.from_numpy(np.stack([o.psf.gmix.get_data().copy() for o in obs]))
+    by_path = {}
+    for device_prior in (True, False):
+        f = LMBatchFitter(model, prior=prior, device_prior=device_prior)
+        by_path[device_prior] = f.go(sb, guesses, psf=psf)
+        assert f.prior_path == ("kernel" if device_prior else "torch")
+    a, b = by_path[True], by_path[False]
+    np.testing.assert_array_equal(a["flags"], b["flags"])
+    okk = a["flags"] == 0
+    assert np.all(np.abs(a["nfev"][okk] - b["nfev"][okk]) <= len(guesses[0]) + 1)
+    assert np.all(np.abs(a["pars"][okk] - b["pars"][okk]) <= 1e-4 * b["pars_err"][okk])
+    np.testing.assert_array_equal(a["pars"], many.arrays["pars"])
     nok = 0
     for i in range(len(obs)):
         one = fitter.go(obs=obs[i], guess=guesses[i])

@@ -103,8 +103,13 @@ def test_batch_form_of_a_host_joint_prior(case):
     tag, jp, npars, kernel = _joint_cases()[case]
     bp = pb.as_batch_prior(jp)
     assert isinstance(bp, pb.PriorSepBatch) and not isinstance(bp, pb.PriorBatchAdapter)
-    assert (getattr(bp, "descriptor", lambda: None)() is not None) == kernel
     assert bp.bounds == jp.bounds
+    # every one of them has a kernel form; ngmix_simple_sep_prior_eval is the
+    # code that kernel runs, on the host
+    from ngmix_amd import _lib
+    desc = bp.descriptor()
+    assert desc is not None
+    L = _lib.lib()
     rng = np.random.RandomState(77 + case)
     pts = np.zeros((400, npars))
     pts[:, 0:2] = rng.normal(scale=0.05, size=(400, 2))
@@ -116,16 +121,26 @@ def test_batch_form_of_a_host_joint_prior(case):
     lnp = bp.get_lnprob_batch(torch.from_numpy(pts)).numpy()
     rows, bad = rows.numpy(), bad.numpy()
     nbad = 0
+    krows, klnp = np.zeros(12), np.zeros(1)
     for i, p in enumerate(pts):
         buf = np.zeros(npars + 2)
+        k = L.ngmix_simple_sep_prior_eval(_lib.ptr(desc), _lib.ptr(p.copy()), _lib.ptr(krows),
+                                          _lib.ptr(klnp))
         try:
             n = jp.fill_fdiff(p, buf)
         except ngmix.GMixRangeError:
             assert bad[i], (tag, i)
             assert lnp[i] == -np.inf
+            assert k == -1
             nbad += 1
             continue
         assert not bad[i], (tag, i, p)
+        assert k == n
+        kfin = np.isfinite(buf[:n])
+        np.testing.assert_array_equal(np.isfinite(krows[:n]), kfin)
+        np.testing.assert_allclose(krows[:n][kfin], buf[:n][kfin], rtol=4e-15, atol=1e-300)
+        if kfin.all():
+            np.testing.assert_allclose(klnp[0], jp.get_lnprob_scalar(p), rtol=1e-14, atol=1e-15)
         assert n == rows.shape[1]
         fin = np.isfinite(buf[:n])
         np.testing.assert_array_equal(np.isfinite(rows[i]), fin)
