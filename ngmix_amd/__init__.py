@@ -53,6 +53,8 @@ from . import batch  # noqa: F401
 from . import prior_batch  # noqa: F401
 from . import lm_batch  # noqa: F401
 from .lm_batch import LMBatchFitter  # noqa: F401
+from . import gaussap  # noqa: F401
+from . import simobs  # noqa: F401
 from . import pipeline  # noqa: F401
 from .pipeline import bootstrap_batch, bootstrap_many  # noqa: F401
 

@@ -1,0 +1,129 @@
+"""
+ngmix_amd.gaussap and ngmix_amd.simobs against the reference's
+(tests/golden/utils.npz, oracle/gen_golden_utils.py): aperture fluxes of every
+model over one launch of the fill kernel + a closed form against the
+reference's per-object matrix inversions (1e-12: the two differ in the order
+of a handful of roundings); noise images exact; simulated observations through
+the render kernel.
+"""
+import numpy as np
+import pytest
+
+import ngmix_amd as ngmix
+from ngmix_amd import gaussap, simobs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,nband", [("gauss", 1), ("exp", 3), ("dev", 1), ("turb", 2),
+                                         ("bdf", 1), ("bdf", 3), ("cm", 2)])
+def test_gaussap_flux_vs_reference(golden, model, nband):
+    g = golden("utils")
+    tag = "gap_%s%d" % (model, nband)
+    pars, mask = g[tag + "_pars"], g[tag + "_mask"]
+    kw = {}
+    if model == "cm":
+        kw = dict(fracdev=g[tag + "_fracdev"], TdByTe=g[tag + "_TdByTe"])
+    for fwhm, key, m in ((0.9, "0.9", mask), (2.5, "2.5", mask), (1.2, "nomask", None)):
+        flux, flags = gaussap.get_gaussap_flux(pars, model, fwhm, mask=m, verbose=False, **kw)
+        rflux, rflags = g["%s_flux_%s" % (tag, key)], g["%s_flags_%s" % (tag, key)]
+        np.testing.assert_array_equal(flags, rflags)
+        assert flags.dtype == rflags.dtype and flux.shape == rflux.shape == (30, nband)
+        np.testing.assert_array_equal(np.isnan(flux), np.isnan(rflux))
+        ok = ~np.isnan(rflux)
+        np.testing.assert_allclose(flux[ok], rflux[ok], rtol=1e-12, atol=1e-13)
+        # (the range-error rows and, with a mask, the rows left out)
+        assert (flags == ngmix.flags.GMIX_RANGE_ERROR).any()
+        assert ((flags == ngmix.flags.NO_ATTEMPT).any()) == (m is not None)
+
+
+@pytest.mark.gpu
+def test_gaussap_single_vector_and_the_per_object_getter(golden):
+    g = golden("utils")
+    flux, flags = gaussap.get_gaussap_flux([0.0, 0.0, 0.1, 0.2, 0.5, 10.0], "exp", 1.5)
+    np.testing.assert_allclose(flux, g["gap_single_flux"], rtol=1e-12)
+    np.testing.assert_array_equal(flags, g["gap_single_flags"])
+    one = ngmix.GMixModel([0.0, 0.0, 0.1, 0.2, 0.5, 10.0], "exp").get_gaussap_flux(fwhm=1.5)
+    np.testing.assert_allclose(one, g["gap_single_flux"][0, 0], rtol=1e-12)
+    with pytest.raises(AssertionError):
+        gaussap.get_gaussap_flux(np.zeros((3, 6)), "exp", 1.0, mask=[True])
+
+
+def test_noise_images_are_the_references(golden):
+    g = golden("utils")
+    w, holes = g["noise_w"], g["noise_holes"]
+    cases = {"plain": (w, {}), "holes_all": (holes, {}), "holes_notall": (holes, {"add_all": False}),
+             "factor": (holes, {"noise_factor": 1.7}), "zero": (np.zeros((4, 5)), {})}
+    for name, (wt, kw) in cases.items():
+        got = simobs.get_noise_image(wt, np.random.RandomState(123), **kw)
+        np.testing.assert_array_equal(got, g["noise_" + name], err_msg=name)
+    assert np.all(np.abs(g["noise_zero"]) > 1e10) and simobs.BIGNOISE == 1.0e15
+    with pytest.raises(ValueError):
+        simobs.get_noise_image(w, None)
+
+
+@pytest.mark.gpu
+def test_simulate_obs_vs_reference(golden):
+    g = golden("utils")
+    j = g["sim_jac"]
+    j = j[0] if j.ndim else j
+    jac = ngmix.Jacobian(row=float(j["row0"]), col=float(j["col0"]), dvdrow=float(j["dvdrow"]),
+                         dvdcol=float(j["dvdcol"]), dudrow=float(j["dudrow"]),
+                         dudcol=float(j["dudcol"]))
+    w = g["sim_weight"]
+    dim = w.shape[0]
+    psf_gm = ngmix.GMix(pars=g["sim_psf_pars"])
+    gm, gm2 = ngmix.GMix(pars=g["sim_gm_pars"]), ngmix.GMix(pars=g["sim_gm2_pars"])
+
+    def obs():
+        pobs = ngmix.Observation(np.zeros((dim, dim)) + 1.0, jacobian=jac, gmix=psf_gm.copy())
+        return ngmix.Observation(np.zeros((dim, dim)), weight=w.copy(), jacobian=jac, psf=pobs)
+
+    def close(a, b):
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-14 * np.abs(b).max())
+    o = simobs.simulate_obs(gm, obs(), add_noise=False)
+    close(o.image, g["sim_model"])
+    np.testing.assert_array_equal(o.weight, g["sim_model_weight"])
+    assert o.noise_image is None and o.has_psf() and o.psf.has_gmix()
+    assert o.jacobian == jac
+    close(simobs.simulate_obs(gm, obs(), add_noise=False, convolve_psf=False).image,
+          g["sim_model_nopsf"])
+    o = simobs.simulate_obs(gm, obs(), rng=np.random.RandomState(9))
+    np.testing.assert_array_equal(o.noise_image, g["sim_noise_image"])
+    close(o.image, g["sim_noisy"])
+    o = simobs.simulate_obs(gm, obs(), rng=np.random.RandomState(9), noise_factor=2.0,
+                            add_all=False)
+    close(o.image, g["sim_noisy_f2"])
+    np.testing.assert_array_equal(o.weight, g["sim_weight_f2"])
+    raw = obs()
+    raw.weight_raw = w * 4.0
+    close(simobs.simulate_obs(gm, raw, rng=np.random.RandomState(9)).image, g["sim_noisy_raw"])
+    close(simobs.simulate_obs(gm, raw, rng=np.random.RandomState(9), use_raw_weight=False).image,
+          g["sim_noisy_raw_unused"])
+    np.testing.assert_array_equal(
+        simobs.simulate_obs(None, obs(), rng=np.random.RandomState(9)).image, g["sim_pure_noise"])
+    ol = ngmix.ObsList()
+    ol.append(obs())
+    ol.append(obs())
+    r = simobs.simulate_obs(gm, ol, rng=np.random.RandomState(10))
+    assert isinstance(r, ngmix.ObsList) and len(r) == 2
+    close(np.array([x.image for x in r]), g["sim_obslist"])
+    mb = ngmix.MultiBandObsList()
+    mb.append(ol)
+    mb.append(ol)
+    r = simobs.simulate_obs([gm, gm2], mb, rng=np.random.RandomState(11))
+    assert isinstance(r, ngmix.MultiBandObsList) and len(r) == 2 and len(r[0]) == 2
+    close(np.array([[x.image for x in band] for band in r]), g["sim_mb"])
+    # the argument checks
+    for bad in (lambda: simobs.simulate_obs(3, obs()), lambda: simobs.simulate_obs(gm, 3),
+                lambda: simobs.simulate_obs(gm, mb), lambda: simobs.simulate_obs([3, 3], mb),
+                lambda: simobs.simulate_obs([gm], mb),
+                lambda: simobs.simulate_obs(gm, obs())):          # noise without an rng
+        with pytest.raises(ValueError):
+            bad()
+    nopsf = ngmix.Observation(np.zeros((dim, dim)), weight=w.copy(), jacobian=jac)
+    with pytest.raises(RuntimeError):
+        simobs.simulate_obs(gm, nopsf, add_noise=False)
+    nogm = ngmix.Observation(np.zeros((dim, dim)), weight=w.copy(), jacobian=jac,
+                             psf=ngmix.Observation(np.ones((dim, dim)), jacobian=jac))
+    with pytest.raises(RuntimeError):
+        simobs.simulate_obs(gm, nogm, add_noise=False)

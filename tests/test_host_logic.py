@@ -746,7 +746,7 @@ _SURFACE_OUT_OF_SCOPE = {
 }
 _ATTRS_OUT_OF_SCOPE = {"make_galsim_object", "get_galsim_wcs"}
 _TOP_OUT_OF_SCOPE = {"GMixND", "gmix_ndim",          # the N-d mixture pdf (sklearn)
-                     "gaussap", "simobs", "metacal", "ksigmamom", "prepsfmom",
+                     "metacal", "ksigmamom", "prepsfmom",
                      "fastexp_nb",            # the numba module; its function is a HIP device fn
                      "NumbaExperimentalFeatureWarning", "warnings"}
 
