@@ -357,9 +357,10 @@ class StampBatch(object):
                      device=None):
         """
         N stamps of ONE shape from HOST arrays -- images, weights (N, nrow,
-        ncol) float64, jacobian records (N,) of the reference dtype or (N, 8)
-        doubles.  What a host-resident catalogue costs is the PCIe transfer of
-        16 bytes per pixel:
+        ncol) float64 (torch tensors: or float32, widened on the device),
+        jacobian records (N,) of the reference dtype or (N, 8) doubles.  What a
+        host-resident catalogue costs is the PCIe transfer of 16 bytes per
+        pixel (8 for float32 stamps):
 
           * numpy arrays: one host-to-device copy of [val | weight | jacobians
             | stamp table] assembled in a staging buffer, the listed pixels
@@ -372,11 +373,21 @@ class StampBatch(object):
         torch = _torch()
         dev = _require_cuda(device)
         if isinstance(images, torch.Tensor):
-            assert images.dtype == torch.float64 and weights.dtype == torch.float64
+            ok = (torch.float64, torch.float32)
+            assert images.dtype in ok and weights.dtype in ok, "float64 or float32 stamps"
             n, nrow, ncol = images.shape
             assert weights.shape == images.shape, "image and weight must match"
+            # float32 stamps (what survey postage stamps are stored as) cross
+            # the link as they are, 4 bytes per value, and are widened on the
+            # device: the conversion is exact, so the float64 arithmetic sees
+            # the values np.array(image, dtype='f8') gives the reference
+            # (observation.py:373-376)
             dval = images.to(dev, non_blocking=True).reshape(-1)
             dw = weights.to(dev, non_blocking=True).reshape(-1)
+            if dval.dtype != torch.float64:
+                dval = dval.to(torch.float64)
+            if dw.dtype != torch.float64:
+                dw = dw.to(torch.float64)
             jr = jac_records if isinstance(jac_records, torch.Tensor) else \
                 torch.from_numpy(np.ascontiguousarray(jac_records).view(np.float64).reshape(n, 8))
             djac = jr.to(dev, non_blocking=True).reshape(n, 8)

@@ -349,3 +349,52 @@ def test_coellip_fitter_go_many(golden):
     r = res[17]
     assert r["flags"] == 0 and r["nfev"] == int(g["coellip3_nfev"])
     assert np.all(np.abs(r["pars"] - g["coellip3_pars"]) <= 1e-3 * g["coellip3_pars_err"])
+
+
+def test_from_stacked_is_from_images():
+    """StampBatch.from_stacked (host arrays -> device in one copy, or from
+    pinned tensors where they lie) holds the same stamps as from_images: the
+    same val / ierr / jacobians / listed-pixel counts, with masked pixels; and
+    float32 tensors, widened on the device, equal the float64 arrays
+    np.array(image, dtype='f8') gives the reference"""
+    import torch
+    rng = np.random.RandomState(3)
+    n, dim = 40, 24
+    img = rng.normal(size=(n, dim, dim))
+    wt = np.abs(rng.normal(size=(n, dim, dim))) + 0.1
+    wt[3, 2, 5] = 0.0
+    wt[7, :, 0] = -1.0
+    jacs = [ngmix.Jacobian(row=11.5 + 0.01 * i, col=11.4, dvdrow=0.26, dvdcol=0.01 * (i % 3),
+                           dudrow=-0.01, dudcol=0.27) for i in range(n)]
+    rec = np.concatenate([j.get_data() for j in jacs])
+    ref = StampBatch.from_images(img, wt, jacs)
+
+    def same(sb, ref):
+        assert sb.n == ref.n
+        np.testing.assert_array_equal(sb.val.cpu().numpy(), ref.val.cpu().numpy())
+        np.testing.assert_array_equal(sb.ierr.cpu().numpy(), ref.ierr.cpu().numpy())
+        np.testing.assert_array_equal(sb.jac.cpu().numpy().reshape(-1),
+                                      ref.jac.cpu().numpy().reshape(-1))
+        np.testing.assert_array_equal(sb.npix_kept, ref.npix_kept)
+        assert sb.any_masked == ref.any_masked
+    same(StampBatch.from_stacked(img, wt, rec), ref)
+
+    def pinned(a):
+        t = torch.empty(a.shape, dtype=torch.from_numpy(a[:0]).dtype, pin_memory=True)
+        t.copy_(torch.from_numpy(a))
+        return t
+    same(StampBatch.from_stacked(pinned(img), pinned(wt), rec), ref)
+    img32, wt32 = img.astype("f4"), wt.astype("f4")
+    ref32 = StampBatch.from_images(img32.astype("f8"), wt32.astype("f8"), jacs)
+    sb32 = StampBatch.from_stacked(pinned(img32), pinned(wt32), rec)
+    same(sb32, ref32)
+    assert sb32.val.dtype == torch.float64
+    # and a fit on it is the fit on the widened arrays, to the bit
+    from ngmix_amd.lm_batch import LMBatchFitter
+    guess = np.tile([0.0, 0.0, 0.0, 0.0, 0.5, 1.0], (n, 1))
+    a = LMBatchFitter("gauss", fit_pars={"maxfev": 20}).go(sb32, guess)
+    b = LMBatchFitter("gauss", fit_pars={"maxfev": 20}).go(ref32, guess)
+    np.testing.assert_array_equal(a["pars"], b["pars"])
+    np.testing.assert_array_equal(a["nfev"], b["nfev"])
+    with pytest.raises(AssertionError):
+        StampBatch.from_stacked(pinned(img32).to(torch.float16), pinned(wt32), rec)
