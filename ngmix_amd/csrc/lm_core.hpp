@@ -664,42 +664,49 @@ NGMIX_HD bool prior_term_row(int kind, const double *par, double x, bool own_fdi
 }
 
 constexpr int PRIOR_KMAX = 4 + NGMIX_PRIOR_MAXMID + NGMIX_PRIOR_MAXBAND;
+constexpr int PRIOR_NMAX = 5 + NGMIX_PRIOR_MAXMID + NGMIX_PRIOR_MAXBAND;
+
+// the prior is separable: parameter j belongs to exactly one row
+NGMIX_HD int prior_row_of(int j) { return j < 2 ? j : (j < 4 ? 2 : j - 1); }
+
+// one row of the prior at x and the ln p of its term: row 0 / 1 the centre
+// terms, 2 the shape term, 3.. the 1-d terms of x[4..] (T, the middle terms, the
+// fluxes); false where the reference raises GMixRangeError
+// (joint_prior.py:86-120, 341-378, 556-590)
+NGMIX_HD bool prior_row(const ngmix_simple_sep_prior &P, const double *x, int row, bool own,
+                        double &val, double &lnp)
+{
+    if (row < 2) {
+        const double cen = row == 0 ? P.cen1 : P.cen2;
+        const double d = cen - x[row];
+        lnp = -0.5 * d * d * (row == 0 ? P.cen_s2inv1 : P.cen_s2inv2);
+        val = own ? (x[row] - cen) * (row == 0 ? P.cen_sinv1 : P.cen_sinv2) : prior_root(lnp);
+        return true;
+    }
+    if (row == 2) {
+        const double gsq = x[2] * x[2] + x[3] * x[3];
+        const double omgsq = 1.0 - gsq;
+        if (omgsq <= 0.0) return false;
+        lnp = 2.0 * log(omgsq) - 0.5 * gsq * P.g_sig2inv;
+        val = prior_root(lnp);
+        return true;
+    }
+    const int m = row - 3;               // 0: T, 1..nmid: middle, then the fluxes
+    const int kind = m == 0 ? P.T_kind : (m <= P.nmid ? P.mid_kind[m - 1] : P.F_kind[m - 1 - P.nmid]);
+    const double *par = m == 0 ? P.T_par : (m <= P.nmid ? P.mid_par[m - 1] : P.F_par[m - 1 - P.nmid]);
+    return prior_term_row(kind, par, x[row + 1], own, val, lnp);
+}
 
 // rows[k] for k = cen1, cen2, g, T, mid_0.., F_0.. ; false when out of range
-// (joint_prior.py:86-120, 341-378, 556-590)
 NGMIX_HD bool simple_sep_rows(const ngmix_simple_sep_prior &P, const double *x,
                               double *rows, double *lnp_total)
 {
     const bool own = P.rows_mode == NGMIX_PRIOR_ROWS_FDIFF;
-    const double d1 = P.cen1 - x[0], d2 = P.cen2 - x[1];
-    double tot = -0.5 * d1 * d1 * P.cen_s2inv1;
-    const double lnp2 = -0.5 * d2 * d2 * P.cen_s2inv2;
-    if (own) {
-        rows[0] = (x[0] - P.cen1) * P.cen_sinv1;
-        rows[1] = (x[1] - P.cen2) * P.cen_sinv2;
-    } else {
-        rows[0] = prior_root(tot);
-        rows[1] = prior_root(lnp2);
-    }
-    tot += lnp2;
-    const double gsq = x[2] * x[2] + x[3] * x[3];
-    const double omgsq = 1.0 - gsq;
-    if (omgsq <= 0.0) return false;
-    const double lng = 2.0 * log(omgsq) - 0.5 * gsq * P.g_sig2inv;
-    rows[2] = prior_root(lng);
-    tot += lng;
-    double lnp;
-    if (!prior_term_row(P.T_kind, P.T_par, x[4], own, rows[3], lnp)) return false;
-    tot += lnp;
-    for (int m = 0; m < P.nmid; m++) {
-        if (!prior_term_row(P.mid_kind[m], P.mid_par[m], x[5 + m], own, rows[4 + m], lnp))
-            return false;
-        tot += lnp;
-    }
-    for (int b = 0; b < P.nband; b++) {
-        if (!prior_term_row(P.F_kind[b], P.F_par[b], x[5 + P.nmid + b], own,
-                            rows[4 + P.nmid + b], lnp))
-            return false;
+    const int k = 4 + P.nmid + P.nband;
+    double tot = 0.0;
+    for (int i = 0; i < k; i++) {
+        double lnp;
+        if (!prior_row(P, x, i, own, rows[i], lnp)) return false;
         tot += lnp;
     }
     if (lnp_total) *lnp_total = tot;
@@ -708,57 +715,66 @@ NGMIX_HD bool simple_sep_rows(const ngmix_simple_sep_prior &P, const double *x,
 
 // the prior rows of one fit at its trial point as normal-equation sums
 // [J^T J upper triangle | J^T r | r.r] over the fit's n = 5 + nmid + nband
-// parameters
+// parameters.  The jacobian of the rows is by one-sided differences (analytic
+// mode: step_rel * max(1, |x_j|), backward where the forward point is out of
+// range, results.py:572-625; forward-difference mode: the state's own fdjac2
+// points).  A step in x_j moves the one row x_j belongs to and no other, so
+// only that row is evaluated again and column j of the jacobian is one number:
+// the sums are those of the full (rows x parameters) difference jacobian, to
+// the bit, at two evaluations of the prior instead of n + 1.
 template <class State>
 NGMIX_HD void simple_sep_normal_sums(const ngmix_simple_sep_prior &P, const State &s,
                                      double step_rel, double *out)
 {
-    constexpr int KMAX = PRIOR_KMAX;
     const int n = s.n, k = 4 + P.nmid + P.nband, nt = n * (n + 1) / 2;
-    double r0[KMAX], rj[KMAX], J[KMAX][LM_NPMAX];
+    const bool own = P.rows_mode == NGMIX_PRIOR_ROWS_FDIFF;
+    double r0[PRIOR_KMAX], col[PRIOR_NMAX], x[PRIOR_NMAX];
     for (int i = 0; i < nt + n + 1; i++) out[i] = 0.0;
-    double x[LM_NPMAX];
-    for (int j = 0; j < LM_NPMAX; j++) x[j] = s.xt[j];
-    if (!simple_sep_rows(P, x, r0, nullptr)) {
+#pragma unroll
+    for (int j = 0; j < PRIOR_NMAX; j++) x[j] = j < n ? s.xt[j] : 0.0;
+    if (n > PRIOR_NMAX || !simple_sep_rows(P, x, r0, nullptr)) {
         out[nt + n] = INFINITY;
         return;
     }
     const bool fd = s.mode == NGMIX_LM_MODE_FD;
-    for (int j = 0; j < n; j++) {
-        double step;
+#pragma unroll
+    for (int j = 0; j < PRIOR_NMAX; j++) {
+        if (j >= n) {
+            col[j] = 0.0;
+            continue;
+        }
+        const int row = prior_row_of(j);
+        double step, rj, lnp;
         bool ok;
         const double xj = x[j];
         if (fd) {
             step = s.hstep[j];
             x[j] = s.xstep[j];
-            ok = simple_sep_rows(P, x, rj, nullptr);
+            ok = prior_row(P, x, row, own, rj, lnp);
         } else {
             step = step_rel * fmax(1.0, fabs(xj));
             x[j] = xj + step;
-            ok = simple_sep_rows(P, x, rj, nullptr);
+            ok = prior_row(P, x, row, own, rj, lnp);
             if (!ok) {
                 step = -step;
                 x[j] = xj + step;
-                ok = simple_sep_rows(P, x, rj, nullptr);
+                ok = prior_row(P, x, row, own, rj, lnp);
             }
         }
         x[j] = xj;
-        for (int i = 0; i < k; i++) {
-            const bool good = ok && fabs(r0[i]) < INFINITY && fabs(rj[i]) < INFINITY;
-            J[i][j] = good ? (rj[i] - r0[i]) / step : 0.0;
-        }
+        const bool good = ok && fabs(r0[row]) < INFINITY && fabs(rj) < INFINITY;
+        col[j] = good ? (rj - r0[row]) / step : 0.0;
     }
+    // J^T J: parameters of different rows do not meet (only g1 with g2 do)
     int t = 0;
-    for (int a = 0; a < n; a++) {
-        for (int b = a; b < n; b++) {
-            double acc = 0.0;
-            for (int i = 0; i < k; i++) acc += J[i][a] * J[i][b];
-            out[t++] = acc;
-        }
-        double acc = 0.0;
-        for (int i = 0; i < k; i++)
-            if (fabs(r0[i]) < INFINITY) acc += J[i][a] * r0[i];
-        out[nt + a] = acc;
+#pragma unroll
+    for (int a = 0; a < PRIOR_NMAX; a++) {
+        if (a >= n) break;
+        const int ra = prior_row_of(a);
+        out[t] = 0.0 + col[a] * col[a];
+        if (a == 2) out[t + 1] = 0.0 + col[2] * col[3];
+        t += n - a;
+        if (fabs(r0[ra]) < INFINITY) out[nt + a] = 0.0 + col[a] * r0[ra];
     }
     double ff = 0.0;
     for (int i = 0; i < k; i++) ff += r0[i] * r0[i];

@@ -1508,11 +1508,11 @@ __global__ __launch_bounds__(BLOCK) void lm_prior_sums_kernel(
     if (o >= nobj) return;
     const lm_state &s = states[o];
     const int n = s.n;
-    double out[NGMIX_LM_NSUMS(LM_NPMAX)];
     if (s.phase == LM_PHASE_DONE) return;
-    lmcore::simple_sep_normal_sums(P, s, step_rel, out);
-    double *dst = obj_sums + o * (int64_t)(n * (n + 1) / 2 + n + 1);
-    for (int i = 0; i < n * (n + 1) / 2 + n + 1; i++) dst[i] = out[i];
+    // (straight into the fit's slot: a private copy of the sums is 960 bytes
+    // of scratch per thread)
+    lmcore::simple_sep_normal_sums(P, s, step_rel,
+                                   obj_sums + o * (int64_t)(n * (n + 1) / 2 + n + 1));
 }
 
 int launch_lm_prior_sums(const lm_state *states, int64_t nobj,
