@@ -604,6 +604,11 @@ typedef struct {
 int ngmix_lm_prior_sums_batch(const ngmix_lm_state *states, int64_t nobj,
                               const ngmix_simple_sep_prior *prior, double step_rel,
                               double *obj_sums, void *stream);
+/* HOST: the same sums for states in host memory (testing aid; the code the
+   kernel runs) */
+int ngmix_lm_prior_sums_host(const ngmix_lm_state *states, int64_t nobj,
+                             const ngmix_simple_sep_prior *prior, double step_rel,
+                             double *obj_sums);
 /* HOST: rows (max 4 + nmid + nband) and ln p of one parameter vector: returns the
    number of rows, or -1 when the point is out of range (testing aid; the same
    code the kernel runs) */

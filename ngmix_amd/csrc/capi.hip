@@ -640,6 +640,22 @@ int ngmix_lm_prior_sums_batch(const ngmix_lm_state *states, int64_t nobj,
                                 (hipStream_t)stream);
 }
 
+int ngmix_lm_prior_sums_host(const ngmix_lm_state *states, int64_t nobj,
+                             const ngmix_simple_sep_prior *prior, double step_rel,
+                             double *obj_sums)
+{
+    if (!states || !prior || !obj_sums || prior->nband < 1 ||
+        prior->nband > NGMIX_PRIOR_MAXBAND || prior->nmid < 0 || prior->nmid > NGMIX_PRIOR_MAXMID)
+        return NGMIX_ERR_BAD_ARG;
+    for (int64_t o = 0; o < nobj; o++) {
+        const int n = states[o].n;
+        if (states[o].phase == LM_PHASE_DONE) continue;
+        lmcore::simple_sep_normal_sums(*prior, states[o], step_rel,
+                                       obj_sums + o * (int64_t)(n * (n + 1) / 2 + n + 1));
+    }
+    return NGMIX_OK;
+}
+
 int ngmix_simple_sep_prior_eval(const ngmix_simple_sep_prior *prior, const double *pars,
                                 double *rows, double *lnprob)
 {

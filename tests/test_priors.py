@@ -200,3 +200,93 @@ def test_pipeline_prior_guess_is_the_prior_drawing_psf_flux_guessers(model):
     assert np.abs(many[:, 0]).max() > 0.05        # centres from the prior, not +-0.01
     with pytest.raises(ValueError):
         pipeline._psfflux_guess(model, 3, 3, 0.5, np.ones((3, 3)), np.random.RandomState(5), prior)
+
+
+@pytest.mark.parametrize("case", range(7))
+@pytest.mark.parametrize("mode", ["analytic", "fd"])
+def test_prior_normal_sums_are_those_of_the_full_difference_jacobian(case, mode):
+    """the prior kernel evaluates, per parameter, only the row that parameter
+    belongs to; its sums [J^T J | J^T r | r.r] must be those of the full
+    (rows x parameters) one-sided difference jacobian -- n + 1 evaluations of
+    every row -- to the BIT.  ngmix_lm_prior_sums_host is the kernel's code on
+    the host; the full jacobian is built here from ngmix_simple_sep_prior_eval
+    rows with the reference's step rule (forward, backward where the forward
+    point is out of range; lmdif: the state's own points)."""
+    from ngmix_amd import _lib, prior_batch as pb
+    tag, jp, npars, _ = _joint_cases()[case]
+    desc = pb.as_batch_prior(jp).descriptor()
+    L = _lib.lib()
+    rng = np.random.RandomState(300 + case)
+    nfit = 60
+    st = np.zeros(nfit, dtype=_lib.LM_STATE_DTYPE)
+    st["n"] = npars
+    st["mode"] = _lib.LM_MODE_FD if mode == "fd" else 0
+    x = np.zeros((nfit, npars))
+    x[:, 0:2] = rng.normal(scale=0.05, size=(nfit, 2))
+    x[:, 2:4] = rng.normal(scale=0.3, size=(nfit, 2))
+    x[:, 4] = rng.uniform(0.01, 2.2, size=nfit)
+    x[:, 5:] = rng.uniform(0.02, 0.98, size=(nfit, npars - 5))
+    x[:, -1] = rng.uniform(-5.0, 420.0, size=nfit)
+    x[5, 2:4] = (0.70710678, 0.70710677)      # the forward step leaves |g| < 1
+    x[6, 4] = 1.9999999999 if "truncgauss" in tag else x[6, 4]
+    st["xt"][:, :npars] = x
+    h = 1.0e-8 * np.maximum(1.0, np.abs(x)) * rng.choice([1.0, -1.0], size=x.shape)
+    st["hstep"][:, :npars] = h
+    st["xstep"][:, :npars] = x + h
+    nsum = npars * (npars + 1) // 2 + npars + 1
+    got = np.full((nfit, nsum), 7.0)
+    assert L.ngmix_lm_prior_sums_host(_lib.ptr(st), nfit, _lib.ptr(desc), 1.0e-8,
+                                      _lib.ptr(got)) == 0
+
+    def rows_at(p):
+        r = np.zeros(12)
+        k = L.ngmix_simple_sep_prior_eval(_lib.ptr(desc), _lib.ptr(np.ascontiguousarray(p)),
+                                          _lib.ptr(r), None)
+        return (None if k < 0 else r[:k].copy())
+    nin = 0
+    for f in range(nfit):
+        r0 = rows_at(x[f])
+        want = np.zeros(nsum)
+        if r0 is None:
+            want[-1] = np.inf
+            np.testing.assert_array_equal(got[f], want)
+            continue
+        nin += 1
+        k = r0.size
+        J = np.zeros((k, npars))
+        for j in range(npars):
+            p = x[f].copy()
+            if mode == "fd":
+                step = h[f, j]
+                p[j] = st["xstep"][f, j]
+                rj = rows_at(p)
+            else:
+                step = 1.0e-8 * max(1.0, abs(x[f, j]))
+                p[j] = x[f, j] + step
+                rj = rows_at(p)
+                if rj is None:
+                    step = -step
+                    p[j] = x[f, j] + step
+                    rj = rows_at(p)
+            for i in range(k):
+                good = rj is not None and np.isfinite(r0[i]) and np.isfinite(rj[i])
+                J[i, j] = (rj[i] - r0[i]) / step if good else 0.0
+        t = 0
+        for a in range(npars):
+            for b in range(a, npars):
+                acc = 0.0
+                for i in range(k):
+                    acc += J[i, a] * J[i, b]
+                want[t] = acc
+                t += 1
+            acc = 0.0
+            for i in range(k):
+                if np.isfinite(r0[i]):
+                    acc += J[i, a] * r0[i]
+            want[npars * (npars + 1) // 2 + a] = acc
+        ff = 0.0
+        for i in range(k):
+            ff += r0[i] * r0[i]
+        want[-1] = ff
+        np.testing.assert_array_equal(got[f], want, err_msg="%s fit %d" % (tag, f))
+    assert nin >= 30
