@@ -723,6 +723,7 @@ class Fitter(object):
             batched = os.environ.get("NGMIX_FITTER_BATCHED", "1") not in ("0", "")
         self.batched = bool(batched)
         self._batch_fitter = None
+        self._kernel_prior = None
 
     def go(self, obs, guess):
         guess = np.asarray(guess, dtype="f8")
@@ -753,14 +754,33 @@ class Fitter(object):
         """the fit as a one-object batch (every epoch / band of the object a
         stamp); fills fm as set_fit_result would and returns True, or returns
         False when the fit is outside what the lock-step driver runs (a prior
-        object of the per-object interface, the noise-image covariance, psf
-        mixtures of different sizes, more parameters than its state holds)"""
+        object the prior kernel has no form for, the noise-image covariance,
+        psf mixtures of different sizes, more parameters than its state
+        holds)"""
         from .lm_batch import LMBatchFitter
         from .batch import GMixBatch
         spec = self._batched_model()
-        if spec is None or self.prior is not None or self.use_noise_image or \
+        if spec is None or self.use_noise_image or \
                 fm.npars > _lib.LM_NPMAX or guess.size != fm.npars:
             return False
+        bprior = None
+        if self.prior is not None:
+            # a joint prior the prior kernel evaluates (joint_prior.py's
+            # separable priors of priors.py terms) rides along; any other
+            # prior object keeps the fit on the MINPACK route
+            if self._kernel_prior is None:
+                from .prior_batch import as_batch_prior
+                try:
+                    cand = as_batch_prior(self.prior)
+                except TypeError:
+                    cand = None
+                has = cand is not None and getattr(cand, "descriptor", lambda: None)() is not None
+                self._kernel_prior = cand if has else False
+            if self._kernel_prior is False:
+                return False
+            bprior = self._kernel_prior
+            if len(bprior.terms) + 4 != fm.npars:
+                return False
         psf = None
         if fm.dopsf:
             if len({len(p) for p in fm._psf_list}) != 1:
@@ -770,7 +790,7 @@ class Fitter(object):
         if self._batch_fitter is None:
             self._batch_fitter = LMBatchFitter(
                 spec[0], fit_pars=self.fit_pars, ngauss=spec[1],
-                analytic_jacobian=self.analytic_jacobian)
+                analytic_jacobian=self.analytic_jacobian, prior=bprior)
         res = self._batch_fitter.go(
             fm._batch, guess[None, :], psf=psf,
             stamp_obj=np.zeros(fm.nimage, dtype=np.int32),

@@ -196,3 +196,51 @@ def test_runner_and_bootstrap_on_either_route(route):
         obs=obs, guess=Guesser(truth, 1)(obs))
     assert other["flags"] == 0 and other["nfev"] == res["nfev"]
     assert np.all(np.abs(other["pars"] - res["pars"]) <= 1e-4 * res["pars_err"])
+
+
+@pytest.mark.parametrize("model", ["exp", "turb", "bdf", "bd"])
+def test_both_routes_with_a_host_joint_prior(model):
+    """Fitter(prior=<joint_prior of priors.py terms>): the batched route puts
+    the prior in its kernel form and keeps the fit inside the device loop; the
+    MINPACK route calls prior.fill_fdiff on the host -- one result dict.  A
+    prior object the kernel has no form for stays on the MINPACK route."""
+    from ngmix_amd import priors, joint_prior
+    rng = np.random.RandomState({"exp": 21, "turb": 22, "bdf": 23, "bd": 24}[model])
+    obs, truth = _object(model, rng, noise=0.02)
+    guess = truth * (1.0 + 0.02 * rng.uniform(-1, 1, size=truth.size))
+    guess[0:2] = truth[0:2] + 0.01 * rng.uniform(-1, 1, size=2)
+    prng = np.random.RandomState(3)
+    cen = priors.CenPrior(0.0, 0.0, SCALE, SCALE, rng=prng)
+    g = priors.GPriorBA(0.3, rng=prng)
+    T = priors.LogNormal(0.6, 0.4, rng=prng)
+    F = priors.TwoSidedErf(-10.0, 1.0, 1.0e4, 100.0, rng=prng)
+    fd = priors.Normal(0.5, 0.2, rng=prng, bounds=(0.0, 1.0))
+    if model == "bdf":
+        prior = joint_prior.PriorBDFSep(cen, g, T, fd, F)
+    elif model == "bd":
+        prior = joint_prior.PriorBDSep(cen, g, T, priors.Normal(0.0, 0.3, rng=prng), fd, F)
+    else:
+        prior = joint_prior.PriorSimpleSep(cen, g, T, F)
+    fb = ngmix.fitting.Fitter(model=model, prior=prior, batched=True)
+    fm = ngmix.fitting.Fitter(model=model, prior=prior, batched=False)
+    a = fb.go(obs=obs, guess=guess)
+    b = fm.go(obs=obs, guess=guess)
+    assert fb._batch_fitter is not None and fb._batch_fitter.prior_path == "kernel"
+    assert fm._batch_fitter is None
+    assert a["ier"] == b["ier"]
+    if model == "exp":
+        assert a["nfev"] == b["nfev"]
+        _compare(a, b, 1e-4, 1e-4)
+    else:
+        _compare(a, b, 5e-2 if model == "bd" else 2e-2, 5e-2 if model == "bd" else 2e-2)
+    # the prior's rows are not part of chi2 / dof on either route
+    assert a["dof"] == a["npix"] - truth.size
+
+    class Mine(priors.LogNormal):
+        pass
+    other = joint_prior.PriorSimpleSep(cen, g, Mine(0.6, 0.4, rng=prng), F)
+    if model == "exp":
+        f = ngmix.fitting.Fitter(model=model, prior=other, batched=True)
+        c = f.go(obs=obs, guess=guess)
+        assert f._batch_fitter is None and c["flags"] == 0
+        np.testing.assert_allclose(c["pars"], b["pars"], rtol=1e-9, atol=1e-12)
