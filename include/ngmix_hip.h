@@ -336,6 +336,14 @@ int ngmix_batch_upload(ngmix_batch *b, const double *images, const double *weigh
 int ngmix_batch_npix_kept(const ngmix_batch *b, int32_t *npix_kept);
 int ngmix_batch_free(ngmix_batch *b);
 
+/* DEVICE: the innermost functions of the fast pixel evaluation over an array
+   (fastexp_nb.py): which = 0 fexp = exp5_smooth(x) (:223-265; no range check:
+   x in (-15.5, 1.5)), 1 apod_window(chi2) (:97-117), 2 apod_window_deriv(chi2)
+   (:120-135).  x, out: n doubles on the device */
+#define NGMIX_FASTEXP_FEXP 0
+#define NGMIX_FASTEXP_APOD 1
+#define NGMIX_FASTEXP_APOD_DERIV 2
+int ngmix_fastexp_batch(const double *x, double *out, int64_t n, int which, void *stream);
 /* ierr = sqrt(max(weight,0)) elementwise (pixels_nb.py:49-52); ierr == weight
  * (in place) is allowed; weight == NULL fills unit ierr */
 int ngmix_weight_to_ierr_batch(const double *weight, double *ierr, int64_t n,

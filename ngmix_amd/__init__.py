@@ -53,6 +53,7 @@ from . import batch  # noqa: F401
 from . import prior_batch  # noqa: F401
 from . import lm_batch  # noqa: F401
 from .lm_batch import LMBatchFitter  # noqa: F401
+from . import fastexp_nb  # noqa: F401
 from . import gaussap  # noqa: F401
 from . import simobs  # noqa: F401
 from . import pipeline  # noqa: F401

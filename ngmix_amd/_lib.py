@@ -262,6 +262,7 @@ SIGNATURES = {
     "ngmix_simple_sep_prior_eval": (_i32, [_vp, _vp, _vp, _vp]),
     "ngmix_lm_advance_host": (_i64, [_vp, _i64, _vp, _vp, _vp]),
     "ngmix_lm_prior_sums_host": (_i32, [_vp, _i64, _vp, _f64, _vp]),
+    "ngmix_fastexp_batch": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "ngmix_lm_eval_batch": (_i32, [_pb, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp,
                                    _vp, _vp, _vp]),
     "ngmix_lm_advance_batch": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,

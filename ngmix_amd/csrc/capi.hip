@@ -509,6 +509,11 @@ int ngmix_deriv_images(const double *gpars, const double *dcov, int64_t ngauss,
 
 // ------------------------------------------------------------- batch forms
 
+int ngmix_fastexp_batch(const double *x, double *out, int64_t n, int which, void *stream)
+{
+    return launch_fastexp(x, out, n, which, (hipStream_t)stream);
+}
+
 int ngmix_weight_to_ierr_batch(const double *weight, double *ierr, int64_t n,
                                void *stream)
 {

@@ -27,6 +27,7 @@ int launch_fill_pixels(ngmix_pixel *pixels, int64_t npixels, const double *image
 int launch_fill_coords(ngmix_coord *coords, int nrow, int ncol,
                        const ngmix_jacobian &jac, hipStream_t s);
 int launch_weight_to_ierr(const double *w, double *ierr, int64_t n, hipStream_t s);
+int launch_fastexp(const double *x, double *out, int64_t n, int which, hipStream_t s);
 int launch_count_kept(ngmix_stamp *stamps, int64_t nstamps, const double *ierr,
                       hipStream_t s);
 

@@ -1253,6 +1253,36 @@ __global__ __launch_bounds__(BLOCK) void count_kept_kernel(ngmix_stamp *stamps,
     if (threadIdx.x == 0) stamps[blockIdx.x].npix_kept = (int)v[0];
 }
 
+// fexp / apod_window / apod_window_deriv over an array: the innermost
+// functions of every fast pixel evaluation, callable on their own
+// (fastexp_nb.py:97-135, 223-265).  which: 0 fexp(x), 1 apod_window(x),
+// 2 apod_window_deriv(x).  No range check, as in the reference: fexp reads its
+// 16-entry table at int(x - 0.5) + 15, so x must lie in (-15.5, 1.5).
+__global__ __launch_bounds__(BLOCK) void fastexp_kernel(const double *__restrict__ x,
+                                                         double *__restrict__ out, int64_t n,
+                                                         int which)
+{
+    __shared__ double tab[16];
+    if (threadIdx.x < 16) tab[threadIdx.x] = c_exp_table[threadIdx.x];
+    __syncthreads();
+    for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * BLOCK) {
+        const double v = x[i];
+        out[i] = which == 0 ? fexp(v, tab) : (which == 1 ? apod_window(v) : apod_window_deriv(v));
+    }
+}
+
+int launch_fastexp(const double *x, double *out, int64_t n, int which, hipStream_t s)
+{
+    if (n <= 0) return NGMIX_OK;
+    if (which < 0 || which > 2) return NGMIX_ERR_BAD_ARG;
+    int64_t nb = (n + BLOCK - 1) / BLOCK;
+    if (nb > 256 * 8) nb = 256 * 8;
+    hipLaunchKernelGGL(fastexp_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, s, x, out, n, which);
+    NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
+}
+
 int launch_weight_to_ierr(const double *w, double *ierr, int64_t n, hipStream_t s)
 {
     if (n <= 0) return NGMIX_OK;

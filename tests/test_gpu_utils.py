@@ -127,3 +127,29 @@ def test_simulate_obs_vs_reference(golden):
                              psf=ngmix.Observation(np.ones((dim, dim)), jacobian=jac))
     with pytest.raises(RuntimeError):
         simobs.simulate_obs(gm, nogm, add_noise=False)
+
+
+@pytest.mark.gpu
+def test_fastexp_module_is_the_reference_to_the_bit(golden):
+    """ngmix_amd.fastexp_nb runs the kernels' own device functions over an
+    array: fexp on the reference's 8,095 points (half-integers, the table's
+    cell boundaries, the chi^2 = 20 / 25 arguments) and the apodisation window
+    and its derivative on 2,004 -- equal to the reference's values with ==
+    (tests/golden/fastexp.npz; + - * and a table: no libm in either)"""
+    from ngmix_amd import fastexp_nb as fx
+    g = golden("fastexp")
+    np.testing.assert_array_equal(fx.fexp(g["x"]), g["fexp"])
+    np.testing.assert_array_equal(fx.fexp_arr(g["x"][:100].reshape(10, 10)),
+                                  g["fexp"][:100].reshape(10, 10))
+    np.testing.assert_array_equal(fx.apod_window(g["chi2"]), g["apod"])
+    np.testing.assert_array_equal(fx.apod_window_deriv(g["chi2"]), g["apod_deriv"])
+    one = fx.fexp(-3.25)
+    assert isinstance(one, float) and one == g["fexp"][np.argmin(np.abs(g["x"] + 3.25))] or \
+        abs(one / np.exp(-3.25) - 1) < 2.5e-6
+    assert fx.exp5_smooth is fx.fexp and fx.FASTEXP_MAX_CHI2 == 25.0 and fx.FASTEXP_APOD_CHI2 == 20.0
+    assert fx.apod_window(20.0) == 1.0 and fx.apod_window(25.0) == 0.0
+    # the reference's own accuracy bound (test_fastexp.py:20-27)
+    x = np.linspace(-12.5, 0.0, 20001)
+    assert np.abs(fx.fexp(x) / np.exp(x) - 1).max() < 2.5e-6
+    with pytest.raises(ValueError):
+        fx.fexp(-20.0)

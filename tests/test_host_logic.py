@@ -740,6 +740,9 @@ _SURFACE_OUT_OF_SCOPE = {
                 "GalsimSpergelFitter"},
     "guessers": {"R50NuFluxGuesser"},            # the Spergel (galsim) fitter's guesser
     "joint_prior": {"PriorSpergelSep"},          # and its joint prior
+    # the older polynomial variants: no kernel of the reference calls them
+    # (fexp = exp5_smooth, fastexp_nb.py:265)
+    "fastexp_nb": {"exp3", "exp4", "exp5"},
     # k-space observations feed the galsim fitters only
     "observation": {"KMultiBandObsList", "KObsList", "KObservation", "get_kmb_obs",
                     "make_iilist", "make_kobs"},
@@ -747,7 +750,6 @@ _SURFACE_OUT_OF_SCOPE = {
 _ATTRS_OUT_OF_SCOPE = {"make_galsim_object", "get_galsim_wcs"}
 _TOP_OUT_OF_SCOPE = {"GMixND", "gmix_ndim",          # the N-d mixture pdf (sklearn)
                      "metacal", "ksigmamom", "prepsfmom",
-                     "fastexp_nb",            # the numba module; its function is a HIP device fn
                      "NumbaExperimentalFeatureWarning", "warnings"}
 
 
