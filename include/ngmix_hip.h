@@ -612,6 +612,25 @@ typedef struct {
 int ngmix_lm_prior_sums_batch(const ngmix_lm_state *states, int64_t nobj,
                               const ngmix_simple_sep_prior *prior, double step_rel,
                               double *obj_sums, void *stream);
+/* DEVICE: what the prior adds to the statistics of the finished fits, at the
+   points they stand at (states[i].x): ffx (nobj,) = the sum of squares of the
+   prior's finite rows -- the part of |f|^2 run_leastsq leaves out of chi2/dof
+   (leastsqbound.py:97; ngmix_lm_finalize_batch's ff_extra) -- and lnp (nobj,)
+   = ln p, which calc_lnprob adds to the loglike (results.py:410-437); outside
+   the prior's range: 0 and -inf */
+int ngmix_lm_prior_finish_batch(const ngmix_lm_state *states, int64_t nobj,
+                                const ngmix_simple_sep_prior *prior, double *ffx,
+                                double *lnp, void *stream);
+/* DEVICE: out[o] = sum of fdiff^2 over the first nskip LISTED pixels of stamp
+   stamp_of[o] under mixture o of gmix (nobj x ngauss normalised records): the
+   reference reserves more residual rows for a joint prior than the prior
+   fills (results.py:1050-1078 against joint_prior.py:86-120), the pixel rows
+   start right after the filled ones (results.py:454-461), and chi2/dof leaves
+   ALL reserved rows out (leastsqbound.py:97) -- so the first pixels go with
+   the prior rows into ff_extra.  fill_fdiff's arithmetic (gmix_nb.py:877-900) */
+int ngmix_first_pixels_fdiff2_batch(const ngmix_batch *batch, const int64_t *stamp_of,
+                                    const ngmix_gauss2d *gmix, int ngauss, int64_t nobj,
+                                    int nskip, double *out, void *stream);
 /* HOST: the same sums for states in host memory (testing aid; the code the
    kernel runs) */
 int ngmix_lm_prior_sums_host(const ngmix_lm_state *states, int64_t nobj,

@@ -645,6 +645,21 @@ int ngmix_lm_prior_sums_batch(const ngmix_lm_state *states, int64_t nobj,
                                 (hipStream_t)stream);
 }
 
+int ngmix_lm_prior_finish_batch(const ngmix_lm_state *states, int64_t nobj,
+                                const ngmix_simple_sep_prior *prior, double *ffx, double *lnp,
+                                void *stream)
+{
+    return launch_lm_prior_finish(states, nobj, prior, ffx, lnp, (hipStream_t)stream);
+}
+
+int ngmix_first_pixels_fdiff2_batch(const ngmix_batch *batch, const int64_t *stamp_of,
+                                    const ngmix_gauss2d *gmix, int ngauss, int64_t nobj,
+                                    int nskip, double *out, void *stream)
+{
+    return launch_first_pixels_fdiff2(batch, stamp_of, gmix, ngauss, nobj, nskip, out,
+                                      (hipStream_t)stream);
+}
+
 int ngmix_lm_prior_sums_host(const ngmix_lm_state *states, int64_t nobj,
                              const ngmix_simple_sep_prior *prior, double step_rel,
                              double *obj_sums)

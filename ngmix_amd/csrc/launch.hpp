@@ -28,6 +28,9 @@ int launch_fill_coords(ngmix_coord *coords, int nrow, int ncol,
                        const ngmix_jacobian &jac, hipStream_t s);
 int launch_weight_to_ierr(const double *w, double *ierr, int64_t n, hipStream_t s);
 int launch_fastexp(const double *x, double *out, int64_t n, int which, hipStream_t s);
+int launch_first_pixels_fdiff2(const ngmix_batch *b, const int64_t *stamp_of,
+                               const ngmix_gauss2d *gm, int ngauss, int64_t nobj, int nskip,
+                               double *out, hipStream_t s);
 int launch_count_kept(ngmix_stamp *stamps, int64_t nstamps, const double *ierr,
                       hipStream_t s);
 
@@ -67,6 +70,9 @@ int launch_lm_advance_team(ngmix_lm_state *states, int64_t nobj, const int64_t *
 int launch_lm_rounds(const ngmix_lm_problem *p, int nrounds, int32_t *counts,
                      int32_t *counts_host, void **events, hipStream_t s);
 
+int launch_lm_prior_finish(const ngmix_lm_state *states, int64_t nobj,
+                           const ngmix_simple_sep_prior *prior, double *ffx, double *lnp,
+                           hipStream_t s);
 int launch_lm_prior_sums(const ngmix_lm_state *states, int64_t nobj,
                          const ngmix_simple_sep_prior *prior, double step_rel,
                          double *obj_sums, hipStream_t s);

@@ -1515,6 +1515,47 @@ __global__ __launch_bounds__(BLOCK) void lm_prior_sums_kernel(
                                    obj_sums + o * (int64_t)(n * (n + 1) / 2 + n + 1));
 }
 
+// what the prior contributes to the statistics of a finished fit, at the
+// point the fit stands at (states[i].x): ffx = the sum of squares of its
+// finite rows -- the part of |f|^2 run_leastsq leaves out of chi2/dof
+// (leastsqbound.py:97) -- and ln p (calc_lnprob adds it, results.py:410-437);
+// a point outside the prior's range: ffx 0, ln p -inf
+__global__ __launch_bounds__(BLOCK) void lm_prior_finish_kernel(
+    const lm_state *__restrict__ states, int64_t nobj, ngmix_simple_sep_prior P,
+    double *__restrict__ ffx, double *__restrict__ lnp)
+{
+    const int64_t o = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+    if (o >= nobj) return;
+    const lm_state &s = states[o];
+    double x[lmcore::PRIOR_NMAX], rows[lmcore::PRIOR_KMAX];
+#pragma unroll
+    for (int j = 0; j < lmcore::PRIOR_NMAX; j++) x[j] = j < s.n ? s.x[j] : 0.0;
+    double tot = 0.0, ff = 0.0;
+    if (s.n > lmcore::PRIOR_NMAX || !lmcore::simple_sep_rows(P, x, rows, &tot)) {
+        tot = -INFINITY;
+    } else {
+        const int k = 4 + P.nmid + P.nband;
+        for (int i = 0; i < k; i++) ff += rows[i] * rows[i];
+        if (!(fabs(ff) < INFINITY)) ff = 0.0;
+    }
+    ffx[o] = ff;
+    lnp[o] = tot;
+}
+
+int launch_lm_prior_finish(const lm_state *states, int64_t nobj,
+                           const ngmix_simple_sep_prior *prior, double *ffx, double *lnp,
+                           hipStream_t s)
+{
+    if (nobj <= 0) return NGMIX_OK;
+    if (!prior || !ffx || !lnp || prior->nband < 1 || prior->nband > NGMIX_PRIOR_MAXBAND ||
+        prior->nmid < 0 || prior->nmid > NGMIX_PRIOR_MAXMID)
+        return NGMIX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(lm_prior_finish_kernel, dim3((unsigned)((nobj + BLOCK - 1) / BLOCK)),
+                       dim3(BLOCK), 0, s, states, nobj, *prior, ffx, lnp);
+    NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
+}
+
 int launch_lm_prior_sums(const lm_state *states, int64_t nobj,
                          const ngmix_simple_sep_prior *prior, double step_rel,
                          double *obj_sums, hipStream_t s)

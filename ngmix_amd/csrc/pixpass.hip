@@ -1283,6 +1283,59 @@ int launch_fastexp(const double *x, double *out, int64_t n, int which, hipStream
     return NGMIX_OK;
 }
 
+// Sum of fdiff^2 over the first nskip LISTED pixels (row-major; weight > 0
+// where the stamp ignores zero weights) of one stamp per object, the model
+// being mixture o of gm (ngauss normalised gaussians).  The reference reserves
+// more residual rows for a joint prior than the prior fills (results.py:
+// 1050-1078 against joint_prior.py:86-120) and leaves all reserved rows out of
+// chi2/dof (leastsqbound.py:97): the first pixel rows go with them.  The
+// arithmetic of fill_fdiff (gmix_nb.py:877-900), pixel by pixel.
+__global__ __launch_bounds__(BLOCK) void first_pixels_fdiff2_kernel(
+    const ngmix_stamp *__restrict__ stamps, const double *__restrict__ val,
+    const double *__restrict__ ierr, const ngmix_jacobian *__restrict__ jac,
+    const int64_t *__restrict__ stamp_of, const ngmix_gauss2d *__restrict__ gm, int ngauss,
+    int64_t nobj, int nskip, double *__restrict__ out)
+{
+    const int64_t o = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+    if (o >= nobj) return;
+    const int64_t si = stamp_of[o];
+    const ngmix_stamp st = stamps[si];
+    const ngmix_jacobian j = jac[si];
+    const bool izw = (st.flags & NGMIX_STAMP_IGNORE_ZERO_WEIGHT) != 0;
+    const double area = j.scale * j.scale;
+    const ngmix_gauss2d *g = gm + o * (int64_t)ngauss;
+    const int npix = st.nrow * st.ncol;
+    double acc = 0.0;
+    int found = 0;
+    for (int p = 0; p < npix && found < nskip; p++) {
+        const double e = ierr[st.pix_off + p];
+        if (izw && !(e > 0.0)) continue;
+        found++;
+        double v, u;
+        jacobian_vu(j, (double)(p / st.ncol), (double)(p % st.ncol), v, u);
+        double model = 0.0;
+        for (int k = 0; k < ngauss; k++)
+            model += gauss_eval_fast(make_eval(g[k]), v, u, area, c_exp_table);
+        const double fd = (model - val[st.pix_off + p]) * e;
+        acc += fd * fd;
+    }
+    out[o] = acc;
+}
+
+int launch_first_pixels_fdiff2(const ngmix_batch *b, const int64_t *stamp_of,
+                               const ngmix_gauss2d *gm, int ngauss, int64_t nobj, int nskip,
+                               double *out, hipStream_t s)
+{
+    if (nobj <= 0) return NGMIX_OK;
+    if (!b || !stamp_of || !gm || !out || ngauss <= 0 || nskip < 0) return NGMIX_ERR_BAD_ARG;
+    hipLaunchKernelGGL(first_pixels_fdiff2_kernel, dim3((unsigned)((nobj + BLOCK - 1) / BLOCK)),
+                       dim3(BLOCK), 0, s, (const ngmix_stamp *)b->stamps, (const double *)b->val,
+                       (const double *)b->ierr, (const ngmix_jacobian *)b->jac, stamp_of, gm,
+                       ngauss, nobj, nskip, out);
+    NGMIX_HIP_CHECK(hipGetLastError());
+    return NGMIX_OK;
+}
+
 int launch_weight_to_ierr(const double *w, double *ierr, int64_t n, hipStream_t s)
 {
     if (n <= 0) return NGMIX_OK;

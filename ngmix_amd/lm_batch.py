@@ -999,11 +999,23 @@ class LMBatchFitter(object):
             # slots than PriorSimpleSep fills (results.py:1050-1078 against
             # joint_prior.py:86-120) while the pixel rows start right after the
             # filled ones (results.py:454-461), so are the first pixels
-            rows, bad = self.prior.fill_fdiff_batch(col("x"))
-            d_ffx = torch.where(bad, torch.zeros_like(rows[:, 0]),
-                                (rows * rows).sum(dim=1))
-            d_ffx = torch.where(torch.isfinite(d_ffx), d_ffx, torch.zeros_like(d_ffx))
-            nskip = get_lm_n_prior_pars(self.model, job.nband) - rows.shape[1]
+            job.d_prior_lnp = None
+            if job.prior_desc is not None:
+                # one launch at the fits' points (the record the prior kernel
+                # evaluated during the rounds)
+                d_ffx = torch.empty(nobj, dtype=torch.float64, device=dev)
+                job.d_prior_lnp = torch.empty(nobj, dtype=torch.float64, device=dev)
+                _lib.check(L.ngmix_lm_prior_finish_batch(
+                    _dptr(d_states), nobj, _lib.ptr(job.prior_desc), _dptr(d_ffx),
+                    _dptr(job.d_prior_lnp), job.stream), "ngmix_lm_prior_finish_batch")
+                nrows = 4 + int(job.prior_desc["nmid"][0]) + int(job.prior_desc["nband"][0])
+            else:
+                rows, bad = self.prior.fill_fdiff_batch(col("x"))
+                d_ffx = torch.where(bad, torch.zeros_like(rows[:, 0]),
+                                    (rows * rows).sum(dim=1))
+                d_ffx = torch.where(torch.isfinite(d_ffx), d_ffx, torch.zeros_like(d_ffx))
+                nrows = rows.shape[1]
+            nskip = get_lm_n_prior_pars(self.model, job.nband) - nrows
             if nskip > 0:
                 d_ffx = d_ffx + self._first_pixels_fdiff2(
                     stamps, psf, col("x"), obj_start, sband, nskip)
@@ -1047,8 +1059,9 @@ class LMBatchFitter(object):
         self._gmix = None
         tot = None
         if not job.loop_stats:
-            tot = self._loglike_at_solutions(stamps, psf, sobj, sband,
-                                             obj_start).contiguous()
+            tot = self._loglike_at_solutions(
+                stamps, psf, sobj, sband, obj_start,
+                prior_lnp=getattr(job, "d_prior_lnp", None)).contiguous()
         # pars | pars_err rows, then twelve contiguous columns (integers and
         # statistics): one kernel, one download, contiguous host views
         ncols = _lib.LM_NCOLS
@@ -1193,41 +1206,15 @@ class LMBatchFitter(object):
             gm, _ = gm.convolve(GMixBatch(pdata.reshape(-1, 13).contiguous(), nobj,
                                           psf.ngauss))
         gm.set_norms()
-        G = gm.data.reshape(nobj, gm.ngauss, 13)
-        # the first nskip listed pixels of stamp s0 (row-major, weight > 0
-        # when the stamp ignores zero weights)
-        ncol = torch.from_numpy(stamps.ncol[s0].astype(np.int64)).to(dev)
-        off = torch.from_numpy(stamps.pix_off[s0]).to(dev)
-        izw = (stamps.flags[s0] & _lib.STAMP_IGNORE_ZERO_WEIGHT) != 0
-        masked = izw & (stamps.npix_kept[s0] != stamps.npix[s0])
-        first = np.tile(np.arange(nskip, dtype=np.int64), (nobj, 1))
-        if np.any(masked):
-            for o in np.nonzero(masked)[0]:
-                a = int(stamps.pix_off[s0[o]])
-                seg = stamps.ierr[a:a + int(stamps.npix[s0[o]])].cpu().numpy()
-                kept = np.nonzero(seg > 0)[0][:nskip]
-                first[o, :kept.size] = kept
-        first = torch.from_numpy(first).to(dev)
-        jac = stamps.jac[d_s0]
-        out = torch.zeros(nobj, dtype=torch.float64, device=dev)
-        for k in range(nskip):
-            pix = first[:, k]
-            r = (pix // ncol).to(torch.float64)
-            c = (pix % ncol).to(torch.float64)
-            v = jac[:, 2] * (r - jac[:, 0]) + jac[:, 3] * (c - jac[:, 1])
-            u = jac[:, 4] * (r - jac[:, 0]) + jac[:, 5] * (c - jac[:, 1])
-            vd = v[:, None] - G[:, :, 1]
-            ud = u[:, None] - G[:, :, 2]
-            chi2 = G[:, :, 10] * vd * vd + G[:, :, 8] * ud * ud - 2.0 * G[:, :, 9] * vd * ud
-            w = (25.0 - chi2) * 0.2
-            apod = torch.where(chi2 > 20.0, w ** 3 * (10.0 + w * (-15.0 + 6.0 * w)),
-                               torch.ones_like(w))
-            val = torch.where((chi2 < 25.0) & (chi2 >= 0.0),
-                              G[:, :, 12] * torch.exp(-0.5 * chi2) * apod,
-                              torch.zeros_like(chi2))
-            model = val.sum(dim=1) * jac[:, 7] ** 2  # area = scale^2 (jacobian_nb.py:33-40)
-            fd = (model - stamps.val[off + pix]) * stamps.ierr[off + pix]
-            out += fd * fd
+        # one launch: the first nskip listed pixels of each object's first
+        # stamp through fill_fdiff's own arithmetic
+        out = torch.empty(nobj, dtype=torch.float64, device=dev)
+        b = stamps._batch(1)
+        with _on_device(dev):
+            st = _lib.lib().ngmix_first_pixels_fdiff2_batch(
+                ctypes.byref(b), _dptr(d_s0), _dptr(gm.data), gm.ngauss, nobj, int(nskip),
+                _dptr(out), _stream())
+        _lib.check(st, "ngmix_first_pixels_fdiff2_batch")
         return out
 
     def states(self):
@@ -1272,7 +1259,7 @@ class LMBatchFitter(object):
         self._gmix = gm0
         return gm, usable
 
-    def _loglike_at_solutions(self, stamps, psf, sobj, sband, obj_start):
+    def _loglike_at_solutions(self, stamps, psf, sobj, sband, obj_start, prior_lnp=None):
         """the device half of FitModel.set_fit_result (results.py:45-72,
         398-408) when the lock-step loop did not carry the statistics
         (forward-difference fits, fits with a prior): one batched get_loglike
@@ -1292,7 +1279,10 @@ class LMBatchFitter(object):
         if self.prior is not None:
             # calc_lnprob adds the joint prior (results.py:410-437)
             tot = tot.clone()
-            tot[:, 0] += self.prior.get_lnprob_batch(usable.contiguous())
+            if prior_lnp is not None:
+                tot[:, 0] += prior_lnp
+            else:
+                tot[:, 0] += self.prior.get_lnprob_batch(usable.contiguous())
         return tot
 
     def _add_stats(self, res, out, nband):
