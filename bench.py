@@ -665,6 +665,55 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
     }
 
 
+def run_c3_prior(device, n=100000, steps=6):
+    """C3 with the reference's separable joint prior, as a caller of the
+    reference builds it (ngmix_amd.joint_prior.PriorSimpleSep of CenPrior,
+    GPriorBA, TwoSidedErf terms): the prior's rows evaluated by the prior kernel
+    inside the lock-step device loop.  Synchronous steps on rank 0 at N = 1,
+    inputs resident in HBM; next to it the same stamps without a prior."""
+    import time
+    import torch
+    from ngmix_amd import priors, joint_prior
+    from ngmix_amd.batch import GMixBatch
+    from ngmix_amd.lm_batch import LMBatchFitter
+    sb, _, pars = make_workload(n, seed=1000, device=device)
+    rng = np.random.RandomState(7)
+    guess = pars * rng.uniform(0.9, 1.1, size=pars.shape)
+    guess[:, 0:2] = pars[:, 0:2] + rng.uniform(-0.05, 0.05, size=(n, 2))
+    guess[:, 2:4] = pars[:, 2:4] + rng.uniform(-0.03, 0.03, size=(n, 2))
+    psf, _ = GMixBatch.from_pars(np.tile([0.0, 0.0, 0.0, 0.0, 0.27, 1.0], (n, 1)), "gauss",
+                                 device=device)
+    prng = np.random.RandomState(11)
+    prior = joint_prior.PriorSimpleSep(
+        priors.CenPrior(0.0, 0.0, SCALE, SCALE, rng=prng), priors.GPriorBA(0.3, rng=prng),
+        priors.TwoSidedErf(-0.1, 0.03, 1.0e3, 1.0, rng=prng),
+        priors.TwoSidedErf(-10.0, 1.0, 1.0e6, 1.0e3, rng=prng))
+
+    def clock(fitter):
+        fitter.go(sb, guess, psf=psf)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = fitter.go(sb, guess, psf=psf)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, res
+    with_prior = LMBatchFitter("exp", prior=prior)
+    dt, res = clock(with_prior)
+    dt0, res0 = clock(LMBatchFitter("exp"))
+    return {
+        "metric": "LM fits/sec with a separable joint prior ('exp' (x) gaussian psf, 48x48 "
+                  "stamps), 1 GPU",
+        "value": n / dt, "unit": "fits/s", "steps": steps, "ms_per_step": dt * 1e3,
+        "prior_path": with_prior.prior_path, "mean_nfev": float(res["nfev"].mean()),
+        "bad_status": int((res["flags"] != 0).sum()),
+        "without_prior": {"value": n / dt0, "ms_per_step": dt0 * 1e3,
+                          "mean_nfev": float(res0["nfev"].mean())},
+        "config": {"workload": "C3 stamps (%d x %dx%d px), PriorSimpleSep(CenPrior, GPriorBA, "
+                               "TwoSidedErf T, TwoSidedErf flux) built from ngmix_amd.priors; "
+                               "synchronous LMBatchFitter.go steps" % (n, NROW, NCOL)},
+    }
+
+
 def run_c3_host(device, n=100000, steps=4):
     """C3 from HOST-RESIDENT arrays: one step = the stamps of a catalogue held
     in pinned host memory (images, weight maps, jacobian records, psf records,
@@ -1639,6 +1688,12 @@ def main():
                 other["C3_host"] = run_c3_host(device, n=min(100000, cap))
             except Exception as e:   # never lose the headline line
                 other["C3_host"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+            # and with the reference's joint prior on the parameters
+            try:
+                other["C3_prior"] = run_c3_prior(device, n=min(100000, cap))
+            except Exception as e:   # never lose the headline line
+                other["C3_prior"] = {"error": repr(e)}
             torch.cuda.empty_cache()
     if rank == 0:
         if other:
