@@ -40,6 +40,8 @@ from .observation import (  # noqa: F401
 from . import admom  # noqa: F401
 from . import em  # noqa: F401
 from . import fitting  # noqa: F401
+from . import gmix_ndim  # noqa: F401
+from .gmix_ndim import GMixND  # noqa: F401
 from . import priors  # noqa: F401
 from . import joint_prior  # noqa: F401
 from . import guessers  # noqa: F401
