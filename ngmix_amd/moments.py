@@ -6,6 +6,7 @@ themselves come from the weighted-sums kernel.
 import numpy as np
 
 from . import flags as ngflags
+from .gexceptions import GMixRangeError
 from . import shape
 from .util import get_ratio_error
 
@@ -54,11 +55,16 @@ def T_to_r50(T):
 
 
 def moms_to_e1e2(M1, M2, T):
-    if isinstance(M1, np.ndarray):
-        return M1 / T, M2 / T
-    if T == 0:
-        return -9999.0, -9999.0
-    return M1 / T, M2 / T
+    """e1 = M1 / T, e2 = M2 / T as M * (1 / T); a size T <= 0 (any, for an
+    array) is a GMixRangeError (moments.py:135-163)"""
+    if isinstance(T, np.ndarray):
+        nbad = int(np.count_nonzero(T <= 0.0))
+        if nbad > 0:
+            raise GMixRangeError("%d T were <= 0.0" % nbad)
+    elif T <= 0.0:
+        raise GMixRangeError("T <= 0.0: %g" % T)
+    Tinv = 1.0 / T
+    return M1 * Tinv, M2 * Tinv
 
 
 def get_Tround(T, g1, g2):

@@ -150,22 +150,23 @@ class Shape(object):
     """a reduced-shear shape (g1, g2)"""
 
     def __init__(self, g1, g2):
-        self.g1 = g1
-        self.g2 = g2
-        g = np.sqrt(g1 * g1 + g2 * g2)
-        if g >= 1.0:
-            raise GMixRangeError("g out of range: %.16g" % g)
+        self.set_g1g2(g1, g2)
 
     def set_g1g2(self, g1, g2):
+        """(g1, g2) and their magnitude .g; |g| >= 1 is a GMixRangeError (the
+        components are stored first, as in the reference)"""
         self.g1 = g1
         self.g2 = g2
         g = np.sqrt(g1 * g1 + g2 * g2)
         if g >= 1.0:
             raise GMixRangeError("g out of range: %.16g" % g)
+        self.g = g
 
     def get_sheared(self, s1, s2=None):
         if isinstance(s1, Shape):
             s1, s2 = s1.g1, s1.g2
+        elif s2 is None:
+            raise ValueError("send s1,s2 or a Shape")
         g1, g2 = shear_reduced(self.g1, self.g2, s1, s2)
         return Shape(g1, g2)
 

@@ -32,10 +32,11 @@ def format_pars(pars, fmt="%8.3g"):
 def print_pars(pars, fmt="%8.3g", front=None, stream=None, logger=None):
     """print (or log) a parameter vector on one line"""
     import sys
-    line = format_pars(pars, fmt=fmt)
+    # (pars None prints as "None"; a logger gets a debug record -- util.py:5-35)
+    line = "%s" % None if pars is None else format_pars(pars, fmt=fmt)
     if front is not None:
         line = "%s %s" % (front, line)
     if logger is not None:
-        logger.info(line)
+        logger.debug(line)
     else:
-        print(line, file=stream if stream is not None else sys.stdout)
+        (stream if stream is not None else sys.stdout).write(line + "\n")

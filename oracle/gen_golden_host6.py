@@ -59,6 +59,39 @@ def main():
                      "get_g1g2sigma", "get_flux"):
             exp[name] = [float(v).hex() for v in np.atleast_1d(getattr(gm, name)())]
         out["getters"].append({"pars": [float(p).hex() for p in pars], "expected": exp})
+    # found by running the reference's own test files against the package
+    # (oracle/audit/run_reference_tests.sh)
+    import io
+    import logging
+    sh = ngmix.Shape(0.3, -0.4)
+    out["shape_g"] = float(sh.g).hex()
+    sh.set_g1g2(0.1, 0.2)
+    out["shape_g_after_set"] = float(sh.g).hex()
+    out["shape_get_sheared_one_arg"] = exc_name(lambda: ngmix.Shape(0.1, 0.2).get_sheared(0.1))
+    buf = io.StringIO()
+    ngmix.print_pars(None, stream=buf)
+    ngmix.print_pars([1.0, 2.0], front="x:", stream=buf)
+    out["print_pars_stream"] = buf.getvalue()
+    rec = []
+    handler = logging.Handler()
+    handler.emit = lambda r: rec.append((r.levelname, r.getMessage()))
+    lg = logging.getLogger("host6")
+    lg.setLevel(logging.DEBUG)
+    lg.addHandler(handler)
+    ngmix.print_pars([1.0, 2.0], logger=lg)
+    out["print_pars_logger"] = rec
+    cases = []
+    rng2 = np.random.RandomState(12)
+    for _ in range(40):
+        M1, M2, T = rng2.normal(), rng2.normal(), rng2.uniform(-0.2, 2.0)
+        try:
+            e = [float(v).hex() for v in ngmix.moments.moms_to_e1e2(M1, M2, T)]
+        except Exception as err:      # noqa: BLE001
+            e = type(err).__name__
+        cases.append({"args": [float(M1).hex(), float(M2).hex(), float(T).hex()], "expected": e})
+    out["moms_to_e1e2"] = cases
+    out["moms_to_e1e2_array_bad"] = exc_name(lambda: ngmix.moments.moms_to_e1e2(
+        np.array([0.1]), np.array([0.2]), np.array([-0.1])))
     with open(OUT, "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)
     print("wrote", OUT)

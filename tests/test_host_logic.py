@@ -855,6 +855,41 @@ def test_host6_behaviours_found_by_the_side_by_side_audit():
         except Exception as e:      # noqa: BLE001
             got = type(e).__name__
         assert got == case["expected"], (case, got)
+    # ---- found by the reference's own tests run against the package
+    import io
+    import logging
+    sh = ngmix.Shape(0.3, -0.4)
+    assert float(sh.g).hex() == g["shape_g"]
+    sh.set_g1g2(0.1, 0.2)
+    assert float(sh.g).hex() == g["shape_g_after_set"]
+    try:
+        ngmix.Shape(0.1, 0.2).get_sheared(0.1)
+        got = None
+    except Exception as e:      # noqa: BLE001
+        got = type(e).__name__
+    assert got == g["shape_get_sheared_one_arg"] == "ValueError"
+    buf = io.StringIO()
+    ngmix.print_pars(None, stream=buf)
+    ngmix.print_pars([1.0, 2.0], front="x:", stream=buf)
+    assert buf.getvalue() == g["print_pars_stream"]
+    rec = []
+    handler = logging.Handler()
+    handler.emit = lambda r: rec.append([r.levelname, r.getMessage()])
+    lg = logging.getLogger("host6-test")
+    lg.setLevel(logging.DEBUG)
+    lg.addHandler(handler)
+    ngmix.print_pars([1.0, 2.0], logger=lg)
+    assert rec == [list(x) for x in g["print_pars_logger"]]
+    for case in g["moms_to_e1e2"]:
+        args = [float.fromhex(a) for a in case["args"]]
+        try:
+            got = [float(v).hex() for v in ngmix.moments.moms_to_e1e2(*args)]
+        except Exception as e:      # noqa: BLE001
+            got = type(e).__name__
+        assert got == case["expected"], (case, got)
+    with pytest.raises(ngmix.GMixRangeError):
+        ngmix.moments.moms_to_e1e2(np.array([0.1]), np.array([0.2]), np.array([-0.1]))
+    assert g["moms_to_e1e2_array_bad"] == "GMixRangeError"
     for case in g["getters"]:
         gm = ngmix.GMix(pars=np.array([float.fromhex(p) for p in case["pars"]]))
         for name, want in case["expected"].items():
