@@ -15,7 +15,7 @@ Compared per stamp: whether the psf fit passed, its attempts, its nfev (lmder
 psf fitter); per object: BootPSFFailure, the epochs kept, flags, attempts, nfev
 (exact for the lmder models) and the parameters.
 
-usage: python tools/fuzz_boot.py [seconds] [seed]"""
+usage: python tools/fuzz_boot.py [seconds] [seed] [prior]"""
 import os
 import sys
 import time
@@ -52,7 +52,22 @@ class Stored(object):
         return np.array(self.table[id(obs)][k])
 
 
-def one_case(seed, models=("exp", "gauss", "dev", "turb"), psf_kinds=("gauss", "coellip")):
+def _joint_prior(rng, nband):
+    """a PriorSimpleSep of ngmix_amd.priors terms, wide enough not to fight the data"""
+    from ngmix_amd import priors, joint_prior
+    prng = np.random.RandomState(int(rng.randint(1 << 30)))
+    T = priors.TwoSidedErf(-0.1, 0.03, 50.0, 1.0, rng=prng) if rng.randint(2) else \
+        priors.LogNormal(0.6, 0.5, rng=prng)
+    F = [priors.TwoSidedErf(-10.0, 1.0, 1.0e5, 100.0, rng=prng) if rng.randint(2) else
+         priors.Normal(180.0, 200.0, rng=prng, bounds=(0.5, None)) for _ in range(nband)]
+    return joint_prior.PriorSimpleSep(
+        priors.CenPrior(0.0, 0.0, 0.263 * rng.uniform(0.5, 2.0), 0.263 * rng.uniform(0.5, 2.0),
+                        rng=prng), priors.GPriorBA(rng.uniform(0.2, 0.4), rng=prng), T,
+        F if nband > 1 else F[0])
+
+
+def one_case(seed, models=("exp", "gauss", "dev", "turb"), psf_kinds=("gauss", "coellip"),
+             with_prior=False):
     rng = np.random.RandomState(seed)
     model = str(rng.choice(list(models)))
     psf_kind = str(rng.choice(list(psf_kinds)))
@@ -135,6 +150,7 @@ def one_case(seed, models=("exp", "gauss", "dev", "turb"), psf_kinds=("gauss", "
         tables.append(table)
         obj_guess.append(og)
 
+    prior = _joint_prior(np.random.RandomState(seed ^ 0x5bd1), nband) if with_prior else None
     # ---- (a) object by object
     ref = []
     for i, mb in enumerate(objs):
@@ -144,7 +160,8 @@ def one_case(seed, models=("exp", "gauss", "dev", "turb"), psf_kinds=("gauss", "
             pf = ngmix.fitting.CoellipFitter(ngauss=2, fit_pars=psf_fp, batched=False)
         psf_runner = PSFRunner(fitter=pf, guesser=Stored(table=tables[i]), ntry=psf_ntry)
         guesser = Stored(seq=obj_guess[i])
-        runner = Runner(fitter=ngmix.fitting.Fitter(model=model, fit_pars=obj_fp, batched=False),
+        runner = Runner(fitter=ngmix.fitting.Fitter(model=model, fit_pars=obj_fp, batched=False,
+                                                    prior=prior),
                         guesser=guesser, ntry=ntry)
         try:
             res = Bootstrapper(runner=runner, psf_runner=psf_runner).go(mb)
@@ -167,7 +184,7 @@ def one_case(seed, models=("exp", "gauss", "dev", "turb"), psf_kinds=("gauss", "
     guess = np.array([[og[t] for og in obj_guess] for t in range(ntry)])
     res = bootstrap_batch(sb, psb, model=model, psf_fitter=psf_kind, psf_ngauss=psf_ng,
                           psf_ntry=psf_ntry, ntry=ntry, psf_guess=np.array(psf_guess).transpose(1, 0, 2),
-                          psf_fit_pars=psf_fp, fit_pars=obj_fp, guess=guess,
+                          psf_fit_pars=psf_fp, fit_pars=obj_fp, guess=guess, prior=prior,
                           stamp_obj=np.array(sobj), stamp_band=np.array(sband))
     return dict(model=model, psf_kind=psf_kind, nobj=nobj, ref=ref, res=res,
                 sobj=np.array(sobj), lmder=model in ("exp", "gauss", "dev"))
@@ -229,13 +246,17 @@ def new_stats():
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     master = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 17)
+    with_prior = len(sys.argv) > 3 and sys.argv[3] == "prior"
     stats = new_stats()
     t0 = time.time()
     ncase = 0
     while time.time() - t0 < budget:
         seed = int(master.randint(1 << 30))
-        compare(one_case(seed), stats, seed)
+        compare(one_case(seed, with_prior=with_prior), stats, seed)
         ncase += 1
+    if with_prior:
+        print("(every object fit carries a random PriorSimpleSep of ngmix_amd.priors terms: the prior kernel "
+              "in the batch, prior.fill_fdiff on the host object by object)")
     print("fuzz_boot: %.0f s, %d cases, %d objects, %d stamps; psf fits failed (epochs dropped): %d, "
           "objects lost to BootPSFFailure: %d, objects that needed a second attempt: %d; objects "
           "that differ from the per-object Bootstrapper: %d (psf fitter 'gauss', lmder: %d of %d; "
