@@ -57,6 +57,8 @@ from . import lm_batch  # noqa: F401
 from .lm_batch import LMBatchFitter  # noqa: F401
 from . import fastexp_nb  # noqa: F401
 from . import gaussap  # noqa: F401
+from . import prepsfmom  # noqa: F401
+from . import ksigmamom  # noqa: F401
 from . import simobs  # noqa: F401
 from . import pipeline  # noqa: F401
 from .pipeline import bootstrap_batch, bootstrap_many  # noqa: F401

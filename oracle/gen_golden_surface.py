@@ -26,7 +26,7 @@ OUT = os.path.join(os.path.dirname(HERE), "tests", "golden", "api_surface.json")
 OUT_SIG = os.path.join(os.path.dirname(HERE), "tests", "golden", "api_signatures.json")
 MODULES = ["gmix", "observation", "jacobian", "shape", "moments", "admom", "em", "fitting",
            "gaussmom", "guessers", "runners", "bootstrap", "pixels", "flags", "gexceptions",
-           "util", "priors", "joint_prior", "gaussap", "simobs", "fastexp_nb", "gmix_ndim"]
+           "util", "priors", "joint_prior", "gaussap", "simobs", "fastexp_nb", "gmix_ndim", "prepsfmom", "ksigmamom"]
 
 
 def public(obj):

@@ -748,7 +748,7 @@ _SURFACE_OUT_OF_SCOPE = {
                     "make_iilist", "make_kobs"},
 }
 _ATTRS_OUT_OF_SCOPE = {"make_galsim_object", "get_galsim_wcs"}
-_TOP_OUT_OF_SCOPE = {"metacal", "ksigmamom", "prepsfmom",
+_TOP_OUT_OF_SCOPE = {"metacal",             # galsim's image shearing
                      "NumbaExperimentalFeatureWarning", "warnings"}
 
 
