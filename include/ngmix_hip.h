@@ -336,6 +336,31 @@ int ngmix_batch_upload(ngmix_batch *b, const double *images, const double *weigh
 int ngmix_batch_npix_kept(const ngmix_batch *b, int32_t *npix_kept);
 int ngmix_batch_free(ngmix_batch *b);
 
+/* DEVICE: the (stamp, mode) stage of the pre-psf Fourier moments
+   (prepsfmom.py:337-422: _measure_moments_fft, _deconvolve_im_psf_inplace),
+   one pass.  The transforms of the apodised, zero-padded image (kim_*), of the
+   psf image (kpsf_*; NULL: a pixel in real space is deconvolved, pix (nmodes,)
+   real) and of a noise image (knoise_*; NULL: the noise power is pnoise_stamp
+   (nstamps,) per stamp; else |knoise|^2 * noise_scale per mode) arrive as
+   arrays of real and of imaginary parts over (stamp, row of modes, column of
+   modes), element (n, a, b) at n * stride_n + a * stride_r + b.  max_amp
+   (nstamps,): |psf
+   transform at k = 0|, amplitudes below 1e-5 of it are held there; py
+   (nstamps, nrows), px (nstamps, ncols) complex128 or both NULL: exp(i k
+   (image centre - psf centre)) per row / column of modes, irow / icol
+   (nmodes,) the row / column of each mode; fk (4, nmodes) = the M+, Mx, Mr,
+   Mf kernels; wgt (nmodes,) = 1, or 2 for a mode that also stands for its
+   conjugate partner (real stamps: half of the plane is transformed).  out
+   (nstamps, 14): the four sums x df2, then the upper triangle of their
+   covariance x df4 */
+int ngmix_prepsf_sums_batch(const double *kim_re, const double *kim_im, const double *kpsf_re,
+                            const double *kpsf_im, const double *pix, const double *knoise_re,
+                            const double *knoise_im, const double *pnoise_stamp,
+                            double noise_scale, const double *max_amp, const double *py,
+                            const double *px, const int32_t *irow, const int32_t *icol,
+                            const double *fk, const double *wgt, int64_t nstamps, int nmodes,
+                            int64_t stride_n, int64_t stride_r, int nrows, int ncols,
+                            double df2, double df4, double *out, void *stream);
 /* DEVICE: the innermost functions of the fast pixel evaluation over an array
    (fastexp_nb.py): which = 0 fexp = exp5_smooth(x) (:223-265; no range check:
    x in (-15.5, 1.5)), 1 apod_window(chi2) (:97-117), 2 apod_window_deriv(chi2)

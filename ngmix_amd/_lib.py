@@ -263,6 +263,8 @@ SIGNATURES = {
     "ngmix_lm_advance_host": (_i64, [_vp, _i64, _vp, _vp, _vp]),
     "ngmix_lm_prior_sums_host": (_i32, [_vp, _i64, _vp, _f64, _vp]),
     "ngmix_fastexp_batch": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "ngmix_prepsf_sums_batch": (_i32, [_vp] * 8 + [_f64] + [_vp] * 7 + [_i64, _i32, _i64, _i64, _i32,
+                                                               _i32, _f64, _f64, _vp, _vp]),
     "ngmix_lm_prior_finish_batch": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ngmix_first_pixels_fdiff2_batch": (_i32, [_pb, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
     "ngmix_lm_eval_batch": (_i32, [_pb, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp,

@@ -509,6 +509,21 @@ int ngmix_deriv_images(const double *gpars, const double *dcov, int64_t ngauss,
 
 // ------------------------------------------------------------- batch forms
 
+int ngmix_prepsf_sums_batch(const double *kim_re, const double *kim_im, const double *kpsf_re,
+                            const double *kpsf_im, const double *pix, const double *knoise_re,
+                            const double *knoise_im, const double *pnoise_stamp,
+                            double noise_scale, const double *max_amp, const double *py,
+                            const double *px, const int32_t *irow, const int32_t *icol,
+                            const double *fk, const double *wgt, int64_t nstamps, int nmodes,
+                            int64_t stride_n, int64_t stride_r, int nrows, int ncols,
+                            double df2, double df4, double *out, void *stream)
+{
+    return launch_prepsf_sums(kim_re, kim_im, kpsf_re, kpsf_im, pix, knoise_re, knoise_im,
+                              pnoise_stamp, noise_scale, max_amp, py, px, irow, icol, fk, wgt,
+                              nstamps, nmodes, stride_n, stride_r, nrows, ncols, df2, df4, out,
+                              (hipStream_t)stream);
+}
+
 int ngmix_fastexp_batch(const double *x, double *out, int64_t n, int which, void *stream)
 {
     return launch_fastexp(x, out, n, which, (hipStream_t)stream);

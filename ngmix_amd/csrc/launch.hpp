@@ -28,6 +28,14 @@ int launch_fill_coords(ngmix_coord *coords, int nrow, int ncol,
                        const ngmix_jacobian &jac, hipStream_t s);
 int launch_weight_to_ierr(const double *w, double *ierr, int64_t n, hipStream_t s);
 int launch_fastexp(const double *x, double *out, int64_t n, int which, hipStream_t s);
+int launch_prepsf_sums(const double *kim_re, const double *kim_im, const double *kpsf_re,
+                       const double *kpsf_im, const double *pix, const double *knoise_re,
+                       const double *knoise_im, const double *pnoise_stamp, double noise_scale,
+                       const double *max_amp, const double *py, const double *px,
+                       const int32_t *irow, const int32_t *icol, const double *fk,
+                       const double *wgt, int64_t nstamps, int M, int64_t stride_n,
+                       int64_t stride_r, int R, int C, double df2, double df4, double *out,
+                       hipStream_t s);
 int launch_first_pixels_fdiff2(const ngmix_batch *b, const int64_t *stamp_of,
                                const ngmix_gauss2d *gm, int ngauss, int64_t nobj, int nskip,
                                double *out, hipStream_t s);

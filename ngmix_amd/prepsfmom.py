@@ -217,35 +217,61 @@ def _padded_fft(images, target_dim, ap_rad, dev):
 
 
 def _mode_plan(kernels, dev):
-    """where the kernel lives in the D x D transform: the rows and columns that
-    hold at least one of its modes, and the position of every mode in that
-    (rows x columns) block -- made once per kernel"""
-    torch = _torch()
+    """
+    Where the kernel lives in the D x D transform -- made once per kernel.
+
+    The stamps are real, so the transform at -k is the conjugate of the one at
+    k, and every term of the sums (real part of image / psf x phase, kernels
+    even in k, |psf|^2, noise power) takes the same value at both: only the
+    half plane of non-negative column frequencies is transformed and a mode
+    with a partner in the other half counts twice.  (Not when the kernel
+    reaches the Nyquist row or column, whose aliased frequencies break the
+    symmetry of the kernels under a sheared jacobian: then every mode is kept.)
+
+    Returns the rows and columns that hold kept modes, and per kept mode its
+    place in the (rows x columns) block, its row and column there, its weight
+    (1 or 2) and its position among the kernel's own arrays.
+    """
     if "plan" not in kernels:
-        rows, cols = np.nonzero(kernels["msk"])
-        urows, irow = np.unique(rows, return_inverse=True)
-        ucols, icol = np.unique(cols, return_inverse=True)
-        kernels["plan"] = (urows, ucols, irow * ucols.size + icol, rows, cols)
-    urows, ucols, pick, rows, cols = kernels["plan"]
-    return urows, ucols, torch.from_numpy(pick).to(dev), rows, cols
+        msk = kernels["msk"]
+        dim = msk.shape[0]
+        rows, cols = np.nonzero(msk)
+        nyq = dim // 2
+        half = dim % 2 == 1 or not (msk[nyq, :].any() or msk[:, nyq].any())
+        if half:
+            keep = np.flatnonzero(cols <= nyq)
+            wgt = np.where(cols[keep] == 0, 1.0, 2.0)
+        else:
+            keep = np.arange(rows.size)
+            wgt = np.ones(rows.size)
+        urows, irow = np.unique(rows[keep], return_inverse=True)
+        ucols, icol = np.unique(cols[keep], return_inverse=True)
+        kernels["plan"] = dict(urows=urows, ucols=ucols,
+                               pick=(irow * ucols.size + icol).astype(np.int32),
+                               irow=irow.astype(np.int32), icol=icol.astype(np.int32), wgt=wgt,
+                               keep=keep, rows=rows[keep], cols=cols[keep])
+    return kernels["plan"]
 
 
 def _transform_at_modes(images, target_dim, ap_rad, kernels, dev):
     """
-    The transform of the apodised, zero-padded stamps AT THE KERNEL'S MODES
-    ONLY: (N, M) complex and the rows / columns of padding in front.
+    The transform of the apodised, zero-padded stamps ON THE ROWS AND COLUMNS
+    OF THE KERNEL'S MODES ONLY: real parts and imaginary parts, each (R, N C) --
+    element (stamp n, row a, column b) at a N C + n C + b --, and the rows /
+    columns of padding in front.
 
     A zero-padded stamp is dim x dim numbers in a D x D frame and the kernel
-    keeps a few hundred of the D^2 modes, clustered about k = 0.  Their values
-    are the separable sums  K[a, b] = sum_rc e^{-2 pi i a (r + pad) / D}
-    im[r, c] e^{-2 pi i b (c + pad) / D}  over the rows a and columns b the
-    kernel touches: two small complex matrix products per stamp (batched, on
-    the matrix cores) instead of a D x D FFT of which all but a per cent is
-    thrown away -- and nothing of size N D^2 is ever written.
+    keeps a disc of modes about k = 0.  Their values are the separable sums
+    K[a, b] = sum_rc e^{-2 pi i a (r + pad) / D} im[r, c] e^{-2 pi i b (c + pad) / D}
+    over the R rows a and C columns b the disc spans: small dense matrix
+    products (on the fp64 matrix cores) instead of a D x D FFT of which all but
+    a few per cent is thrown away -- nothing of size N D^2 is ever written, and
+    the stamps being real, real products on the real and imaginary parts of
+    the factors.
     """
     torch = _torch()
     n, dim, _ = images.shape
-    urows, ucols, pick, _, _ = _mode_plan(kernels, dev)
+    plan = _mode_plan(kernels, dev)
     d_im = _to_device(images, dev)
     if ap_rad > 0:
         edge = torch.from_numpy(_apodization_edge(dim, ap_rad)).to(dev)
@@ -254,13 +280,21 @@ def _transform_at_modes(images, target_dim, ap_rad, kernels, dev):
     pos = np.arange(dim) + before
 
     def factors(modes):
-        # e^{-2 pi i a p / D} with the product a p reduced modulo D exactly
-        # (integers), so the phase is as accurate at the far modes as at k = 0
+        # cos and -sin of 2 pi a p / D with the product a p reduced modulo D
+        # exactly (integers): as accurate at the far modes as at k = 0
         k = (np.outer(modes, pos) % target_dim) * (2.0 * np.pi / target_dim)
-        return torch.from_numpy(np.cos(k) - 1j * np.sin(k)).to(dev)
-    er, ec = factors(urows), factors(ucols)              # (R, dim), (C, dim)
-    block = torch.matmul(torch.matmul(er[None], d_im.to(torch.complex128)), ec.T[None])
-    return block.reshape(n, -1)[:, pick], before
+        return torch.from_numpy(np.cos(k)).to(dev), torch.from_numpy(-np.sin(k)).to(dev)
+    er_re, er_im = factors(plan["urows"])                # (R, dim)
+    ec_re, ec_im = factors(plan["ucols"])                # (C, dim)
+    # along the columns, then along the rows; the stamps laid out (row, stamp,
+    # column) so that each step is ONE product over all stamps: (dim N, dim) x
+    # (dim, C), then (R, dim) x (dim, N C)
+    by_row = d_im.permute(1, 0, 2).reshape(dim * n, dim)
+    t_re = torch.matmul(by_row, ec_re.T).reshape(dim, -1)          # (dim, N C)
+    t_im = torch.matmul(by_row, ec_im.T).reshape(dim, -1)
+    re = torch.matmul(er_re, t_re).addmm_(er_im, t_im, alpha=-1.0)  # (R, N C)
+    im = torch.matmul(er_re, t_im).addmm_(er_im, t_re)
+    return re, im, before
 
 
 def _same_wcs(a, b):
@@ -391,83 +425,139 @@ class PrePSFMom(object):
         eff_pad_factor = target_dim / dim
         kernels = _kernels(self.kind, target_dim, float(self.fwhm), deriv,
                            float(self.fwhm_smooth))
-        flat = torch.from_numpy(np.flatnonzero(kernels["msk"].reshape(-1))).to(dev)
+        plan = _mode_plan(kernels, dev)
+        nmodes, nr, nc = plan["pick"].size, plan["urows"].size, plan["ucols"].size
         full = bool(os.environ.get("NGMIX_PREPSF_FULL_FFT"))      # A/B switch: every mode by FFT
+        d_urows = torch.from_numpy(plan["urows"]).to(dev)
+        d_ucols = torch.from_numpy(plan["ucols"]).to(dev)
+
+        # where element (stamp n, row a, column b) of a transform lies
+        stride_n, stride_r = (nr * nc, nc) if full else (nc, n * nc)
 
         def transform(stamps, ap_rad):
             if full:
                 k, pad = _padded_fft(stamps, target_dim, ap_rad, dev)
-                return k.reshape(n, -1)[:, flat], pad
+                k = k[:, d_urows][:, :, d_ucols].reshape(n, -1)
+                return k.real.contiguous(), k.imag.contiguous(), pad
             return _transform_at_modes(stamps, target_dim, ap_rad, kernels, dev)
-        kim, before = transform(images, self.ap_rad)
+        kim_re, kim_im, before = transform(images, self.ap_rad)
         im_row, im_col = cen[:, 0] + before, cen[:, 1] + before
+        kpsf_re = kpsf_im = pix = None
         if psf_images is not None:
-            kpsf, pbefore = transform(psf_images, 0)
+            kpsf_re, kpsf_im, pbefore = transform(psf_images, 0)
             psf_row, psf_col = psf_cen[:, 0] + pbefore, psf_cen[:, 1] + pbefore
             # the psf's flux: its transform at k = 0, the sum of its pixels
-            max_amp = _to_device(psf_images, dev).reshape(n, -1).sum(dim=1).abs()
+            max_amp = _to_device(psf_images, dev).reshape(n, -1).sum(dim=1).abs().contiguous()
         else:
             # a pixel in real space
             f = np.sinc(np.fft.fftfreq(target_dim))
-            pix = (f.reshape(-1, 1) * f.reshape(1, -1)).reshape(-1)
-            max_amp = torch.full((n,), float(abs(pix[0])), dtype=torch.float64, device=dev)
-            kpsf = torch.from_numpy(pix).to(dev)[flat].to(torch.complex128)[None].repeat(n, 1)
+            max_amp = torch.full((n,), float(abs(f[0] * f[0])), dtype=torch.float64, device=dev)
+            pix = torch.from_numpy(f[plan["rows"]] * f[plan["cols"]]).to(dev).contiguous()
             psf_row = psf_col = np.zeros(n)
 
-        # ---- deconvolve: amplitudes of the psf below 1e-5 of its flux are held there
-        min_amp = (1e-5 * max_amp)[:, None]
-        amp = kpsf.abs()
-        low = amp <= min_amp
-        safe = torch.where(amp == 0, torch.ones_like(amp), amp)
-        kpsf = torch.where(low & (amp != 0), kpsf / safe * min_amp, kpsf)
-        kpsf = torch.where(low & (amp == 0), min_amp.to(torch.complex128).expand_as(kpsf), kpsf)
-        kim = kim / kpsf
-
-        # ---- the centres: exp(i k (centre of the image - centre of the psf))
+        # ---- the centres: exp(i k (centre of the image - centre of the psf)), separable: one
+        # cosine / sine per (stamp, row of modes) and per (stamp, column of modes)
         drow, dcol = im_row - psf_row, im_col - psf_col
+        py = px = None
         if np.any(drow != 0) or np.any(dcol != 0):
             f = np.fft.fftfreq(target_dim)
-            rows, cols = np.nonzero(kernels["msk"])
-            fy = torch.from_numpy(f[rows]).to(dev)[None, :]
-            fx = torch.from_numpy(f[cols]).to(dev)[None, :]
-            ky = fy * torch.from_numpy(2.0 * np.pi * drow).to(dev)[:, None]
-            kx = fx * torch.from_numpy(2.0 * np.pi * dcol).to(dev)[:, None]
-            phase = torch.complex(torch.cos(kx), torch.sin(kx)) * \
-                torch.complex(torch.cos(ky), torch.sin(ky))
-            kim = kim * phase
+            ky = torch.from_numpy(f[plan["urows"]]).to(dev)[None, :] * \
+                torch.from_numpy(2.0 * np.pi * drow).to(dev)[:, None]
+            kx = torch.from_numpy(f[plan["ucols"]]).to(dev)[None, :] * \
+                torch.from_numpy(2.0 * np.pi * dcol).to(dev)[:, None]
+            py = torch.complex(torch.cos(ky), torch.sin(ky)).contiguous()
+            px = torch.complex(torch.cos(kx), torch.sin(kx)).contiguous()
+        d_irow = torch.from_numpy(plan["irow"]).to(dev)
+        d_icol = torch.from_numpy(plan["icol"]).to(dev)
+        d_wgt = torch.from_numpy(plan["wgt"]).to(dev)
 
         # ---- the noise power per mode
+        kn_re = kn_im = pnoise_stamp = None
         if self.use_noise_image:
             if noise_images is None:
                 raise ValueError('obs.noise must be set when use_noise_image=True')
-            knoise, _ = transform(noise_images, 0)
-            pnoise = knoise.abs() ** 2 * eff_pad_factor ** 2
+            kn_re, kn_im, _ = transform(noise_images, 0)
         else:
             w = _to_device(weights, dev).reshape(n, -1)
             pos_w = w > 0
             tot_var = torch.where(pos_w, 1.0 / torch.where(pos_w, w, torch.ones_like(w)),
                                   torch.zeros_like(w)).sum(dim=1)
-            pnoise = (tot_var * eff_pad_factor ** 2)[:, None]
+            pnoise_stamp = (tot_var * eff_pad_factor ** 2).contiguous()
 
-        # ---- the moments: inverse transforms evaluated at the centre only
+        # ---- deconvolution, phases and the fourteen sums: one pass over (stamp, mode)
         df2 = (1 / target_dim) ** 2
         df4 = df2 * df2
-        fk = {k: torch.from_numpy(kernels[k]).to(dev) for k in ("fkp", "fkc", "fkr", "fkf")}
-        order = ("fkp", "fkc", "fkr", "fkf")
-        mom = torch.full((n, 6), float("nan"), dtype=torch.float64, device=dev)
-        for c, k in enumerate(order):
-            mom[:, 2 + c] = (kim.real * fk[k][None, :]).sum(dim=1) * df2
-        # (the kernels are real: kern_i conj(kern_j) / |psf|^2 has no imaginary part)
-        w = pnoise / (kpsf.real ** 2 + kpsf.imag ** 2)
-        cov = torch.zeros((n, 6, 6), dtype=torch.float64, device=dev)
-        cov[:, 0, 0] = 1.0
-        cov[:, 1, 1] = 1.0
+        fk = torch.from_numpy(np.stack([kernels[k][plan["keep"]]
+                                        for k in ("fkp", "fkc", "fkr", "fkf")])).to(dev)
+        if os.environ.get("NGMIX_PREPSF_TORCH_SUMS"):        # A/B switch: the same stage in torch ops
+            def modes(t):      # (N, M) from wherever the transform lies
+                if t is None:
+                    return None
+                at = (torch.arange(n, device=dev) * stride_n)[:, None] + \
+                    (d_irow.long() * stride_r + d_icol.long())[None, :]
+                return t.reshape(-1)[at]
+            sums = _sums_torch(modes(kim_re), modes(kim_im), modes(kpsf_re), modes(kpsf_im), pix,
+                               modes(kn_re), modes(kn_im), pnoise_stamp, eff_pad_factor ** 2,
+                               max_amp, py, px, d_irow, d_icol, fk, d_wgt, df2, df4)
+        else:
+            from . import _lib
+            from .batch import _dptr, _stream
+            sums = torch.empty((n, 14), dtype=torch.float64, device=dev)
+
+            def ptr(t):
+                return None if t is None else _dptr(t)
+            with torch.cuda.device(dev):
+                st = _lib.lib().ngmix_prepsf_sums_batch(
+                    ptr(kim_re), ptr(kim_im), ptr(kpsf_re), ptr(kpsf_im), ptr(pix), ptr(kn_re),
+                    ptr(kn_im), ptr(pnoise_stamp), float(eff_pad_factor ** 2), ptr(max_amp),
+                    None if py is None else _dptr(torch.view_as_real(py)),
+                    None if px is None else _dptr(torch.view_as_real(px)),
+                    ptr(d_irow), ptr(d_icol), ptr(fk), ptr(d_wgt), n, int(nmodes),
+                    int(stride_n), int(stride_r), int(nr), int(nc), df2, df4, ptr(sums), _stream())
+            _lib.check(st, "ngmix_prepsf_sums_batch")
+        sums = sums.cpu().numpy()
+        mom = np.full((n, 6), np.nan)
+        mom[:, 2:6] = sums[:, :4]
+        cov = np.zeros((n, 6, 6))
+        cov[:, 0, 0] = cov[:, 1, 1] = 1.0        # (as the reference leaves them)
+        t = 4
         for a in range(4):
             for b in range(a, 4):
-                v = (fk[order[a]] * fk[order[b]] * w).sum(dim=1) * df4
-                cov[:, 2 + a, 2 + b] = v
-                cov[:, 2 + b, 2 + a] = v
-        return mom.cpu().numpy(), cov.cpu().numpy(), kernels, target_dim
+                cov[:, 2 + a, 2 + b] = cov[:, 2 + b, 2 + a] = sums[:, t]
+                t += 1
+        return mom, cov, kernels, target_dim
+
+
+def _sums_torch(kim_re, kim_im, kpsf_re, kpsf_im, pix, kn_re, kn_im, pnoise_stamp, noise_scale,
+                max_amp, py, px, d_irow, d_icol, fk, wgt, df2, df4):
+    """the (stamp, mode) stage written as torch operations: what
+    ngmix_prepsf_sums_batch does in one pass (kept as the check of the kernel)"""
+    torch = _torch()
+    n = kim_re.shape[0]
+    kim = torch.complex(kim_re, kim_im)
+    if kpsf_re is None:
+        kpsf = pix.to(torch.complex128)[None].repeat(n, 1)
+    else:
+        kpsf = torch.complex(kpsf_re, kpsf_im)
+    min_amp = (1e-5 * max_amp)[:, None]
+    amp = kpsf.abs()
+    low = amp <= min_amp
+    safe = torch.where(amp == 0, torch.ones_like(amp), amp)
+    kpsf = torch.where(low & (amp != 0), kpsf / safe * min_amp, kpsf)
+    kpsf = torch.where(low & (amp == 0), min_amp.to(torch.complex128).expand_as(kpsf), kpsf)
+    kim = kim / kpsf
+    if py is not None:
+        kim = kim * (px[:, d_icol.long()] * py[:, d_irow.long()])
+    if kn_re is not None:
+        pnoise = (kn_re ** 2 + kn_im ** 2) * noise_scale
+    else:
+        pnoise = pnoise_stamp[:, None]
+    w = wgt[None, :] * pnoise / (kpsf.real ** 2 + kpsf.imag ** 2)
+    cols = [(kim.real * (fk[c] * wgt)[None, :]).sum(dim=1) * df2 for c in range(4)]
+    for a in range(4):
+        for b in range(a, 4):
+            cols.append((fk[a] * fk[b] * w).sum(dim=1) * df4)
+    return torch.stack(cols, dim=1)
 
 
 class KSigmaMom(PrePSFMom):

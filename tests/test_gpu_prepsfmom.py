@@ -141,3 +141,20 @@ def test_go_many_is_go(golden):
         np.testing.assert_allclose(r["sums_cov"], one["sums_cov"], rtol=1e-11, atol=1e-20)
     nopsf = fitter.go_many(obs[:4], no_psf=True)
     assert all(r["flags"] == 0 for r in nopsf) and nopsf[0]["T"] > many[0]["T"]
+
+
+@pytest.mark.parametrize("tag", ["pgauss", "ksigma_shear", "pgauss_nopsf", "pgauss_noiseim"])
+def test_the_fused_kernel_is_the_torch_stage(golden, tag, monkeypatch):
+    """ngmix_prepsf_sums_batch (deconvolution, phases, the fourteen sums in one
+    pass) against the same stage as torch operations, and the transform at the
+    kernel's modes against a full zero-padded FFT"""
+    g = golden("prepsf")
+    kw, gokw = CASES[tag]
+    obs = _obs(g, tag)
+    base = prepsfmom.PrePSFMom(**kw).go(obs, **gokw)
+    for env in ("NGMIX_PREPSF_TORCH_SUMS", "NGMIX_PREPSF_FULL_FFT"):
+        monkeypatch.setenv(env, "1")
+        other = prepsfmom.PrePSFMom(**kw).go(obs, **gokw)
+        monkeypatch.delenv(env)
+        _close(other["sums"], base["sums"], env)
+        _close(other["sums_cov"], base["sums_cov"], env)
