@@ -290,10 +290,14 @@ def _transform_at_modes(images, target_dim, ap_rad, kernels, dev):
     # column) so that each step is ONE product over all stamps: (dim N, dim) x
     # (dim, C), then (R, dim) x (dim, N C)
     by_row = d_im.permute(1, 0, 2).reshape(dim * n, dim)
-    t_re = torch.matmul(by_row, ec_re.T).reshape(dim, -1)          # (dim, N C)
-    t_im = torch.matmul(by_row, ec_im.T).reshape(dim, -1)
-    re = torch.matmul(er_re, t_re).addmm_(er_im, t_im, alpha=-1.0)  # (R, N C)
-    im = torch.matmul(er_re, t_im).addmm_(er_im, t_re)
+    nc = ec_re.shape[0]
+    t = torch.empty((2 * dim, n * nc), dtype=torch.float64, device=dev)   # [t_re ; t_im]
+    torch.matmul(by_row, ec_re.T, out=t[:dim].view(dim * n, nc))
+    torch.matmul(by_row, ec_im.T, out=t[dim:].view(dim * n, nc))
+    # re = er_re t_re - er_im t_im, im = er_im t_re + er_re t_im: one product
+    # each over the stacked halves (inner dimension 2 dim)
+    re = torch.matmul(torch.cat([er_re, -er_im], dim=1), t)         # (R, N C)
+    im = torch.matmul(torch.cat([er_im, er_re], dim=1), t)
     return re, im, before
 
 

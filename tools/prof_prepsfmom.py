@@ -8,7 +8,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from ngmix_amd.prepsfmom import PGaussMom  # noqa: E402
 
-n, dim = 10000, 33
+n, dim = (int(sys.argv[1]) if len(sys.argv) > 1 else 10000), 33
 rng = np.random.RandomState(1)
 images = torch.from_numpy(rng.normal(size=(n, dim, dim))).cuda()
 weights = torch.full((n, dim, dim), 2500.0, dtype=torch.float64).cuda()
