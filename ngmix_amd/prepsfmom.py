@@ -406,6 +406,20 @@ class PrePSFMom(object):
                for i in range(len(obs_list))]
         return res, kernels, target_dim
 
+    def go_batch(self, images, weights, cen, deriv, psf_images=None, psf_cen=None,
+                 noise_images=None):
+        """
+        A catalogue as arrays in, arrays out: the arguments of measure_arrays;
+        returns the dict of per-stamp arrays of moments.make_mom_result_batch
+        (flags, flux, flux_err, T, T_err, e, e_err, e_cov, s2n, sums, sums_cov,
+        ... every key of go()'s dict but the flag strings), one vectorised pass
+        over the sums.
+        """
+        from .moments import make_mom_result_batch
+        mom, cov, kernels, _ = self.measure_arrays(images, weights, cen, deriv, psf_images,
+                                                   psf_cen, noise_images)
+        return make_mom_result_batch(mom, cov, sums_norm=kernels["fk00"])
+
     def measure_arrays(self, images, weights, cen, deriv, psf_images=None, psf_cen=None,
                        noise_images=None):
         """

@@ -158,3 +158,34 @@ def test_the_fused_kernel_is_the_torch_stage(golden, tag, monkeypatch):
         monkeypatch.delenv(env)
         _close(other["sums"], base["sums"], env)
         _close(other["sums_cov"], base["sums_cov"], env)
+
+
+def test_go_batch_arrays_are_the_per_object_dicts(golden):
+    """go_batch (arrays in, arrays out: make_mom_result_batch over the sums)
+    against go() stamp by stamp, including stamps whose moments fail (a flux
+    sum driven negative)"""
+    g = golden("prepsf")
+    o = _obs(g, "pgauss")
+    rng = np.random.RandomState(8)
+    n = 12
+    images = np.stack([o.image + 0.02 * rng.normal(size=o.image.shape) for _ in range(n)])
+    images[3] = -images[3]                       # negative flux: flags set
+    weights = np.stack([o.weight] * n)
+    pimages = np.stack([o.psf.image] * n)
+    j, pj = o.jacobian, o.psf.jacobian
+    cen = np.tile([j.row0, j.col0], (n, 1))
+    pcen = np.tile([pj.row0, pj.col0], (n, 1))
+    fitter = prepsfmom.PGaussMom(1.2)
+    res = fitter.go_batch(images, weights, cen, (j.dvdrow, j.dvdcol, j.dudrow, j.dudcol), pimages,
+                          pcen)
+    assert (res["flags"] != 0).sum() >= 1
+    for i in range(n):
+        one = fitter.go(ngmix.Observation(images[i], weight=weights[i], jacobian=j, psf=o.psf))
+        for k in ("flags", "flux_flags", "T_flags"):
+            assert res[k][i] == one[k], (k, i)
+        for k in ("flux", "flux_err", "T", "T_err", "s2n", "e1", "e2", "e", "e_err", "e_cov",
+                  "sums", "sums_cov"):
+            a, b = np.asarray(res[k][i], dtype="f8"), np.asarray(one[k], dtype="f8")
+            np.testing.assert_array_equal(np.isfinite(a), np.isfinite(b), err_msg=k)
+            fin = np.isfinite(b)
+            np.testing.assert_allclose(a[fin], b[fin], rtol=1e-10, atol=1e-14, err_msg=k)
