@@ -189,3 +189,24 @@ def test_go_batch_arrays_are_the_per_object_dicts(golden):
             np.testing.assert_array_equal(np.isfinite(a), np.isfinite(b), err_msg=k)
             fin = np.isfinite(b)
             np.testing.assert_allclose(a[fin], b[fin], rtol=1e-10, atol=1e-14, err_msg=k)
+
+
+@pytest.mark.parametrize("case", range(36))
+def test_random_sweep_vs_reference(golden, case):
+    """36 configurations drawn over kernels, kernel sizes, stamp sizes 21-52,
+    psf stamps of other sizes, padding factors, apodisation widths, smoothing,
+    sheared jacobians, centre offsets, with / without a psf
+    (tests/golden/prepsf_sweep.npz, oracle/gen_golden_prepsf_sweep.py)"""
+    g = golden("prepsf_sweep")
+    tag = "c%02d" % case
+    conf = g[tag + "_conf"]
+    kw = dict(kernel=("pgauss", "ksigma")[int(conf[0])], fwhm=float(conf[1]),
+              pad_factor=float(conf[2]), ap_rad=float(conf[3]), fwhm_smooth=float(conf[4]))
+    im, pim = g[tag + "_im"].astype("f8"), g[tag + "_pim"].astype("f8")
+    wt = np.full(im.shape, float(g[tag + "_wt0"]))
+    obs = ngmix.Observation(im, weight=wt, jacobian=_jac(g[tag + "_jac"]),
+                            psf=ngmix.Observation(pim, jacobian=_jac(g[tag + "_pjac"])))
+    res = prepsfmom.PrePSFMom(**kw).go(obs, no_psf=bool(conf[5]))
+    assert res["flags"] == int(g[tag + "_flags"])
+    for k in ("flux", "flux_err", "T", "T_err", "s2n", "e1", "e2", "e_err", "sums", "sums_cov"):
+        _close(res[k], g["%s_%s" % (tag, k)], "%s %s" % (tag, k))
