@@ -372,8 +372,13 @@ class PrePSFMom(object):
 
     # ---- a catalogue: one batch per (image size, psf size, jacobian derivatives)
     def go_many(self, obs_list, no_psf=False):
-        """the results of go(obs) for every obs, in order; stamps of one shape
-        and pixel scale are measured as one batch on the device"""
+        """
+        The measurements of go(obs) for every obs: stamps of one shape and
+        pixel scale are measured as one batch on the device.  Returns a
+        PrePSFManyResults: res[i] is go(obs_list[i])'s dict (made when asked
+        for), res["T"], res["e"], res["flags"] ... the arrays over the
+        catalogue (moments.make_mom_result_batch).
+        """
         psfs = [_check_obs_and_get_psf_obs(o, no_psf) for o in obs_list]
         groups = {}
         for i, (o, p) in enumerate(zip(obs_list, psfs)):
@@ -381,14 +386,20 @@ class PrePSFMom(object):
             key = (o.image.shape[0], None if p is None else p.image.shape[0],
                    j.dvdrow, j.dvdcol, j.dudrow, j.dudcol)
             groups.setdefault(key, []).append(i)
-        out = [None] * len(obs_list)
+        n = len(obs_list)
+        sums, cov, norm = np.zeros((n, 6)), np.zeros((n, 6, 6)), np.zeros(n)
         for idx in groups.values():
-            res, _, _ = self._measure([obs_list[i] for i in idx], [psfs[i] for i in idx])
-            for i, r in zip(idx, res):
-                out[i] = r
-        return out
+            m, c, kernels, _ = self._measure_sums([obs_list[i] for i in idx], [psfs[i] for i in idx])
+            sums[idx], cov[idx], norm[idx] = m, c, kernels["fk00"]
+        return PrePSFManyResults(sums, cov, norm)
 
     def _measure(self, obs_list, psf_list):
+        mom, cov, kernels, target_dim = self._measure_sums(obs_list, psf_list)
+        res = [make_mom_result(mom[i], cov[i], sums_norm=kernels["fk00"])
+               for i in range(len(obs_list))]
+        return res, kernels, target_dim
+
+    def _measure_sums(self, obs_list, psf_list):
         first, pfirst = obs_list[0], psf_list[0]
         jac = first.jacobian
         if self.use_noise_image and not all(o.has_noise() for o in obs_list):
@@ -402,9 +413,7 @@ class PrePSFMom(object):
             None if pfirst is None else np.array([[p.jacobian.row0, p.jacobian.col0]
                                                   for p in psf_list]),
             np.stack([o.noise for o in obs_list]) if self.use_noise_image else None)
-        res = [make_mom_result(mom[i], cov[i], sums_norm=kernels["fk00"])
-               for i in range(len(obs_list))]
-        return res, kernels, target_dim
+        return mom, cov, kernels, target_dim
 
     def go_batch(self, images, weights, cen, deriv, psf_images=None, psf_cen=None,
                  noise_images=None):
@@ -576,6 +585,45 @@ def _sums_torch(kim_re, kim_im, kpsf_re, kpsf_im, pix, kn_re, kn_im, pnoise_stam
         for b in range(a, 4):
             cols.append((fk[a] * fk[b] * w).sum(dim=1) * df4)
     return torch.stack(cols, dim=1)
+
+
+class PrePSFManyResults(object):
+    """the measurements of a catalogue: by position the per-object result dict
+    of go() (moments.make_mom_result on that stamp's sums, made when asked for),
+    by key the arrays over the catalogue (moments.make_mom_result_batch, made
+    once when first asked for); len() and iteration are over the stamps"""
+
+    def __init__(self, sums, sums_cov, sums_norm):
+        self.sums, self.sums_cov, self.sums_norm = sums, sums_cov, sums_norm
+        self._arrays = None
+
+    def __len__(self):
+        return self.sums.shape[0]
+
+    def arrays(self):
+        if self._arrays is None:
+            from .moments import make_mom_result_batch
+            self._arrays = make_mom_result_batch(self.sums, self.sums_cov,
+                                                 sums_norm=self.sums_norm)
+        return self._arrays
+
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            return self.arrays()[key]
+        if isinstance(key, slice):
+            return [self[i] for i in range(*key.indices(len(self)))]
+        i = int(key)
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(key)
+        return make_mom_result(self.sums[i], self.sums_cov[i], sums_norm=self.sums_norm[i])
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def keys(self):
+        return self.arrays().keys()
 
 
 class KSigmaMom(PrePSFMom):

@@ -141,6 +141,13 @@ def test_go_many_is_go(golden):
         np.testing.assert_allclose(r["sums_cov"], one["sums_cov"], rtol=1e-11, atol=1e-20)
     nopsf = fitter.go_many(obs[:4], no_psf=True)
     assert all(r["flags"] == 0 for r in nopsf) and nopsf[0]["T"] > many[0]["T"]
+    # by key: the arrays over the catalogue
+    assert many["T"].shape == (len(obs),) and many["e"].shape == (len(obs), 2)
+    np.testing.assert_allclose(many["T"], [r["T"] for r in many], rtol=1e-12)
+    np.testing.assert_array_equal(many["flags"], [r["flags"] for r in many])
+    assert len(many[2:5]) == 3 and many[-1]["flux"] == many[len(obs) - 1]["flux"]
+    with pytest.raises(IndexError):
+        many[len(obs)]
 
 
 @pytest.mark.parametrize("tag", ["pgauss", "ksigma_shear", "pgauss_nopsf", "pgauss_noiseim"])
