@@ -758,7 +758,6 @@ class Fitter(object):
         psf mixtures of different sizes, more parameters than its state
         holds)"""
         from .lm_batch import LMBatchFitter
-        from .batch import GMixBatch
         spec = self._batched_model()
         if spec is None or self.use_noise_image or \
                 fm.npars > _lib.LM_NPMAX or guess.size != fm.npars:
