@@ -665,6 +665,50 @@ def run_c3(args, rank, world, device, backend, nstamps=None, steps=None):
     }
 
 
+def run_prepsf(device, n=100000, steps=4):
+    """the Fourier-space pre-psf moments (ngmix/prepsfmom.py PGaussMom /
+    KSigmaMom) over a catalogue resident in HBM: n 33x33 stamps with their psf
+    stamps, padded to 132x132, as one batch (ngmix_amd.prepsfmom.measure_arrays).
+    Synchronous steps on rank 0 at N = 1."""
+    import time
+    import torch
+    from ngmix_amd.prepsfmom import PGaussMom, KSigmaMom
+    dim, scale = 33, 0.2
+    gen = torch.Generator(device=device)
+    gen.manual_seed(5)
+    ax = torch.arange(dim, dtype=torch.float64, device=device) - 16.0
+    r2 = (ax[:, None] ** 2 + ax[None, :] ** 2) * scale ** 2
+    psf = torch.exp(-0.5 * r2 / 0.15) * (scale ** 2 / (2 * np.pi * 0.15))
+    obj = 50.0 * torch.exp(-0.5 * r2 / 0.40) * (scale ** 2 / (2 * np.pi * 0.40))
+    images = obj[None] + 0.02 * torch.randn((n, dim, dim), dtype=torch.float64, device=device,
+                                            generator=gen)
+    pimages = psf[None] + 1.0e-4 * torch.randn((n, dim, dim), dtype=torch.float64, device=device,
+                                               generator=gen)
+    weights = torch.full((n, dim, dim), 1.0 / 0.02 ** 2, dtype=torch.float64, device=device)
+    rng = np.random.RandomState(3)
+    cen = np.tile([16.0, 16.0], (n, 1)) + rng.uniform(-0.3, 0.3, size=(n, 2))
+    deriv = (scale, 0.0, 0.0, scale)
+    out = {"metric": "pre-psf Fourier moments, stamps/sec (33x33 stamps + psf stamps padded to "
+                     "132x132), 1 GPU", "unit": "stamps/s", "steps": steps,
+           "config": {"workload": "%d stamps of 33x33 px with 33x33 psf stamps resident in HBM; "
+                                  "measure_arrays: transform at the kernel's modes, deconvolution, "
+                                  "centre phases, moment and covariance sums" % n}}
+    for name, fitter in (("PGaussMom", PGaussMom(1.2)), ("KSigmaMom", KSigmaMom(2.0))):
+        fitter.measure_arrays(images, weights, cen, deriv, pimages, cen)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            mom, cov, kernels, padded = fitter.measure_arrays(images, weights, cen, deriv, pimages,
+                                                              cen)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[name] = {"value": n / dt, "ms_per_step": dt * 1e3,
+                     "modes_kept": int(kernels["plan"]["irow"].size), "padded_dim": int(padded),
+                     "mean_flux": float(np.mean(mom[:, 5])), "finite": bool(np.isfinite(mom[:, 2:]).all())}
+    out["value"] = out["PGaussMom"]["value"]
+    return out
+
+
 def run_c3_prior(device, n=100000, steps=6):
     """C3 with the reference's separable joint prior, as a caller of the
     reference builds it (ngmix_amd.joint_prior.PriorSimpleSep of CenPrior,
@@ -1688,6 +1732,11 @@ def main():
                 other["C3_host"] = run_c3_host(device, n=min(100000, cap))
             except Exception as e:   # never lose the headline line
                 other["C3_host"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+            try:
+                other["prepsfmom"] = run_prepsf(device, n=min(100000, cap))
+            except Exception as e:   # never lose the headline line
+                other["prepsfmom"] = {"error": repr(e)}
             torch.cuda.empty_cache()
             # and with the reference's joint prior on the parameters
             try:
